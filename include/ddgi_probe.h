@@ -1,0 +1,244 @@
+/*
+ * ddgi_probe.h — C ABI of the MI355X-native DDGI probe-update engine (libddgi_probe.so).
+ *
+ * This is the drop-in boundary for the *probe path* of the reference renderer
+ * (helenl9098/Dynamic-Diffuse-Global-Illumination-Minecraft, an RVPT fork).  The reference has no
+ * plugin API: the boundary is a set of RVPT member functions plus one Vulkan descriptor-set
+ * contract.  Every entry point below cites the reference interface (file:line, relative to the
+ * reference root) it replaces.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative ddgi_status; the message for the calling
+ *     thread's last failure is ddgi_last_error().  Nothing throws across this ABI.
+ *     (reference: bool returns + VK_CHECK_RESULT abort, src/rvpt/rvpt.cpp:499-592, vk_util.h:18-27)
+ *   - the handle owns all device memory it allocates; caller owns every host array it passes;
+ *     no caller pointer is retained past the call except by the explicit *_bind_* functions.
+ *   - one handle = one GPU + one HIP stream.  Calls on one handle are not re-entrant.
+ *     ddgi_probe_update is asynchronous on the handle's stream; ddgi_read_textures/ddgi_sample
+ *     synchronise.  (reference: single-threaded frame loop, src/rvpt/main.cpp:80-96)
+ *   - there is NO CPU fallback: every compute entry point fails with DDGI_ERR_NO_DEVICE when no
+ *     gfx950 device is usable.
+ */
+#ifndef DDGI_PROBE_H
+#define DDGI_PROBE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDGI_ABI_VERSION 1
+
+/* ---- wire formats: byte-identical to the reference's UBO/SSBO records ------------------------ */
+
+/* RVPT::IrradianceField, src/rvpt/rvpt.h:82-90 == GLSL block probe_pass.comp:33-40 (std140), 48 B */
+typedef struct ddgi_irradiance_field
+{
+    int32_t probe_count[3];      /* @0  probes along x, y, z (default 9,7,9)                    */
+    int32_t side_length;         /* @12 integer probe spacing (rvpt.h:85)                       */
+    float hysteresis;            /* @16 blend coefficient (dormant in the reference)            */
+    int32_t sqrt_rays_per_probe; /* @20 s; rays per probe = s*s                                 */
+    int32_t _pad0[2];            /* @24                                                         */
+    float field_origin[3];       /* @32 world position of the field centre (default 1.4,0,1)    */
+    uint8_t visualize;           /* @44 host-only flag                                          */
+    uint8_t _pad1[3];
+} ddgi_irradiance_field;
+
+/* RVPT::RenderSettings, src/rvpt/rvpt.h:70-80 == probe_pass.comp:15-26, 32 B */
+typedef struct ddgi_render_settings
+{
+    int32_t screen_width;     /* unused by the probe path */
+    int32_t screen_height;    /* unused by the probe path */
+    int32_t max_bounces;      /* default 8 */
+    int32_t camera_mode;      /* unused */
+    int32_t render_mode;      /* unused */
+    int32_t scene;            /* 0 cave, 1 Cornell box, 2 house */
+    float time;               /* +2 per frame (rvpt.cpp:281); only animated lights read it */
+    int32_t visualize_probes; /* unused */
+} ddgi_render_settings;
+
+/* struct ProbeRay, src/rvpt/probe.h:5-19 == structs.glsl:22-27 (std430), 48 B */
+typedef struct ddgi_probe_ray
+{
+    float origin[3];
+    float _pad0;
+    float direction[3]; /* unit length */
+    float _pad1;
+    float probe_info[3]; /* (probe_index, tile_x, tile_y) stored as floats */
+    float _pad2;
+} ddgi_probe_ray;
+
+/* struct Light, assets/shaders/structs.glsl:54-59 (a shader constant in the reference) */
+typedef struct ddgi_light
+{
+    float intensity;
+    float col[3];
+    float pos[3];
+} ddgi_light;
+
+#define DDGI_MAX_LIGHTS 8
+
+typedef enum ddgi_status
+{
+    DDGI_OK = 0,
+    DDGI_ERR_INVALID_ARGUMENT = -1,
+    DDGI_ERR_NO_DEVICE = -2,   /* no usable gfx950 GPU: the product has no CPU path */
+    DDGI_ERR_HIP = -3,         /* a HIP runtime call failed; see ddgi_last_error() */
+    DDGI_ERR_OUT_OF_MEMORY = -4,
+    DDGI_ERR_NOT_READY = -5,   /* e.g. probe_update before any rays were generated/uploaded */
+    DDGI_ERR_UNSUPPORTED = -6
+} ddgi_status;
+
+/* Pipeline selection.
+ *   REF  — exactly the reference's LIVE behaviour: host-supplied stratified rays, one texel per
+ *          ray, rgba8 textures, distance texture all zero, 5x5 box-filter sampling.
+ *   DDGI — the reference's dormant pieces switched on: in-kernel spherical-Fibonacci rays,
+ *          octahedral irradiance + depth-moment tiles, hysteresis blend, Chebyshev visibility. */
+typedef enum ddgi_mode
+{
+    DDGI_MODE_REF = 0,
+    DDGI_MODE_DDGI = 1
+} ddgi_mode;
+
+typedef struct ddgi_engine* ddgi_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+
+/* Replaces RVPT::RVPT + initialize() for the probe path (src/rvpt/rvpt.cpp:212-264: context_init,
+ * create_rendering_resources 757-924 [probe pipeline + the two probe images 873-890],
+ * add_per_frame_data 926-1030 [probe SSBO 949-952]).  `device` is the HIP device ordinal. */
+int ddgi_create(const ddgi_irradiance_field* field, const ddgi_render_settings* settings,
+                int device, ddgi_handle* out);
+
+/* Same, for one rank of a z-slab sharded grid (new — the reference is single-GPU).
+ * The rank owns probes with z in [rank*cz/world, (rank+1)*cz/world); cz % world must be 0.
+ * Textures are still allocated for the whole grid so an all-gather can fill in the other slabs. */
+int ddgi_create_sharded(const ddgi_irradiance_field* field, const ddgi_render_settings* settings,
+                        int device, int rank, int world, ddgi_handle* out);
+
+/* Replaces RVPT::shutdown (rvpt.cpp:433-468). */
+int ddgi_destroy(ddgi_handle h);
+
+/* Replaces RVPT::recreate_probe_textures (rvpt.cpp:661-755): new counts / rays / spacing /
+ * origin; textures are re-created zeroed, probe rays must be regenerated or re-uploaded. */
+int ddgi_configure(ddgi_handle h, const ddgi_irradiance_field* field,
+                   const ddgi_render_settings* settings);
+
+int ddgi_set_mode(ddgi_handle h, int mode /* ddgi_mode */);
+
+/* Overrides the light table of one scene (the reference compiles them into the shader,
+ * structs.glsl:61-89; defaults here are the shipped tables).  n <= DDGI_MAX_LIGHTS. */
+int ddgi_set_lights(ddgi_handle h, int scene, const ddgi_light* lights, int n);
+
+/* ---- probe rays (REF mode) -------------------------------------------------------------------- */
+
+/* Replaces RVPT::generate_probe_rays + generate_samples (rvpt.cpp:1147-1224) followed by
+ * probe_buffer.copy_to(probe_rays) (rvpt.cpp:285).  The reference draws its jitter from the
+ * unseeded C rand(); here the glibc TYPE_3 generator is restated, `seed` seeds it on the first
+ * call (seed 1 == an unseeded glibc process) and later calls continue the sequence exactly as
+ * repeated calls do in the reference.  Pass reseed != 0 to restart it. */
+int ddgi_generate_probe_rays(ddgi_handle h, uint32_t seed, int reseed);
+
+/* Replaces probe_buffer.copy_to(probe_rays) (rvpt.cpp:285, vk_util.h:508-518) for caller-made
+ * rays.  n must equal the (local slab's) probe count * s*s for the current configuration, in
+ * the reference's order: probe-major (p = py*cx*cz + pz*cx + px), ray i = y*s + x.
+ * For a sharded handle pass the FULL-grid array; the handle keeps only its slab. */
+int ddgi_upload_probe_rays(ddgi_handle h, const ddgi_probe_ray* rays, size_t n);
+
+/* Copies the handle's current host-side ray array (what generate produced) into `rays`
+ * (capacity n records, full grid).  New: lets a caller inspect what the reference keeps in
+ * RVPT::probe_rays (rvpt.h:113). */
+int ddgi_get_probe_rays(ddgi_handle h, ddgi_probe_ray* rays, size_t n);
+
+/* ---- the hot path ------------------------------------------------------------------------------ */
+
+/* Replaces, per frame: RVPT::update()'s uploads (rvpt.cpp:281-287) + the probe half of
+ * record_compute_command_buffer (barrier + vkCmdDispatch, rvpt.cpp:1105-1129) + Queue::submit
+ * (rvpt.cpp:378-380).  Asynchronous on the handle's stream.  `settings` may be NULL to reuse the
+ * last one; the function does NOT add +2 to time (the caller's RVPT::update does, rvpt.cpp:281). */
+int ddgi_probe_update(ddgi_handle h, const ddgi_render_settings* settings);
+
+/* Waits for the stream (≙ Fence::wait, vk_util.cpp:94-97; here without the 1 s timeout). */
+int ddgi_synchronize(ddgi_handle h);
+
+/* Device time of the kernels of the most recent completed ddgi_probe_update, measured with HIP
+ * events recorded on the handle's stream around each launch.  Any pointer may be NULL.
+ * Synchronises.  blend_ms is 0 in REF mode. */
+int ddgi_last_update_ms(ddgi_handle h, float* trace_ms, float* blend_ms, float* total_ms);
+
+/* ---- outputs ----------------------------------------------------------------------------------- */
+
+/* New (the reference has no readback path): copies both probe textures to the
+ * host in the reference's raster layout — R8G8B8A8_UNORM, W = cx*cz*s, H = cy*s, probe p's tile
+ * at ((p mod cx*cz)*s, (p div cx*cz)*s)  (rvpt.cpp:873-890, probe_pass.comp:139-145).
+ * REF mode only.  Each array holds 4*W*H bytes.  Either pointer may be NULL.  Synchronises. */
+int ddgi_read_textures(ddgi_handle h, uint8_t* albedo_rgba8, uint8_t* distance_rgba8);
+
+/* DDGI mode: copies the float tiles to the host, probe-major in reference probe order p:
+ * irradiance [P][8][8][4] f32 (6x6 interior + 1 texel border, rgb + unused a) and
+ * depth moments [P][16][16][2] f32 (14x14 interior + border; mean distance, mean squared).
+ * Either pointer may be NULL.  Synchronises. */
+int ddgi_read_tiles(ddgi_handle h, float* irradiance, float* depth);
+
+/* Replaces get_diffuse_gi (assets/shaders/intersection.glsl:1306-1409) as called from
+ * integrator_DDGI / integrator_indirect (integrators.glsl:67,205) for a batch of n shading
+ * points: pos_xyz/nrm_xyz are n*3 floats (Isect.pos / Isect.normal), rgb_out n*3 floats,
+ * cage_idx8_out n*8 int32 = probe_index_1d of the 8 cage corners in the shader's order
+ * (offset = (i>>2, i>>1, i)&1), or -1 for every corner when the shader returns magenta early.
+ * Host pointers; synchronises.  cage_idx8_out may be NULL. */
+int ddgi_sample(ddgi_handle h, const float* pos_xyz, const float* nrm_xyz, size_t n,
+                float* rgb_out, int32_t* cage_idx8_out);
+
+/* ---- device-pointer level (for hosts that own device memory / streams, e.g. PyTorch) ---------- */
+
+/* Uses `hip_stream` (a hipStream_t) for all subsequent work of this handle; NULL = default. */
+int ddgi_set_stream(ddgi_handle h, void* hip_stream);
+
+/* Device addresses and byte sizes of the full-grid, slab-major buffers
+ *   REF : tex0 = albedo   [cz][cy][cx][s][s] rgba8,  tex1 = distance, same shape
+ *   DDGI: tex0 = irradiance [cz][cy][cx][8][8] 4xf32, tex1 = depth [cz][cy][cx][16][16] 2xf32
+ * and of this rank's contiguous slab inside each (offset/bytes), which is what an all-gather
+ * exchanges. */
+int ddgi_device_textures(ddgi_handle h, void** tex0, size_t* tex0_bytes, void** tex1,
+                         size_t* tex1_bytes, size_t* slab_offset0, size_t* slab_bytes0,
+                         size_t* slab_offset1, size_t* slab_bytes1);
+
+/* Makes the handle use caller-allocated full-grid device buffers (same layout/size as above)
+ * instead of its own, so that e.g. torch.distributed.all_gather_into_tensor can run in place.
+ * The caller keeps ownership and must keep them alive while bound.  NULLs rebind the internal
+ * buffers. */
+int ddgi_bind_textures(ddgi_handle h, void* tex0, void* tex1);
+
+/* ddgi_sample on device pointers, asynchronous on the handle's stream. */
+int ddgi_sample_device(ddgi_handle h, const float* d_pos_xyz, const float* d_nrm_xyz, size_t n,
+                       float* d_rgb_out, int32_t* d_cage_idx8_out);
+
+/* ---- introspection ------------------------------------------------------------------------------ */
+
+int ddgi_abi_version(void);
+const char* ddgi_last_error(void);
+
+/* Geometry helpers shared by every caller (pure host arithmetic, usable without a GPU):
+ * reference raster size (rvpt.cpp:873-874) and the tile origin of probe p
+ * (probe_pass.comp:139-145). */
+int ddgi_texture_size(const ddgi_irradiance_field* field, int* width, int* height);
+int ddgi_probe_tile_origin(const ddgi_irradiance_field* field, int probe_index, int* x, int* y);
+
+/* Host evaluation of the baked scene the kernels traverse (block type 0..13 at integer voxel
+ * id; replaces getBlockAt, intersection.glsl:699-826, which the reference evaluates per march
+ * step on the GPU).  Usable without a GPU; exists so the bake can be checked against the
+ * oracle. */
+int ddgi_scene_block_at(int scene, int x, int y, int z);
+
+/* The pinned elementary functions the engine uses on host and device ("Arithmetic
+ * pinning"); exported so tests can compare them with libm and with the oracle's restatement. */
+float ddgi_pinned_sinf(float x);
+float ddgi_pinned_cosf(float x);
+float ddgi_pinned_acosf(float x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDGI_PROBE_H */

@@ -1,0 +1,1394 @@
+/*
+ * oracle/ddgi_oracle.c — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, load or call
+ * this file.  The product (dynamic-diffuse-global-illumination-minecraft_amd/, libddgi_probe.so)
+ * never links, imports or executes anything under oracle/.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path
+ *  and its arithmetic lives in GLSL compute shaders that cannot be compiled or
+ * run in the build container (no glslang / Vulkan / lavapipe; the CMake build needs network
+ * FetchContent and glm/GLFW, so oracle/_ref is "unbuildable" by the rules of this project).
+ * What pins this restatement instead: the hand-derived known-answer values of SURVEY.md
+ * Appendix D (re-derived by tests/test_oracle_kat.py), glibc's real rand() for the host jitter,
+ * and structural invariants of the reference code (tests/test_oracle_invariants.py).
+ *
+ * What it is: a plain-C (C11, binary32 arithmetic, -ffp-contract=off) restatement of the LIVE
+ * probe path of the reference, function by function, each citing the reference file:line
+ * (relative to the reference root) it follows:
+ *   host   src/rvpt/rvpt.cpp:1145-1224   generate_samples / generate_probe_rays
+ *   device assets/shaders/probe_pass.comp, intersection.glsl, structs.glsl
+ * plus the DDGI-mode (north-star) pipeline whose pieces are dormant in the reference; those
+ * functions cite the dormant reference lines and, where the reference has nothing, the DDGI
+ * paper the reference's README cites (Majercik et al., JCGT 8(2), 2019).
+ *
+ * Two arithmetic modes (oracle_set_arith):
+ *   LITERAL (0)  every GLSL operator evaluated as one IEEE binary32 operation in source order,
+ *                '/' is IEEE division, no fused multiply-add, sin/cos/acos/sqrt from libm.
+ *   PINNED  (1)  the build's pinned arithmetic (DESIGN.md "Arithmetic pinning"): identical except
+ *                for an explicit, documented list of places (dot products and point-on-ray as fma
+ *                chains, x/d in the voxel march as x*(1/d), x/0.1 as x*10, pinned sin/cos/acos,
+ *                fract clamped below 1) — all inside the precision GLSL/Vulkan allow a driver.
+ *                The HIP kernels implement exactly this mode, so they can be compared bit for bit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "pinned_math.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------- */
+/* wire formats (must match include/ddgi_probe.h; the oracle deliberately does not include it)   */
+
+typedef struct
+{
+    int32_t probe_count[3];
+    int32_t side_length;
+    float hysteresis;
+    int32_t sqrt_rays_per_probe;
+    int32_t _pad0[2];
+    float field_origin[3];
+    uint8_t visualize;
+    uint8_t _pad1[3];
+} o_field; /* rvpt.h:82-90, 48 B */
+
+typedef struct
+{
+    int32_t screen_width, screen_height, max_bounces, camera_mode, render_mode, scene;
+    float time;
+    int32_t visualize_probes;
+} o_settings; /* rvpt.h:70-80, 32 B */
+
+typedef struct
+{
+    float origin[3], _p0, direction[3], _p1, probe_info[3], _p2;
+} o_probe_ray; /* probe.h:5-19, 48 B */
+
+typedef struct
+{
+    float intensity;
+    float col[3];
+    float pos[3];
+} o_light; /* structs.glsl:54-59 */
+
+typedef struct
+{
+    float x, y, z;
+} v3;
+typedef struct
+{
+    float x, y;
+} v2;
+
+#define O_INF INFINITY
+#define O_MAX_LIGHTS 8
+
+/* ------------------------------------------------------------------------------------------- */
+/* arithmetic mode                                                                               */
+
+static int g_pinned = 1;
+
+void oracle_set_arith(int pinned) { g_pinned = pinned ? 1 : 0; }
+int oracle_get_arith(void) { return g_pinned; }
+
+/* GLSL min/max (spec: max(x,y) = x < y ? y : x ; min(x,y) = y < x ? y : x) */
+static inline float gmax(float x, float y) { return x < y ? y : x; }
+static inline float gmin(float x, float y) { return y < x ? y : x; }
+static inline float gclamp(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline float gsign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+static inline float gmix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+
+/* float -> int as GLSL int(x): truncation; NaN -> 0 and saturation as v_cvt_i32_f32 does */
+static inline int32_t gint(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT32_MAX;
+    if (x <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)x;
+}
+
+static inline float o_fract(float x)
+{
+    float f = x - floorf(x);
+    if (g_pinned && f >= 1.0f) f = 0x1.fffffep-1f; /* P7: v_fract_f32 semantics */
+    return f;
+}
+
+static inline float o_sin(float x) { return g_pinned ? opm_sinf(x) : sinf(x); }
+static inline float o_cos(float x) { return g_pinned ? opm_cosf(x) : cosf(x); }
+static inline float o_acos(float x) { return g_pinned ? opm_acosf(x) : acosf(x); }
+
+static inline v3 V3(float x, float y, float z)
+{
+    v3 r = {x, y, z};
+    return r;
+}
+static inline v3 vadd(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vmul(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 vscale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 vdivs(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+
+/* P2: dot products are fma chains in PINNED mode */
+static inline float dot3(v3 a, v3 b)
+{
+    if (g_pinned) return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x));
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+static inline float dot2(v2 a, v2 b)
+{
+    if (g_pinned) return fmaf(a.y, b.y, a.x * b.x);
+    return a.x * b.x + a.y * b.y;
+}
+static inline float length3(v3 a) { return sqrtf(dot3(a, a)); }
+static inline float length2(v2 a) { return sqrtf(dot2(a, a)); }
+
+/* P3: normalize(v) = v * (1/sqrt(dot(v,v))) in PINNED mode, v / length(v) in LITERAL mode */
+static inline v3 normalize3(v3 a)
+{
+    if (g_pinned)
+    {
+        float inv = 1.0f / sqrtf(dot3(a, a));
+        return vscale(a, inv);
+    }
+    return vdivs(a, length3(a));
+}
+static inline v2 normalize2(v2 a)
+{
+    v2 r;
+    if (g_pinned)
+    {
+        float inv = 1.0f / sqrtf(dot2(a, a));
+        r.x = a.x * inv;
+        r.y = a.y * inv;
+    }
+    else
+    {
+        float l = length2(a);
+        r.x = a.x / l;
+        r.y = a.y / l;
+    }
+    return r;
+}
+
+/* P4: point on a ray o + d*t is one fma per component in PINNED mode */
+static inline v3 ray_at(v3 o, v3 d, float t)
+{
+    if (g_pinned) return V3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z));
+    return V3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
+}
+
+/* GLSL cross (spec): (x[1]*y[2]-y[1]*x[2], x[2]*y[0]-y[2]*x[0], x[0]*y[1]-y[0]*x[1]) */
+static inline v3 cross3(v3 a, v3 b)
+{
+    return V3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* a7 — per-thread RNG, probe_pass.comp:45-71                                                    */
+
+uint32_t oracle_wang_hash(uint32_t seed)
+{
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed *= 9u;
+    seed = seed ^ (seed >> 4);
+    seed *= 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+
+static inline uint32_t rand_xorshift(uint32_t* state)
+{
+    uint32_t s = *state;
+    s ^= (s << 13);
+    s ^= (s >> 17);
+    s ^= (s << 5);
+    *state = s;
+    return s;
+}
+
+/* probe_pass.comp:68-71: uint -> float (round to nearest) then / 2^32 (exact scaling) */
+static inline float rng_rand(uint32_t* state) { return (float)rand_xorshift(state) / 4294967296.0f; }
+
+/* KAT helper: out_u = {wang_hash, xorshift#1, xorshift#2}, out_f = {rand#1, rand#2} */
+void oracle_rng_kat(uint32_t p_idx, uint32_t* out_u, float* out_f)
+{
+    uint32_t st = oracle_wang_hash(p_idx);
+    out_u[0] = st;
+    uint32_t st2 = st;
+    out_u[1] = rand_xorshift(&st2);
+    out_u[2] = rand_xorshift(&st2);
+    st2 = st;
+    out_f[0] = rng_rand(&st2);
+    out_f[1] = rng_rand(&st2);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Q1 — the host jitter source.  rvpt.cpp:1161-1162 calls the C library rand(), never seeded.    */
+/* glibc's rand() is random_r TYPE_3 (x^31 + x^3 + 1 additive feedback, LCG-16807 seeding, first  */
+/* 310 outputs discarded, result >> 1); restated here from its published algorithm               */
+/* (glibc stdlib/random_r.c).  tests/test_oracle_kat.py checks it against the real rand().       */
+
+typedef struct
+{
+    uint32_t ring[31];
+    uint32_t k; /* number of ring updates so far */
+    int32_t seeded;
+} o_rand_state;
+
+void oracle_glibc_srand(o_rand_state* st, uint32_t seed)
+{
+    int32_t r[34];
+    if (seed == 0) seed = 1;
+    r[0] = (int32_t)seed;
+    for (int i = 1; i < 31; i++)
+    {
+        int64_t word = r[i - 1];
+        int64_t hi = word / 127773;
+        int64_t lo = word % 127773;
+        word = 16807 * lo - 2836 * hi;
+        if (word < 0) word += 2147483647;
+        r[i] = (int32_t)word;
+    }
+    for (int i = 0; i < 31; i++) st->ring[i] = (uint32_t)r[i];
+    /* ring[j] holds r[k-31+..]; with k counted from 31: r[k] = r[k-31] + r[k-3] */
+    st->k = 31;
+    st->seeded = 1;
+    /* r[31..33] = r[0..2] is what the additive recurrence would NOT give; glibc instead sets
+       fptr = &state[3], rptr = &state[0] and runs 310 discarded steps of
+       *fptr += *rptr.  That is r[k mod 31 at fptr] = r[fptr] + r[rptr], i.e. with a 31-word
+       ring: new[(k+3) mod 31] = old[(k+3) mod 31] + old[k mod 31].  Equivalent closed form
+       used below. */
+    for (int i = 0; i < 310; i++)
+    {
+        uint32_t f = (st->k - 31 + 3) % 31, rp = (st->k - 31) % 31;
+        st->ring[f] += st->ring[rp];
+        st->k++;
+    }
+}
+
+int32_t oracle_glibc_rand(o_rand_state* st)
+{
+    if (!st->seeded) oracle_glibc_srand(st, 1);
+    uint32_t f = (st->k - 31 + 3) % 31, rp = (st->k - 31) % 31;
+    st->ring[f] += st->ring[rp];
+    uint32_t result = st->ring[f] >> 1;
+    st->k++;
+    return (int32_t)result;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* a4 — generate_samples, rvpt.cpp:1147-1173 (#define PI 3.1415926 at 1145)                      */
+/* Argument evaluation order pinned to g++'s (right to left): the y jitter takes the first       */
+/* rand() draw, the x jitter the second.                                          */
+
+static void generate_samples(v3* out, int s, o_rand_state* rs)
+{
+    const double PI_HOST = 3.1415926;
+    float inv_sqrt = 1.f / (float)s;
+    const float rand_max_f = (float)2147483647; /* float(RAND_MAX) = 2147483648.0f */
+    int i = 0;
+    for (int y = 0; y < s; y++)
+    {
+        for (int x = 0; x < s; x++)
+        {
+            float jy = (float)oracle_glibc_rand(rs) / rand_max_f; /* 2nd ctor argument, drawn 1st */
+            float jx = (float)oracle_glibc_rand(rs) / rand_max_f;
+            float sx = ((float)x + jx) * inv_sqrt;
+            float sy = ((float)y + jy) * inv_sqrt;
+            float z = 1 - (2 * sx);
+            /* cosf(2.0f * PI * sample.y): the product is formed in double, cosf takes a float */
+            float ang = (float)(2.0 * PI_HOST * (double)sy);
+            float rxy = sqrtf(1 - (z * z));
+            out[i] = V3(o_cos(ang) * rxy, o_sin(ang) * rxy, z);
+            i++;
+        }
+    }
+}
+
+/* glm::normalize (glm 0.9.9.8, detail/func_geometric.inl — the reference fetches glm at
+ * configure time, external/CMakeLists.txt:22-26; not vendored): v * inversesqrt(dot(v,v)) with
+ * dot = x*x + y*y + z*z and inversesqrt(x) = 1/sqrt(x). Identical in both arithmetic modes
+ * except for the fma chain of P2. */
+static inline v3 glm_normalize(v3 a)
+{
+    float inv = 1.0f / sqrtf(dot3(a, a));
+    return vscale(a, inv);
+}
+
+/* a5 — RVPT::generate_probe_rays, rvpt.cpp:1177-1224.  `rs` carries the rand() sequence across
+ * calls exactly as the process-global rand() does in the reference. */
+void oracle_generate_probe_rays(const o_field* f, o_rand_state* rs, o_probe_ray* out)
+{
+    int cx = f->probe_count[0], cy = f->probe_count[1], cz = f->probe_count[2];
+    int s = f->sqrt_rays_per_probe;
+    int n = s * s;
+    int num_probes = cx * cy * cz;
+    v3* samples = (v3*)malloc(sizeof(v3) * (size_t)n);
+    generate_samples(samples, s, rs);
+    for (int p = 0; p < num_probes; p++)
+    {
+        int py = p / (cx * cz);
+        int leftover = p - (py * cx * cz);
+        int pz = leftover / cx;
+        int px = leftover - pz * cx;
+        /* probe_index_3d - ((dim - 1) / 2): integer arithmetic, then float (rvpt.cpp:1199-1201) */
+        v3 origin = V3((float)(px - (cx - 1) / 2), (float)(py - (cy - 1) / 2),
+                       (float)(pz - (cz - 1) / 2));
+        origin = vscale(origin, (float)f->side_length);
+        origin = vadd(origin, V3(f->field_origin[0], f->field_origin[1], f->field_origin[2]));
+        int x = 0, y = 0;
+        for (int i = 0; i < n; i++)
+        {
+            o_probe_ray* r = &out[(size_t)p * n + i];
+            v3 d = glm_normalize(samples[i]);
+            memset(r, 0, sizeof(*r));
+            r->origin[0] = origin.x, r->origin[1] = origin.y, r->origin[2] = origin.z;
+            r->direction[0] = d.x, r->direction[1] = d.y, r->direction[2] = d.z;
+            r->probe_info[0] = (float)p, r->probe_info[1] = (float)x, r->probe_info[2] = (float)y;
+            x++;
+            if (x >= s)
+            {
+                x = 0;
+                y++;
+            }
+        }
+    }
+    free(samples);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* a12 — noise, intersection.glsl:400-499                                                        */
+
+/* intersection.glsl:400 */
+static float random1(v3 p)
+{
+    return o_fract(o_sin(dot3(p, V3(127.1f, 311.7f, 191.999f))) * 43758.5453f);
+}
+/* intersection.glsl:402 */
+static float noise2D(float px, float py)
+{
+    v2 p = {px, py}, k = {127.1f, 311.7f};
+    return o_fract(o_sin(dot2(p, k)) * 43758.5453f);
+}
+/* intersection.glsl:404-419 */
+static float interpNoise2D(float x, float y)
+{
+    int intX = gint(floorf(x));
+    float fractX = o_fract(x);
+    int intY = gint(floorf(y));
+    float fractY = o_fract(y);
+    float v1 = noise2D((float)intX, (float)intY);
+    float v2_ = noise2D((float)(intX + 1), (float)intY);
+    float v3_ = noise2D((float)intX, (float)(intY + 1));
+    float v4 = noise2D((float)(intX + 1), (float)(intY + 1));
+    float i1 = gmix(v1, v2_, fractX);
+    float i2 = gmix(v3_, v4, fractX);
+    return gmix(i1, i2, fractY);
+}
+/* intersection.glsl:421-435; pow(2.f,i) and pow(0.5,i) are exact powers of two (P8) */
+static float fbm(float x, float y)
+{
+    float total = 0;
+    for (int i = 1; i <= 8; i++)
+    {
+        float freq = ldexpf(1.0f, i);
+        float amp = ldexpf(1.0f, -i);
+        total += interpNoise2D(x * freq, y * freq) * amp;
+    }
+    return total;
+}
+/* intersection.glsl:437-439: fract(sin(vec2(203.311*i, i*sin(0.324+140*i)))).x — only .x is used */
+static float noise1(float i) { return o_fract(o_sin(203.311f * i)); }
+/* intersection.glsl:441-448 */
+static float interpNoise1D(float x)
+{
+    float intX = floorf(x);
+    float fractX = o_fract(x);
+    float v1 = noise1(intX);
+    float v2_ = noise1(intX + 1.0f);
+    return gmix(v1, v2_, fractX);
+}
+/* intersection.glsl:450-463 */
+static float fbm1D(float x)
+{
+    float total = 0.0f;
+    for (int i = 0; i < 8; i++)
+    {
+        float freq = ldexpf(1.0f, i);
+        float amp = ldexpf(1.0f, -i);
+        total += interpNoise1D(x * freq) * amp;
+    }
+    return total;
+}
+/* intersection.glsl:465-471 (cell_size 5.0). Note the parenthesisation of line 469: the second
+ * component is sin(dot(p,(269.5,183.3)) * 43758.5453); neither is scaled after the sin. */
+static v2 generate_point(v2 cell)
+{
+    v2 p = cell;
+    v2 k1 = {127.1f, 311.7f}, k2 = {269.5f, 183.3f};
+    float a = o_sin(dot2(p, k1));
+    float b = o_sin(dot2(p, k2) * 43758.5453f);
+    p.x += o_fract(a);
+    p.y += o_fract(b);
+    p.x *= 5.0f;
+    p.y *= 5.0f;
+    return p;
+}
+/* intersection.glsl:473-499 */
+static float worleyNoise(v2 pixel)
+{
+    v2 cell = {floorf(pixel.x / 5.0f), floorf(pixel.y / 5.0f)};
+    v2 point = generate_point(cell);
+    v2 dlt = {pixel.x - point.x, pixel.y - point.y};
+    float shortest = length2(dlt);
+    for (float i = -1.0f; i <= 1.0f; i += 1.0f)
+    {
+        float ncx = cell.x + i;
+        for (float j = -1.0f; j <= 1.0f; j += 1.0f)
+        {
+            float ncy = cell.y + j;
+            v2 nc = {ncx, ncy};
+            v2 np = generate_point(nc);
+            v2 dd = {pixel.x - np.x, pixel.y - np.y};
+            float dist = length2(dd);
+            if (dist < shortest) shortest = dist;
+        }
+    }
+    return shortest / 5.0f;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* a11 — getBlockAt and the mushroom SDFs, intersection.glsl:321, 538-826                        */
+
+static float sdSphere(v3 p, float s) { return length3(p) - s; } /* :321 */
+
+/* :538-542 */
+static float sdRoundBox(v3 p, v3 b, float r)
+{
+    v3 q = V3(fabsf(p.x) - b.x, fabsf(p.y) - b.y, fabsf(p.z) - b.z);
+    v3 qm = V3(gmax(q.x, 0.0f), gmax(q.y, 0.0f), gmax(q.z, 0.0f));
+    return length3(qm) + gmin(gmax(q.x, gmax(q.y, q.z)), 0.0f) - r;
+}
+/* :544-552 */
+static int tiny_mushroom(v3 p)
+{
+    if (sdRoundBox(p, V3(1.0f, 0.5f, 1.0f), 0) <= 0) return 7;
+    if (p.x == 0 && p.z == 0 && p.y < 0) return 9;
+    return 0;
+}
+/* :554-570 */
+static int small_mushroom(v3 p)
+{
+    if (sdRoundBox(p, V3(1.0f, 0.5f, 1.0f), 1.0f) <= 0)
+    {
+        if (p.y > 0) return 8;
+        if (p.y == 0) return 7;
+        if (p.y < 0) return 6;
+    }
+    if (p.x == 0 && p.z == 0 && p.y < 0) return 9;
+    return 0;
+}
+/* :572-594 */
+static int medium_mushroom(v3 p)
+{
+    if (sdRoundBox(p, V3(2, 0.5f, 2), 1.0f) <= 0)
+    {
+        if (p.y > 0) return 6;
+        if (p.y == 0) return 7;
+        if (p.y < 0) return 8;
+    }
+    if (p.x == 0 && p.z == 0 && p.y < 0 && p.y > -7) return 9;
+    if (p.x == 1 && p.z == 0 && p.y < -5 && p.y > -12) return 9;
+    if (p.x == 2 && p.z == 0 && p.y < -10) return 9;
+    return 0;
+}
+/* :596-618 */
+static int large_mushroom(v3 p, int dir)
+{
+    if (sdRoundBox(p, V3(3, 0.5f, 3), 1.5f) <= 0)
+    {
+        if (p.y > 0) return 6;
+        if (p.y == 0) return 8;
+        if (p.y < 0) return 7;
+    }
+    if (p.x == 0 && p.z == 0 && p.y < 0 && p.y > -9) return 9;
+    if (p.x == 0 && p.z == (float)dir && p.y < -7 && p.y > -18) return 9;
+    if (p.x == 0 && p.z == (float)(2 * dir) && p.y < -16) return 9;
+    return 0;
+}
+/* :630-697 */
+static int all_mushrooms(v3 c)
+{
+    if (c.x < 0 && c.z > 0)
+    {
+        if (c.x < -16)
+        {
+            if (c.z > 20) return tiny_mushroom(vsub(c, V3(-19, -12, 22)));
+            if (c.z < 4) return tiny_mushroom(vsub(c, V3(-18, -12, 2)));
+            int check = large_mushroom(vsub(c, V3(-22, 3, 8)), -1);
+            if (check != 0) return check;
+            check = medium_mushroom(vsub(c, V3(-27, -4, 16)));
+            if (check != 0) return check;
+            return 0;
+        }
+        else
+        {
+            if (c.z > 10 && c.x > -6) return tiny_mushroom(vsub(c, V3(-4, -14, 12)));
+            if (c.z < 14) return medium_mushroom(vsub(c, V3(-4, -1, 6)));
+            return small_mushroom(vsub(c, V3(-10, -8, 18)));
+        }
+    }
+    if (c.x < 0 && c.z < 0)
+    {
+        if (c.x < -16)
+        {
+            if (c.x < -28)
+            {
+                if (c.z < -16) return tiny_mushroom(vsub(c, V3(-32, -14, -20)));
+                return tiny_mushroom(vsub(c, V3(-30, -12, -12)));
+            }
+            if (c.z > -10) return small_mushroom(vsub(c, V3(-25, -7, -4)));
+            return medium_mushroom(vsub(c, V3(-20, -3, -20)));
+        }
+        else
+        {
+            if (c.x < -12 && c.z > -12) return tiny_mushroom(vsub(c, V3(-14, -15, -10)));
+            if (c.z > -10 && c.x > -4) return tiny_mushroom(vsub(c, V3(-2, -12, -2)));
+            if (c.z < -10) return small_mushroom(vsub(c, V3(-5, -9, -14)));
+            return large_mushroom(vsub(c, V3(-8, 8, -6)), 1);
+        }
+    }
+    if (c.x > 0 && c.z < 0)
+    {
+        if (c.z > -5) return tiny_mushroom(vsub(c, V3(6, -14, -3)));
+        if (c.z < -14)
+        {
+            if (c.x > 18) return tiny_mushroom(vsub(c, V3(20, -7, -16)));
+            return large_mushroom(vsub(c, V3(14, 10, -20)), -1);
+        }
+        return medium_mushroom(vsub(c, V3(6, -6, -10)));
+    }
+    return 0;
+}
+
+/* :699-826 */
+static int getBlockAt(v3 c, int scene)
+{
+    if (scene == 0)
+    {
+        if (c.y > 17.0f) return 0;
+        if (c.y < -15)
+        {
+            if (c.y < -18)
+            {
+                float r = fbm(c.x * 0.3f, c.z * 0.3f);
+                int d = gint(floorf(r * 2.0f));
+                if (d == 0) return 12;
+            }
+            float r = fbm(c.x * 0.058f, c.z * 0.058f);
+            int d = gint(floorf(r * 5.0f));
+            if ((float)(-21 + d) >= c.y)
+            {
+                if (c.y == -18) return 13;
+                return 11;
+            }
+        }
+        if (sdSphere(c, 20.0f) > 0.0f)
+            if (sdSphere(vadd(c, V3(16, 8, -10)), 20.0f) > 0.0f)
+                if (sdSphere(vadd(c, V3(-13, -1, 19)), 18.0f) > 0.0f)
+                    if (sdSphere(vadd(c, V3(20, 15, 15)), 21.0f) > 0.0f) return 10;
+        return all_mushrooms(c);
+    }
+    else if (scene == 1)
+    {
+        if (c.x == -10)
+            if (fabsf(c.y) < 10 && fabsf(c.z - 15) < 10) return 2;
+        if (c.x == 10)
+            if (fabsf(c.y) < 10 && fabsf(c.z - 15) < 10) return 3;
+        if (fabsf(c.y) == 10)
+            if (fabsf(c.x) < 10 && fabsf(c.z - 15) < 10) return 5;
+        if (c.z == 25)
+            if (fabsf(c.x) < 10 && fabsf(c.y) < 10) return 5;
+        if (fabsf(c.x + 3) < 3 && fabsf(c.y + 7) < 3 && fabsf(c.z - 13) < 3) return 5;
+        if (fabsf(c.x - 4) < 3 && fabsf(c.y + 4) < 6 && fabsf(c.z - 16) < 3) return 5;
+    }
+    else if (scene == 2)
+    {
+        if (c.y == -5) return 1;
+        if (fabsf(c.x) == 25)
+            if (fabsf(c.y) < 5 && fabsf(c.z) < 15) return 2;
+        if (c.y == 5)
+            if (fabsf(c.x) < 25 && fabsf(c.z) < 15) return 5;
+        if (c.z == -15)
+            if (fabsf(c.x) < 25 && fabsf(c.y) < 5) return 3;
+        if (c.z == 15)
+        {
+            if (fabsf(c.x - 10) < 2 && fabsf(c.y + 1) < 4) return 0;
+            if (fabsf(c.x) < 25 && fabsf(c.y) < 5) return 3;
+        }
+    }
+    else
+    {
+        return 0;
+    }
+    return 0;
+}
+
+int oracle_get_block_at(float x, float y, float z, int scene) { return getBlockAt(V3(x, y, z), scene); }
+
+/* ------------------------------------------------------------------------------------------- */
+/* a13 — getUVs :828-863, dotsPattern :865-870, getColorAt :872-1047                             */
+
+static v2 getUVs(v3 point, v3 normal)
+{
+    v2 uv = {0, 0};
+    if (normal.y == 0)
+    {
+        if (normal.x == 0)
+        {
+            if (gsign(normal.z) > 0)
+            {
+                uv.x = ceilf(point.x) - point.x;
+                uv.y = point.y - floorf(point.y);
+            }
+            else
+            {
+                uv.x = point.x - floorf(point.x);
+                uv.y = point.y - floorf(point.y);
+            }
+        }
+        else
+        {
+            if (gsign(normal.x) < 1)
+            {
+                uv.x = ceilf(point.z) - point.z;
+                uv.y = point.y - floorf(point.y);
+            }
+            else
+            {
+                uv.x = point.z - floorf(point.z);
+                uv.y = point.y - floorf(point.y);
+            }
+        }
+    }
+    else
+    {
+        if (gsign(normal.y) < 0)
+        {
+            uv.x = point.x - floorf(point.x);
+            uv.y = ceilf(point.z) - point.z;
+        }
+        else
+        {
+            uv.x = point.x - floorf(point.x);
+            uv.y = point.z - floorf(point.z);
+        }
+    }
+    return uv;
+}
+
+/* GLSL mod(x,y) = x - y*floor(x/y) */
+static inline float gmod(float x, float y) { return x - y * floorf(x / y); }
+
+static float dotsPattern(v2 point, float radius, float cellSize)
+{
+    float c = 4.0f * radius * cellSize;
+    float h = c / 2.0f;
+    point.x = gmod(point.x + h, c) - h;
+    point.y = gmod(point.y + h, c) - h;
+    return length2(point) - radius;
+}
+
+static inline v3 vmix(v3 a, v3 b, float t) { return V3(gmix(a.x, b.x, t), gmix(a.y, b.y, t), gmix(a.z, b.z, t)); }
+
+static v3 getColorAt(v3 point, int block_type, v3 normal)
+{
+    if (block_type == 1)
+    {
+        float r = 0.3f; /* :890-891: random1 result is overwritten */
+        if (point.x < 0 && point.z > 0)
+        {
+            if (point.x < -16) return V3(0.8f, 0.4f, 0.2f);
+            return V3(0.1f, r, 0.2f);
+        }
+        if (point.x < 0 && point.z < 0)
+        {
+            if (point.x < -16) return V3(0.4f, 0.8f, 0.2f);
+            return V3(0.99f, r, r);
+        }
+        if (point.x > 0 && point.z < 0) return V3(0.1f, r, 0.5f);
+        return V3(0.99f, r, r);
+    }
+    else if (block_type == 2)
+        return V3(.95f, 0, 0);
+    else if (block_type == 3)
+        return V3(0, .95f, 0);
+    else if (block_type == 4)
+        return V3(0, 0, .95f);
+    else if (block_type == 5)
+        return V3(0.95f, 0.95f, 0.95f);
+    else if (block_type == 6)
+    {
+        v2 xz = {point.x, point.z};
+        float w = worleyNoise(xz);
+        if (w < 0.35f) return V3(1, 0, 0.223f);
+        return V3(1, 0.2f, 0);
+    }
+    else if (block_type == 7)
+    {
+        v3 green = V3(0.8f, 1, 0);
+        v2 xz = {point.x + 5.0f, point.z + 5.0f};
+        float w = worleyNoise(xz);
+        if (w < 0.25f)
+        {
+            /* green - (w * (vec3(0.5) - green)) */
+            return V3(green.x - (w * (0.5f - green.x)), green.y - (w * (0.5f - green.y)),
+                      green.z - (w * (0.5f - green.z)));
+        }
+        return V3(1, 0, 0.011f);
+    }
+    else if (block_type == 8)
+    {
+        v3 light_orange = V3(1, 0.313f, 0);
+        v3 dark_purple = V3(1, 0, 0.223f);
+        v2 g = getUVs(point, normal);
+        /* mat2(0.707,-0.707,0.707,0.707) * g, column-major: col0*g.x + col1*g.y */
+        v2 uv = {0.707f * g.x + 0.707f * g.y, -0.707f * g.x + 0.707f * g.y};
+        float radius = 0.05f;
+        float dist = dotsPattern(uv, radius, 1.8f);
+        float circle = (radius - dist) * 100.0f;
+        float alpha = gclamp(circle, 0.0f, 1.0f);
+        return vmix(light_orange, dark_purple, alpha);
+    }
+    else if (block_type == 9)
+    {
+        v2 uvs = getUVs(point, normal);
+        float val = fbm(uvs.x * 5, point.z);
+        val += 0.5f * fbm1D(point.x);
+        val = gclamp(val, 0.0f, 1.0f);
+        return vmix(V3(0.3f, 0.1f, 0.3f), V3(0.9f, 0.9f, 0.9f), val);
+    }
+    else if (block_type == 10)
+    {
+        v3 color = V3(0.568f, 0.133f, 0.439f);
+        if (point.y < -8)
+            color = V3(0.349f, 0.133f, 0.427f);
+        else if (point.y < -6)
+            color = V3(0.568f, 0.133f, 0.439f);
+        else if (point.y < -5)
+            color = V3(0.639f, 0.176f, 0.725f);
+        else if (point.y < 0)
+            color = V3(0.274f, 0.188f, 0.772f);
+        else if (point.y < 4)
+            color = V3(0.341f, 0.270f, 0.768f);
+        else if (point.y < 6)
+            color = V3(0.368f, 0.203f, 0.415f);
+        else if (point.y < 11)
+            color = V3(0.470f, 0.270f, 0.729f);
+        v2 uv = getUVs(point, normal);
+        float r = fbm(0.05f, (uv.y + point.y) * 0.3f);
+        v3 wallColor = V3(0, 0.666f, 1);
+        if (point.x < -1)
+            wallColor = V3(0.294f, 0.007f, 0.152f);
+        else if (point.x < 6 && point.x >= -1)
+        {
+            float gradient = point.x / 7.0f;
+            float rr = random1(V3(ceilf(point.x), ceilf(point.y), ceilf(point.z)));
+            if (rr < gradient)
+                wallColor = V3(0, 0.666f, 1);
+            else
+                wallColor = V3(0.294f, 0.007f, 0.152f);
+        }
+        return vmix(wallColor, color, r);
+    }
+    else if (block_type == 11)
+    {
+        v3 color = V3(0.294f, 0.007f, 0.152f);
+        v3 moldcolor = V3(0.901f, 0.992f, 0.427f);
+        float r = (random1(V3(ceilf(point.x), ceilf(point.y), ceilf(point.z))) / 3);
+        v3 combined = vmix(color, moldcolor, r);
+        v2 uv = getUVs(point, normal);
+        r = fbm(uv.x * 2.0f, uv.y * 2.0f);
+        combined = vmix(combined, V3(0.294f, 0.007f, 0.152f), r / 2.0f);
+        return combined;
+    }
+    else if (block_type == 12 || block_type == 13)
+    {
+        v2 uv = getUVs(point, normal);
+        v3 base_green = block_type == 12 ? V3(0.356f, 1, 0.101f) : V3(0.803f, 1, 0.341f);
+        v3 base_purple = V3(0.619f, 1, 0.278f);
+        v2 c = {uv.x - 0.5f, uv.y - 0.5f};
+        v2 axis = normalize2(c);
+        float r = interpNoise2D(axis.x, axis.y);
+        /* distance(uv, vec2(0.5)) = length(uv - 0.5) */
+        float t = 2.f * length2(c) + r * 0.3f;
+        return vmix(base_green, base_purple, t);
+    }
+    return V3(0, 0, 0); /* unreachable for types 1..13; GLSL leaves it undefined */
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* a26 — Isect, intersection.glsl:37-74 (only the fields the probe path reads)                   */
+
+typedef struct
+{
+    float t;
+    v3 pos;
+    v3 normal;
+    v3 base_color; /* mat.base_color = albedo.xyz */
+    int type;      /* 2 light, 3 block */
+} Isect;
+
+typedef struct
+{
+    v3 o, d;
+} Ray;
+
+/* a14 — shipped light tables, structs.glsl:61-89; overridable for the dormant tables */
+typedef struct
+{
+    int n[3];
+    o_light l[3][O_MAX_LIGHTS];
+} o_light_tables;
+
+static const o_light_tables k_shipped_lights = {
+    {1, 1, 2},
+    {{{100.f, {1.f, 1.f, 1.f}, {4, 17.5f, 8.5f}}},
+     {{15.f, {1.f, 1.f, 1.f}, {0, 8, 13}}},
+     {{1.f, {1.f, 1.f, 1.f}, {5, 9.3f, 36.5f}}, {1.f, {1.f, 1.f, 1.f}, {0, 0, 0}}}}};
+
+typedef struct
+{
+    int scene;
+    int max_bounces;
+    int nl;
+    o_light lights[O_MAX_LIGHTS];
+} TraceCtx;
+
+/* a9 — intersect_sphere, intersection.glsl:78-121 (unit sphere at the origin) */
+static int intersect_sphere(Ray ray, float mint, float maxt, Isect* info)
+{
+    float A = dot3(ray.d, ray.d);
+    float B = -dot3(ray.d, ray.o);
+    float C = dot3(ray.o, ray.o) - 1;
+    float D = B * B - A * C;
+    D = D > 0 ? sqrtf(D) : O_INF;
+    float t1, t2;
+    if (g_pinned)
+    {
+        float invA = 1.0f / A; /* P5: one division, two multiplies */
+        t1 = (B - D) * invA;
+        t2 = (B + D) * invA;
+    }
+    else
+    {
+        t1 = (B - D) / A;
+        t2 = (B + D) / A;
+    }
+    t1 = (mint < t1 && t1 < maxt) ? t1 : O_INF;
+    t2 = (mint < t2 && t2 < maxt) ? t2 : O_INF;
+    info->t = gmin(t1, t2);
+    info->pos = ray_at(ray.o, ray.d, info->t);
+    info->normal = info->pos;
+    return info->t < O_INF;
+}
+
+/* a10 — grid_march, intersection.glsl:1051-1100 */
+static int grid_march(Ray ray, Isect* info, int scene, int* iters_out)
+{
+    v3 p = ray.o;
+    v3 d = normalize3(ray.d);
+    float inv[3], cc[3];
+    if (g_pinned)
+    {
+        /* P5: x/d evaluated as x*(1/d); for d == 0 the axis never limits the step (the GLSL is
+           0/0 there) */
+        float dd[3] = {d.x, d.y, d.z};
+        for (int a = 0; a < 3; a++)
+        {
+            inv[a] = (dd[a] == 0.0f) ? O_INF : 1.0f / dd[a];
+            cc[a] = (dd[a] >= 0.0f) ? 1.0f : 0.0f;
+        }
+    }
+    float curr_t = 0.0f;
+    for (int i = 0; i < 125; i++)
+    {
+        float t2x, t2y, t2z;
+        float fx = o_fract(p.x), fy = o_fract(p.y), fz = o_fract(p.z);
+        if (g_pinned)
+        {
+            /* max(-f/d, (1-f)/d) == (c - f)*(1/d) with c = (d >= 0) */
+            t2x = (cc[0] - fx) * inv[0];
+            t2y = (cc[1] - fy) * inv[1];
+            t2z = (cc[2] - fz) * inv[2];
+        }
+        else
+        {
+            t2x = gmax((-fx) / d.x, (1.f - fx) / d.x);
+            t2y = gmax((-fy) / d.y, (1.f - fy) / d.y);
+            t2z = gmax((-fz) / d.z, (1.f - fz) / d.z);
+        }
+        float min_val = gmin(gmin(t2x, t2y), t2z) + 0.0001f;
+        curr_t += min_val;
+        p = ray_at(ray.o, d, curr_t);
+        v3 cell = V3(ceilf(p.x), ceilf(p.y), ceilf(p.z));
+        v3 pi = V3(cell.x - 0.5f, cell.y - 0.5f, cell.z - 0.5f);
+        int block_type = getBlockAt(cell, scene);
+        if (block_type > 0)
+        {
+            info->t = curr_t;
+            v3 diff = normalize3(vsub(p, pi));
+            float dv[3] = {diff.x, diff.y, diff.z};
+            float nv[3] = {0, 0, 0};
+            float mx = 0.0f;
+            for (int k = 0; k < 3; k++)
+            {
+                if (fabsf(dv[k]) > mx)
+                {
+                    mx = fabsf(dv[k]);
+                    nv[0] = nv[1] = nv[2] = 0;
+                    nv[k] = gsign(dv[k]) * 1;
+                }
+            }
+            v3 normal = V3(nv[0], nv[1], nv[2]);
+            info->normal = normalize3(normal);
+            info->base_color = getColorAt(p, block_type, normalize3(normal));
+            if (iters_out) *iters_out = i + 1;
+            return block_type;
+        }
+    }
+    if (iters_out) *iters_out = 125;
+    return 0;
+}
+
+/* a15 — intersect_scene, intersection.glsl:1244-1301 (mint = 0, maxt = INF at every call site
+ * of the probe path; grid_march ignores both) */
+static int intersect_scene(const TraceCtx* cx, Ray ray, Isect* info)
+{
+    float closest_t = O_INF;
+    info->t = closest_t;
+    info->pos = V3(0, 0, 0);
+    info->normal = V3(0, 0, 0);
+    info->base_color = V3(0, 0, 0);
+    info->type = 0;
+    Isect tmp;
+    memset(&tmp, 0, sizeof(tmp));
+    for (int i = 0; i < cx->nl; i++)
+    {
+        v3 lp = V3(cx->lights[i].pos[0], cx->lights[i].pos[1], cx->lights[i].pos[2]);
+        Ray tr;
+        if (g_pinned)
+        {
+            /* P5: x / 0.1 evaluated as x * 10 */
+            tr.o = vscale(vsub(ray.o, lp), 10.0f);
+            tr.d = vscale(ray.d, 10.0f);
+        }
+        else
+        {
+            tr.o = vdivs(vsub(ray.o, lp), 0.1f);
+            tr.d = vdivs(ray.d, 0.1f);
+        }
+        intersect_sphere(tr, 0.0f, closest_t, &tmp);
+        if (tmp.t < closest_t)
+        {
+            *info = tmp;
+            /* Q12: convert_old_material() of an unassigned Material — undefined in the reference;
+               pinned to zero here (base_color = 0) */
+            info->base_color = V3(0, 0, 0);
+            info->type = 2;
+        }
+        closest_t = gmin(tmp.t, closest_t);
+    }
+    if (grid_march(ray, &tmp, cx->scene, NULL))
+    {
+        if (tmp.t < closest_t)
+        {
+            *info = tmp;
+            closest_t = info->t;
+            info->type = 3;
+        }
+    }
+    if (closest_t < O_INF)
+    {
+        info->normal = normalize3(info->normal);
+        info->pos = ray_at(ray.o, ray.d, info->t);
+    }
+    else
+    {
+        info->normal = V3(0, 0, 0);
+        info->pos = V3(0, 0, 0);
+    }
+    info->pos = vadd(info->pos, vscale(info->normal, 0.001f));
+    return closest_t < O_INF;
+}
+
+/* a16 — get_direct_lighting, probe_pass.comp:180-215 */
+static v3 get_direct_lighting(const TraceCtx* cx, const Isect* info)
+{
+    v3 direct = V3(0, 0, 0);
+    int num_visible = 0;
+    for (int i = 0; i < cx->nl; i++)
+    {
+        const o_light* l = &cx->lights[i];
+        v3 lp = V3(l->pos[0], l->pos[1], l->pos[2]);
+        v3 lc = V3(l->col[0], l->col[1], l->col[2]);
+        Ray feeler;
+        feeler.o = info->pos;
+        feeler.d = normalize3(vsub(lp, info->pos));
+        Isect tmp;
+        if (intersect_scene(cx, feeler, &tmp))
+        {
+            float lambert = gclamp(dot3(normalize3(info->normal), normalize3(vsub(lp, info->pos))), 0.0f, 1.0f);
+            if (tmp.type == 2)
+            {
+                float dist = length3(vsub(lp, info->pos));
+                /* lambert * l.col * l.intensity / dist, left to right */
+                v3 c = vscale(lc, lambert);
+                c = vscale(c, l->intensity);
+                c = vdivs(c, dist);
+                direct = vadd(direct, c);
+            }
+            else
+            {
+                return vscale(vscale(info->base_color, 0.2f), lambert);
+            }
+            num_visible++;
+        }
+    }
+    if (num_visible != 0) return vdivs(vmul(info->base_color, direct), (float)num_visible);
+    return V3(0, 0, 0);
+}
+
+/* a8 — calculate_random_dir_hemisphere, probe_pass.comp:147-178 */
+static v3 random_dir_hemisphere(v3 normal, uint32_t* rng)
+{
+    const float TWO_PI_F = 6.2831853071795864769252867665590057683943f;
+    const float SQRT_OF_ONE_THIRD = 0.5773502691896257645091487805019574556476f;
+    float up = sqrtf(rng_rand(rng));
+    float over = sqrtf(1 - up * up);
+    float around = rng_rand(rng) * TWO_PI_F;
+    v3 dnn;
+    if (fabsf(normal.x) < SQRT_OF_ONE_THIRD)
+        dnn = V3(1, 0, 0);
+    else if (fabsf(normal.y) < SQRT_OF_ONE_THIRD)
+        dnn = V3(0, 1, 0);
+    else
+        dnn = V3(0, 0, 1);
+    v3 p1 = normalize3(cross3(normal, dnn));
+    v3 p2 = normalize3(cross3(normal, p1));
+    float ca = o_cos(around) * over, sa = o_sin(around) * over;
+    return vadd(vadd(vscale(normal, up), vscale(p1, ca)), vscale(p2, sa));
+}
+
+/* rgba8 UNORM store (Vulkan float->unorm: clamp to [0,1], scale by 255, round to nearest).
+ * Ties are pinned to even, NaN to 0. */
+static inline uint8_t unorm8(float x)
+{
+    if (!(x > 0.0f)) return 0;
+    if (x > 1.0f) x = 1.0f;
+    return (uint8_t)rintf(x * 255.0f);
+}
+
+/* a17 — probe main, probe_pass.comp:253-303: trace one probe ray; RNG seeded by its buffer index
+ * (p_idx == index, probe_pass.comp:55-57,259-260) */
+static v3 trace_probe_ray(const TraceCtx* cx, const o_probe_ray* pr, uint32_t ray_index)
+{
+    uint32_t rng = oracle_wang_hash(ray_index);
+    Ray ray;
+    ray.o = V3(pr->origin[0], pr->origin[1], pr->origin[2]);
+    ray.d = V3(pr->direction[0], pr->direction[1], pr->direction[2]);
+    v3 color = V3(0, 0, 0);
+    Isect hit;
+    for (int i = 0; i < cx->max_bounces; i++)
+    {
+        if (intersect_scene(cx, ray, &hit))
+            color = vadd(color, get_direct_lighting(cx, &hit));
+        else
+            break;
+        ray.o = vadd(hit.pos, vscale(hit.normal, 0.0001f));
+        ray.d = random_dir_hemisphere(hit.normal, &rng);
+    }
+    return vdivs(color, (float)cx->max_bounces);
+}
+
+static void make_ctx(TraceCtx* cx, const o_settings* st, const o_light* lights, int nl)
+{
+    cx->scene = st->scene;
+    cx->max_bounces = st->max_bounces;
+    if (lights)
+    {
+        cx->nl = nl;
+        memcpy(cx->lights, lights, sizeof(o_light) * (size_t)nl);
+    }
+    else if (st->scene >= 0 && st->scene <= 2)
+    {
+        cx->nl = k_shipped_lights.n[st->scene];
+        memcpy(cx->lights, k_shipped_lights.l[st->scene], sizeof(o_light) * (size_t)cx->nl);
+    }
+    else
+        cx->nl = 0;
+}
+
+/* a6/a17 — the REF-mode probe update: every ray -> one rgba8 texel of the W x H raster
+ * (probe_pass.comp:139-145,256-271,301-302).  lights == NULL selects the shipped table.
+ * first_ray / n_rays select a contiguous range of the ray buffer (the RNG seed is the absolute
+ * ray index).  colors_f32, when not NULL, receives the unquantised rgb per processed ray. */
+void oracle_probe_update(const o_field* f, const o_settings* st, const o_probe_ray* rays,
+                         uint64_t first_ray, uint64_t n_rays, const o_light* lights, int nl,
+                         uint8_t* albedo, uint8_t* distance, float* colors_f32, int nthreads)
+{
+    TraceCtx cx;
+    make_ctx(&cx, st, lights, nl);
+    int cxz = f->probe_count[0] * f->probe_count[2];
+    int s = f->sqrt_rays_per_probe;
+    int W = cxz * s;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t k = 0; k < (int64_t)n_rays; k++)
+    {
+        uint64_t idx = first_ray + (uint64_t)k;
+        const o_probe_ray* pr = &rays[idx];
+        v3 c = trace_probe_ray(&cx, pr, (uint32_t)idx);
+        if (colors_f32)
+        {
+            colors_f32[3 * k + 0] = c.x;
+            colors_f32[3 * k + 1] = c.y;
+            colors_f32[3 * k + 2] = c.z;
+        }
+        int probe = gint(pr->probe_info[0]);
+        int y_probe = probe / cxz;
+        int x_probe = probe - y_probe * cxz;
+        int tx = x_probe * s + gint(pr->probe_info[1]);
+        int ty = y_probe * s + gint(pr->probe_info[2]);
+        size_t o = ((size_t)ty * (size_t)W + (size_t)tx) * 4;
+        if (albedo)
+        {
+            albedo[o + 0] = unorm8(c.x);
+            albedo[o + 1] = unorm8(c.y);
+            albedo[o + 2] = unorm8(c.z);
+            albedo[o + 3] = 255;
+        }
+        if (distance) distance[o + 0] = distance[o + 1] = distance[o + 2] = distance[o + 3] = 0;
+    }
+}
+
+int oracle_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* KAT helper: one grid_march from o along d (any length). out = {t, nx,ny,nz, r,g,b, px,py,pz} */
+int oracle_grid_march(const float* o, const float* d, int scene, float* out, int* iters)
+{
+    Ray r;
+    r.o = V3(o[0], o[1], o[2]);
+    r.d = V3(d[0], d[1], d[2]);
+    Isect info;
+    memset(&info, 0, sizeof(info));
+    int block = grid_march(r, &info, scene, iters);
+    if (block)
+    {
+        v3 dn = normalize3(r.d);
+        v3 p = ray_at(r.o, dn, info.t);
+        out[0] = info.t;
+        out[1] = info.normal.x, out[2] = info.normal.y, out[3] = info.normal.z;
+        out[4] = info.base_color.x, out[5] = info.base_color.y, out[6] = info.base_color.z;
+        out[7] = p.x, out[8] = p.y, out[9] = p.z;
+    }
+    return block;
+}
+
+/* KAT helper: getColorAt */
+void oracle_get_color_at(const float* point, int type, const float* normal, float* rgb)
+{
+    v3 c = getColorAt(V3(point[0], point[1], point[2]), type, V3(normal[0], normal[1], normal[2]));
+    rgb[0] = c.x, rgb[1] = c.y, rgb[2] = c.z;
+}
+
+/* KAT helper: intersect_scene; out = {t, px,py,pz, nx,ny,nz, r,g,b}; returns type (0 = miss) */
+int oracle_intersect_scene(const o_settings* st, const float* o, const float* d, float* out)
+{
+    TraceCtx cx;
+    make_ctx(&cx, st, NULL, 0);
+    Ray r;
+    r.o = V3(o[0], o[1], o[2]);
+    r.d = V3(d[0], d[1], d[2]);
+    Isect info;
+    if (!intersect_scene(&cx, r, &info)) return 0;
+    out[0] = info.t;
+    out[1] = info.pos.x, out[2] = info.pos.y, out[3] = info.pos.z;
+    out[4] = info.normal.x, out[5] = info.normal.y, out[6] = info.normal.z;
+    out[7] = info.base_color.x, out[8] = info.base_color.y, out[9] = info.base_color.z;
+    return info.type;
+}
+
+float oracle_sinf(float x) { return o_sin(x); }
+float oracle_cosf(float x) { return o_cos(x); }
+float oracle_acosf(float x) { return o_acos(x); }
+
+/* ------------------------------------------------------------------------------------------- */
+/* a21/a22/a23 — the REF-mode sampler                                                            */
+
+typedef struct
+{
+    const o_field* f;
+    const uint8_t* albedo;   /* W*H*4 raster */
+    const uint8_t* distance; /* W*H*4 raster */
+    int W, H;
+} SampleCtx;
+
+/* rgba8 UNORM load: c / 255 (exact IEEE division) */
+static inline v3 image_load(const uint8_t* img, int W, int x, int y)
+{
+    const uint8_t* p = img + ((size_t)y * (size_t)W + (size_t)x) * 4;
+    return V3((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f);
+}
+
+/* a21 — get_text_coord_from_probe_number, intersection.glsl:1152-1174; returns 0 for (-1,-1) */
+static int text_coord_from_probe_number(const o_field* f, int probe_number, int* ox, int* oy)
+{
+    int x_dim = f->probe_count[0] * f->probe_count[2];
+    if (probe_number >= x_dim * f->probe_count[1]) return 0;
+    if (probe_number < 0 || x_dim < 0) return 0;
+    /* int(mod(probe_number, x_dim)) on floats, int(floor(probe_number / x_dim)) on ints */
+    int rx = gint(gmod((float)probe_number, (float)x_dim));
+    int ry = probe_number / x_dim;
+    if (ry >= f->probe_count[1]) return 0;
+    *ox = rx * f->sqrt_rays_per_probe;
+    *oy = ry * f->sqrt_rays_per_probe;
+    return 1;
+}
+
+/* a22 — sample_probe, intersection.glsl:1176-1240 (shader PI = full precision, probe_pass.comp:4) */
+static v3 sample_probe(const SampleCtx* sc, int probe_number, v3 dir, int texture_to_sample)
+{
+    int cx0, cy0;
+    if (!text_coord_from_probe_number(sc->f, probe_number, &cx0, &cy0)) return V3(1, 0, 1);
+    int s = sc->f->sqrt_rays_per_probe;
+    v3 id = normalize3(dir);
+    int rx = gint(((-1.0f * (id.z - 1.0f)) / 2.0f) * (float)s);
+    if (rx == s) rx = 0;
+    float sqrt_z = sqrtf(1.0f - (id.z * id.z));
+    const float PI_F = 3.1415926535897932384626433832795f;
+    int ry = gint((o_acos(id.x / sqrt_z) / (2.0f * PI_F)) * (float)s);
+    int sx = cx0 + rx, sy = cy0 + ry;
+    v3 result = image_load(sc->albedo, sc->W, sx, sy);
+    int count = 0;
+    for (int x = -2; x <= 2; x++)
+    {
+        int temp = sx + x;
+        if (temp < cx0 || temp >= cx0 + s) continue;
+        for (int y = -2; y <= 2; y++)
+        {
+            int yy = sy + y;
+            if (yy < cy0 || yy >= cy0 + s) continue;
+            count++;
+            if (texture_to_sample == 0)
+                result = vadd(result, image_load(sc->albedo, sc->W, temp, yy));
+            else if (texture_to_sample == 1)
+                result = vadd(result, image_load(sc->distance, sc->W, temp, yy));
+        }
+    }
+    return vdivs(result, (float)count);
+}
+
+/* a23 — get_diffuse_gi, intersection.glsl:1306-1409.  cage[8] receives probe_index_1d per
+ * corner, or all -1 when the shader returns magenta. */
+static v3 get_diffuse_gi(const SampleCtx* sc, v3 pos, v3 nrm, int32_t* cage)
+{
+    const o_field* f = sc->f;
+    int cxn = f->probe_count[0], cyn = f->probe_count[1], czn = f->probe_count[2];
+    float side = (float)f->side_length;
+    v3 origin = V3(f->field_origin[0], f->field_origin[1], f->field_origin[2]);
+    v3 N = normalize3(nrm);
+    for (int i = 0; i < 8; i++) cage[i] = -1;
+    v3 rel = vdivs(vsub(pos, origin), side);
+    int base[3] = {gint(floorf(rel.x)), gint(floorf(rel.y)), gint(floorf(rel.z))};
+    /* Q6: int(vec3) keeps the x component, so every axis is checked against probe_count.x */
+    int lo = gint(-floorf((float)cxn / 2.0f));
+    int hi = gint(floorf((float)cxn / 2.0f) - 1);
+    for (int i = 0; i < 3; i++)
+        if (base[i] < lo || base[i] > hi) return V3(1, 0, 1);
+    v3 base_world = vadd(V3((float)(base[0] * f->side_length), (float)(base[1] * f->side_length),
+                            (float)(base[2] * f->side_length)),
+                         origin);
+    v3 irradiance = V3(0, 0, 0);
+    float sum_weight = 0.0f;
+    v3 a = vdivs(vsub(pos, base_world), side);
+    v3 alpha = V3(gclamp(a.x, 0, 1), gclamp(a.y, 0, 1), gclamp(a.z, 0, 1));
+    int32_t idx8[8];
+    for (int i = 0; i < 8; i++)
+    {
+        int off[3] = {(i >> 2) & 1, (i >> 1) & 1, i & 1};
+        int cur[3] = {base[0] + off[0], base[1] + off[1], base[2] + off[2]};
+        /* Q4: shift by counts/2 (integer division) */
+        int sh[3] = {cur[0] + cxn / 2, cur[1] + cyn / 2, cur[2] + czn / 2};
+        int idx = sh[1] * cxn * czn + sh[2] * cxn + sh[0];
+        if (idx < 0 || idx >= cxn * cyn * czn) return V3(1, 0, 1);
+        idx8[i] = idx;
+        v3 offf = V3((float)off[0], (float)off[1], (float)off[2]);
+        v3 tri = V3(gmix(1.0f - alpha.x, alpha.x, offf.x), gmix(1.0f - alpha.y, alpha.y, offf.y),
+                    gmix(1.0f - alpha.z, alpha.z, offf.z));
+        v3 probe_pos = vadd(base_world, V3((float)(off[0] * f->side_length), (float)(off[1] * f->side_length),
+                                           (float)(off[2] * f->side_length)));
+        v3 dir = normalize3(vsub(probe_pos, pos));
+        float temp = gmax(0.0001f, (dot3(dir, N) + 1.0f) * 0.5f);
+        float weight = temp * temp + 0.2f;
+        /* Chebyshev term (1363-1383) is computed from the all-zero distance texture and its
+           multiply is commented out: no observable effect (Q11). */
+        weight = gmax(0.000001f, weight);
+        const float crush = 0.2f;
+        if (weight < crush) weight *= weight * weight * (1.f / (crush * crush));
+        weight *= tri.x * tri.y * tri.z;
+        v3 smp = sample_probe(sc, idx, N, 0);
+        irradiance = vadd(irradiance, vscale(smp, weight));
+        sum_weight += weight;
+    }
+    for (int i = 0; i < 8; i++) cage[i] = idx8[i];
+    return vdivs(irradiance, sum_weight);
+}
+
+void oracle_sample(const o_field* f, const uint8_t* albedo, const uint8_t* distance,
+                   const float* pos, const float* nrm, uint64_t n, float* rgb, int32_t* cage8)
+{
+    SampleCtx sc;
+    sc.f = f;
+    sc.albedo = albedo;
+    sc.distance = distance;
+    sc.W = f->probe_count[0] * f->probe_count[2] * f->sqrt_rays_per_probe;
+    sc.H = f->probe_count[1] * f->sqrt_rays_per_probe;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++)
+    {
+        int32_t cage[8];
+        v3 c = get_diffuse_gi(&sc, V3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]),
+                              V3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]), cage);
+        rgb[3 * i] = c.x, rgb[3 * i + 1] = c.y, rgb[3 * i + 2] = c.z;
+        if (cage8) memcpy(cage8 + 8 * i, cage, sizeof(cage));
+    }
+}
+
+/* KAT helper: sample_probe's texel inversion only; returns (rx, ry) */
+void oracle_sample_texel(const o_field* f, const float* dir, int* rx_out, int* ry_out)
+{
+    int s = f->sqrt_rays_per_probe;
+    v3 id = normalize3(V3(dir[0], dir[1], dir[2]));
+    int rx = gint(((-1.0f * (id.z - 1.0f)) / 2.0f) * (float)s);
+    if (rx == s) rx = 0;
+    float sqrt_z = sqrtf(1.0f - (id.z * id.z));
+    const float PI_F = 3.1415926535897932384626433832795f;
+    *rx_out = rx;
+    *ry_out = gint((o_acos(id.x / sqrt_z) / (2.0f * PI_F)) * (float)s);
+}
