@@ -1,0 +1,34 @@
+"""Builds libddgi_probe.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_HERE, "libddgi_probe.so")
+_SOURCES = ["ddgi_kernels.hip", "ddgi_host.cpp", "ddgi_engine.cpp", "ddgi_pinned_math.h", "ddgi_scene.h",
+            "ddgi_types.h", "ddgi_host.h", "Makefile"]
+
+
+def library_path():
+    return _SO
+
+
+def _stale():
+    if not os.path.exists(_SO):
+        return True
+    t = os.path.getmtime(_SO)
+    deps = [os.path.join(_CSRC, s) for s in _SOURCES]
+    deps.append(os.path.join(_HERE, "..", "include", "ddgi_probe.h"))
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 ... -shared -o libddgi_probe.so; returns the path."""
+    if force or _stale():
+        cmd = ["make", "-C", _CSRC] + (["-B"] if force else [])
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if verbose or res.returncode != 0:
+            print(res.stdout)
+        if res.returncode != 0:
+            raise RuntimeError("building libddgi_probe.so failed:\n" + res.stdout)
+    return _SO

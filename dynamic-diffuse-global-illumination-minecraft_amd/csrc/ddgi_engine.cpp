@@ -1,0 +1,628 @@
+// ddgi_engine.cpp — the C ABI of include/ddgi_probe.h: handle, device memory, launches.
+// There is no CPU compute path in this library: every compute entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ddgi_host.h"
+#include "ddgi_pinned_math.h"
+#include "ddgi_types.h"
+
+namespace ddgi {
+hipError_t launch_probe_trace_ref(const TraceArgs& args, int grid_blocks, hipStream_t stream);
+hipError_t launch_probe_sample_ref(const SampleArgs& args, hipStream_t stream);
+hipError_t trace_kernel_occupancy(int* blocks_per_cu, size_t lds_bytes);
+}  // namespace ddgi
+
+using namespace ddgi;
+
+static_assert(sizeof(ddgi_irradiance_field) == 48, "IrradianceField must be 48 bytes (rvpt.h:82-90)");
+static_assert(sizeof(ddgi_render_settings) == 32, "RenderSettings must be 32 bytes (rvpt.h:70-80)");
+static_assert(sizeof(ddgi_probe_ray) == 48, "ProbeRay must be 48 bytes (probe.h:5-19)");
+static_assert(offsetof(ddgi_irradiance_field, field_origin) == 32, "std140 layout");
+
+// ---- error reporting ---------------------------------------------------------------------------------
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do                                                                                                  \
+    {                                                                                                   \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY                              \
+                        : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? DDGI_ERR_NO_DEVICE  \
+                                                                                   : DDGI_ERR_HIP,      \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                                 \
+    } while (0)
+
+// ---- the handle ----------------------------------------------------------------------------------------
+
+struct ddgi_engine
+{
+    int device = 0;
+    int rank = 0, world = 1;
+    int mode = DDGI_MODE_REF;
+    ddgi_irradiance_field field{};
+    ddgi_render_settings settings{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+
+    // lights per scene
+    LightK lights[3][kMaxLights];
+    int n_lights[3] = {0, 0, 0};
+
+    // baked scene on device (per scene id, uploaded lazily)
+    struct DevScene
+    {
+        uint32_t* bits = nullptr;
+        uint8_t* types = nullptr;
+        SceneK k{};
+        bool ready = false;
+    } dev_scene[3];
+
+    // rays
+    GlibcRand rand;
+    bool rand_seeded = false;
+    std::vector<ddgi_probe_ray> host_rays;  // full grid (what RVPT::probe_rays holds)
+    float4* d_rays = nullptr;               // local slab
+    size_t d_rays_capacity = 0;             // in rays
+    uint32_t n_local_rays = 0;
+
+    // textures (REF: rgba8 texels, slab-major)
+    void* own_tex[2] = {nullptr, nullptr};
+    void* tex[2] = {nullptr, nullptr};
+    size_t tex_bytes[2] = {0, 0};
+
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool timed = false;
+    int wait_threshold = 16;
+};
+
+static GridK make_grid(const ddgi_engine* e)
+{
+    GridK g;
+    g.cx = e->field.probe_count[0];
+    g.cy = e->field.probe_count[1];
+    g.cz = e->field.probe_count[2];
+    g.s = e->field.sqrt_rays_per_probe;
+    g.side = e->field.side_length;
+    for (int a = 0; a < 3; ++a) g.origin[a] = e->field.field_origin[a];
+    g.hysteresis = e->field.hysteresis;
+    g.czl = g.cz / e->world;
+    g.z0 = e->rank * g.czl;
+    return g;
+}
+
+static int validate_config(const ddgi_irradiance_field* f, const ddgi_render_settings* s, int world)
+{
+    if (!f || !s) return fail(DDGI_ERR_INVALID_ARGUMENT, "null field/settings");
+    for (int a = 0; a < 3; ++a)
+        if (f->probe_count[a] < 1) return fail(DDGI_ERR_INVALID_ARGUMENT, "probe_count[%d] = %d < 1", a, f->probe_count[a]);
+    if (f->sqrt_rays_per_probe < 1) return fail(DDGI_ERR_INVALID_ARGUMENT, "sqrt_rays_per_probe < 1");
+    if (f->side_length < 1) return fail(DDGI_ERR_INVALID_ARGUMENT, "side_length < 1");
+    const unsigned long long probes = 1ull * f->probe_count[0] * f->probe_count[1] * f->probe_count[2];
+    // probe_info.x carries the probe index as a float (probe.h:18): exact only below 2^24
+    if (probes >= (1ull << 24)) return fail(DDGI_ERR_UNSUPPORTED, "more than 2^24 probes: probe_info.x (float) cannot index them");
+    const unsigned long long rays = probes * f->sqrt_rays_per_probe * f->sqrt_rays_per_probe;
+    if (rays >= (1ull << 32)) return fail(DDGI_ERR_UNSUPPORTED, "more than 2^32 probe rays: the reference's uint RNG seed wraps");
+    if (s->scene < 0 || s->scene > 2) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2}", s->scene);
+    if (world < 1 || f->probe_count[2] % world != 0)
+        return fail(DDGI_ERR_INVALID_ARGUMENT, "probe_count.z = %d is not divisible by world = %d", f->probe_count[2], world);
+    return DDGI_OK;
+}
+
+static int alloc_textures(ddgi_engine* e)
+{
+    for (int i = 0; i < 2; ++i)
+    {
+        if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
+        e->own_tex[i] = nullptr;
+    }
+    const size_t probes = static_cast<size_t>(e->field.probe_count[0]) * e->field.probe_count[1] * e->field.probe_count[2];
+    const size_t s2 = static_cast<size_t>(e->field.sqrt_rays_per_probe) * e->field.sqrt_rays_per_probe;
+    e->tex_bytes[0] = e->tex_bytes[1] = probes * s2 * 4;
+    for (int i = 0; i < 2; ++i)
+    {
+        HIP_TRY(hipMalloc(&e->own_tex[i], e->tex_bytes[i]));
+        // the reference leaves the images undefined until the first probe pass (rvpt.cpp:873-890);
+        // here they start zeroed
+        HIP_TRY(hipMemsetAsync(e->own_tex[i], 0, e->tex_bytes[i], e->stream));
+        e->tex[i] = e->own_tex[i];
+    }
+    return DDGI_OK;
+}
+
+static int ensure_scene(ddgi_engine* e, int scene)
+{
+    ddgi_engine::DevScene& d = e->dev_scene[scene];
+    if (d.ready) return DDGI_OK;
+    const SceneBake& b = baked_scene(scene);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.bits), b.bits.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.types), b.types.size()));
+    HIP_TRY(hipMemcpy(d.bits, b.bits.data(), b.bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.types, b.types.data(), b.types.size(), hipMemcpyHostToDevice));
+    for (int a = 0; a < 3; ++a)
+    {
+        d.k.lo[a] = b.lo[a];
+        d.k.hi[a] = b.hi[a];
+    }
+    d.k.nx = b.dim[0];
+    d.k.nxy = b.dim[0] * b.dim[1];
+    d.k.bias = (b.lo[2] * b.dim[1] + b.lo[1]) * b.dim[0] + b.lo[0];
+    d.k.nwords = static_cast<int>(b.bits.size());
+    d.k.face_empty = b.face_empty;
+    d.k.bits = d.bits;
+    d.k.types = d.types;
+    d.ready = true;
+    return DDGI_OK;
+}
+
+static int upload_local_rays(ddgi_engine* e)
+{
+    const GridK g = make_grid(e);
+    const size_t n = static_cast<size_t>(g.s) * g.s;
+    const size_t local_probes = static_cast<size_t>(g.cx) * g.cy * g.czl;
+    const size_t local_rays = local_probes * n;
+    if (local_rays > e->d_rays_capacity)
+    {
+        if (e->d_rays) (void)hipFree(e->d_rays);
+        e->d_rays = nullptr;
+        e->d_rays_capacity = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_rays), local_rays * sizeof(ddgi_probe_ray)));
+        e->d_rays_capacity = local_rays;
+    }
+    // this rank's probes in reference order: for each y, the z-range [z0, z0+czl) is one contiguous run
+    const size_t run = static_cast<size_t>(g.czl) * g.cx * n;  // rays per (y) run
+    for (int y = 0; y < g.cy; ++y)
+    {
+        const size_t src = (static_cast<size_t>(y) * g.cx * g.cz + static_cast<size_t>(g.z0) * g.cx) * n;
+        const size_t dst = static_cast<size_t>(y) * run;
+        HIP_TRY(hipMemcpyAsync(reinterpret_cast<ddgi_probe_ray*>(e->d_rays) + dst, e->host_rays.data() + src,
+                               run * sizeof(ddgi_probe_ray), hipMemcpyHostToDevice, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->n_local_rays = static_cast<uint32_t>(local_rays);
+    return DDGI_OK;
+}
+
+// ---- C ABI -----------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int ddgi_abi_version(void) { return DDGI_ABI_VERSION; }
+
+const char* ddgi_last_error(void) { return g_last_error.c_str(); }
+
+int ddgi_create_sharded(const ddgi_irradiance_field* field, const ddgi_render_settings* settings, int device,
+                        int rank, int world, ddgi_handle* out)
+{
+    if (!out) return fail(DDGI_ERR_INVALID_ARGUMENT, "null out handle");
+    *out = nullptr;
+    if (int rc = validate_config(field, settings, world)) return rc;
+    if (rank < 0 || rank >= world) return fail(DDGI_ERR_INVALID_ARGUMENT, "rank %d not in [0,%d)", rank, world);
+    int count = 0;
+    hipError_t he = hipGetDeviceCount(&count);
+    if (he != hipSuccess || count <= 0)
+        return fail(DDGI_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    he == hipSuccess ? "device count is 0" : hipGetErrorString(he));
+    if (device < 0 || device >= count) return fail(DDGI_ERR_NO_DEVICE, "device %d not in [0,%d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DDGI_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+
+    ddgi_engine* e = new (std::nothrow) ddgi_engine();
+    if (!e) return fail(DDGI_ERR_OUT_OF_MEMORY, "host allocation failed");
+    e->device = device;
+    e->rank = rank;
+    e->world = world;
+    e->field = *field;
+    e->settings = *settings;
+    e->num_cus = prop.multiProcessorCount;
+    for (int s = 0; s < 3; ++s) shipped_lights(s, e->lights[s], &e->n_lights[s]);
+    int rc = DDGI_OK;
+    do
+    {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+        {
+            rc = fail(DDGI_ERR_HIP, "hipStreamCreate failed");
+            break;
+        }
+        e->own_stream = true;
+        for (int i = 0; i < 3; ++i)
+            if (hipEventCreate(&e->ev[i]) != hipSuccess) rc = fail(DDGI_ERR_HIP, "hipEventCreate failed");
+        if (rc) break;
+        rc = alloc_textures(e);
+    } while (0);
+    if (rc)
+    {
+        ddgi_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return DDGI_OK;
+}
+
+int ddgi_create(const ddgi_irradiance_field* field, const ddgi_render_settings* settings, int device, ddgi_handle* out)
+{
+    return ddgi_create_sharded(field, settings, device, 0, 1, out);
+}
+
+int ddgi_destroy(ddgi_handle e)
+{
+    if (!e) return DDGI_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (int i = 0; i < 2; ++i)
+        if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
+    if (e->d_rays) (void)hipFree(e->d_rays);
+    for (auto& d : e->dev_scene)
+    {
+        if (d.bits) (void)hipFree(d.bits);
+        if (d.types) (void)hipFree(d.types);
+    }
+    for (auto& ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return DDGI_OK;
+}
+
+int ddgi_configure(ddgi_handle e, const ddgi_irradiance_field* field, const ddgi_render_settings* settings)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (int rc = validate_config(field, settings, e->world)) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->field = *field;
+    e->settings = *settings;
+    e->host_rays.clear();
+    e->n_local_rays = 0;
+    e->timed = false;
+    return alloc_textures(e);
+}
+
+int ddgi_set_mode(ddgi_handle e, int mode)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (mode != DDGI_MODE_REF) return fail(DDGI_ERR_UNSUPPORTED, "mode %d not available in this build", mode);
+    e->mode = mode;
+    return DDGI_OK;
+}
+
+int ddgi_set_lights(ddgi_handle e, int scene, const ddgi_light* lights, int n)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (scene < 0 || scene > 2 || n < 0 || n > kMaxLights || (n > 0 && !lights))
+        return fail(DDGI_ERR_INVALID_ARGUMENT, "bad light table (scene %d, n %d)", scene, n);
+    for (int i = 0; i < n; ++i)
+    {
+        e->lights[scene][i].intensity = lights[i].intensity;
+        for (int a = 0; a < 3; ++a)
+        {
+            e->lights[scene][i].col[a] = lights[i].col[a];
+            e->lights[scene][i].pos[a] = lights[i].pos[a];
+        }
+    }
+    e->n_lights[scene] = n;
+    return DDGI_OK;
+}
+
+int ddgi_generate_probe_rays(ddgi_handle e, uint32_t seed, int reseed)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    if (!e->rand_seeded || reseed)
+    {
+        e->rand.seed(seed);
+        e->rand_seeded = true;
+    }
+    generate_probe_rays(e->field, e->rand, e->host_rays);
+    return upload_local_rays(e);
+}
+
+int ddgi_upload_probe_rays(ddgi_handle e, const ddgi_probe_ray* rays, size_t n)
+{
+    if (!e || !rays) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/rays");
+    HIP_TRY(hipSetDevice(e->device));
+    const GridK g = make_grid(e);
+    const size_t probes = static_cast<size_t>(g.cx) * g.cy * g.cz;
+    const size_t expect = probes * g.s * g.s;
+    if (n != expect) return fail(DDGI_ERR_INVALID_ARGUMENT, "expected %zu rays (full grid), got %zu", expect, n);
+    // the reference's shader trusts probe_info blindly (Q13); an out-of-range tile would write
+    // outside the texture, so reject it here
+    for (size_t i = 0; i < n; ++i)
+    {
+        const float p = rays[i].probe_info[0], tx = rays[i].probe_info[1], ty = rays[i].probe_info[2];
+        if (!(p >= 0.0f && p < static_cast<float>(probes) && tx >= 0.0f && tx < static_cast<float>(g.s) && ty >= 0.0f &&
+              ty < static_cast<float>(g.s)))
+            return fail(DDGI_ERR_INVALID_ARGUMENT, "ray %zu: probe_info (%g,%g,%g) outside the grid", i, p, tx, ty);
+    }
+    e->host_rays.assign(rays, rays + n);
+    return upload_local_rays(e);
+}
+
+int ddgi_get_probe_rays(ddgi_handle e, ddgi_probe_ray* rays, size_t n)
+{
+    if (!e || !rays) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/rays");
+    if (e->host_rays.empty()) return fail(DDGI_ERR_NOT_READY, "no probe rays generated or uploaded yet");
+    if (n < e->host_rays.size()) return fail(DDGI_ERR_INVALID_ARGUMENT, "capacity %zu < %zu rays", n, e->host_rays.size());
+    std::memcpy(rays, e->host_rays.data(), e->host_rays.size() * sizeof(ddgi_probe_ray));
+    return DDGI_OK;
+}
+
+int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (settings)
+    {
+        if (settings->scene < 0 || settings->scene > 2) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2}", settings->scene);
+        e->settings = *settings;
+    }
+    if (e->n_local_rays == 0) return fail(DDGI_ERR_NOT_READY, "ddgi_probe_update before any probe rays were generated/uploaded");
+    HIP_TRY(hipSetDevice(e->device));
+    const int scene = e->settings.scene;
+    if (int rc = ensure_scene(e, scene)) return rc;
+
+    TraceArgs a{};
+    a.grid = make_grid(e);
+    a.scene = e->dev_scene[scene].k;
+    a.scene_id = scene;
+    a.max_bounces = e->settings.max_bounces;
+    a.nl = e->n_lights[scene];
+    for (int i = 0; i < a.nl; ++i) a.lights[i] = e->lights[scene][i];
+    a.rays = e->d_rays;
+    a.n_rays = e->n_local_rays;
+    a.albedo = static_cast<uint32_t*>(e->tex[0]);
+    a.distance = static_cast<uint32_t*>(e->tex[1]);
+    a.wait_threshold = e->wait_threshold;
+
+    const size_t lds = static_cast<size_t>(a.scene.nwords) * sizeof(uint32_t);
+    int per_cu = 0;
+    HIP_TRY(trace_kernel_occupancy(&per_cu, lds));
+    if (per_cu < 1) return fail(DDGI_ERR_UNSUPPORTED, "scene bitmap (%zu B) does not fit in LDS", lds);
+    const uint32_t chunks = (a.n_rays + kTraceBlock - 1) / kTraceBlock;
+    uint32_t grid = static_cast<uint32_t>(e->num_cus) * static_cast<uint32_t>(per_cu);
+    if (grid > chunks) grid = chunks;
+
+    HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+    HIP_TRY(launch_probe_trace_ref(a, static_cast<int>(grid), e->stream));
+    HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+    HIP_TRY(hipEventRecord(e->ev[2], e->stream));
+    e->timed = true;
+    return DDGI_OK;
+}
+
+int ddgi_synchronize(ddgi_handle e)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return DDGI_OK;
+}
+
+int ddgi_last_update_ms(ddgi_handle e, float* trace_ms, float* blend_ms, float* total_ms)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (!e->timed) return fail(DDGI_ERR_NOT_READY, "no probe update has been issued yet");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipEventSynchronize(e->ev[2]));
+    float t01 = 0.f, t12 = 0.f, t02 = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t01, e->ev[0], e->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&t12, e->ev[1], e->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&t02, e->ev[0], e->ev[2]));
+    if (trace_ms) *trace_ms = t01;
+    if (blend_ms) *blend_ms = e->mode == DDGI_MODE_REF ? 0.f : t12;
+    if (total_ms) *total_ms = t02;
+    return DDGI_OK;
+}
+
+int ddgi_read_textures(ddgi_handle e, uint8_t* albedo, uint8_t* distance)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (e->mode != DDGI_MODE_REF) return fail(DDGI_ERR_UNSUPPORTED, "ddgi_read_textures is REF-mode only; use ddgi_read_tiles");
+    HIP_TRY(hipSetDevice(e->device));
+    const GridK g = make_grid(e);
+    const size_t s = g.s, s2 = s * s;
+    const size_t W = static_cast<size_t>(g.cx) * g.cz * s;
+    std::vector<uint32_t> slab(e->tex_bytes[0] / 4);
+    uint8_t* outs[2] = {albedo, distance};
+    for (int t = 0; t < 2; ++t)
+    {
+        if (!outs[t]) continue;
+        HIP_TRY(hipMemcpyAsync(slab.data(), e->tex[t], e->tex_bytes[t], hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        uint32_t* raster = reinterpret_cast<uint32_t*>(outs[t]);
+        // slab-major [z][y][x][ty][tx] -> reference raster: tile of probe p at ((p mod cx*cz)*s, (p div cx*cz)*s)
+        for (int z = 0; z < g.cz; ++z)
+            for (int y = 0; y < g.cy; ++y)
+                for (int x = 0; x < g.cx; ++x)
+                {
+                    const uint32_t* tile = slab.data() + ((static_cast<size_t>(z) * g.cy + y) * g.cx + x) * s2;
+                    const size_t col0 = (static_cast<size_t>(z) * g.cx + x) * s;
+                    const size_t row0 = static_cast<size_t>(y) * s;
+                    for (size_t ty = 0; ty < s; ++ty)
+                        std::memcpy(raster + (row0 + ty) * W + col0, tile + ty * s, s * 4);
+                }
+    }
+    return DDGI_OK;
+}
+
+int ddgi_read_tiles(ddgi_handle e, float*, float*)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode is not available in this build");
+}
+
+int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, size_t n, float* d_rgb, int32_t* d_cage)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (n == 0) return DDGI_OK;
+    if (!d_pos || !d_nrm || !d_rgb) return fail(DDGI_ERR_INVALID_ARGUMENT, "null device pointer");
+    if (n > 0xffffffffull) return fail(DDGI_ERR_INVALID_ARGUMENT, "too many points");
+    HIP_TRY(hipSetDevice(e->device));
+    SampleArgs a{};
+    a.grid = make_grid(e);
+    a.albedo = static_cast<const uint32_t*>(e->tex[0]);
+    a.distance = static_cast<const uint32_t*>(e->tex[1]);
+    a.pos = d_pos;
+    a.nrm = d_nrm;
+    a.rgb = d_rgb;
+    a.cage = d_cage;
+    a.n = static_cast<uint32_t>(n);
+    HIP_TRY(launch_probe_sample_ref(a, e->stream));
+    return DDGI_OK;
+}
+
+int ddgi_sample(ddgi_handle e, const float* pos, const float* nrm, size_t n, float* rgb, int32_t* cage)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (n == 0) return DDGI_OK;
+    if (!pos || !nrm || !rgb) return fail(DDGI_ERR_INVALID_ARGUMENT, "null pointer");
+    HIP_TRY(hipSetDevice(e->device));
+    float *d_pos = nullptr, *d_nrm = nullptr, *d_rgb = nullptr;
+    int32_t* d_cage = nullptr;
+    int rc = DDGI_OK;
+    auto cleanup = [&] {
+        if (d_pos) (void)hipFree(d_pos);
+        if (d_nrm) (void)hipFree(d_nrm);
+        if (d_rgb) (void)hipFree(d_rgb);
+        if (d_cage) (void)hipFree(d_cage);
+    };
+#define TRY_OR_CLEAN(expr)                                                                     \
+    do                                                                                         \
+    {                                                                                          \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+        {                                                                                      \
+            cleanup();                                                                         \
+            return fail(e_ == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY : DDGI_ERR_HIP,     \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                        \
+        }                                                                                      \
+    } while (0)
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_pos), n * 12));
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_nrm), n * 12));
+    TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_rgb), n * 12));
+    if (cage) TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_cage), n * 32));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_pos, pos, n * 12, hipMemcpyHostToDevice, e->stream));
+    TRY_OR_CLEAN(hipMemcpyAsync(d_nrm, nrm, n * 12, hipMemcpyHostToDevice, e->stream));
+    rc = ddgi_sample_device(e, d_pos, d_nrm, n, d_rgb, d_cage);
+    if (rc)
+    {
+        cleanup();
+        return rc;
+    }
+    TRY_OR_CLEAN(hipMemcpyAsync(rgb, d_rgb, n * 12, hipMemcpyDeviceToHost, e->stream));
+    if (cage) TRY_OR_CLEAN(hipMemcpyAsync(cage, d_cage, n * 32, hipMemcpyDeviceToHost, e->stream));
+    TRY_OR_CLEAN(hipStreamSynchronize(e->stream));
+#undef TRY_OR_CLEAN
+    cleanup();
+    return DDGI_OK;
+}
+
+int ddgi_set_stream(ddgi_handle e, void* hip_stream)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->own_stream) (void)hipStreamDestroy(e->stream);
+    e->own_stream = false;
+    e->stream = static_cast<hipStream_t>(hip_stream);
+    return DDGI_OK;
+}
+
+int ddgi_device_textures(ddgi_handle e, void** tex0, size_t* tex0_bytes, void** tex1, size_t* tex1_bytes,
+                         size_t* slab_offset0, size_t* slab_bytes0, size_t* slab_offset1, size_t* slab_bytes1)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (tex0) *tex0 = e->tex[0];
+    if (tex1) *tex1 = e->tex[1];
+    if (tex0_bytes) *tex0_bytes = e->tex_bytes[0];
+    if (tex1_bytes) *tex1_bytes = e->tex_bytes[1];
+    const size_t sb0 = e->tex_bytes[0] / e->world, sb1 = e->tex_bytes[1] / e->world;
+    if (slab_offset0) *slab_offset0 = sb0 * e->rank;
+    if (slab_bytes0) *slab_bytes0 = sb0;
+    if (slab_offset1) *slab_offset1 = sb1 * e->rank;
+    if (slab_bytes1) *slab_bytes1 = sb1;
+    return DDGI_OK;
+}
+
+int ddgi_bind_textures(ddgi_handle e, void* tex0, void* tex1)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if ((tex0 == nullptr) != (tex1 == nullptr)) return fail(DDGI_ERR_INVALID_ARGUMENT, "bind both textures or neither");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->tex[0] = tex0 ? tex0 : e->own_tex[0];
+    e->tex[1] = tex1 ? tex1 : e->own_tex[1];
+    return DDGI_OK;
+}
+
+int ddgi_texture_size(const ddgi_irradiance_field* f, int* width, int* height)
+{
+    if (!f) return fail(DDGI_ERR_INVALID_ARGUMENT, "null field");
+    if (width) *width = f->probe_count[0] * f->probe_count[2] * f->sqrt_rays_per_probe;  // rvpt.cpp:873
+    if (height) *height = f->probe_count[1] * f->sqrt_rays_per_probe;                    // rvpt.cpp:874
+    return DDGI_OK;
+}
+
+int ddgi_probe_tile_origin(const ddgi_irradiance_field* f, int probe_index, int* x, int* y)
+{
+    if (!f) return fail(DDGI_ERR_INVALID_ARGUMENT, "null field");
+    const int w = f->probe_count[0] * f->probe_count[2];
+    if (w <= 0 || probe_index < 0 || probe_index >= w * f->probe_count[1])
+        return fail(DDGI_ERR_INVALID_ARGUMENT, "probe index %d out of range", probe_index);
+    const int yp = probe_index / w;  // probe_pass.comp:139-145
+    if (x) *x = (probe_index - yp * w) * f->sqrt_rays_per_probe;
+    if (y) *y = yp * f->sqrt_rays_per_probe;
+    return DDGI_OK;
+}
+
+int ddgi_generate_probe_rays_host(const ddgi_irradiance_field* f, uint32_t seed, int skip_calls, ddgi_probe_ray* rays, size_t n)
+{
+    if (!f || !rays) return fail(DDGI_ERR_INVALID_ARGUMENT, "null field/rays");
+    ddgi_render_settings st{};
+    if (int rc = validate_config(f, &st, 1)) return rc;
+    const size_t expect = static_cast<size_t>(f->probe_count[0]) * f->probe_count[1] * f->probe_count[2] *
+                          f->sqrt_rays_per_probe * f->sqrt_rays_per_probe;
+    if (n != expect) return fail(DDGI_ERR_INVALID_ARGUMENT, "expected room for %zu rays, got %zu", expect, n);
+    GlibcRand rng;
+    rng.seed(seed);
+    // each generate_probe_rays() call draws 2*s*s values (rvpt.cpp:1161-1162)
+    for (long long i = 0; i < 2ll * skip_calls * f->sqrt_rays_per_probe * f->sqrt_rays_per_probe; ++i) (void)rng.next();
+    std::vector<ddgi_probe_ray> tmp;
+    generate_probe_rays(*f, rng, tmp);
+    std::memcpy(rays, tmp.data(), tmp.size() * sizeof(ddgi_probe_ray));
+    return DDGI_OK;
+}
+
+int ddgi_scene_block_at(int scene, int x, int y, int z)
+{
+    if (scene < 0 || scene > 2) return 0;
+    return baked_scene(scene).block_at(x, y, z);
+}
+
+float ddgi_pinned_sinf(float x) { return pm::sinf_pinned(x); }
+float ddgi_pinned_cosf(float x) { return pm::cosf_pinned(x); }
+float ddgi_pinned_acosf(float x) { return pm::acosf_pinned(x); }
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+// ddgi_host.cpp — host half of the probe path: scene bake and probe-ray generation.
+// (compiled as HIP only so that it can share ddgi_scene.h with the device code; no kernels here)
+#include "ddgi_host.h"
+
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "ddgi_scene.h"
+
+namespace ddgi {
+
+// ---- scene bake -----------------------------------------------------------------------------------
+//
+// The reference evaluates getBlockAt (intersection.glsl:699-826: SDF spheres, 8-octave fbm, if-chains)
+// at EVERY voxel step of EVERY ray.  The engine evaluates it once per voxel on the host and the
+// kernels traverse the result.  The bake covers an inclusive voxel-id box chosen per scene such
+// that the world outside is exactly the axis-wise extrusion of the box's outermost layer, so a
+// clamped lookup reproduces the procedural function for every voxel a ray can visit:
+//   cave    hollow = union of 4 spheres, cut by y > 17 (empty above) and the fbm floor (solid
+//           for y <= -21): box x[-42,32] y[-21,18] z[-38,31]; sides/bottom layers solid (for
+//           y <= 17), top layer empty.
+//   Cornell walls at |x|,|y| = 10, z = 25, open front: box x,y[-11,11] z[4,26]; all layers empty.
+//   house   walls |x| = 25, |z| = 15, roof y = 5, unbounded floor plane y = -5:
+//           box x[-26,26] y[-6,6] z[-16,16]; the floor row of each side layer extrudes to the plane.
+// tests/test_scene_bake.py checks the clamped lookup against the oracle's procedural getBlockAt on
+// a box far larger than the bake.
+
+static void scene_box(int scene, int lo[3], int hi[3])
+{
+    static const int boxes[3][6] = {
+        {-42, -21, -38, 32, 18, 31},
+        {-11, -11, 4, 11, 11, 26},
+        {-26, -6, -16, 26, 6, 16},
+    };
+    for (int a = 0; a < 3; ++a)
+    {
+        lo[a] = boxes[scene][a];
+        hi[a] = boxes[scene][3 + a];
+    }
+}
+
+static SceneBake bake_scene(int scene)
+{
+    SceneBake b;
+    b.scene = scene;
+    scene_box(scene, b.lo, b.hi);
+    for (int a = 0; a < 3; ++a) b.dim[a] = b.hi[a] - b.lo[a] + 1;
+    const size_t n = static_cast<size_t>(b.dim[0]) * b.dim[1] * b.dim[2];
+    b.types.assign(n, 0);
+    b.bits.assign((n + 31) / 32, 0u);
+    size_t i = 0;
+    for (int z = b.lo[2]; z <= b.hi[2]; ++z)
+        for (int y = b.lo[1]; y <= b.hi[1]; ++y)
+            for (int x = b.lo[0]; x <= b.hi[0]; ++x, ++i)
+            {
+                const int t = block_at(mk3(static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)), scene);
+                b.types[i] = static_cast<uint8_t>(t);
+                if (t > 0) b.bits[i >> 5] |= (1u << (i & 31));
+            }
+    // which border layers are entirely empty (march_escaped in the trace kernel)
+    unsigned fe = 0;
+    for (int axis = 0; axis < 3; ++axis)
+        for (int side = 0; side < 2; ++side)
+        {
+            bool empty = true;
+            int c[3];
+            const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+            c[axis] = side ? b.hi[axis] : b.lo[axis];
+            for (c[a1] = b.lo[a1]; c[a1] <= b.hi[a1] && empty; ++c[a1])
+                for (c[a2] = b.lo[a2]; c[a2] <= b.hi[a2]; ++c[a2])
+                    if (b.block_at(c[0], c[1], c[2]) > 0)
+                    {
+                        empty = false;
+                        break;
+                    }
+            if (empty) fe |= 1u << (2 * axis + side);
+        }
+    b.face_empty = fe;
+    return b;
+}
+
+int SceneBake::block_at(int x, int y, int z) const
+{
+    x = x < lo[0] ? lo[0] : (x > hi[0] ? hi[0] : x);
+    y = y < lo[1] ? lo[1] : (y > hi[1] ? hi[1] : y);
+    z = z < lo[2] ? lo[2] : (z > hi[2] ? hi[2] : z);
+    const size_t i = (static_cast<size_t>(z - lo[2]) * dim[1] + (y - lo[1])) * dim[0] + (x - lo[0]);
+    return types[i];
+}
+
+const SceneBake& baked_scene(int scene)
+{
+    static std::array<SceneBake, 3> cache;
+    static std::array<std::once_flag, 3> once;
+    std::call_once(once[scene], [scene] { cache[scene] = bake_scene(scene); });
+    return cache[scene];
+}
+
+// ---- glibc rand() ---------------------------------------------------------------------------------
+// random_r TYPE_3 as published in glibc stdlib/random_r.c: 31-word additive feedback generator
+// x[n] = x[n-31] + x[n-3]; state seeded by the Lehmer LCG 16807 (Schrage's method), the first 310
+// outputs discarded, each result shifted right by one.
+
+void GlibcRand::seed(uint32_t s)
+{
+    if (s == 0) s = 1;
+    int32_t word = static_cast<int32_t>(s);
+    ring[0] = static_cast<uint32_t>(word);
+    for (int i = 1; i < 31; ++i)
+    {
+        const int32_t hi = word / 127773;
+        const int32_t lo = word % 127773;
+        word = 16807 * lo - 2836 * hi;
+        if (word < 0) word += 2147483647;
+        ring[i] = static_cast<uint32_t>(word);
+    }
+    step = 0;
+    for (int i = 0; i < 310; ++i) (void)next();
+}
+
+int32_t GlibcRand::next()
+{
+    const uint32_t f = (step + 3u) % 31u, r = step % 31u;
+    ring[f] += ring[r];
+    step += 1;
+    return static_cast<int32_t>(ring[f] >> 1);
+}
+
+// ---- probe rays -------------------------------------------------------------------------------------
+
+void generate_probe_rays(const ddgi_irradiance_field& f, GlibcRand& rng, std::vector<ddgi_probe_ray>& out)
+{
+    const int cx = f.probe_count[0], cy = f.probe_count[1], cz = f.probe_count[2];
+    const int s = f.sqrt_rays_per_probe;
+    const int n = s * s;
+    const size_t probes = static_cast<size_t>(cx) * cy * cz;
+
+    // generate_samples (rvpt.cpp:1147-1173): stratified jitter on [0,1)^2 warped to the unit sphere.
+    // The reference's host PI is 3.1415926 (rvpt.cpp:1145) and the angle product is formed in
+    // double before cosf/sinf narrow it.  Jitter draw order is g++'s: y first, then x (Q1).
+    std::vector<f3> dirs(static_cast<size_t>(n));
+    const float inv_s = 1.f / static_cast<float>(s);
+    const float rand_max = static_cast<float>(2147483647);
+    for (int y = 0, i = 0; y < s; ++y)
+        for (int x = 0; x < s; ++x, ++i)
+        {
+            const float jy = static_cast<float>(rng.next()) / rand_max;
+            const float jx = static_cast<float>(rng.next()) / rand_max;
+            const float u = (static_cast<float>(x) + jx) * inv_s;
+            const float v = (static_cast<float>(y) + jy) * inv_s;
+            const float z = 1 - (2 * u);
+            const float phi = static_cast<float>(2.0 * 3.1415926 * static_cast<double>(v));
+            const float rxy = sqrtf(1 - (z * z));
+            const pm::SinCos sc = pm::sincos_core(phi);
+            // glm::normalize = v * inversesqrt(dot(v,v))  (rvpt.cpp:1212)
+            dirs[i] = normalize3(f3{static_cast<float>(sc.c) * rxy, static_cast<float>(sc.s) * rxy, z});
+        }
+
+    out.resize(probes * static_cast<size_t>(n));
+    ddgi_probe_ray* dst = out.data();
+    for (size_t p = 0; p < probes; ++p)
+    {
+        const int pi = static_cast<int>(p);
+        const int py = pi / (cx * cz);
+        const int rem = pi - py * cx * cz;
+        const int pz = rem / cx;
+        const int px = rem - pz * cx;
+        // Q4: integer (dim-1)/2, then * side_length (int -> float), then + origin (rvpt.cpp:1199-1205)
+        float org[3] = {static_cast<float>(px - (cx - 1) / 2), static_cast<float>(py - (cy - 1) / 2),
+                        static_cast<float>(pz - (cz - 1) / 2)};
+        for (int a = 0; a < 3; ++a) org[a] = org[a] * static_cast<float>(f.side_length) + f.field_origin[a];
+        for (int i = 0; i < n; ++i, ++dst)
+        {
+            std::memset(dst, 0, sizeof(*dst));
+            dst->origin[0] = org[0], dst->origin[1] = org[1], dst->origin[2] = org[2];
+            dst->direction[0] = dirs[i].x, dst->direction[1] = dirs[i].y, dst->direction[2] = dirs[i].z;
+            dst->probe_info[0] = static_cast<float>(pi);
+            dst->probe_info[1] = static_cast<float>(i % s);
+            dst->probe_info[2] = static_cast<float>(i / s);
+        }
+    }
+}
+
+void shipped_lights(int scene, LightK* out, int* n)
+{
+    static const LightK cave[] = {{100.f, {1.f, 1.f, 1.f}, {4.f, 17.5f, 8.5f}}};
+    static const LightK cornell[] = {{15.f, {1.f, 1.f, 1.f}, {0.f, 8.f, 13.f}}};
+    static const LightK house[] = {{1.f, {1.f, 1.f, 1.f}, {5.f, 9.3f, 36.5f}}, {1.f, {1.f, 1.f, 1.f}, {0.f, 0.f, 0.f}}};
+    const LightK* src = nullptr;
+    int cnt = 0;
+    if (scene == 0) src = cave, cnt = 1;
+    else if (scene == 1) src = cornell, cnt = 1;
+    else if (scene == 2) src = house, cnt = 2;
+    for (int i = 0; i < cnt; ++i) out[i] = src[i];
+    *n = cnt;
+}
+
+}  // namespace ddgi

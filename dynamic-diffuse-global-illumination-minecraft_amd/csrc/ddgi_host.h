@@ -1,0 +1,43 @@
+// ddgi_host.h — host-side pieces of the probe path: scene bake, probe-ray generation.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "ddgi_types.h"
+
+namespace ddgi {
+
+// Baked voxel scene (host copy).  See ddgi_host.cpp: bake_scene().
+struct SceneBake
+{
+    int scene = -1;
+    int lo[3] = {0, 0, 0};
+    int hi[3] = {0, 0, 0};
+    int dim[3] = {0, 0, 0};
+    unsigned face_empty = 0;
+    std::vector<uint32_t> bits;  // 1 bit / voxel, linear index (z*ny + y)*nx + x
+    std::vector<uint8_t> types;  // block type 0..13 / voxel
+    int block_at(int x, int y, int z) const;  // clamped lookup = the world the kernels see
+};
+
+const SceneBake& baked_scene(int scene);  // cached, thread-safe; scene in {0,1,2}
+
+// glibc rand() (random_r TYPE_3) restated: the reference draws its ray jitter from the unseeded C
+// library generator (src/rvpt/rvpt.cpp:1161-1162).
+struct GlibcRand
+{
+    uint32_t ring[31];
+    uint32_t step = 0;
+    void seed(uint32_t s);
+    int32_t next();
+};
+
+// generate_samples + RVPT::generate_probe_rays (src/rvpt/rvpt.cpp:1147-1224): full-grid array in
+// the reference's order (probe-major p = py*cx*cz + pz*cx + px, ray i = y*s + x).
+void generate_probe_rays(const ddgi_irradiance_field& f, GlibcRand& rng, std::vector<ddgi_probe_ray>& out);
+
+// Default light tables (assets/shaders/structs.glsl:61-89, the shipped ones).
+void shipped_lights(int scene, LightK* out, int* n);
+
+}  // namespace ddgi

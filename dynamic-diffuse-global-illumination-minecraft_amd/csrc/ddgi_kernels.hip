@@ -1,0 +1,533 @@
+// ddgi_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the DDGI probe path.
+//
+//   k_probe_trace_ref   REF mode probe update: one lane = one probe ray, multi-bounce direct light,
+//                       one rgba8 texel per ray.  Replaces assets/shaders/probe_pass.comp:main
+//                       (253-303) and everything it calls in intersection.glsl.
+//   k_probe_sample_ref  REF mode 8-probe-cage sampler.  Replaces get_diffuse_gi / sample_probe
+//                       (intersection.glsl:1176-1240, 1306-1409).
+//
+// All arithmetic is the engine's pinned binary32 arithmetic (DESIGN.md "Arithmetic pinning");
+// this file is compiled with -ffp-contract=off so that only the fmaf() written in the source fuse.
+#include <hip/hip_runtime.h>
+
+#include "ddgi_scene.h"
+#include "ddgi_types.h"
+
+namespace ddgi {
+
+#define DDGI_D __device__ __forceinline__
+
+// ---- per-ray RNG: wang_hash seed + xorshift32 (probe_pass.comp:45-71) -------------------------
+
+DDGI_D uint32_t wang_hash(uint32_t seed)
+{
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed *= 9u;
+    seed = seed ^ (seed >> 4);
+    seed *= 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+
+DDGI_D float rng_next(uint32_t& s)
+{
+    s ^= (s << 13);
+    s ^= (s >> 17);
+    s ^= (s << 5);
+    return static_cast<float>(s) * 0x1.0p-32f;  // uint -> float (RNE), exact scale by 2^-32
+}
+
+// ---- one voxel march + the light spheres of intersect_scene, as resumable per-lane state ------
+
+struct March
+{
+    f3 ro;   // ray origin
+    f3 rd;   // ray direction exactly as given (bounce rays are not unit length)
+    f3 dn;   // normalize(rd): the direction grid_march steps along (intersection.glsl:1055)
+    f3 inv;  // 1/dn per axis (+inf where dn == 0)                                  [P5]
+    f3 cc;   // 1 where dn >= 0 else 0: boundary distance = (cc - fract(p)) * inv   [P5]
+    f3 p;    // current march position
+    float t;   // curr_t
+    float tl;  // nearest light-sphere hit along (ro, rd), +inf if none (intersection.glsl:1264-1279)
+    int it;    // march iterations done
+    int lid;   // which light gave tl
+};
+
+DDGI_D float axis_inv(float d) { return d == 0.0f ? __builtin_inff() : 1.0f / d; }
+
+DDGI_D void start_march(March& m, f3 o, f3 d, const TraceArgs& A)
+{
+    m.ro = o;
+    m.rd = d;
+    m.dn = normalize3(d);
+    m.inv = f3{axis_inv(m.dn.x), axis_inv(m.dn.y), axis_inv(m.dn.z)};
+    m.cc = f3{m.dn.x >= 0.0f ? 1.0f : 0.0f, m.dn.y >= 0.0f ? 1.0f : 0.0f, m.dn.z >= 0.0f ? 1.0f : 0.0f};
+    m.p = o;
+    m.t = 0.0f;
+    m.it = 0;
+    // light spheres of radius 0.1: unit-sphere quadratic in a space scaled by 10 (x/0.1 := x*10)
+    float closest = __builtin_inff();
+    int lid = -1;
+    for (int i = 0; i < A.nl; ++i)
+    {
+        const f3 lp{A.lights[i].pos[0], A.lights[i].pos[1], A.lights[i].pos[2]};
+        const f3 so = (o - lp) * 10.0f;
+        const f3 sd = d * 10.0f;
+        const float qa = dot3(sd, sd);
+        const float qb = -dot3(sd, so);
+        const float qc = dot3(so, so) - 1.0f;
+        float disc = qb * qb - qa * qc;
+        disc = disc > 0.0f ? sqrtf(disc) : __builtin_inff();
+        const float inv_a = 1.0f / qa;
+        float t1 = (qb - disc) * inv_a;
+        float t2 = (qb + disc) * inv_a;
+        t1 = (0.0f < t1 && t1 < closest) ? t1 : __builtin_inff();
+        t2 = (0.0f < t2 && t2 < closest) ? t2 : __builtin_inff();
+        const float ts = gl_min(t1, t2);
+        if (ts < closest) lid = i;
+        closest = gl_min(ts, closest);
+    }
+    m.tl = closest;
+    m.lid = lid;
+}
+
+// Linear cell index of voxel id (x,y,z) clamped into the baked box.  Outside the box the world is
+// the extrusion of the border layer (ddgi_scene_bake.cpp), so clamping is exact.
+DDGI_D int cell_index(const SceneK& S, int x, int y, int z)
+{
+    x = min(max(x, S.lo[0]), S.hi[0]);
+    y = min(max(y, S.lo[1]), S.hi[1]);
+    z = min(max(z, S.lo[2]), S.hi[2]);
+    return z * S.nxy + y * S.nx + x - S.bias;
+}
+
+// One grid_march iteration (intersection.glsl:1059-1069).  Returns true if the voxel reached is
+// occupied.
+DDGI_D bool march_step(March& m, const SceneK& S, const uint32_t* __restrict__ s_bits)
+{
+    const float fx = gl_fract(m.p.x), fy = gl_fract(m.p.y), fz = gl_fract(m.p.z);
+    const float tx = (m.cc.x - fx) * m.inv.x;
+    const float ty = (m.cc.y - fy) * m.inv.y;
+    const float tz = (m.cc.z - fz) * m.inv.z;
+    const float step = fminf(fminf(tx, ty), tz) + 0.0001f;
+    m.t += step;
+    m.p = ray_at(m.ro, m.dn, m.t);
+    const int idx = cell_index(S, static_cast<int>(ceilf(m.p.x)), static_cast<int>(ceilf(m.p.y)),
+                               static_cast<int>(ceilf(m.p.z)));
+    m.it += 1;
+    return (s_bits[idx >> 5] >> (idx & 31)) & 1u;
+}
+
+// True when the march can no longer hit a block: the position is outside the baked box on some
+// axis, moving away from it, and the border layer it left through is entirely empty (so the whole
+// half space beyond is empty).  Skipping the remaining iterations does not change any result.
+DDGI_D bool march_escaped(const March& m, const SceneK& S)
+{
+    const int x = static_cast<int>(ceilf(m.p.x)), y = static_cast<int>(ceilf(m.p.y)), z = static_cast<int>(ceilf(m.p.z));
+    const unsigned fe = S.face_empty;
+    bool out = false;
+    out |= (x < S.lo[0]) && (m.dn.x <= 0.0f) && (fe & 1u);
+    out |= (x > S.hi[0]) && (m.dn.x >= 0.0f) && (fe & 2u);
+    out |= (y < S.lo[1]) && (m.dn.y <= 0.0f) && (fe & 4u);
+    out |= (y > S.hi[1]) && (m.dn.y >= 0.0f) && (fe & 8u);
+    out |= (z < S.lo[2]) && (m.dn.z <= 0.0f) && (fe & 16u);
+    out |= (z > S.hi[2]) && (m.dn.z >= 0.0f) && (fe & 32u);
+    return out;
+}
+
+// calculate_random_dir_hemisphere (probe_pass.comp:147-178)
+DDGI_D f3 hemisphere_dir(f3 n, uint32_t& rng)
+{
+    const float kTwoPi = 6.2831853071795864769252867665590057683943f;
+    const float kSqrtThird = 0.5773502691896257645091487805019574556476f;
+    const float up = sqrtf(rng_next(rng));
+    const float over = sqrtf(1.0f - up * up);
+    const float around = rng_next(rng) * kTwoPi;
+    f3 other;
+    if (fabsf(n.x) < kSqrtThird) other = mk3(1, 0, 0);
+    else if (fabsf(n.y) < kSqrtThird) other = mk3(0, 1, 0);
+    else other = mk3(0, 0, 1);
+    const f3 p1 = normalize3(cross3(n, other));
+    const f3 p2 = normalize3(cross3(n, p1));
+    const pm::SinCos sc = pm::sincos_core(around);
+    const float ca = static_cast<float>(sc.c) * over;
+    const float sa = static_cast<float>(sc.s) * over;
+    return (n * up + p1 * ca) + p2 * sa;
+}
+
+// rgba8 UNORM pack: clamp to [0,1], *255, round to nearest even; NaN -> 0
+DDGI_D uint32_t unorm8(float x)
+{
+    if (!(x > 0.0f)) return 0u;
+    x = x > 1.0f ? 1.0f : x;
+    return static_cast<uint32_t>(rintf(x * 255.0f));
+}
+
+// Slab-major probe slot of reference probe index p = y*cx*cz + z*cx + x  ->  (z*cy + y)*cx + x
+DDGI_D int slab_slot(const GridK& G, int p)
+{
+    const int cxz = G.cx * G.cz;
+    const int y = p / cxz;
+    const int rem = p - y * cxz;
+    const int z = rem / G.cx;
+    const int x = rem - z * G.cx;
+    return (z * G.cy + y) * G.cx + x;
+}
+
+enum : int
+{
+    kPrimary = 0,
+    kFeeler = 1
+};
+
+// ------------------------------------------------------------------------------------------------
+// k_probe_trace_ref
+//
+// Mapping: persistent workgroups of 256 lanes; each takes chunks of 256 consecutive local rays
+// (for s = 16 one chunk = one probe).  The occupancy bitmap of the baked scene is staged into LDS
+// once per workgroup; block types are fetched from global memory (L2) only on a hit.
+//
+// Control flow: every lane runs a small state machine {primary march, feeler march} over ONE
+// shared march loop, so lanes in different bounces / light feelers of their paths still execute
+// the same march_step instructions.  A lane whose march ended parks ("waiting") until
+// A.wait_threshold lanes of the wave are parked or none is marching; then all parked lanes resolve
+// their hit (shading, next ray) together.  Results do not depend on this scheduling.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_bits[];
+    for (int i = threadIdx.x; i < A.scene.nwords; i += kTraceBlock) s_bits[i] = A.scene.bits[i];
+    __syncthreads();
+
+    const GridK& G = A.grid;
+    const int rays_per_probe = G.s * G.s;
+    const uint32_t n_chunks = (A.n_rays + kTraceBlock - 1) / kTraceBlock;
+    const float inf = __builtin_inff();
+
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
+    {
+        const uint32_t r = chunk * kTraceBlock + threadIdx.x;  // local ray index
+        const bool in_range = r < A.n_rays;
+
+        // local (y, zl, x) probe enumeration -> reference probe index p -> global ray index
+        uint32_t global_ray = 0;
+        f3 o = mk3(0, 0, 0), d = mk3(1, 0, 0);
+        int dst_probe = 0, tile_x = 0, tile_y = 0;
+        if (in_range)
+        {
+            const int pl = static_cast<int>(r / static_cast<uint32_t>(rays_per_probe));
+            const int i = static_cast<int>(r) - pl * rays_per_probe;
+            const int slab_row = G.czl * G.cx;
+            const int y = pl / slab_row;
+            const int rem = pl - y * slab_row;
+            const int p = y * G.cx * G.cz + G.z0 * G.cx + rem;
+            global_ray = static_cast<uint32_t>(p) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i);
+            const float4* rec = A.rays + 3 * static_cast<size_t>(r);
+            const float4 a = rec[0], b = rec[1], c = rec[2];
+            o = mk3(a.x, a.y, a.z);
+            d = mk3(b.x, b.y, b.z);
+            dst_probe = static_cast<int>(c.x);  // int(probe_info.x), probe_pass.comp:269
+            tile_x = static_cast<int>(c.y);
+            tile_y = static_cast<int>(c.z);
+        }
+
+        uint32_t rng = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
+        f3 color = mk3(0, 0, 0);
+        int bounce = 0;
+        int phase = kPrimary;
+        f3 hpos = mk3(0, 0, 0), hnrm = mk3(0, 0, 0), hcol = mk3(0, 0, 0), direct = mk3(0, 0, 0);
+        int li = 0, nvis = 0;
+
+        March m;
+        bool marching = in_range && A.max_bounces > 0;
+        bool waiting = false;
+        bool hit_block = false;
+        if (marching) start_march(m, o, d, A);
+        else
+        {
+            m.ro = m.rd = m.dn = m.inv = m.cc = m.p = mk3(0, 0, 0);
+            m.t = 0.0f, m.tl = inf, m.it = 0, m.lid = -1;
+        }
+
+        for (;;)
+        {
+            // ---- shared march loop ----
+            int trips = 0;
+            for (;;)
+            {
+                const unsigned long long mb = __ballot(marching);
+                if (mb == 0ull) break;
+                if (__popcll(__ballot(waiting)) >= A.wait_threshold) break;
+                if (marching)
+                {
+                    const bool occ = march_step(m, A.scene, s_bits);
+                    bool fin = occ | (m.t >= m.tl) | (m.it >= kMarchIters);
+                    if (!fin && ((trips & 7) == 7)) fin = march_escaped(m, A.scene);
+                    if (fin)
+                    {
+                        hit_block = occ;
+                        marching = false;
+                        waiting = true;
+                    }
+                }
+                ++trips;
+            }
+            if (__ballot(waiting) == 0ull) break;  // nobody marching, nobody waiting: chunk done
+
+            // ---- resolve finished marches (intersect_scene's tail + caller) ----
+            if (waiting)
+            {
+                waiting = false;
+                const bool block_wins = hit_block && (m.t < m.tl);   // temp_isect.t < closest_t
+                const bool any_hit = block_wins || (m.tl < inf);    // closest_t < INF
+                bool lighting_done = false;
+                f3 contribution = mk3(0, 0, 0);
+
+                if (phase == kPrimary)
+                {
+                    if (!any_hit)
+                    {
+                        bounce = A.max_bounces;  // probe_pass.comp:288-290 break
+                    }
+                    else
+                    {
+                        f3 nraw;
+                        float th;
+                        if (block_wins)
+                        {
+                            th = m.t;
+                            const f3 cell = cell_id(m.p);
+                            const f3 centre = f3{cell.x - 0.5f, cell.y - 0.5f, cell.z - 0.5f};
+                            const f3 diff = normalize3(m.p - centre);
+                            // axis of the largest |component|, first wins on ties (:1075-1086)
+                            f3 n = mk3(0, 0, 0);
+                            float best = 0.0f;
+                            if (fabsf(diff.x) > best) { best = fabsf(diff.x); n = mk3(gl_sign(diff.x), 0, 0); }
+                            if (fabsf(diff.y) > best) { best = fabsf(diff.y); n = mk3(0, gl_sign(diff.y), 0); }
+                            if (fabsf(diff.z) > best) { best = fabsf(diff.z); n = mk3(0, 0, gl_sign(diff.z)); }
+                            const f3 nn = normalize3(n);
+                            const int idx = cell_index(A.scene, static_cast<int>(cell.x), static_cast<int>(cell.y), static_cast<int>(cell.z));
+                            const int type = A.scene.types[idx];
+                            hcol = block_albedo(m.p, type, nn);
+                            nraw = nn;
+                        }
+                        else
+                        {
+                            th = m.tl;
+                            const LightK& L = A.lights[m.lid];
+                            const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
+                            nraw = ray_at((m.ro - lp) * 10.0f, m.rd * 10.0f, th);  // sphere-space position
+                            hcol = mk3(0, 0, 0);  // Q12: unassigned Material, pinned to zero
+                        }
+                        hnrm = normalize3(nraw);
+                        hpos = ray_at(m.ro, m.rd, th) + hnrm * 0.001f;
+                        li = 0;
+                        nvis = 0;
+                        direct = mk3(0, 0, 0);
+                        if (A.nl > 0)
+                        {
+                            phase = kFeeler;
+                            const LightK& L = A.lights[0];
+                            start_march(m, hpos, normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos), A);
+                            marching = true;
+                        }
+                        else
+                            lighting_done = true;
+                    }
+                }
+                else  // kFeeler: get_direct_lighting's loop body (probe_pass.comp:186-207)
+                {
+                    const LightK& L = A.lights[li];
+                    const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
+                    bool early = false;
+                    if (any_hit)
+                    {
+                        const float lambert = gl_clamp(dot3(normalize3(hnrm), normalize3(lp - hpos)), 0.0f, 1.0f);
+                        if (!block_wins)
+                        {
+                            const float dist = length3(lp - hpos);
+                            const f3 lc{L.col[0], L.col[1], L.col[2]};
+                            direct = direct + div3((lc * lambert) * L.intensity, dist);
+                            nvis += 1;
+                        }
+                        else
+                        {
+                            contribution = (hcol * 0.2f) * lambert;  // Q10 early return
+                            early = true;
+                        }
+                    }
+                    li += 1;
+                    if (early) lighting_done = true;
+                    else if (li < A.nl)
+                    {
+                        const LightK& Ln = A.lights[li];
+                        start_march(m, hpos, normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos), A);
+                        marching = true;
+                    }
+                    else
+                    {
+                        if (nvis != 0) contribution = div3(hcol * direct, static_cast<float>(nvis));
+                        lighting_done = true;
+                    }
+                }
+
+                if (lighting_done)
+                {
+                    color = color + contribution;
+                    bounce += 1;
+                    if (bounce < A.max_bounces)
+                    {
+                        phase = kPrimary;
+                        const f3 no = hpos + hnrm * 0.0001f;
+                        const f3 nd = hemisphere_dir(hnrm, rng);
+                        start_march(m, no, nd, A);
+                        marching = true;
+                    }
+                }
+            }
+        }
+
+        if (in_range)
+        {
+            const f3 c = div3(color, static_cast<float>(A.max_bounces));  // Q14: always /max_bounces
+            const uint32_t texel = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
+            const size_t dst = static_cast<size_t>(slab_slot(G, dst_probe)) * rays_per_probe + tile_y * G.s + tile_x;
+            A.albedo[dst] = texel;
+            A.distance[dst] = 0u;  // `distances` is never assigned (probe_pass.comp:276,302)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_probe_sample_ref — one lane per shading point
+// ------------------------------------------------------------------------------------------------
+
+DDGI_D f3 load_rgb(const uint32_t* tex, size_t i)
+{
+    const uint32_t v = tex[i];
+    return f3{static_cast<float>(v & 255u) / 255.0f, static_cast<float>((v >> 8) & 255u) / 255.0f,
+              static_cast<float>((v >> 16) & 255u) / 255.0f};
+}
+
+// sample_probe (intersection.glsl:1176-1240) against the slab-major texel buffer
+DDGI_D f3 sample_probe_ref(const GridK& G, const uint32_t* albedo, const uint32_t* tex, int probe, f3 dir)
+{
+    const int cxz = G.cx * G.cz;
+    // get_text_coord_from_probe_number (:1152-1174): out of range -> magenta
+    if (probe >= cxz * G.cy || probe < 0) return mk3(1, 0, 1);
+    const int s = G.s;
+    const f3 id = normalize3(dir);
+    int rx = gl_int(((-1.0f * (id.z - 1.0f)) / 2.0f) * static_cast<float>(s));
+    if (rx == s) rx = 0;
+    const float sqrt_z = sqrtf(1.0f - (id.z * id.z));
+    const float kPi = 3.1415926535897932384626433832795f;
+    const int ry = gl_int((pm::acosf_pinned(id.x / sqrt_z) / (2.0f * kPi)) * static_cast<float>(s));
+    const size_t base = static_cast<size_t>(slab_slot(G, probe)) * s * s;
+    f3 result = load_rgb(albedo, base + ry * s + rx);
+    int count = 0;
+    for (int dx = -2; dx <= 2; ++dx)
+    {
+        const int x = rx + dx;
+        if (x < 0 || x >= s) continue;
+        for (int dy = -2; dy <= 2; ++dy)
+        {
+            const int y = ry + dy;
+            if (y < 0 || y >= s) continue;
+            count += 1;
+            result = result + load_rgb(tex, base + y * s + x);
+        }
+    }
+    return div3(result, static_cast<float>(count));
+}
+
+__global__ __launch_bounds__(256) void k_probe_sample_ref(const SampleArgs A)
+{
+    const GridK& G = A.grid;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const f3 pos{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]};
+    const f3 N = normalize3(f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]});
+    const f3 origin{G.origin[0], G.origin[1], G.origin[2]};
+    const float side = static_cast<float>(G.side);
+
+    int cage[8];
+    for (int k = 0; k < 8; ++k) cage[k] = -1;
+    f3 out = mk3(1, 0, 1);
+    bool ok = true;
+
+    const f3 rel = div3(pos - origin, side);
+    const int bx = gl_int(floorf(rel.x)), by = gl_int(floorf(rel.y)), bz = gl_int(floorf(rel.z));
+    // Q6: every axis is bounds-checked against probe_count.x
+    const int lo = gl_int(-floorf(static_cast<float>(G.cx) / 2.0f));
+    const int hi = gl_int(floorf(static_cast<float>(G.cx) / 2.0f) - 1.0f);
+    if (bx < lo || bx > hi || by < lo || by > hi || bz < lo || bz > hi) ok = false;
+
+    if (ok)
+    {
+        const f3 base_world = f3{static_cast<float>(bx * G.side), static_cast<float>(by * G.side), static_cast<float>(bz * G.side)} + origin;
+        const f3 a = div3(pos - base_world, side);
+        const f3 alpha{gl_clamp(a.x, 0.0f, 1.0f), gl_clamp(a.y, 0.0f, 1.0f), gl_clamp(a.z, 0.0f, 1.0f)};
+        f3 irradiance = mk3(0, 0, 0);
+        float sum_weight = 0.0f;
+        const int n_probes = G.cx * G.cy * G.cz;
+        for (int k = 0; k < 8 && ok; ++k)
+        {
+            const int ox = (k >> 2) & 1, oy = (k >> 1) & 1, oz = k & 1;  // Q7 corner order
+            const int sx = bx + ox + G.cx / 2, sy = by + oy + G.cy / 2, sz = bz + oz + G.cz / 2;  // Q4
+            const int idx = sy * G.cx * G.cz + sz * G.cx + sx;
+            if (idx < 0 || idx >= n_probes)
+            {
+                ok = false;
+                break;
+            }
+            cage[k] = idx;
+            const f3 tri{ox ? alpha.x : 1.0f - alpha.x, oy ? alpha.y : 1.0f - alpha.y, oz ? alpha.z : 1.0f - alpha.z};
+            const f3 probe_pos = base_world + f3{static_cast<float>(ox * G.side), static_cast<float>(oy * G.side), static_cast<float>(oz * G.side)};
+            const f3 dir = normalize3(probe_pos - pos);
+            const float tmp = gl_max(0.0001f, (dot3(dir, N) + 1.0f) * 0.5f);
+            float weight = tmp * tmp + 0.2f;
+            weight = gl_max(0.000001f, weight);
+            const float crush = 0.2f;
+            if (weight < crush) weight *= weight * weight * (1.f / (crush * crush));  // unreachable (Q11)
+            weight *= tri.x * tri.y * tri.z;
+            const f3 smp = sample_probe_ref(G, A.albedo, A.albedo, idx, N);
+            irradiance = irradiance + smp * weight;
+            sum_weight += weight;
+        }
+        if (ok) out = div3(irradiance, sum_weight);
+    }
+    if (!ok)
+    {
+        out = mk3(1, 0, 1);
+        for (int k = 0; k < 8; ++k) cage[k] = -1;
+    }
+    A.rgb[3 * i] = out.x;
+    A.rgb[3 * i + 1] = out.y;
+    A.rgb[3 * i + 2] = out.z;
+    if (A.cage)
+        for (int k = 0; k < 8; ++k) A.cage[8 * i + k] = cage[k];
+}
+
+// ---- launchers (called from ddgi_engine.cpp) -----------------------------------------------------
+
+hipError_t launch_probe_trace_ref(const TraceArgs& args, int grid_blocks, hipStream_t stream)
+{
+    const size_t lds = static_cast<size_t>(args.scene.nwords) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_probe_trace_ref, dim3(grid_blocks), dim3(kTraceBlock), lds, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t launch_probe_sample_ref(const SampleArgs& args, hipStream_t stream)
+{
+    const unsigned blocks = (args.n + 255u) / 256u;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_probe_sample_ref, dim3(blocks), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
+
+hipError_t trace_kernel_occupancy(int* blocks_per_cu, size_t lds_bytes)
+{
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_probe_trace_ref, kTraceBlock, lds_bytes);
+}
+
+}  // namespace ddgi

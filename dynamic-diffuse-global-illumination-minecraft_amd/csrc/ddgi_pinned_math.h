@@ -1,0 +1,111 @@
+// ddgi_pinned_math.h — the engine's pinned elementary functions, host + device (gfx950).
+//
+// GLSL lets the driver choose the precision of sin/cos/acos (Vulkan: abs. error 2^-11 for sin/cos
+// on [-pi,pi]); the reference's noise hashes fract(sin(x)*43758.5453)
+// (assets/shaders/intersection.glsl:400-402,438,469) amplify that freedom into visible
+// differences between GPUs.  This engine pins ONE definition that a CPU and a gfx950 evaluate to
+// the same bits: binary64 +, *, fma, sqrt, rint only, one final rounding to binary32.
+// See DESIGN.md "Arithmetic pinning" (P6).  tests/ compare these with libm (closeness) and with
+// the oracle's independent restatement (bit equality).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#define DDGI_HD __host__ __device__ __forceinline__
+
+namespace ddgi {
+namespace pm {
+
+struct SinCos
+{
+    double s, c;
+};
+
+// Reduce x to r in [-pi/4, pi/4] with k = rint(x*2/pi): two fma's against a 106-bit pi/2 give
+// |error| < 2^-53 for |x| < 2^31; then 13th/14th-order Taylor polynomials (truncation < 2e-14).
+DDGI_HD SinCos sincos_core(float xf)
+{
+    const double kTwoOverPi = 0x1.45f306dc9c883p-1;
+    const double kPio2Hi = 0x1.921fb54442d18p+0;
+    const double kPio2Lo = 0x1.1a62633145c07p-54;
+    SinCos out;
+    const double x = static_cast<double>(xf);
+    if (!(fabs(x) < 2147483648.0))
+    {
+        out.s = out.c = __builtin_nan("");
+        return out;
+    }
+    const double k = rint(x * kTwoOverPi);
+    double r = fma(-k, kPio2Hi, x);
+    r = fma(-k, kPio2Lo, r);
+    const double z = r * r;
+
+    double ps = 0x1.6124613a86d09p-33;           //  1/13!
+    ps = fma(ps, z, -0x1.ae64567f544e4p-26);     // -1/11!
+    ps = fma(ps, z, 0x1.71de3a556c734p-19);      //  1/9!
+    ps = fma(ps, z, -0x1.a01a01a01a01ap-13);     // -1/7!
+    ps = fma(ps, z, 0x1.1111111111111p-7);       //  1/5!
+    ps = fma(ps, z, -0x1.5555555555555p-3);      // -1/3!
+    const double sr = fma(r * z, ps, r);
+
+    double pc = -0x1.93974a8c07c9dp-37;          // -1/14!
+    pc = fma(pc, z, 0x1.1eed8eff8d898p-29);      //  1/12!
+    pc = fma(pc, z, -0x1.27e4fb7789f5cp-22);     // -1/10!
+    pc = fma(pc, z, 0x1.a01a01a01a01ap-16);      //  1/8!
+    pc = fma(pc, z, -0x1.6c16c16c16c17p-10);     // -1/6!
+    pc = fma(pc, z, 0x1.5555555555555p-5);       //  1/4!
+    pc = fma(pc, z, -0x1.0p-1);                  // -1/2!
+    const double cr = fma(z, pc, 1.0);
+
+    const int q = static_cast<int>(static_cast<long long>(k) & 3);
+    const bool swap = (q & 1) != 0;
+    const double s0 = swap ? cr : sr;
+    const double c0 = swap ? sr : cr;
+    out.s = (q & 2) ? -s0 : s0;
+    out.c = ((q + 1) & 2) ? -c0 : c0;
+    return out;
+}
+
+DDGI_HD float sinf_pinned(float x) { return static_cast<float>(sincos_core(x).s); }
+DDGI_HD float cosf_pinned(float x) { return static_cast<float>(sincos_core(x).c); }
+
+// (asin(x) - x)/x^3 on z = x^2 <= 0.25: the rational approximation published in fdlibm's
+// e_asin.c (Sun Microsystems, 1993), numerator pS0..pS5 and denominator 1,qS1..qS4.
+DDGI_HD double asin_ratio(double z)
+{
+    double num = fma(3.47933107596021167570e-05, z, 7.91534994289814532176e-04);
+    num = fma(num, z, -4.00555345006794114027e-02);
+    num = fma(num, z, 2.01212532134862925881e-01);
+    num = fma(num, z, -3.25565818622400915405e-01);
+    num = fma(num, z, 1.66666666666666657415e-01);
+    num = num * z;
+    double den = fma(7.70381505559019352791e-02, z, -6.88283971605453293030e-01);
+    den = fma(den, z, 2.02094576023350569471e+00);
+    den = fma(den, z, -2.40339491173441421878e+00);
+    den = fma(den, z, 1.0);
+    return num / den;
+}
+
+DDGI_HD float acosf_pinned(float xf)
+{
+    const double kPi = 0x1.921fb54442d18p+1;
+    const double kPio2 = 0x1.921fb54442d18p+0;
+    const double x = static_cast<double>(xf);
+    if (!(fabs(x) <= 1.0)) return __builtin_nanf("");
+    if (fabs(x) < 0.5)
+    {
+        const double a = fma(x, asin_ratio(x * x), x);
+        return static_cast<float>(kPio2 - a);
+    }
+    const bool neg = x < 0.0;
+    const double z = (neg ? (1.0 + x) : (1.0 - x)) * 0.5;
+    const double s = sqrt(z);
+    const double a = fma(s, asin_ratio(z), s);
+    return static_cast<float>(neg ? (kPi - 2.0 * a) : (2.0 * a));
+}
+
+}  // namespace pm
+}  // namespace ddgi

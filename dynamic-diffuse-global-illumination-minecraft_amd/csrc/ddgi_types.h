@@ -1,0 +1,77 @@
+// ddgi_types.h — host/device shared argument blocks of the probe-path kernels.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/ddgi_probe.h"
+
+namespace ddgi {
+
+constexpr int kMaxLights = DDGI_MAX_LIGHTS;
+constexpr int kMarchIters = 125;  // grid_march's loop bound, intersection.glsl:1059
+constexpr int kTraceBlock = 256;  // threads per workgroup = 4 wave64
+
+struct LightK
+{
+    float intensity;
+    float col[3];
+    float pos[3];
+};
+
+// A baked scene (ddgi_scene_bake.cpp): 1 bit/voxel occupancy + 1 byte/voxel block type over an
+// inclusive voxel-id box that contains everything that is not an extrusion of its border layer.
+struct SceneK
+{
+    int lo[3];
+    int hi[3];
+    int nx;   // cells per row (x extent)
+    int nxy;  // cells per z-slice (x extent * y extent)
+    int bias; // (lo.z*ny + lo.y)*nx + lo.x : linear index = z*nxy + y*nx + x - bias
+    int nwords;            // 32-bit words in the occupancy bitmap
+    unsigned face_empty;   // bit (2*axis + side): that border layer is entirely empty
+    const uint32_t* bits;  // device
+    const uint8_t* types;  // device
+};
+
+// Probe-grid geometry shared by all kernels.
+struct GridK
+{
+    int cx, cy, cz;  // probe counts
+    int s;           // sqrt rays per probe
+    int side;        // integer probe spacing
+    float origin[3];
+    float hysteresis;
+    int z0, czl;  // this rank's z-slab: probes with z in [z0, z0+czl)
+};
+
+struct TraceArgs
+{
+    GridK grid;
+    SceneK scene;
+    int scene_id;
+    int max_bounces;
+    int nl;
+    LightK lights[kMaxLights];
+    const float4* rays;   // local slab's ProbeRay records (3 x float4 each), reference p order
+    uint32_t n_rays;      // local ray count
+    uint32_t* albedo;     // full-grid slab-major rgba8 texels [cz][cy][cx][s][s]
+    uint32_t* distance;   // same shape
+    int wait_threshold;   // event batching: handle finished marches once this many lanes wait
+};
+
+struct SampleArgs
+{
+    GridK grid;
+    const uint32_t* albedo;
+    const uint32_t* distance;
+    const float* pos;  // n*3
+    const float* nrm;  // n*3
+    float* rgb;        // n*3
+    int32_t* cage;     // n*8 or null
+    uint32_t n;
+};
+
+}  // namespace ddgi

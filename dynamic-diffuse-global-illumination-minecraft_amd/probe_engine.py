@@ -1,0 +1,306 @@
+"""ctypes binding of libddgi_probe.so (include/ddgi_probe.h).
+
+Mirrors, for the probe path only, the public surface of the reference's `class RVPT`
+(src/rvpt/rvpt.h:33-92): the `ir` (IrradianceField) and `render_settings` records,
+`generate_probe_rays()`, the per-frame `update()`/`draw()` pair (here: `probe_update()`), and
+`recreate_probe_textures()` (here: `configure()`).  All compute happens in the HIP library; if it
+cannot be loaded, or no gfx950 GPU is present, calls raise DDGIError — there is no fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import build_library, library_path
+
+MODE_REF = 0
+MODE_DDGI = 1
+
+
+class DDGIError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"ddgi error {code}: {message}")
+        self.code = code
+
+
+class IrradianceField(C.Structure):
+    """RVPT::IrradianceField (src/rvpt/rvpt.h:82-90), 48 bytes, std140."""
+    _fields_ = [
+        ("probe_count", C.c_int32 * 3),
+        ("side_length", C.c_int32),
+        ("hysteresis", C.c_float),
+        ("sqrt_rays_per_probe", C.c_int32),
+        ("_pad0", C.c_int32 * 2),
+        ("field_origin", C.c_float * 3),
+        ("visualize", C.c_uint8),
+        ("_pad1", C.c_uint8 * 3),
+    ]
+
+
+class RenderSettings(C.Structure):
+    """RVPT::RenderSettings (src/rvpt/rvpt.h:70-80), 32 bytes."""
+    _fields_ = [
+        ("screen_width", C.c_int32),
+        ("screen_height", C.c_int32),
+        ("max_bounces", C.c_int32),
+        ("camera_mode", C.c_int32),
+        ("render_mode", C.c_int32),
+        ("scene", C.c_int32),
+        ("time", C.c_float),
+        ("visualize_probes", C.c_int32),
+    ]
+
+
+class Light(C.Structure):
+    """struct Light (assets/shaders/structs.glsl:54-59)."""
+    _fields_ = [("intensity", C.c_float), ("col", C.c_float * 3), ("pos", C.c_float * 3)]
+
+
+PROBE_RAY_DTYPE = np.dtype(
+    [("origin", "<f4", 3), ("_p0", "<f4"), ("direction", "<f4", 3), ("_p1", "<f4"),
+     ("probe_info", "<f4", 3), ("_p2", "<f4")])
+LIGHT_DTYPE = np.dtype([("intensity", "<f4"), ("col", "<f4", 3), ("pos", "<f4", 3)])
+assert C.sizeof(IrradianceField) == 48 and C.sizeof(RenderSettings) == 32
+assert PROBE_RAY_DTYPE.itemsize == 48 and LIGHT_DTYPE.itemsize == 28 == C.sizeof(Light)
+
+
+def make_field(counts=(9, 7, 9), side=11, s=20, origin=(1.4, 0.0, 1.0), hysteresis=0.9):
+    """Defaults are the reference's (rvpt.h:84-88)."""
+    f = IrradianceField()
+    f.probe_count[:] = [int(c) for c in counts]
+    f.side_length = int(side)
+    f.hysteresis = float(hysteresis)
+    f.sqrt_rays_per_probe = int(s)
+    f.field_origin[:] = [float(o) for o in origin]
+    f.visualize = 1
+    return f
+
+
+def make_settings(scene=0, max_bounces=8, time=0.0):
+    st = RenderSettings()
+    st.screen_width, st.screen_height = 1600, 900
+    st.max_bounces = int(max_bounces)
+    st.scene = int(scene)
+    st.time = float(time)
+    return st
+
+
+_lib = None
+
+_VP = C.c_void_p
+_SIGNATURES = {
+    "ddgi_create": (C.c_int, [_VP, _VP, C.c_int, C.POINTER(_VP)]),
+    "ddgi_create_sharded": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "ddgi_destroy": (C.c_int, [_VP]),
+    "ddgi_configure": (C.c_int, [_VP, _VP, _VP]),
+    "ddgi_set_mode": (C.c_int, [_VP, C.c_int]),
+    "ddgi_set_lights": (C.c_int, [_VP, C.c_int, _VP, C.c_int]),
+    "ddgi_generate_probe_rays": (C.c_int, [_VP, C.c_uint32, C.c_int]),
+    "ddgi_upload_probe_rays": (C.c_int, [_VP, _VP, C.c_size_t]),
+    "ddgi_get_probe_rays": (C.c_int, [_VP, _VP, C.c_size_t]),
+    "ddgi_probe_update": (C.c_int, [_VP, _VP]),
+    "ddgi_synchronize": (C.c_int, [_VP]),
+    "ddgi_last_update_ms": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "ddgi_read_textures": (C.c_int, [_VP, _VP, _VP]),
+    "ddgi_read_tiles": (C.c_int, [_VP, _VP, _VP]),
+    "ddgi_sample": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP, _VP]),
+    "ddgi_set_stream": (C.c_int, [_VP, _VP]),
+    "ddgi_device_textures": (C.c_int, [_VP] + [C.POINTER(_VP), C.POINTER(C.c_size_t)] * 2 + [C.POINTER(C.c_size_t)] * 4),
+    "ddgi_bind_textures": (C.c_int, [_VP, _VP, _VP]),
+    "ddgi_sample_device": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP, _VP]),
+    "ddgi_abi_version": (C.c_int, []),
+    "ddgi_last_error": (C.c_char_p, []),
+    "ddgi_texture_size": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ddgi_probe_tile_origin": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ddgi_generate_probe_rays_host": (C.c_int, [_VP, C.c_uint32, C.c_int, _VP, C.c_size_t]),
+    "ddgi_scene_block_at": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ddgi_pinned_sinf": (C.c_float, [C.c_float]),
+    "ddgi_pinned_cosf": (C.c_float, [C.c_float]),
+    "ddgi_pinned_acosf": (C.c_float, [C.c_float]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load_library(build=True):
+    """Loads (building first if stale and `build`) libddgi_probe.so; raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if build and os.environ.get("DDGI_NO_BUILD", "0") != "1":
+            try:
+                build_library()
+            except Exception:
+                if not os.path.exists(library_path()):
+                    raise
+        if not os.path.exists(library_path()):
+            raise DDGIError(-2, f"{library_path()} is missing: build it with __graft_entry__.build()")
+        lib = C.CDLL(library_path())
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise DDGIError(rc, load_library().ddgi_last_error().decode("utf-8", "replace"))
+
+
+def texture_size(field):
+    w, h = C.c_int(), C.c_int()
+    _check(load_library().ddgi_texture_size(C.byref(field), C.byref(w), C.byref(h)))
+    return w.value, h.value
+
+
+def probe_tile_origin(field, probe_index):
+    x, y = C.c_int(), C.c_int()
+    _check(load_library().ddgi_probe_tile_origin(C.byref(field), probe_index, C.byref(x), C.byref(y)))
+    return x.value, y.value
+
+
+def generate_probe_rays_host(field, seed=1, skip_calls=0):
+    """Host-only RVPT::generate_probe_rays (rvpt.cpp:1147-1224); no GPU needed."""
+    c = field.probe_count
+    n = c[0] * c[1] * c[2] * field.sqrt_rays_per_probe ** 2
+    rays = np.zeros(n, dtype=PROBE_RAY_DTYPE)
+    _check(load_library().ddgi_generate_probe_rays_host(C.byref(field), seed, skip_calls,
+                                                        rays.ctypes.data_as(C.c_void_p), n))
+    return rays
+
+
+def scene_block_at(scene, x, y, z):
+    return load_library().ddgi_scene_block_at(scene, x, y, z)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class ProbeEngine:
+    """One GPU's probe path.  Attributes `ir` and `render_settings` mirror RVPT's public members."""
+
+    def __init__(self, field, settings, device=0, rank=0, world=1):
+        self._lib = load_library()
+        self.ir = field
+        self.render_settings = settings
+        self.rank, self.world = rank, world
+        self._h = C.c_void_p()
+        _check(self._lib.ddgi_create_sharded(C.byref(field), C.byref(settings), device, rank, world,
+                                             C.byref(self._h)))
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ddgi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    shutdown = close  # RVPT::shutdown
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- configuration -------------------------------------------------------------------------
+    def configure(self, field=None, settings=None):
+        """RVPT::recreate_probe_textures (rvpt.cpp:661-755)."""
+        if field is not None:
+            self.ir = field
+        if settings is not None:
+            self.render_settings = settings
+        _check(self._lib.ddgi_configure(self._h, C.byref(self.ir), C.byref(self.render_settings)))
+
+    recreate_probe_textures = configure
+
+    def set_mode(self, mode):
+        _check(self._lib.ddgi_set_mode(self._h, mode))
+
+    def set_lights(self, scene, lights):
+        arr = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+        _check(self._lib.ddgi_set_lights(self._h, scene, _ptr(arr), len(arr)))
+
+    # -- rays ----------------------------------------------------------------------------------
+    @property
+    def num_probes(self):
+        c = self.ir.probe_count
+        return c[0] * c[1] * c[2]
+
+    @property
+    def num_rays(self):
+        return self.num_probes * self.ir.sqrt_rays_per_probe ** 2
+
+    def generate_probe_rays(self, seed=1, reseed=False):
+        """RVPT::generate_probe_rays (rvpt.cpp:1177-1224) + upload (rvpt.cpp:285)."""
+        _check(self._lib.ddgi_generate_probe_rays(self._h, seed, 1 if reseed else 0))
+
+    def upload_probe_rays(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=PROBE_RAY_DTYPE)
+        _check(self._lib.ddgi_upload_probe_rays(self._h, _ptr(rays), len(rays)))
+
+    def get_probe_rays(self):
+        rays = np.zeros(self.num_rays, dtype=PROBE_RAY_DTYPE)
+        _check(self._lib.ddgi_get_probe_rays(self._h, _ptr(rays), len(rays)))
+        return rays
+
+    # -- hot path ------------------------------------------------------------------------------
+    def probe_update(self, settings=None):
+        """The probe half of RVPT::update + draw (rvpt.cpp:265-290, 1096-1129). Asynchronous."""
+        if settings is not None:
+            self.render_settings = settings
+        _check(self._lib.ddgi_probe_update(self._h, C.byref(self.render_settings)))
+
+    def synchronize(self):
+        _check(self._lib.ddgi_synchronize(self._h))
+
+    def last_update_ms(self):
+        t, b, tot = C.c_float(), C.c_float(), C.c_float()
+        _check(self._lib.ddgi_last_update_ms(self._h, C.byref(t), C.byref(b), C.byref(tot)))
+        return {"trace_ms": t.value, "blend_ms": b.value, "total_ms": tot.value}
+
+    # -- outputs -------------------------------------------------------------------------------
+    def read_textures(self):
+        """(albedo, distance) as uint8 [H, W, 4] in the reference's raster layout."""
+        w, h = texture_size(self.ir)
+        albedo = np.empty((h, w, 4), dtype=np.uint8)
+        distance = np.empty((h, w, 4), dtype=np.uint8)
+        _check(self._lib.ddgi_read_textures(self._h, _ptr(albedo), _ptr(distance)))
+        return albedo, distance
+
+    def sample(self, pos, nrm, want_cage=True):
+        """get_diffuse_gi (intersection.glsl:1306-1409) for a batch: -> (rgb [n,3], cage [n,8])."""
+        pos = np.ascontiguousarray(pos, dtype=np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(nrm, dtype=np.float32).reshape(-1, 3)
+        n = pos.shape[0]
+        rgb = np.empty((n, 3), dtype=np.float32)
+        cage = np.empty((n, 8), dtype=np.int32) if want_cage else None
+        _check(self._lib.ddgi_sample(self._h, _ptr(pos), _ptr(nrm), n, _ptr(rgb), _ptr(cage)))
+        return rgb, cage
+
+    # -- device-pointer level ------------------------------------------------------------------
+    def set_stream(self, hip_stream_ptr):
+        _check(self._lib.ddgi_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def device_textures(self):
+        t0, t1 = C.c_void_p(), C.c_void_p()
+        b0, b1, so0, sb0, so1, sb1 = (C.c_size_t() for _ in range(6))
+        _check(self._lib.ddgi_device_textures(self._h, C.byref(t0), C.byref(b0), C.byref(t1), C.byref(b1),
+                                              C.byref(so0), C.byref(sb0), C.byref(so1), C.byref(sb1)))
+        return {"tex0": t0.value, "tex0_bytes": b0.value, "tex1": t1.value, "tex1_bytes": b1.value,
+                "slab_offset0": so0.value, "slab_bytes0": sb0.value, "slab_offset1": so1.value,
+                "slab_bytes1": sb1.value}
+
+    def bind_textures(self, tex0_ptr, tex1_ptr):
+        _check(self._lib.ddgi_bind_textures(self._h, C.c_void_p(tex0_ptr), C.c_void_p(tex1_ptr)))
+
+    def sample_device(self, pos_ptr, nrm_ptr, n, rgb_ptr, cage_ptr=None):
+        _check(self._lib.ddgi_sample_device(self._h, C.c_void_p(pos_ptr), C.c_void_p(nrm_ptr), n,
+                                            C.c_void_p(rgb_ptr), C.c_void_p(cage_ptr) if cage_ptr else None))

@@ -226,6 +226,13 @@ const char* ddgi_last_error(void);
 int ddgi_texture_size(const ddgi_irradiance_field* field, int* width, int* height);
 int ddgi_probe_tile_origin(const ddgi_irradiance_field* field, int probe_index, int* x, int* y);
 
+/* Host-only form of ddgi_generate_probe_rays (no handle, no GPU): seeds a fresh generator with
+ * `seed`, discards `skip_calls` whole generate_probe_rays() calls' worth of draws for this
+ * configuration (so call k of a process can be reproduced), and writes the full-grid array.
+ * n must be probe_count.x*y*z * s*s. */
+int ddgi_generate_probe_rays_host(const ddgi_irradiance_field* field, uint32_t seed, int skip_calls,
+                                  ddgi_probe_ray* rays, size_t n);
+
 /* Host evaluation of the baked scene the kernels traverse (block type 0..13 at integer voxel
  * id; replaces getBlockAt, intersection.glsl:699-826, which the reference evaluates per march
  * step on the GPU).  Usable without a GPU; exists so the bake can be checked against the

@@ -1,0 +1,83 @@
+// tests/device_math_check.hip — checks, on a real gfx950, the IEEE assumptions the pinned
+// arithmetic rests on: the product's host+device headers must evaluate to the same bits on the CPU
+// and on the GPU (correctly rounded /, sqrt; v_fract clamp; binary64 fma/rint/sqrt; int casts).
+// Built and run by tests/test_gpu_device_math.py.  Prints "OK" or the first mismatches.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../dynamic-diffuse-global-illumination-minecraft_amd/csrc/ddgi_scene.h"
+
+using namespace ddgi;
+
+constexpr int kOuts = 16;
+
+__host__ __device__ inline void eval(float a, float b, float c, float* o)
+{
+    o[0] = pm::sinf_pinned(a * 1000.0f);
+    o[1] = pm::cosf_pinned(a * 1000.0f);
+    o[2] = pm::acosf_pinned(gl_clamp(a * 0.11f, -1.0f, 1.0f));
+    o[3] = gl_fract(a);
+    o[4] = a / b;
+    o[5] = sqrtf(fabsf(a));
+    o[6] = 1.0f / b;
+    const f3 n = normalize3(f3{a, b, c});
+    o[7] = n.x;
+    o[8] = n.y;
+    o[9] = n.z;
+    o[10] = random1(f3{floorf(a), floorf(b), floorf(c)});
+    o[11] = fbm2(a * 0.3f, b * 0.3f);
+    o[12] = worley(f2{a, b});
+    o[13] = static_cast<float>(static_cast<int>(ceilf(a)));
+    o[14] = fbm1(c);
+    const f3 col = block_albedo(f3{a, b, c}, 6 + (static_cast<int>(fabsf(c)) % 8), f3{0.0f, 1.0f, 0.0f});
+    o[15] = col.x + col.y * 2.0f + col.z * 4.0f;
+}
+
+__global__ void k(const float* in, float* out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) eval(in[3 * i], in[3 * i + 1], in[3 * i + 2], out + kOuts * i);
+}
+
+int main()
+{
+    const int n = 1 << 16;
+    std::vector<float> in(3 * n), host(kOuts * n), dev(kOuts * n);
+    std::mt19937 g(1);
+    std::uniform_real_distribution<float> u(-40.0f, 40.0f);
+    for (auto& v : in) v = u(g);
+    // edge cases for fract / division
+    const float edges[] = {-1e-9f, 1e-9f, -0.0f, 0.0f, 1.0f, -1.0f, 16777216.0f, -3.9999998f, 0.99999994f, 1e-38f, 3e-39f, -3e-39f};
+    for (int i = 0; i < 12; ++i) in[3 * i] = edges[i], in[3 * i + 1] = edges[(i + 5) % 12] + 3.0f;
+    for (int i = 0; i < n; ++i) eval(in[3 * i], in[3 * i + 1], in[3 * i + 2], host.data() + kOuts * i);
+    float *din, *dout;
+    if (hipMalloc(&din, in.size() * 4) != hipSuccess || hipMalloc(&dout, dev.size() * 4) != hipSuccess) { printf("FAIL hipMalloc\n"); return 2; }
+    hipMemcpy(din, in.data(), in.size() * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k, dim3((n + 255) / 256), dim3(256), 0, 0, din, dout, n);
+    if (hipMemcpy(dev.data(), dout, dev.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { printf("FAIL memcpy\n"); return 2; }
+    long bad[kOuts] = {0};
+    int shown = 0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < kOuts; ++j)
+        {
+            uint32_t a, b;
+            std::memcpy(&a, &host[kOuts * i + j], 4);
+            std::memcpy(&b, &dev[kOuts * i + j], 4);
+            const bool both_nan = (host[kOuts * i + j] != host[kOuts * i + j]) && (dev[kOuts * i + j] != dev[kOuts * i + j]);
+            if (a != b && !both_nan)
+            {
+                bad[j]++;
+                if (shown++ < 20)
+                    printf("mismatch out[%d] in=(%.9g,%.9g,%.9g) host=%.9g (%08x) dev=%.9g (%08x)\n", j, in[3 * i], in[3 * i + 1],
+                           in[3 * i + 2], host[kOuts * i + j], a, dev[kOuts * i + j], b);
+            }
+        }
+    long total = 0;
+    for (int j = 0; j < kOuts; ++j) { total += bad[j]; if (bad[j]) printf("out[%d]: %ld mismatches\n", j, bad[j]); }
+    printf(total == 0 ? "OK\n" : "FAIL\n");
+    return total == 0 ? 0 : 1;
+}

@@ -1,0 +1,17 @@
+"""Runs tests/device_math_check.hip on the GPU: host and device must evaluate the product's
+pinned arithmetic headers to identical bits (the premise of the bit-exact parity tests)."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_host_and_device_evaluate_pinned_arithmetic_identically(tmp_path):
+    exe = tmp_path / "device_math_check"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                    "-fno-fast-math", os.path.join(HERE, "device_math_check.hip"), "-o", str(exe)], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
