@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — probe-rays/s and ms/frame of the DDGI probe update on MI355X.
+
+A "step" is one probe update (one frame's probe pass) of BASELINE.json's headline configuration
+C3: Minecraft cave scene, 32x16x32 probes x 256 rays (4 194 304 probe rays), max_bounces = 8,
+shipped light table, REF mode (the reference's live behaviour), ray jitter seed 1.  Inputs (the
+48 B/ray ProbeRay buffer, the baked scene) are resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1: the probe grid is sharded by z-slab (cz/N layers per rank); every step each rank traces its
+slab and the blended textures are exchanged with one RCCL all-gather per texture over xGMI
+(torch.distributed, backend nccl).  Total work is fixed, so `scaling` is "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
+dominant kernel (k_probe_trace_ref) and, at N = 1, `cpu_baseline` (the CPU oracle timed on the
+box's host cores over a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOAD = {
+    "name": "c3_cave_32x16x32_probes_x256_rays_ref",
+    "counts": (32, 16, 32),
+    "side": 2,
+    "s": 16,
+    "origin": (1.4, 0.0, 1.0),
+    "scene": 0,
+    "max_bounces": 8,
+    "seed": 1,
+}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_RAY = 56        # 48 B ProbeRay read + two 4 B rgba8 texel writes
+
+
+def _traffic_from_profiles():
+    """Per-launch HBM bytes of k_probe_trace_ref from the committed rocprofv3 --pmc passes
+    (profiles/*_traffic.json, written by tools/pmc_traffic.py); None if not collected."""
+    import glob
+
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+            if d.get("workload") == WORKLOAD["name"] and d.get("kernel", "").startswith("k_probe_trace"):
+                best = d.get("hbm_bytes_per_launch", best)
+        except Exception:
+            pass
+    return best
+
+
+def cpu_baseline(n_probes=96):
+    """The oracle (a CPU restatement of the reference's algorithm: procedural getBlockAt per march
+    step, exactly what the reference's shader does) over a bounded, evenly spread sample of the
+    workload's probes, all host threads."""
+    from oracle import oracle_py as O
+
+    O.set_arith(True)
+    w = WORKLOAD
+    f = O.make_field(w["counts"], w["side"], w["s"], w["origin"])
+    st = O.make_settings(w["scene"], w["max_bounces"])
+    rays = O.generate_probe_rays(f, O.new_rand_state(w["seed"]))
+    total = w["counts"][0] * w["counts"][1] * w["counts"][2]
+    probes = np.linspace(0, total - 1, n_probes).astype(np.int32)
+    O.probe_update_probes(f, st, rays, probes[:8])  # warm
+    t0 = time.perf_counter()
+    O.probe_update_probes(f, st, rays, probes)
+    dt = time.perf_counter() - t0
+    nrays = len(probes) * w["s"] ** 2
+    return {
+        "value": nrays / dt,
+        "unit": "rays/s",
+        "cores": O.num_threads(),
+        "kind": "port",
+        "sample": f"{len(probes)} of {total} probes evenly spread over the grid ({nrays} rays), {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-probes", type=int, default=96)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import ddgi_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    w = WORKLOAD
+    field = ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"])
+    settings = ddgi_amd.make_settings(w["scene"], w["max_bounces"])
+    eng = ddgi_amd.ProbeEngine(field, settings, device=local_rank, rank=rank, world=world)
+    stream = torch.cuda.current_stream()
+    eng.set_stream(stream.cuda_stream)          # kernels + collectives share torch's stream
+    eng.generate_probe_rays(seed=w["seed"])     # ray buffer resident in HBM from here on
+
+    tex = None
+    if world > 1:
+        from ddgi_amd import distributed as ddist
+
+        tex = ddist.ShardedTextures(eng, torch.device("cuda", local_rank))
+
+    def step():
+        eng.probe_update()
+        if tex is not None:
+            tex.all_gather()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel durations of the timed steps: HIP events recorded on the launch stream by the engine
+    trace_ms, _ = eng.update_history_ms(min(args.steps, 64))
+    kernel_ms = float(np.mean(trace_ms)) if len(trace_ms) else float("nan")
+
+    total_rays = eng.num_rays
+    local_rays = total_rays // world
+    ms_per_step = elapsed / args.steps * 1e3
+    achieved = ALGO_BYTES_PER_RAY * local_rays / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "probe_rays_per_sec",
+        "value": total_rays / (elapsed / args.steps),
+        "unit": "rays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": w["name"],
+            "probes": list(w["counts"]),
+            "rays_per_probe": w["s"] ** 2,
+            "probe_rays": total_rays,
+            "scene": "minecraft_cave",
+            "max_bounces": w["max_bounces"],
+            "mode": "REF",
+            "parallelism": f"zslab{world}" + ("+allgather" if world > 1 else ""),
+        },
+        "roofline": {
+            "kernel": "k_probe_trace_ref",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": _traffic_from_profiles(),
+            "algorithmic_bytes_per_launch": ALGO_BYTES_PER_RAY * local_rays,
+            "kernel_ms": kernel_ms,
+            "note": "the trace kernel is VALU-issue bound (dependent voxel steps), not HBM bound; see DESIGN.md",
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_probes)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -91,8 +91,9 @@ struct ddgi_engine
     void* tex[2] = {nullptr, nullptr};
     size_t tex_bytes[2] = {0, 0};
 
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    bool timed = false;
+    static constexpr int kRing = 64;  // timing history: one event triple per recent update
+    hipEvent_t ev[kRing][3] = {};
+    unsigned long long updates = 0;
     int wait_threshold = 16;
 };
 
@@ -248,8 +249,9 @@ int ddgi_create_sharded(const ddgi_irradiance_field* field, const ddgi_render_se
             break;
         }
         e->own_stream = true;
-        for (int i = 0; i < 3; ++i)
-            if (hipEventCreate(&e->ev[i]) != hipSuccess) rc = fail(DDGI_ERR_HIP, "hipEventCreate failed");
+        for (auto& triple : e->ev)
+            for (auto& ev : triple)
+                if (hipEventCreate(&ev) != hipSuccess) rc = fail(DDGI_ERR_HIP, "hipEventCreate failed");
         if (rc) break;
         rc = alloc_textures(e);
     } while (0);
@@ -280,8 +282,9 @@ int ddgi_destroy(ddgi_handle e)
         if (d.bits) (void)hipFree(d.bits);
         if (d.types) (void)hipFree(d.types);
     }
-    for (auto& ev : e->ev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto& triple : e->ev)
+        for (auto& ev : triple)
+            if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return DDGI_OK;
@@ -297,7 +300,7 @@ int ddgi_configure(ddgi_handle e, const ddgi_irradiance_field* field, const ddgi
     e->settings = *settings;
     e->host_rays.clear();
     e->n_local_rays = 0;
-    e->timed = false;
+    e->updates = 0;
     return alloc_textures(e);
 }
 
@@ -404,11 +407,12 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     uint32_t grid = static_cast<uint32_t>(e->num_cus) * static_cast<uint32_t>(per_cu);
     if (grid > chunks) grid = chunks;
 
-    HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+    hipEvent_t* ev = e->ev[e->updates % ddgi_engine::kRing];
+    HIP_TRY(hipEventRecord(ev[0], e->stream));
     HIP_TRY(launch_probe_trace_ref(a, static_cast<int>(grid), e->stream));
-    HIP_TRY(hipEventRecord(e->ev[1], e->stream));
-    HIP_TRY(hipEventRecord(e->ev[2], e->stream));
-    e->timed = true;
+    HIP_TRY(hipEventRecord(ev[1], e->stream));
+    HIP_TRY(hipEventRecord(ev[2], e->stream));
+    e->updates += 1;
     return DDGI_OK;
 }
 
@@ -423,16 +427,37 @@ int ddgi_synchronize(ddgi_handle e)
 int ddgi_last_update_ms(ddgi_handle e, float* trace_ms, float* blend_ms, float* total_ms)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
-    if (!e->timed) return fail(DDGI_ERR_NOT_READY, "no probe update has been issued yet");
+    if (e->updates == 0) return fail(DDGI_ERR_NOT_READY, "no probe update has been issued yet");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipEventSynchronize(e->ev[2]));
+    hipEvent_t* ev = e->ev[(e->updates - 1) % ddgi_engine::kRing];
+    HIP_TRY(hipEventSynchronize(ev[2]));
     float t01 = 0.f, t12 = 0.f, t02 = 0.f;
-    HIP_TRY(hipEventElapsedTime(&t01, e->ev[0], e->ev[1]));
-    HIP_TRY(hipEventElapsedTime(&t12, e->ev[1], e->ev[2]));
-    HIP_TRY(hipEventElapsedTime(&t02, e->ev[0], e->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&t01, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&t12, ev[1], ev[2]));
+    HIP_TRY(hipEventElapsedTime(&t02, ev[0], ev[2]));
     if (trace_ms) *trace_ms = t01;
     if (blend_ms) *blend_ms = e->mode == DDGI_MODE_REF ? 0.f : t12;
     if (total_ms) *total_ms = t02;
+    return DDGI_OK;
+}
+
+int ddgi_update_history_ms(ddgi_handle e, float* trace_ms, float* blend_ms, int capacity, int* n_out)
+{
+    if (!e || !n_out || capacity < 0) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/n_out");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    unsigned long long have = e->updates < static_cast<unsigned long long>(ddgi_engine::kRing) ? e->updates : ddgi_engine::kRing;
+    if (have > static_cast<unsigned long long>(capacity)) have = capacity;
+    for (unsigned long long i = 0; i < have; ++i)
+    {
+        hipEvent_t* ev = e->ev[(e->updates - have + i) % ddgi_engine::kRing];
+        float t01 = 0.f, t12 = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t01, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&t12, ev[1], ev[2]));
+        if (trace_ms) trace_ms[i] = t01;
+        if (blend_ms) blend_ms[i] = e->mode == DDGI_MODE_REF ? 0.f : t12;
+    }
+    *n_out = static_cast<int>(have);
     return DDGI_OK;
 }
 

@@ -79,14 +79,18 @@ DDGI_HD f3 cross3(f3 a, f3 b)
 // ---- noise (intersection.glsl:400-499) --------------------------------------------------------
 
 DDGI_HD float hash_sin(float x) { return pm::sinf_pinned(x); }
+// Hash arguments reach 1e6..1e8 where one ulp of the argument is a different sine altogether, so
+// their dot products are evaluated literally (two products, plain adds), not as fma chains.
+DDGI_HD float hash_dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DDGI_HD float hash_dot2(f2 a, f2 b) { return a.x * b.x + a.y * b.y; }
 
 DDGI_HD float random1(f3 p)  // :400
 {
-    return gl_fract(hash_sin(dot3(p, mk3(127.1f, 311.7f, 191.999f))) * 43758.5453f);
+    return gl_fract(hash_sin(hash_dot3(p, mk3(127.1f, 311.7f, 191.999f))) * 43758.5453f);
 }
 DDGI_HD float noise2D(float px, float py)  // :402
 {
-    return gl_fract(hash_sin(dot2(f2{px, py}, f2{127.1f, 311.7f})) * 43758.5453f);
+    return gl_fract(hash_sin(hash_dot2(f2{px, py}, f2{127.1f, 311.7f})) * 43758.5453f);
 }
 DDGI_HD float interp_noise2D(float x, float y)  // :404-419
 {
@@ -131,8 +135,8 @@ DDGI_HD float fbm1(float x)  // :450-463 — i = 0..7
 }
 DDGI_HD f2 worley_point(f2 cell)  // generate_point :467-471 (cell_size 5)
 {
-    const float a = hash_sin(dot2(cell, f2{127.1f, 311.7f}));
-    const float b = hash_sin(dot2(cell, f2{269.5f, 183.3f}) * 43758.5453f);
+    const float a = hash_sin(hash_dot2(cell, f2{127.1f, 311.7f}));
+    const float b = hash_sin(hash_dot2(cell, f2{269.5f, 183.3f}) * 43758.5453f);
     return f2{(cell.x + gl_fract(a)) * 5.0f, (cell.y + gl_fract(b)) * 5.0f};
 }
 DDGI_HD float worley(f2 pixel)  // :473-499

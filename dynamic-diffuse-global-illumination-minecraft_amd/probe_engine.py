@@ -101,6 +101,7 @@ _SIGNATURES = {
     "ddgi_probe_update": (C.c_int, [_VP, _VP]),
     "ddgi_synchronize": (C.c_int, [_VP]),
     "ddgi_last_update_ms": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "ddgi_update_history_ms": (C.c_int, [_VP, _VP, _VP, C.c_int, C.POINTER(C.c_int)]),
     "ddgi_read_textures": (C.c_int, [_VP, _VP, _VP]),
     "ddgi_read_tiles": (C.c_int, [_VP, _VP, _VP]),
     "ddgi_sample": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP, _VP]),
@@ -265,6 +266,14 @@ class ProbeEngine:
         t, b, tot = C.c_float(), C.c_float(), C.c_float()
         _check(self._lib.ddgi_last_update_ms(self._h, C.byref(t), C.byref(b), C.byref(tot)))
         return {"trace_ms": t.value, "blend_ms": b.value, "total_ms": tot.value}
+
+    def update_history_ms(self, capacity=64):
+        """Kernel times of the most recent updates (oldest first), from HIP events on the stream."""
+        tr = np.zeros(capacity, dtype=np.float32)
+        bl = np.zeros(capacity, dtype=np.float32)
+        n = C.c_int()
+        _check(self._lib.ddgi_update_history_ms(self._h, _ptr(tr), _ptr(bl), capacity, C.byref(n)))
+        return tr[: n.value].copy(), bl[: n.value].copy()
 
     # -- outputs -------------------------------------------------------------------------------
     def read_textures(self):

@@ -168,6 +168,11 @@ int ddgi_synchronize(ddgi_handle h);
  * Synchronises.  blend_ms is 0 in REF mode. */
 int ddgi_last_update_ms(ddgi_handle h, float* trace_ms, float* blend_ms, float* total_ms);
 
+/* Per-kernel device times (HIP events on the handle's stream) of the most recent updates, oldest
+ * first: up to `capacity` entries, at most the last 64 updates.  Synchronises.  Lets a caller time
+ * the kernels of a whole timed region without synchronising inside it. */
+int ddgi_update_history_ms(ddgi_handle h, float* trace_ms, float* blend_ms, int capacity, int* n_out);
+
 /* ---- outputs ----------------------------------------------------------------------------------- */
 
 /* New (the reference has no readback path): copies both probe textures to the

@@ -365,16 +365,22 @@ void oracle_generate_probe_rays(const o_field* f, o_rand_state* rs, o_probe_ray*
 /* ------------------------------------------------------------------------------------------- */
 /* a12 — noise, intersection.glsl:400-499                                                        */
 
+/* The arguments of the sin() hashes reach 1e6..1e8, where one ulp of the argument is a different
+ * sine altogether; their dot products are therefore evaluated literally (no fma) in BOTH
+ * arithmetic modes, so the two modes hash the same argument. */
+static inline float hdot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline float hdot2(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
+
 /* intersection.glsl:400 */
 static float random1(v3 p)
 {
-    return o_fract(o_sin(dot3(p, V3(127.1f, 311.7f, 191.999f))) * 43758.5453f);
+    return o_fract(o_sin(hdot3(p, V3(127.1f, 311.7f, 191.999f))) * 43758.5453f);
 }
 /* intersection.glsl:402 */
 static float noise2D(float px, float py)
 {
     v2 p = {px, py}, k = {127.1f, 311.7f};
-    return o_fract(o_sin(dot2(p, k)) * 43758.5453f);
+    return o_fract(o_sin(hdot2(p, k)) * 43758.5453f);
 }
 /* intersection.glsl:404-419 */
 static float interpNoise2D(float x, float y)
@@ -432,8 +438,8 @@ static v2 generate_point(v2 cell)
 {
     v2 p = cell;
     v2 k1 = {127.1f, 311.7f}, k2 = {269.5f, 183.3f};
-    float a = o_sin(dot2(p, k1));
-    float b = o_sin(dot2(p, k2) * 43758.5453f);
+    float a = o_sin(hdot2(p, k1));
+    float b = o_sin(hdot2(p, k2) * 43758.5453f);
     p.x += o_fract(a);
     p.y += o_fract(b);
     p.x *= 5.0f;
@@ -1177,6 +1183,39 @@ void oracle_probe_update(const o_field* f, const o_settings* st, const o_probe_r
             albedo[o + 3] = 255;
         }
         if (distance) distance[o + 0] = distance[o + 1] = distance[o + 2] = distance[o + 3] = 0;
+    }
+}
+
+/* Same, for a list of probes (all s*s rays of each, reference order) in one parallel loop.
+ * Used for sampled checks of the full-size configurations and for bench.py's cpu_baseline. */
+void oracle_probe_update_probes(const o_field* f, const o_settings* st, const o_probe_ray* rays,
+                                const int32_t* probes, int n_probes, uint8_t* albedo, int nthreads)
+{
+    TraceCtx cx;
+    make_ctx(&cx, st, NULL, 0);
+    int cxz = f->probe_count[0] * f->probe_count[2];
+    int s = f->sqrt_rays_per_probe;
+    int n = s * s;
+    int W = cxz * s;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t k = 0; k < (int64_t)n_probes * n; k++)
+    {
+        uint64_t idx = (uint64_t)probes[k / n] * (uint64_t)n + (uint64_t)(k % n);
+        const o_probe_ray* pr = &rays[idx];
+        v3 c = trace_probe_ray(&cx, pr, (uint32_t)idx);
+        int probe = gint(pr->probe_info[0]);
+        int y_probe = probe / cxz;
+        int x_probe = probe - y_probe * cxz;
+        int tx = x_probe * s + gint(pr->probe_info[1]);
+        int ty = y_probe * s + gint(pr->probe_info[2]);
+        size_t o = ((size_t)ty * (size_t)W + (size_t)tx) * 4;
+        albedo[o + 0] = unorm8(c.x);
+        albedo[o + 1] = unorm8(c.y);
+        albedo[o + 2] = unorm8(c.z);
+        albedo[o + 3] = 255;
     }
 }
 

@@ -156,6 +156,18 @@ def probe_update(field, settings, rays, first=0, count=None, lights=None, nthrea
     return (albedo, dist, colors) if want_float else (albedo, dist)
 
 
+def probe_update_probes(field, settings, rays, probes, nthreads=0, albedo=None):
+    """REF-mode update of the listed probes only (one parallel loop) -> albedo[H,W,4] u8."""
+    W, H = texture_size(field)
+    if albedo is None:
+        albedo = np.zeros((H, W, 4), dtype=np.uint8)
+    probes = np.ascontiguousarray(probes, dtype=np.int32)
+    lib().oracle_probe_update_probes(
+        C.byref(field), C.byref(settings), rays.ctypes.data_as(C.c_void_p),
+        probes.ctypes.data_as(C.c_void_p), len(probes), albedo.ctypes.data_as(C.c_void_p), nthreads)
+    return albedo
+
+
 def sample(field, albedo, distance, pos, nrm):
     pos = np.ascontiguousarray(pos, dtype=np.float32)
     nrm = np.ascontiguousarray(nrm, dtype=np.float32)

@@ -55,7 +55,7 @@ def test_probe_update_other_bounce_counts(ddgi, oracle, bounces):
     assert np.array_equal(albedo, want_a)
 
 
-@pytest.mark.parametrize("name,frac", [("c2_cornell", 0.999), ("cave_small", 0.99)])
+@pytest.mark.parametrize("name,frac", [("c2_cornell", 0.999), ("cave_small", 0.999)])
 def test_probe_update_within_tolerance_of_literal_oracle(ddgi, oracle, name, frac):
     with _engine(ddgi, name) as eng:
         eng.generate_probe_rays(seed=1)
@@ -66,7 +66,7 @@ def test_probe_update_within_tolerance_of_literal_oracle(ddgi, oracle, name, fra
     oracle.set_arith(True)
     diff = np.abs(albedo[..., :3].astype(np.int32) - want_a[..., :3].astype(np.int32))
     assert (diff <= 1).mean() >= frac
-    assert diff.mean() < (0.05 if name == "c2_cornell" else 0.5)
+    assert diff.mean() < 0.05
 
 
 def test_uploaded_rays_and_readback_of_generated_rays(ddgi, oracle):
@@ -170,7 +170,8 @@ def test_full_size_c3_properties_and_sampled_oracle_check(ddgi, oracle):
     rays = oracle.generate_probe_rays(f, oracle.new_rand_state(1))
     st = oracle.make_settings(scene, 8)
     rng = np.random.default_rng(5)
-    for p in rng.choice(32 * 16 * 32, size=24, replace=False):
-        want, _ = oracle.probe_update(f, st, rays, first=int(p) * 256, count=256)
+    probes = rng.choice(32 * 16 * 32, size=64, replace=False)
+    want = oracle.probe_update_probes(f, st, rays, probes)
+    for p in probes:
         x0, y0 = ddgi.probe_tile_origin(ddgi.make_field(counts, side, s, origin), int(p))
         assert np.array_equal(a1[y0:y0 + 16, x0:x0 + 16], want[y0:y0 + 16, x0:x0 + 16]), f"probe {p}"
