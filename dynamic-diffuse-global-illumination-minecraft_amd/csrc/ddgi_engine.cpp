@@ -2,8 +2,10 @@
 // There is no CPU compute path in this library: every compute entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -17,6 +19,8 @@ namespace ddgi {
 hipError_t launch_probe_trace_ref(const TraceArgs& args, int grid_blocks, hipStream_t stream);
 hipError_t launch_probe_sample_ref(const SampleArgs& args, hipStream_t stream);
 hipError_t trace_kernel_occupancy(int* blocks_per_cu, size_t lds_bytes);
+int wf_pool_size(int nwords, bool multi_light, size_t lds_limit);
+hipError_t launch_probe_trace_wf(const TraceArgs& args, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream);
 }  // namespace ddgi
 
 using namespace ddgi;
@@ -78,6 +82,10 @@ struct ddgi_engine
         bool ready = false;
     } dev_scene[3];
 
+    // memoised lattice hashes on device
+    float* d_noise[3] = {nullptr, nullptr, nullptr};
+    NoiseLut noise{};
+
     // rays
     GlibcRand rand;
     bool rand_seeded = false;
@@ -94,7 +102,9 @@ struct ddgi_engine
     static constexpr int kRing = 64;  // timing history: one event triple per recent update
     hipEvent_t ev[kRing][3] = {};
     unsigned long long updates = 0;
-    int wait_threshold = 16;
+    int wait_threshold = 64;
+    uint32_t* d_work = nullptr;             // chunk counter of the wavefront trace kernel
+    unsigned long long* d_stats = nullptr;  // profiling aid, allocated on first ddgi_trace_stats(enable)
 };
 
 static GridK make_grid(const ddgi_engine* e)
@@ -173,6 +183,25 @@ static int ensure_scene(ddgi_engine* e, int scene)
     d.k.bits = d.bits;
     d.k.types = d.types;
     d.ready = true;
+    return DDGI_OK;
+}
+
+static int ensure_noise(ddgi_engine* e)
+{
+    if (e->noise.n2 || std::getenv("DDGI_NO_NOISE_LUT")) return DDGI_OK;
+    const NoiseLutHost& h = noise_lut_host();
+    const std::vector<float>* src[3] = {&h.n2, &h.n1, &h.wp};
+    for (int i = 0; i < 3; ++i)
+    {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_noise[i]), src[i]->size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(e->d_noise[i], src[i]->data(), src[i]->size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    e->noise.n2 = e->d_noise[0];
+    e->noise.n2_x0 = h.n2_x0, e->noise.n2_nx = h.n2_nx, e->noise.n2_y0 = h.n2_y0, e->noise.n2_ny = h.n2_ny;
+    e->noise.n1 = e->d_noise[1];
+    e->noise.n1_i0 = h.n1_i0, e->noise.n1_n = h.n1_n;
+    e->noise.wp = e->d_noise[2];
+    e->noise.wp_c0 = h.wp_c0, e->noise.wp_n = h.wp_n;
     return DDGI_OK;
 }
 
@@ -277,6 +306,10 @@ int ddgi_destroy(ddgi_handle e)
     for (int i = 0; i < 2; ++i)
         if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
     if (e->d_rays) (void)hipFree(e->d_rays);
+    if (e->d_stats) (void)hipFree(e->d_stats);
+    if (e->d_work) (void)hipFree(e->d_work);
+    for (auto& p : e->d_noise)
+        if (p) (void)hipFree(p);
     for (auto& d : e->dev_scene)
     {
         if (d.bits) (void)hipFree(d.bits);
@@ -385,6 +418,7 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     HIP_TRY(hipSetDevice(e->device));
     const int scene = e->settings.scene;
     if (int rc = ensure_scene(e, scene)) return rc;
+    if (int rc = ensure_noise(e)) return rc;
 
     TraceArgs a{};
     a.grid = make_grid(e);
@@ -398,18 +432,43 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     a.albedo = static_cast<uint32_t*>(e->tex[0]);
     a.distance = static_cast<uint32_t*>(e->tex[1]);
     a.wait_threshold = e->wait_threshold;
+    a.stats = e->d_stats;
+    a.noise = e->noise;
+    if (const char* v = std::getenv("DDGI_WAIT_THRESHOLD")) a.wait_threshold = std::atoi(v);
+    if (const char* v = std::getenv("DDGI_ABLATE")) a.ablate = std::atoi(v);
+    if (const char* v = std::getenv("DDGI_WF_TAIL")) a.wf_tail = std::atoi(v);
+    if (const char* v = std::getenv("DDGI_WF_FETCH")) a.wf_fetch = std::atoi(v);
 
-    const size_t lds = static_cast<size_t>(a.scene.nwords) * sizeof(uint32_t);
-    int per_cu = 0;
-    HIP_TRY(trace_kernel_occupancy(&per_cu, lds));
-    if (per_cu < 1) return fail(DDGI_ERR_UNSUPPORTED, "scene bitmap (%zu B) does not fit in LDS", lds);
-    const uint32_t chunks = (a.n_rays + kTraceBlock - 1) / kTraceBlock;
-    uint32_t grid = static_cast<uint32_t>(e->num_cus) * static_cast<uint32_t>(per_cu);
-    if (grid > chunks) grid = chunks;
+    // Kernel choice: the wavefront kernel (one persistent 1024-lane workgroup per CU, ray pool in
+    // LDS) whenever its pool fits next to the scene bitmap; the ray-per-lane kernel otherwise
+    // (or when DDGI_TRACE_KERNEL=lane asks for it, e.g. to cross-check the two).
+    const char* kernel_env = std::getenv("DDGI_TRACE_KERNEL");
+    const bool force_lane = kernel_env && std::strcmp(kernel_env, "lane") == 0;
+    int pool = (force_lane || a.max_bounces < 1) ? 0 : wf_pool_size(a.scene.nwords, a.nl > 1, 160 * 1024);
+    if (const char* v = std::getenv("DDGI_WF_POOL")) pool = pool ? std::min(pool, std::max(1024, std::atoi(v) / 64 * 64)) : 0;
 
     hipEvent_t* ev = e->ev[e->updates % ddgi_engine::kRing];
-    HIP_TRY(hipEventRecord(ev[0], e->stream));
-    HIP_TRY(launch_probe_trace_ref(a, static_cast<int>(grid), e->stream));
+    if (pool > 0)
+    {
+        if (!e->d_work) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_work), sizeof(uint32_t)));
+        const uint32_t chunks = (a.n_rays + 4095u) / 4096u;
+        uint32_t grid = static_cast<uint32_t>(e->num_cus);
+        if (grid > chunks) grid = chunks;
+        HIP_TRY(hipEventRecord(ev[0], e->stream));
+        HIP_TRY(launch_probe_trace_wf(a, pool, static_cast<int>(grid), e->d_work, e->stream));
+    }
+    else
+    {
+        const size_t lds = static_cast<size_t>(a.scene.nwords) * sizeof(uint32_t);
+        int per_cu = 0;
+        HIP_TRY(trace_kernel_occupancy(&per_cu, lds));
+        if (per_cu < 1) return fail(DDGI_ERR_UNSUPPORTED, "scene bitmap (%zu B) does not fit in LDS", lds);
+        const uint32_t chunks = (a.n_rays + kTraceBlock - 1) / kTraceBlock;
+        uint32_t grid = static_cast<uint32_t>(e->num_cus) * static_cast<uint32_t>(per_cu);
+        if (grid > chunks) grid = chunks;
+        HIP_TRY(hipEventRecord(ev[0], e->stream));
+        HIP_TRY(launch_probe_trace_ref(a, static_cast<int>(grid), e->stream));
+    }
     HIP_TRY(hipEventRecord(ev[1], e->stream));
     HIP_TRY(hipEventRecord(ev[2], e->stream));
     e->updates += 1;
@@ -458,6 +517,26 @@ int ddgi_update_history_ms(ddgi_handle e, float* trace_ms, float* blend_ms, int 
         if (blend_ms) blend_ms[i] = e->mode == DDGI_MODE_REF ? 0.f : t12;
     }
     *n_out = static_cast<int>(have);
+    return DDGI_OK;
+}
+
+int ddgi_trace_stats(ddgi_handle e, int enable, unsigned long long* out8)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (out8)
+    {
+        std::memset(out8, 0, 16 * sizeof(unsigned long long));
+        if (e->d_stats) HIP_TRY(hipMemcpy(out8, e->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    if (enable && !e->d_stats) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_stats), 16 * sizeof(unsigned long long)));
+    if (e->d_stats) HIP_TRY(hipMemset(e->d_stats, 0, 16 * sizeof(unsigned long long)));
+    if (!enable && e->d_stats)
+    {
+        (void)hipFree(e->d_stats);
+        e->d_stats = nullptr;
+    }
     return DDGI_OK;
 }
 

@@ -98,6 +98,46 @@ const SceneBake& baked_scene(int scene)
     return cache[scene];
 }
 
+// ---- memoised lattice hashes ----------------------------------------------------------------------
+// Rectangles chosen from the lattice points the three scenes can touch (ddgi_scene.h call sites):
+//   noise2D : cave wall   fbm2(0.05, (uv.y+p.y)*0.3): ix in [0,13],  iy in [-1700, 1500]
+//             cave ground fbm2(uv*2)                 : ix, iy in [0, 513]
+//             moss/mold   interp_noise2D(axis)       : ix, iy in [-1, 2]
+//             -> ix in [-2, 518), iy in [-2048, 2048)   (8.5 MB; the hot rows stay L2 resident)
+//             the mushroom stem's fbm2(uv.x*5, p.z) mostly falls outside and is computed.
+//   noise1  : stem fbm1(p.x): i in [-42*128, 32*128] -> [-8192, 8192)
+//   worley  : cell = floor(pixel/5) +- 1 with pixel in [-50, 45] -> cells [-16, 16)
+static NoiseLutHost build_noise_lut()
+{
+    NoiseLutHost t;
+    t.n2_x0 = -2, t.n2_nx = 520, t.n2_y0 = -2048, t.n2_ny = 4096;
+    t.n1_i0 = -8192, t.n1_n = 16384;
+    t.wp_c0 = -16, t.wp_n = 32;
+    t.n2.resize(static_cast<size_t>(t.n2_nx) * t.n2_ny);
+    for (int ix = 0; ix < t.n2_nx; ++ix)
+        for (int iy = 0; iy < t.n2_ny; ++iy)
+            t.n2[static_cast<size_t>(ix) * t.n2_ny + iy] = noise2D(static_cast<float>(ix + t.n2_x0), static_cast<float>(iy + t.n2_y0));
+    t.n1.resize(t.n1_n);
+    for (int i = 0; i < t.n1_n; ++i) t.n1[i] = noise1(static_cast<float>(i + t.n1_i0));
+    t.wp.resize(static_cast<size_t>(t.wp_n) * t.wp_n * 2);
+    for (int cx = 0; cx < t.wp_n; ++cx)
+        for (int cy = 0; cy < t.wp_n; ++cy)
+        {
+            const f2 q = worley_point_eval(f2{static_cast<float>(cx + t.wp_c0), static_cast<float>(cy + t.wp_c0)});
+            t.wp[(static_cast<size_t>(cx) * t.wp_n + cy) * 2 + 0] = q.x;
+            t.wp[(static_cast<size_t>(cx) * t.wp_n + cy) * 2 + 1] = q.y;
+        }
+    return t;
+}
+
+const NoiseLutHost& noise_lut_host()
+{
+    static NoiseLutHost lut;
+    static std::once_flag once;
+    std::call_once(once, [] { lut = build_noise_lut(); });
+    return lut;
+}
+
 // ---- glibc rand() ---------------------------------------------------------------------------------
 // random_r TYPE_3 as published in glibc stdlib/random_r.c: 31-word additive feedback generator
 // x[n] = x[n-31] + x[n-3]; state seeded by the Lehmer LCG 16807 (Schrage's method), the first 310

@@ -37,6 +37,16 @@ struct GlibcRand
 // the reference's order (probe-major p = py*cx*cz + pz*cx + px, ray i = y*s + x).
 void generate_probe_rays(const ddgi_irradiance_field& f, GlibcRand& rng, std::vector<ddgi_probe_ray>& out);
 
+// Host copy of the memoised lattice hashes (ddgi_scene.h: NoiseLut).  Scene independent.
+struct NoiseLutHost
+{
+    int n2_x0, n2_nx, n2_y0, n2_ny;
+    int n1_i0, n1_n;
+    int wp_c0, wp_n;
+    std::vector<float> n2, n1, wp;
+};
+const NoiseLutHost& noise_lut_host();  // cached, thread-safe
+
 // Default light tables (assets/shaders/structs.glsl:61-89, the shipped ones).
 void shipped_lights(int scene, LightK* out, int* n);
 

@@ -8,171 +8,9 @@
 //
 // All arithmetic is the engine's pinned binary32 arithmetic (DESIGN.md "Arithmetic pinning");
 // this file is compiled with -ffp-contract=off so that only the fmaf() written in the source fuse.
-#include <hip/hip_runtime.h>
-
-#include "ddgi_scene.h"
-#include "ddgi_types.h"
+#include "ddgi_device.h"
 
 namespace ddgi {
-
-#define DDGI_D __device__ __forceinline__
-
-// ---- per-ray RNG: wang_hash seed + xorshift32 (probe_pass.comp:45-71) -------------------------
-
-DDGI_D uint32_t wang_hash(uint32_t seed)
-{
-    seed = (seed ^ 61u) ^ (seed >> 16);
-    seed *= 9u;
-    seed = seed ^ (seed >> 4);
-    seed *= 0x27d4eb2du;
-    seed = seed ^ (seed >> 15);
-    return seed;
-}
-
-DDGI_D float rng_next(uint32_t& s)
-{
-    s ^= (s << 13);
-    s ^= (s >> 17);
-    s ^= (s << 5);
-    return static_cast<float>(s) * 0x1.0p-32f;  // uint -> float (RNE), exact scale by 2^-32
-}
-
-// ---- one voxel march + the light spheres of intersect_scene, as resumable per-lane state ------
-
-struct March
-{
-    f3 ro;   // ray origin
-    f3 rd;   // ray direction exactly as given (bounce rays are not unit length)
-    f3 dn;   // normalize(rd): the direction grid_march steps along (intersection.glsl:1055)
-    f3 inv;  // 1/dn per axis (+inf where dn == 0)                                  [P5]
-    f3 cc;   // 1 where dn >= 0 else 0: boundary distance = (cc - fract(p)) * inv   [P5]
-    f3 p;    // current march position
-    float t;   // curr_t
-    float tl;  // nearest light-sphere hit along (ro, rd), +inf if none (intersection.glsl:1264-1279)
-    int it;    // march iterations done
-    int lid;   // which light gave tl
-};
-
-DDGI_D float axis_inv(float d) { return d == 0.0f ? __builtin_inff() : 1.0f / d; }
-
-DDGI_D void start_march(March& m, f3 o, f3 d, const TraceArgs& A)
-{
-    m.ro = o;
-    m.rd = d;
-    m.dn = normalize3(d);
-    m.inv = f3{axis_inv(m.dn.x), axis_inv(m.dn.y), axis_inv(m.dn.z)};
-    m.cc = f3{m.dn.x >= 0.0f ? 1.0f : 0.0f, m.dn.y >= 0.0f ? 1.0f : 0.0f, m.dn.z >= 0.0f ? 1.0f : 0.0f};
-    m.p = o;
-    m.t = 0.0f;
-    m.it = 0;
-    // light spheres of radius 0.1: unit-sphere quadratic in a space scaled by 10 (x/0.1 := x*10)
-    float closest = __builtin_inff();
-    int lid = -1;
-    for (int i = 0; i < A.nl; ++i)
-    {
-        const f3 lp{A.lights[i].pos[0], A.lights[i].pos[1], A.lights[i].pos[2]};
-        const f3 so = (o - lp) * 10.0f;
-        const f3 sd = d * 10.0f;
-        const float qa = dot3(sd, sd);
-        const float qb = -dot3(sd, so);
-        const float qc = dot3(so, so) - 1.0f;
-        float disc = qb * qb - qa * qc;
-        disc = disc > 0.0f ? sqrtf(disc) : __builtin_inff();
-        const float inv_a = 1.0f / qa;
-        float t1 = (qb - disc) * inv_a;
-        float t2 = (qb + disc) * inv_a;
-        t1 = (0.0f < t1 && t1 < closest) ? t1 : __builtin_inff();
-        t2 = (0.0f < t2 && t2 < closest) ? t2 : __builtin_inff();
-        const float ts = gl_min(t1, t2);
-        if (ts < closest) lid = i;
-        closest = gl_min(ts, closest);
-    }
-    m.tl = closest;
-    m.lid = lid;
-}
-
-// Linear cell index of voxel id (x,y,z) clamped into the baked box.  Outside the box the world is
-// the extrusion of the border layer (ddgi_scene_bake.cpp), so clamping is exact.
-DDGI_D int cell_index(const SceneK& S, int x, int y, int z)
-{
-    x = min(max(x, S.lo[0]), S.hi[0]);
-    y = min(max(y, S.lo[1]), S.hi[1]);
-    z = min(max(z, S.lo[2]), S.hi[2]);
-    return z * S.nxy + y * S.nx + x - S.bias;
-}
-
-// One grid_march iteration (intersection.glsl:1059-1069).  Returns true if the voxel reached is
-// occupied.
-DDGI_D bool march_step(March& m, const SceneK& S, const uint32_t* __restrict__ s_bits)
-{
-    const float fx = gl_fract(m.p.x), fy = gl_fract(m.p.y), fz = gl_fract(m.p.z);
-    const float tx = (m.cc.x - fx) * m.inv.x;
-    const float ty = (m.cc.y - fy) * m.inv.y;
-    const float tz = (m.cc.z - fz) * m.inv.z;
-    const float step = fminf(fminf(tx, ty), tz) + 0.0001f;
-    m.t += step;
-    m.p = ray_at(m.ro, m.dn, m.t);
-    const int idx = cell_index(S, static_cast<int>(ceilf(m.p.x)), static_cast<int>(ceilf(m.p.y)),
-                               static_cast<int>(ceilf(m.p.z)));
-    m.it += 1;
-    return (s_bits[idx >> 5] >> (idx & 31)) & 1u;
-}
-
-// True when the march can no longer hit a block: the position is outside the baked box on some
-// axis, moving away from it, and the border layer it left through is entirely empty (so the whole
-// half space beyond is empty).  Skipping the remaining iterations does not change any result.
-DDGI_D bool march_escaped(const March& m, const SceneK& S)
-{
-    const int x = static_cast<int>(ceilf(m.p.x)), y = static_cast<int>(ceilf(m.p.y)), z = static_cast<int>(ceilf(m.p.z));
-    const unsigned fe = S.face_empty;
-    bool out = false;
-    out |= (x < S.lo[0]) && (m.dn.x <= 0.0f) && (fe & 1u);
-    out |= (x > S.hi[0]) && (m.dn.x >= 0.0f) && (fe & 2u);
-    out |= (y < S.lo[1]) && (m.dn.y <= 0.0f) && (fe & 4u);
-    out |= (y > S.hi[1]) && (m.dn.y >= 0.0f) && (fe & 8u);
-    out |= (z < S.lo[2]) && (m.dn.z <= 0.0f) && (fe & 16u);
-    out |= (z > S.hi[2]) && (m.dn.z >= 0.0f) && (fe & 32u);
-    return out;
-}
-
-// calculate_random_dir_hemisphere (probe_pass.comp:147-178)
-DDGI_D f3 hemisphere_dir(f3 n, uint32_t& rng)
-{
-    const float kTwoPi = 6.2831853071795864769252867665590057683943f;
-    const float kSqrtThird = 0.5773502691896257645091487805019574556476f;
-    const float up = sqrtf(rng_next(rng));
-    const float over = sqrtf(1.0f - up * up);
-    const float around = rng_next(rng) * kTwoPi;
-    f3 other;
-    if (fabsf(n.x) < kSqrtThird) other = mk3(1, 0, 0);
-    else if (fabsf(n.y) < kSqrtThird) other = mk3(0, 1, 0);
-    else other = mk3(0, 0, 1);
-    const f3 p1 = normalize3(cross3(n, other));
-    const f3 p2 = normalize3(cross3(n, p1));
-    const pm::SinCos sc = pm::sincos_core(around);
-    const float ca = static_cast<float>(sc.c) * over;
-    const float sa = static_cast<float>(sc.s) * over;
-    return (n * up + p1 * ca) + p2 * sa;
-}
-
-// rgba8 UNORM pack: clamp to [0,1], *255, round to nearest even; NaN -> 0
-DDGI_D uint32_t unorm8(float x)
-{
-    if (!(x > 0.0f)) return 0u;
-    x = x > 1.0f ? 1.0f : x;
-    return static_cast<uint32_t>(rintf(x * 255.0f));
-}
-
-// Slab-major probe slot of reference probe index p = y*cx*cz + z*cx + x  ->  (z*cy + y)*cx + x
-DDGI_D int slab_slot(const GridK& G, int p)
-{
-    const int cxz = G.cx * G.cz;
-    const int y = p / cxz;
-    const int rem = p - y * cxz;
-    const int z = rem / G.cx;
-    const int x = rem - z * G.cx;
-    return (z * G.cy + y) * G.cx + x;
-}
 
 enum : int
 {
@@ -204,6 +42,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
     const uint32_t n_chunks = (A.n_rays + kTraceBlock - 1) / kTraceBlock;
     const float inf = __builtin_inff();
 
+    unsigned long long st_trips = 0, st_lane_steps = 0, st_rounds = 0, st_lane_events = 0;
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x)
     {
         const uint32_t r = chunk * kTraceBlock + threadIdx.x;  // local ray index
@@ -258,6 +97,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
                 const unsigned long long mb = __ballot(marching);
                 if (mb == 0ull) break;
                 if (__popcll(__ballot(waiting)) >= A.wait_threshold) break;
+                st_trips += 1;
+                st_lane_steps += __popcll(mb);
                 if (marching)
                 {
                     const bool occ = march_step(m, A.scene, s_bits);
@@ -275,6 +116,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
             if (__ballot(waiting) == 0ull) break;  // nobody marching, nobody waiting: chunk done
 
             // ---- resolve finished marches (intersect_scene's tail + caller) ----
+            st_rounds += 1;
+            st_lane_events += __popcll(__ballot(waiting));
             if (waiting)
             {
                 waiting = false;
@@ -308,7 +151,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
                             const f3 nn = normalize3(n);
                             const int idx = cell_index(A.scene, static_cast<int>(cell.x), static_cast<int>(cell.y), static_cast<int>(cell.z));
                             const int type = A.scene.types[idx];
-                            hcol = block_albedo(m.p, type, nn);
+                            hcol = (A.ablate & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(m.p, type, nn, A.noise);
                             nraw = nn;
                         }
                         else
@@ -379,7 +222,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
                     {
                         phase = kPrimary;
                         const f3 no = hpos + hnrm * 0.0001f;
-                        const f3 nd = hemisphere_dir(hnrm, rng);
+                        const f3 nd = (A.ablate & 2) ? normalize3(hnrm + mk3(0.3f, 0.2f, 0.1f)) : hemisphere_dir(hnrm, rng);
                         start_march(m, no, nd, A);
                         marching = true;
                     }
@@ -395,6 +238,14 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
             A.albedo[dst] = texel;
             A.distance[dst] = 0u;  // `distances` is never assigned (probe_pass.comp:276,302)
         }
+    }
+    if (A.stats && (threadIdx.x & 63) == 0)
+    {
+        atomicAdd(&A.stats[0], st_trips);
+        atomicAdd(&A.stats[1], st_lane_steps);
+        atomicAdd(&A.stats[2], st_rounds);
+        atomicAdd(&A.stats[3], st_lane_events);
+        atomicAdd(&A.stats[4], 1ull);
     }
 }
 

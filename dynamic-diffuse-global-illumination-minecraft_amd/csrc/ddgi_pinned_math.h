@@ -26,7 +26,7 @@ struct SinCos
 
 // Reduce x to r in [-pi/4, pi/4] with k = rint(x*2/pi): two fma's against a 106-bit pi/2 give
 // |error| < 2^-53 for |x| < 2^31; then 13th/14th-order Taylor polynomials (truncation < 2e-14).
-DDGI_HD SinCos sincos_core(float xf)
+__host__ __device__ __attribute__((noinline)) inline SinCos sincos_core(float xf)
 {
     const double kTwoOverPi = 0x1.45f306dc9c883p-1;
     const double kPio2Hi = 0x1.921fb54442d18p+0;

@@ -92,18 +92,46 @@ DDGI_HD float noise2D(float px, float py)  // :402
 {
     return gl_fract(hash_sin(hash_dot2(f2{px, py}, f2{127.1f, 311.7f})) * 43758.5453f);
 }
-DDGI_HD float interp_noise2D(float x, float y)  // :404-419
+// Memoised lattice hashes.  Every hash above is a pure function of INTEGER lattice coordinates, so
+// the host evaluates it once over the rectangle of lattice points the scenes actually touch
+// (ddgi_host.cpp: build_noise_lut) and the kernels load the stored binary32 value instead of
+// re-evaluating a binary64 sine; outside the rectangle (or with null tables) the hash is computed.
+// A stored value IS the function's value, so results are unchanged bit for bit.
+struct NoiseLut
+{
+    // noise2D(ix, iy) for ix in [x0, x0+nx), iy in [y0, y0+ny); index (ix-x0)*ny + (iy-y0)
+    const float* n2 = nullptr;
+    int n2_x0 = 0, n2_nx = 0, n2_y0 = 0, n2_ny = 0;
+    // noise1(i) for i in [n1_i0, n1_i0+n1_n)
+    const float* n1 = nullptr;
+    int n1_i0 = 0, n1_n = 0;
+    // worley_point(cx, cy) for cx, cy in [wp_c0, wp_c0+wp_n): 2 floats each, index ((cx-c0)*n + (cy-c0))*2
+    const float* wp = nullptr;
+    int wp_c0 = 0, wp_n = 0;
+};
+
+DDGI_HD float interp_noise2D(float x, float y, const NoiseLut& L = NoiseLut())  // :404-419
 {
     const float fx0 = floorf(x), fy0 = floorf(y);
     const int ix = gl_int(fx0), iy = gl_int(fy0);
     const float tx = gl_fract(x), ty = gl_fract(y);
-    const float x0 = static_cast<float>(ix), x1 = static_cast<float>(ix + 1);
-    const float y0 = static_cast<float>(iy), y1 = static_cast<float>(iy + 1);
-    const float a = noise2D(x0, y0), b = noise2D(x1, y0), c = noise2D(x0, y1), d = noise2D(x1, y1);
+    float a, b, c, d;
+    const unsigned ux = static_cast<unsigned>(ix - L.n2_x0), uy = static_cast<unsigned>(iy - L.n2_y0);
+    if (L.n2 && ux < static_cast<unsigned>(L.n2_nx - 1) && uy < static_cast<unsigned>(L.n2_ny - 1))
+    {
+        const float* q = L.n2 + static_cast<size_t>(ux) * L.n2_ny + uy;
+        a = q[0], c = q[1], b = q[L.n2_ny], d = q[L.n2_ny + 1];
+    }
+    else
+    {
+        const float x0 = static_cast<float>(ix), x1 = static_cast<float>(ix + 1);
+        const float y0 = static_cast<float>(iy), y1 = static_cast<float>(iy + 1);
+        a = noise2D(x0, y0), b = noise2D(x1, y0), c = noise2D(x0, y1), d = noise2D(x1, y1);
+    }
     return gl_mix(gl_mix(a, b, tx), gl_mix(c, d, tx), ty);
 }
 // :421-435 — freq = 2^i, amp = 2^-i for i = 1..8 (P8: exact powers of two)
-DDGI_HD float fbm2(float x, float y)
+DDGI_HD float fbm2(float x, float y, const NoiseLut& L = NoiseLut())
 {
     float total = 0.0f;
     float freq = 1.0f, amp = 1.0f;
@@ -111,45 +139,61 @@ DDGI_HD float fbm2(float x, float y)
     {
         freq *= 2.0f;
         amp *= 0.5f;
-        total += interp_noise2D(x * freq, y * freq) * amp;
+        total += interp_noise2D(x * freq, y * freq, L) * amp;
     }
     return total;
 }
 DDGI_HD float noise1(float i) { return gl_fract(hash_sin(203.311f * i)); }  // :437-439 (.x only)
-DDGI_HD float interp_noise1D(float x)                                        // :441-448
+DDGI_HD float noise1_at(float i, const NoiseLut& L)
+{
+    const unsigned u = static_cast<unsigned>(gl_int(i) - L.n1_i0);
+    if (L.n1 && u < static_cast<unsigned>(L.n1_n)) return L.n1[u];
+    return noise1(i);
+}
+DDGI_HD float interp_noise1D(float x, const NoiseLut& L = NoiseLut())  // :441-448
 {
     const float i0 = floorf(x);
-    return gl_mix(noise1(i0), noise1(i0 + 1.0f), gl_fract(x));
+    return gl_mix(noise1_at(i0, L), noise1_at(i0 + 1.0f, L), gl_fract(x));
 }
-DDGI_HD float fbm1(float x)  // :450-463 — i = 0..7
+DDGI_HD float fbm1(float x, const NoiseLut& L = NoiseLut())  // :450-463 — i = 0..7
 {
     float total = 0.0f;
     float freq = 1.0f, amp = 1.0f;
     for (int i = 0; i < 8; ++i)
     {
-        total += interp_noise1D(x * freq) * amp;
+        total += interp_noise1D(x * freq, L) * amp;
         freq *= 2.0f;
         amp *= 0.5f;
     }
     return total;
 }
-DDGI_HD f2 worley_point(f2 cell)  // generate_point :467-471 (cell_size 5)
+DDGI_HD f2 worley_point_eval(f2 cell)  // generate_point :467-471 (cell_size 5)
 {
     const float a = hash_sin(hash_dot2(cell, f2{127.1f, 311.7f}));
     const float b = hash_sin(hash_dot2(cell, f2{269.5f, 183.3f}) * 43758.5453f);
     return f2{(cell.x + gl_fract(a)) * 5.0f, (cell.y + gl_fract(b)) * 5.0f};
 }
-DDGI_HD float worley(f2 pixel)  // :473-499
+DDGI_HD f2 worley_point(f2 cell, const NoiseLut& L)
+{
+    const unsigned ux = static_cast<unsigned>(gl_int(cell.x) - L.wp_c0), uy = static_cast<unsigned>(gl_int(cell.y) - L.wp_c0);
+    if (L.wp && ux < static_cast<unsigned>(L.wp_n) && uy < static_cast<unsigned>(L.wp_n))
+    {
+        const float* q = L.wp + (static_cast<size_t>(ux) * L.wp_n + uy) * 2;
+        return f2{q[0], q[1]};
+    }
+    return worley_point_eval(cell);
+}
+DDGI_HD float worley(f2 pixel, const NoiseLut& L = NoiseLut())  // :473-499
 {
     const f2 cell{floorf(pixel.x / 5.0f), floorf(pixel.y / 5.0f)};
-    f2 q = worley_point(cell);
+    f2 q = worley_point(cell, L);
     float best = length2(f2{pixel.x - q.x, pixel.y - q.y});
     for (int i = -1; i <= 1; ++i)
     {
         const float cxn = cell.x + static_cast<float>(i);
         for (int j = -1; j <= 1; ++j)
         {
-            q = worley_point(f2{cxn, cell.y + static_cast<float>(j)});
+            q = worley_point(f2{cxn, cell.y + static_cast<float>(j)}, L);
             const float d = length2(f2{pixel.x - q.x, pixel.y - q.y});
             if (d < best) best = d;
         }
@@ -331,7 +375,7 @@ DDGI_HD float dots_pattern(f2 q, float radius, float cell)
 
 DDGI_HD f3 cell_id(f3 p) { return f3{ceilf(p.x), ceilf(p.y), ceilf(p.z)}; }
 
-DDGI_HD f3 block_albedo(f3 p, int type, f3 n)
+DDGI_HD f3 block_albedo(f3 p, int type, f3 n, const NoiseLut& L = NoiseLut())
 {
     switch (type)
     {
@@ -348,10 +392,10 @@ DDGI_HD f3 block_albedo(f3 p, int type, f3 n)
         case 4: return mk3(0.0f, 0.0f, 0.95f);
         case 5: return mk3(0.95f, 0.95f, 0.95f);
         case 6:  // :920-927
-            return worley(f2{p.x, p.z}) < 0.35f ? mk3(1.0f, 0.0f, 0.223f) : mk3(1.0f, 0.2f, 0.0f);
+            return worley(f2{p.x, p.z}, L) < 0.35f ? mk3(1.0f, 0.0f, 0.223f) : mk3(1.0f, 0.2f, 0.0f);
         case 7:  // :928-936
         {
-            const float w = worley(f2{p.x + 5.0f, p.z + 5.0f});
+            const float w = worley(f2{p.x + 5.0f, p.z + 5.0f}, L);
             if (w < 0.25f) return mk3(0.8f - (w * (0.5f - 0.8f)), 1.0f - (w * (0.5f - 1.0f)), 0.0f - (w * (0.5f - 0.0f)));
             return mk3(1.0f, 0.0f, 0.011f);
         }
@@ -366,8 +410,8 @@ DDGI_HD f3 block_albedo(f3 p, int type, f3 n)
         case 9:  // :954-963 — stem
         {
             const f2 g = face_uv(p, n);
-            float v = fbm2(g.x * 5.0f, p.z);
-            v += 0.5f * fbm1(p.x);
+            float v = fbm2(g.x * 5.0f, p.z, L);
+            v += 0.5f * fbm1(p.x, L);
             v = gl_clamp(v, 0.0f, 1.0f);
             return gl_mix3(mk3(0.3f, 0.1f, 0.3f), mk3(0.9f, 0.9f, 0.9f), v);
         }
@@ -382,7 +426,7 @@ DDGI_HD f3 block_albedo(f3 p, int type, f3 n)
             else if (p.y < 6.0f) band = mk3(0.368f, 0.203f, 0.415f);
             else if (p.y < 11.0f) band = mk3(0.470f, 0.270f, 0.729f);
             const f2 g = face_uv(p, n);
-            const float r = fbm2(0.05f, (g.y + p.y) * 0.3f);
+            const float r = fbm2(0.05f, (g.y + p.y) * 0.3f, L);
             const f3 blue = mk3(0.0f, 0.666f, 1.0f), red = mk3(0.294f, 0.007f, 0.152f);
             f3 wall = blue;
             if (p.x < -1.0f) wall = red;
@@ -396,7 +440,7 @@ DDGI_HD f3 block_albedo(f3 p, int type, f3 n)
             float r = random1(cell_id(p)) / 3.0f;
             f3 c = gl_mix3(base, mk3(0.901f, 0.992f, 0.427f), r);
             const f2 g = face_uv(p, n);
-            r = fbm2(g.x * 2.0f, g.y * 2.0f);
+            r = fbm2(g.x * 2.0f, g.y * 2.0f, L);
             return gl_mix3(c, base, r / 2.0f);
         }
         case 12:  // :1022-1034 moss, :1035-1046 mold — same pattern, different base colour
@@ -405,7 +449,7 @@ DDGI_HD f3 block_albedo(f3 p, int type, f3 n)
             const f2 g = face_uv(p, n);
             const f2 c{g.x - 0.5f, g.y - 0.5f};
             const f2 axis = normalize2(c);
-            const float r = interp_noise2D(axis.x, axis.y);
+            const float r = interp_noise2D(axis.x, axis.y, L);
             const f3 base = (type == 12) ? mk3(0.356f, 1.0f, 0.101f) : mk3(0.803f, 1.0f, 0.341f);
             return gl_mix3(base, mk3(0.619f, 1.0f, 0.278f), 2.0f * length2(c) + r * 0.3f);
         }

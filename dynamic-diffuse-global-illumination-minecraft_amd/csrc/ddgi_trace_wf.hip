@@ -1,0 +1,577 @@
+// ddgi_trace_wf.hip — k_probe_trace_wf: the REF-mode probe update (assets/shaders/probe_pass.comp:main
+// and everything it calls) scheduled as a wavefront path tracer inside ONE persistent 1024-lane
+// workgroup per CU.  Same per-ray arithmetic, in the same order, as k_probe_trace_ref
+// (ddgi_kernels.hip), hence bit-identical results; only the schedule differs.
+//
+// Why a different schedule: per ray the path alternates ~15 voxel marches (1..125 dependent steps
+// each, heavy tailed) with hit shading whose cost depends on the block type hit.  With one ray
+// bound to one lane, a wave spends ~3/4 of its march-loop issue slots on parked lanes and every
+// shading round pays for every block type present in the wave.
+//
+// Here rays are NOT bound to lanes.  A pool of P rays (P ~ 1.3 x the lane count) lives in LDS as a
+// structure of arrays (24 dwords/ray: the reference's Ray + Isect + accumulators) next to the
+// scene's occupancy bitmap, and the 16 waves run dense phases over compacted lists of pool slots:
+//   A  scan    refill free slots with new rays (48 B ProbeRay records), list the slots whose next
+//              action is a voxel march
+//   B  march   every lane pulls march tasks from the list (wave-aggregated LDS atomic), steps them,
+//              and pulls another when its own finishes; once the list is drained the stragglers run
+//              kWfTailSteps more steps and are parked (t, iteration count) until the next round
+//   C  sort    finished marches are bucketed by what has to happen next: hit shading per block
+//              type (the procedural albedo is a switch over 13 block types), light hit / miss,
+//              light-feeler result
+//   D  events  waves claim 64-lane groups of ONE bucket, most expensive buckets first:
+//              hit shading (+ feeler set-up) or light evaluation (+ bounce set-up, or texel
+//              store and slot release)
+// ------------------------------------------------------------------------------------------------
+#include "ddgi_device.h"
+
+namespace ddgi {
+
+constexpr int kWfThreads = 1024;  // 16 wave64 = 4 per SIMD
+constexpr int kWfWaves = kWfThreads / 64;
+constexpr int kWfMaxPool = 2 * kWfThreads;
+constexpr int kWfTailSteps = 16;     // straggler steps after the march list is drained
+constexpr int kWfFetchLanes = 16;    // pull new march tasks once this many lanes are idle
+constexpr uint32_t kWfChunk = 4096;  // rays a workgroup claims at a time from the global counter
+constexpr int kWfBuckets = 9;
+
+enum : uint32_t
+{
+    kSlotEmpty = 0,
+    kSlotMarch = 1,
+    kSlotEvPrimary = 2,
+    kSlotEvFeeler = 3,
+    // flags word: [1:0] state, [2] feeler march, [3] voxel hit, [11:4] march iterations,
+    //             [15:12] light id + 1, [19:16] block type of the voxel hit
+    kFlagFeeler = 4,
+    kFlagHit = 8,
+};
+
+struct WfShared  // control block at the start of dynamic LDS (32 dwords)
+{
+    uint32_t n_march, head_march, cur, end;
+    uint32_t live, group_head, n_groups, pad;
+    uint32_t bucket_count[kWfBuckets + 1];  // entries per bucket
+    uint32_t bucket_base[kWfBuckets + 1];   // first list index of each bucket
+    uint32_t pad2[4];
+};
+static_assert(sizeof(WfShared) == 32 * 4, "control block is 32 dwords");
+
+struct WfPool
+{
+    float* ro[3];   // march origin (for a light feeler: the hit position)
+    float* dn[3];   // normalize(direction): the direction the march steps along
+    float* inv[3];  // 1/dn (+inf where dn == 0)
+    float* t;
+    float* tl;
+    uint32_t* flags;
+    float* hn[3];   // hit normal (live while the feelers of a hit are in flight)
+    float* hc[3];   // hit albedo; during a PRIMARY march: the ray direction exactly as given
+    float* col[3];
+    uint32_t* rng;
+    uint32_t* cnt;  // [7:0] bounce, [11:8] light index, [15:12] visible lights
+    uint32_t* dst;
+    float* dir[3];  // accumulated direct light; only when there is more than one light
+    uint16_t* list;
+};
+
+constexpr int wf_dwords_per_ray(bool multi_light) { return multi_light ? 27 : 24; }
+
+DDGI_D f3 ld3(float* const* a, uint32_t i) { return f3{a[0][i], a[1][i], a[2][i]}; }
+DDGI_D void st3(float* const* a, uint32_t i, f3 v)
+{
+    a[0][i] = v.x;
+    a[1][i] = v.y;
+    a[2][i] = v.z;
+}
+
+// Appends one entry per lane with pred to a list whose fill count is *counter; returns the lane's
+// index (valid only where pred).  One LDS atomic per wave.
+DDGI_D uint32_t wave_append(bool pred, uint32_t* counter, int lane)
+{
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    const uint32_t cnt = static_cast<uint32_t>(__popcll(mask));
+    uint32_t base = 0;
+    const int leader = __ffsll(static_cast<long long>(mask)) - 1;
+    if (lane == leader) base = atomicAdd(counter, cnt);
+    base = __shfl(base, leader);
+    return base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
+}
+
+// Which event bucket a block type's hit shading belongs to; buckets are processed in this order,
+// most expensive first (ddgi_scene.h: block_albedo).
+DDGI_D uint32_t shade_bucket(int type)
+{
+    switch (type)
+    {
+        case 9: return 0;             // mushroom stem: two fbm's, lattice mostly outside the LUT
+        case 10: return 1;            // cave wall
+        case 11: return 2;            // cave ground
+        case 12: case 13: return 3;   // moss / mold
+        case 6: case 7: return 4;     // worley caps
+        case 8: return 5;             // dotted cap
+        default: return 6;            // flat colours
+    }
+}
+constexpr uint32_t kBucketNoBlock = 7;  // primary march that ended on a light sphere or missed
+constexpr uint32_t kBucketFeeler = 8;
+
+// A new voxel march for pool slot `slot` (intersect_scene's set-up, intersection.glsl:1253-1279 +
+// grid_march's, 1053-1058): origin, normalised direction and its reciprocal, light spheres.
+DDGI_D void wf_post_march(const WfPool& P, uint32_t slot, f3 o, f3 d, bool feeler, const TraceArgs& A)
+{
+    float tl;
+    int lid;
+    light_spheres(o, d, A, tl, lid);
+    const f3 dn = normalize3(d);
+    st3(P.ro, slot, o);
+    st3(P.dn, slot, dn);
+    st3(P.inv, slot, f3{axis_inv(dn.x), axis_inv(dn.y), axis_inv(dn.z)});
+    if (!feeler) st3(P.hc, slot, d);  // the hit albedo is dead until this march is shaded
+    P.t[slot] = 0.0f;
+    P.tl[slot] = tl;
+    P.flags[slot] = kSlotMarch | (feeler ? kFlagFeeler : 0u) | (static_cast<uint32_t>(lid + 1) << 12);
+}
+
+DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, const TraceArgs& A)
+{
+    const f3 c = div3(color, static_cast<float>(A.max_bounces));  // Q14: always /max_bounces
+    const uint32_t texel = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
+    const uint32_t dst = P.dst[slot];
+    A.albedo[dst] = texel;
+    A.distance[dst] = 0u;  // `distances` is never assigned (probe_pass.comp:276,302)
+    P.flags[slot] = kSlotEmpty;
+}
+
+// End of get_direct_lighting for one hit: accumulate, then bounce or finish (probe_pass.comp:286-292).
+DDGI_D void wf_lighting_done(const WfPool& P, uint32_t slot, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A)
+{
+    const f3 color = ld3(P.col, slot) + contribution;
+    const uint32_t bounce = (cnt & 255u) + 1u;
+    if (static_cast<int>(bounce) < A.max_bounces)
+    {
+        st3(P.col, slot, color);
+        P.cnt[slot] = bounce;
+        uint32_t rng = P.rng[slot];
+        const f3 no = hpos + hnrm * 0.0001f;
+        const f3 nd = (A.ablate & 2) ? normalize3(hnrm + mk3(0.3f, 0.2f, 0.1f)) : hemisphere_dir(hnrm, rng);
+        P.rng[slot] = rng;
+        wf_post_march(P, slot, no, nd, false, A);
+    }
+    else
+        wf_finish_ray(P, slot, color, A);
+}
+
+__global__ __launch_bounds__(kWfThreads) void k_probe_trace_wf(const TraceArgs A, const int pool_size, uint32_t* __restrict__ work_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t wf_lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t PS = static_cast<uint32_t>(pool_size);
+    const bool multi_light = A.nl > 1;
+    const int tail_steps = A.wf_tail > 0 ? A.wf_tail : kWfTailSteps;
+    const int fetch_lanes = A.wf_fetch > 0 ? A.wf_fetch : kWfFetchLanes;
+
+    // ---- carve LDS: control block | occupancy bitmap | pool arrays | slot list ----
+    WfShared* sh = reinterpret_cast<WfShared*>(wf_lds);
+    uint32_t* s_bits = wf_lds + 32;
+    uint32_t* cursor = s_bits + ((A.scene.nwords + 3) & ~3);
+    WfPool P;
+    auto takef = [&]() { float* p = reinterpret_cast<float*>(cursor); cursor += PS; return p; };
+    auto takeu = [&]() { uint32_t* p = cursor; cursor += PS; return p; };
+    for (int a = 0; a < 3; ++a) P.ro[a] = takef();
+    for (int a = 0; a < 3; ++a) P.dn[a] = takef();
+    for (int a = 0; a < 3; ++a) P.inv[a] = takef();
+    P.t = takef();
+    P.tl = takef();
+    P.flags = takeu();
+    for (int a = 0; a < 3; ++a) P.hn[a] = takef();
+    for (int a = 0; a < 3; ++a) P.hc[a] = takef();
+    for (int a = 0; a < 3; ++a) P.col[a] = takef();
+    P.rng = takeu();
+    P.cnt = takeu();
+    P.dst = takeu();
+    for (int a = 0; a < 3; ++a) P.dir[a] = multi_light ? takef() : nullptr;
+    P.list = reinterpret_cast<uint16_t*>(cursor);
+
+    for (int i = tid; i < A.scene.nwords; i += kWfThreads) s_bits[i] = A.scene.bits[i];
+    for (uint32_t i = tid; i < PS; i += kWfThreads) P.flags[i] = kSlotEmpty;
+    const uint32_t n_chunks = (A.n_rays + kWfChunk - 1) / kWfChunk;
+    if (tid == 0)
+    {
+        sh->n_march = sh->head_march = 0;
+        sh->live = 0;
+        sh->group_head = sh->n_groups = 0;
+        const uint32_t c = atomicAdd(work_counter, 1u);
+        sh->cur = c < n_chunks ? c * kWfChunk : 0u;
+        sh->end = c < n_chunks ? min(c * kWfChunk + kWfChunk, A.n_rays) : 0u;
+    }
+    if (tid <= kWfBuckets) sh->bucket_count[tid] = 0u;
+    __syncthreads();
+
+    const GridK& G = A.grid;
+    const int rays_per_probe = G.s * G.s;
+    const float inf = __builtin_inff();
+    unsigned long long st_trips = 0, st_lane_steps = 0, st_groups = 0, st_lane_events = 0, st_iters = 0, st_fetches = 0;
+    long long cy[6] = {0, 0, 0, 0, 0, 0};
+
+    for (;;)
+    {
+        // ================= A: refill free slots, list the marches =================
+        const long long c0 = A.stats ? clock64() : 0;
+        bool any_live = false;
+        for (uint32_t slot = tid; slot < PS; slot += kWfThreads)
+        {
+            uint32_t fl = P.flags[slot];
+            // claim a new ray for an empty slot (wave-aggregated claim on the workgroup's range)
+            const bool want = (fl & 3u) == kSlotEmpty;
+            const unsigned long long wm = __ballot(want);
+            if (wm != 0ull)
+            {
+                uint32_t base = 0;
+                const int leader = __ffsll(static_cast<long long>(wm)) - 1;
+                if (lane == leader) base = atomicAdd(&sh->cur, static_cast<uint32_t>(__popcll(wm)));
+                base = __shfl(base, leader);
+                const uint32_t r = base + static_cast<uint32_t>(__popcll(wm & ((1ull << lane) - 1ull)));
+                if (want && r < sh->end)
+                {
+                    // local (y, zl, x) probe enumeration -> reference probe index p -> global ray index
+                    const int pl = static_cast<int>(r / static_cast<uint32_t>(rays_per_probe));
+                    const int i = static_cast<int>(r) - pl * rays_per_probe;
+                    const int slab_row = G.czl * G.cx;
+                    const int y = pl / slab_row;
+                    const int rem = pl - y * slab_row;
+                    const int p = y * G.cx * G.cz + G.z0 * G.cx + rem;
+                    const uint32_t global_ray = static_cast<uint32_t>(p) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i);
+                    const float4* rec = A.rays + 3 * static_cast<size_t>(r);
+                    const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+                    const int dst_probe = static_cast<int>(rc.x);  // int(probe_info.x), probe_pass.comp:269
+                    P.dst[slot] = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.s + static_cast<int>(rc.y);
+                    P.rng[slot] = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
+                    P.cnt[slot] = 0u;
+                    st3(P.col, slot, mk3(0, 0, 0));
+                    wf_post_march(P, slot, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), false, A);
+                    fl = kSlotMarch;
+                }
+            }
+            const bool is_march = (fl & 3u) == kSlotMarch;
+            const uint32_t idx = wave_append(is_march, &sh->n_march, lane);
+            if (is_march) P.list[idx] = static_cast<uint16_t>(slot);
+            any_live |= (fl & 3u) != kSlotEmpty;
+        }
+        if (__ballot(any_live) != 0ull && lane == 0) sh->live = 1u;
+        __syncthreads();
+        if (sh->live == 0u) break;  // nothing in flight and no ray left to claim
+        st_iters += 1;
+        if (st_iters > (1ull << 20)) break;  // safety net: never spin forever on the GPU
+
+        // ================= B: march =================
+        const long long c1 = A.stats ? clock64() : 0;
+        if (tid == 0 && sh->cur >= sh->end)  // range used up: claim the next chunk for the following round
+        {
+            const uint32_t c = atomicAdd(work_counter, 1u);
+            sh->cur = c < n_chunks ? c * kWfChunk : 0u;
+            sh->end = c < n_chunks ? min(c * kWfChunk + kWfChunk, A.n_rays) : 0u;
+        }
+        {
+            const uint32_t n_list = sh->n_march;
+            March m;
+            m.ro = m.rd = m.dn = m.inv = m.cc = m.p = mk3(0, 0, 0);
+            m.t = 0.0f, m.tl = inf, m.it = 0, m.lid = -1, m.cell = 0;
+            uint32_t slot = 0, fl = 0;
+            bool have = false, exhausted = false;
+            int tail = 0, trips = 0;
+            for (;;)
+            {
+                const unsigned long long idle_mask = __ballot(!have);
+                if (!exhausted && (__popcll(idle_mask) >= fetch_lanes))
+                {
+                    st_fetches += 1;
+                    const uint32_t idx = wave_append(!have, &sh->head_march, lane);
+                    const uint32_t top = __shfl(idx, 63 - __builtin_clzll(idle_mask)) + 1u;  // one past the wave's last claim
+                    if (!have && idx < n_list)
+                    {
+                        slot = P.list[idx];
+                        fl = P.flags[slot];
+                        m.ro = ld3(P.ro, slot);
+                        m.dn = ld3(P.dn, slot);
+                        m.inv = ld3(P.inv, slot);
+                        m.t = P.t[slot];
+                        m.tl = P.tl[slot];
+                        m.it = static_cast<int>((fl >> 4) & 255u);
+                        // inv is +inf for dn == +-0, so (inv > 0) == (dn >= 0)
+                        m.cc = f3{m.inv.x > 0.0f ? 1.0f : 0.0f, m.inv.y > 0.0f ? 1.0f : 0.0f, m.inv.z > 0.0f ? 1.0f : 0.0f};
+                        m.p = ray_at(m.ro, m.dn, m.t);
+                        have = true;
+                    }
+                    if (top >= n_list) exhausted = true;
+                }
+                const unsigned long long hb = __ballot(have);
+                if (hb == 0ull)
+                {
+                    if (exhausted) break;
+                    continue;
+                }
+                st_trips += 1;
+                st_lane_steps += __popcll(hb);
+                if (have)
+                {
+                    const bool occ = march_step(m, A.scene, s_bits);
+                    bool fin = occ | (m.t >= m.tl) | (m.it >= kMarchIters);
+                    if (!fin && ((trips & 7) == 7)) fin = march_escaped(m, A.scene);
+                    if (fin)
+                    {
+                        const uint32_t type = occ ? static_cast<uint32_t>(A.scene.types[m.cell]) : 0u;
+                        P.t[slot] = m.t;
+                        P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) |
+                                        (occ ? kFlagHit : 0u) | (type << 16);
+                        have = false;
+                    }
+                }
+                ++trips;
+                if (exhausted && ++tail >= tail_steps)
+                {
+                    if (have)  // park the straggler: it resumes from (t, it) next round
+                    {
+                        P.t[slot] = m.t;
+                        P.flags[slot] = (fl & ~0xff0u) | (static_cast<uint32_t>(m.it) << 4);
+                    }
+                    break;
+                }
+            }
+        }
+        const long long c1b = A.stats ? clock64() : 0;
+        __syncthreads();
+
+        // ================= C: bucket the finished marches =================
+        const long long c2 = A.stats ? clock64() : 0;
+        uint32_t my_bucket[2], my_rank[2];
+        {
+            int k = 0;
+            for (uint32_t slot = tid; slot < PS; slot += kWfThreads, ++k)
+            {
+                const uint32_t fl = P.flags[slot];
+                const uint32_t st = fl & 3u;
+                uint32_t b = kWfBuckets;  // none
+                if (st == kSlotEvFeeler) b = kBucketFeeler;
+                else if (st == kSlotEvPrimary)
+                {
+                    const bool block_wins = (fl & kFlagHit) && (P.t[slot] < P.tl[slot]);
+                    b = block_wins ? shade_bucket(static_cast<int>((fl >> 16) & 15u)) : kBucketNoBlock;
+                }
+                my_bucket[k] = b;
+                my_rank[k] = (b < kWfBuckets) ? atomicAdd(&sh->bucket_count[b], 1u) : 0u;
+            }
+        }
+        __syncthreads();
+        if (tid == 0)
+        {
+            uint32_t base = 0, groups = 0;
+            for (int b = 0; b < kWfBuckets; ++b)
+            {
+                sh->bucket_base[b] = base;
+                base += sh->bucket_count[b];
+                groups += (sh->bucket_count[b] + 63u) / 64u;
+            }
+            sh->n_groups = groups;
+            sh->group_head = 0;
+            sh->n_march = sh->head_march = 0;
+            sh->live = 0;
+        }
+        __syncthreads();
+        {
+            int k = 0;
+            for (uint32_t slot = tid; slot < PS; slot += kWfThreads, ++k)
+                if (my_bucket[k] < kWfBuckets) P.list[sh->bucket_base[my_bucket[k]] + my_rank[k]] = static_cast<uint16_t>(slot);
+        }
+        __syncthreads();
+
+        // ================= D: events, in 64-lane groups of one bucket =================
+        const long long c3 = A.stats ? clock64() : 0;
+        for (;;)
+        {
+            uint32_t g = 0;
+            if (lane == 0) g = atomicAdd(&sh->group_head, 1u);
+            g = __shfl(g, 0);
+            if (g >= sh->n_groups) break;
+            // locate the group: bucket b, 64-entry window w inside it
+            uint32_t b = 0, first = 0;
+            for (; b < kWfBuckets; ++b)
+            {
+                const uint32_t gb = (sh->bucket_count[b] + 63u) / 64u;
+                if (g < first + gb) break;
+                first += gb;
+            }
+            const uint32_t e = (g - first) * 64u + lane;
+            const bool valid = e < sh->bucket_count[b];
+            st_groups += 1;
+            st_lane_events += __popcll(__ballot(valid));
+            if (!valid) continue;
+            const uint32_t slot = P.list[sh->bucket_base[b] + e];
+            const uint32_t fl = P.flags[slot];
+            const float t = P.t[slot], tl = P.tl[slot];
+            const f3 ro = ld3(P.ro, slot);
+            const bool block_wins = (fl & kFlagHit) && (t < tl);  // temp_isect.t < closest_t
+            const bool any_hit = block_wins || (tl < inf);       // closest_t < INF
+            if (b != kBucketFeeler)
+            {
+                if (!any_hit)
+                {
+                    wf_finish_ray(P, slot, ld3(P.col, slot), A);  // probe_pass.comp:288-290 break
+                    continue;
+                }
+                const f3 rd = ld3(P.hc, slot);  // the ray direction as given (see WfPool::hc)
+                f3 nraw, hcol;
+                float th;
+                if (block_wins)
+                {
+                    th = t;
+                    const f3 p = ray_at(ro, ld3(P.dn, slot), t);  // the march position at the hit
+                    const f3 cell = cell_id(p);
+                    const f3 centre = f3{cell.x - 0.5f, cell.y - 0.5f, cell.z - 0.5f};
+                    const f3 diff = normalize3(p - centre);
+                    // axis of the largest |component|, first wins on ties (:1075-1086)
+                    f3 n = mk3(0, 0, 0);
+                    float best = 0.0f;
+                    if (fabsf(diff.x) > best) { best = fabsf(diff.x); n = mk3(gl_sign(diff.x), 0, 0); }
+                    if (fabsf(diff.y) > best) { best = fabsf(diff.y); n = mk3(0, gl_sign(diff.y), 0); }
+                    if (fabsf(diff.z) > best) { best = fabsf(diff.z); n = mk3(0, 0, gl_sign(diff.z)); }
+                    const f3 nn = normalize3(n);
+                    const int type = static_cast<int>((fl >> 16) & 15u);
+                    hcol = (A.ablate & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
+                    nraw = nn;
+                }
+                else
+                {
+                    th = tl;
+                    const LightK& L = A.lights[static_cast<int>((fl >> 12) & 15u) - 1];
+                    const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
+                    nraw = ray_at((ro - lp) * 10.0f, rd * 10.0f, th);  // sphere-space position
+                    hcol = mk3(0, 0, 0);  // Q12: unassigned Material, pinned to zero
+                }
+                const f3 hnrm = normalize3(nraw);
+                const f3 hpos = ray_at(ro, rd, th) + hnrm * 0.001f;
+                st3(P.hn, slot, hnrm);
+                const uint32_t cnt = P.cnt[slot] & 255u;  // light index 0, no visible light yet
+                if (A.nl > 0)
+                {
+                    P.cnt[slot] = cnt;
+                    if (multi_light) st3(P.dir, slot, mk3(0, 0, 0));
+                    const LightK& L = A.lights[0];
+                    wf_post_march(P, slot, hpos, normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos), true, A);
+                    st3(P.hc, slot, hcol);
+                }
+                else
+                {
+                    st3(P.hc, slot, hcol);
+                    wf_lighting_done(P, slot, mk3(0, 0, 0), hpos, hnrm, cnt, A);
+                }
+            }
+            else  // a light feeler came back: get_direct_lighting's loop body (probe_pass.comp:186-207)
+            {
+                const f3 hpos = ro;  // a feeler starts at the hit position
+                const f3 hnrm = ld3(P.hn, slot), hcol = ld3(P.hc, slot);
+                const uint32_t cnt = P.cnt[slot];
+                int li = static_cast<int>((cnt >> 8) & 15u);
+                int nvis = static_cast<int>((cnt >> 12) & 15u);
+                f3 direct = multi_light ? ld3(P.dir, slot) : mk3(0, 0, 0);
+                const LightK& L = A.lights[li];
+                const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
+                f3 contribution = mk3(0, 0, 0);
+                bool early = false;
+                if (any_hit)
+                {
+                    const float lambert = gl_clamp(dot3(normalize3(hnrm), normalize3(lp - hpos)), 0.0f, 1.0f);
+                    if (!block_wins)
+                    {
+                        const float dist = length3(lp - hpos);
+                        const f3 lc{L.col[0], L.col[1], L.col[2]};
+                        direct = direct + div3((lc * lambert) * L.intensity, dist);
+                        nvis += 1;
+                    }
+                    else
+                    {
+                        contribution = (hcol * 0.2f) * lambert;  // Q10 early return
+                        early = true;
+                    }
+                }
+                li += 1;
+                if (!early && li < A.nl)
+                {
+                    P.cnt[slot] = (cnt & 255u) | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
+                    if (multi_light) st3(P.dir, slot, direct);
+                    const LightK& Ln = A.lights[li];
+                    wf_post_march(P, slot, hpos, normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos), true, A);
+                }
+                else
+                {
+                    if (!early && nvis != 0) contribution = div3(hcol * direct, static_cast<float>(nvis));
+                    wf_lighting_done(P, slot, contribution, hpos, hnrm, cnt, A);
+                }
+            }
+        }
+        const long long c4 = A.stats ? clock64() : 0;
+        __syncthreads();
+        if (tid <= kWfBuckets) sh->bucket_count[tid] = 0u;  // read again only after the next barrier
+        if (A.stats)
+        {
+            const long long c5 = clock64();
+            cy[0] += c1 - c0;   // A incl. its barrier
+            cy[1] += c1b - c1;  // B work
+            cy[2] += c2 - c1b;  // B barrier wait
+            cy[3] += c3 - c2;   // C incl. barriers
+            cy[4] += c4 - c3;   // D work
+            cy[5] += c5 - c4;   // D barrier wait
+        }
+    }
+
+    if (A.stats && lane == 0)
+    {
+        atomicAdd(&A.stats[0], st_trips);
+        atomicAdd(&A.stats[1], st_lane_steps);
+        atomicAdd(&A.stats[2], st_groups);
+        atomicAdd(&A.stats[3], st_lane_events);
+        atomicAdd(&A.stats[4], 1ull);
+        if (wave == 0) atomicAdd(&A.stats[5], st_iters);
+        atomicAdd(&A.stats[6], st_fetches);
+        for (int k = 0; k < 6; ++k) atomicAdd(&A.stats[8 + k], static_cast<unsigned long long>(cy[k]));
+    }
+}
+
+// ---- launchers (called from ddgi_engine.cpp) -----------------------------------------------------
+
+// LDS bytes of k_probe_trace_wf for a pool of `pool` rays
+static size_t wf_lds_bytes(int nwords, int pool, bool multi_light)
+{
+    return (32 + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * wf_dwords_per_ray(multi_light) * 4 +
+           static_cast<size_t>(pool) * 2 + 16;
+}
+
+// Largest pool (multiple of 64, at most 2 per lane) that fits in `lds_limit` bytes; 0 if not even
+// one ray per lane fits (then the caller uses k_probe_trace_ref).
+int wf_pool_size(int nwords, bool multi_light, size_t lds_limit)
+{
+    int pool = kWfMaxPool;
+    while (pool >= kWfThreads && wf_lds_bytes(nwords, pool, multi_light) > lds_limit) pool -= 64;
+    return pool >= kWfThreads ? pool : 0;
+}
+
+hipError_t launch_probe_trace_wf(const TraceArgs& args, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream)
+{
+    const size_t lds = wf_lds_bytes(args.scene.nwords, pool, args.nl > 1);
+    static bool attr_set = false;
+    if (!attr_set)
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_wf), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_probe_trace_wf, dim3(grid_blocks), dim3(kWfThreads), lds, stream, args, pool, work_counter);
+    return hipGetLastError();
+}
+
+}  // namespace ddgi

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/ddgi_probe.h"
+#include "ddgi_scene.h"
 
 namespace ddgi {
 
@@ -60,6 +61,11 @@ struct TraceArgs
     uint32_t* albedo;     // full-grid slab-major rgba8 texels [cz][cy][cx][s][s]
     uint32_t* distance;   // same shape
     int wait_threshold;   // event batching: handle finished marches once this many lanes wait
+    NoiseLut noise;       // memoised lattice hashes (device pointers)
+    unsigned long long* stats;  // profiling aid (null = off): [0] march-loop trips, [1] lane-steps, [2] event rounds, [3] lane-events, [4] waves
+    int wf_tail;          // wavefront kernel: straggler steps after the march list is drained (0 = default)
+    int wf_fetch;         // wavefront kernel: idle lanes that trigger a task fetch (0 = default)
+    int ablate;           // profiling ablations (DDGI_ABLATE env, default 0 = exact): 1 constant albedo, 2 constant bounce direction
 };
 
 struct SampleArgs

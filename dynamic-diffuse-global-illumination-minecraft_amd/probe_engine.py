@@ -102,6 +102,7 @@ _SIGNATURES = {
     "ddgi_synchronize": (C.c_int, [_VP]),
     "ddgi_last_update_ms": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "ddgi_update_history_ms": (C.c_int, [_VP, _VP, _VP, C.c_int, C.POINTER(C.c_int)]),
+    "ddgi_trace_stats": (C.c_int, [_VP, C.c_int, _VP]),
     "ddgi_read_textures": (C.c_int, [_VP, _VP, _VP]),
     "ddgi_read_tiles": (C.c_int, [_VP, _VP, _VP]),
     "ddgi_sample": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP, _VP]),
@@ -274,6 +275,14 @@ class ProbeEngine:
         n = C.c_int()
         _check(self._lib.ddgi_update_history_ms(self._h, _ptr(tr), _ptr(bl), capacity, C.byref(n)))
         return tr[: n.value].copy(), bl[: n.value].copy()
+
+    def trace_stats(self, enable=True):
+        """Profiling aid: utilisation counters of the trace kernel since the last call."""
+        out = np.zeros(16, dtype=np.uint64)
+        _check(self._lib.ddgi_trace_stats(self._h, 1 if enable else 0, _ptr(out)))
+        keys = ("trips", "lane_steps", "event_rounds", "lane_events", "waves", "rounds", "fetches", "_7",
+                "cyc_scan", "cyc_march", "cyc_march_wait", "cyc_list", "cyc_events", "cyc_events_wait")
+        return dict(zip(keys, (int(v) for v in out[:14])))
 
     # -- outputs -------------------------------------------------------------------------------
     def read_textures(self):

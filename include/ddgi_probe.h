@@ -173,6 +173,13 @@ int ddgi_last_update_ms(ddgi_handle h, float* trace_ms, float* blend_ms, float* 
  * the kernels of a whole timed region without synchronising inside it. */
 int ddgi_update_history_ms(ddgi_handle h, float* trace_ms, float* blend_ms, int capacity, int* n_out);
 
+/* Profiling aid (no reference counterpart): enables/disables and reads the trace kernel's
+ * utilisation counters accumulated since the last call: out16 = {march-loop trips summed over
+ * waves, lane-steps, event groups, lane-events, waves, rounds, task fetches, 0, and shader-clock
+ * cycles per phase (scan, march, march barrier, list, events, events barrier), 0, 0}.
+ * Synchronises. */
+int ddgi_trace_stats(ddgi_handle h, int enable, unsigned long long* out16);
+
 /* ---- outputs ----------------------------------------------------------------------------------- */
 
 /* New (the reference has no readback path): copies both probe textures to the

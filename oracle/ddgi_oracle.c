@@ -906,8 +906,28 @@ static int intersect_sphere(Ray ray, float mint, float maxt, Isect* info)
 }
 
 /* a10 — grid_march, intersection.glsl:1051-1100 */
+/* optional workload statistics (oracle_stats): [0] marches, [1] march steps, [2..15] hits by type */
+static long long g_stats[16];
+static int g_stats_on = 0;
+void oracle_stats(int enable, long long* out16)
+{
+    if (out16) memcpy(out16, g_stats, sizeof(g_stats));
+    if (enable >= 0)
+    {
+        g_stats_on = enable;
+        memset(g_stats, 0, sizeof(g_stats));
+    }
+}
+static inline void stat_add(int k, long long v)
+{
+    if (!g_stats_on) return;
+#pragma omp atomic
+    g_stats[k] += v;
+}
+
 static int grid_march(Ray ray, Isect* info, int scene, int* iters_out)
 {
+    stat_add(0, 1);
     v3 p = ray.o;
     v3 d = normalize3(ray.d);
     float inv[3], cc[3];
@@ -948,6 +968,8 @@ static int grid_march(Ray ray, Isect* info, int scene, int* iters_out)
         int block_type = getBlockAt(cell, scene);
         if (block_type > 0)
         {
+            stat_add(1, i + 1);
+            stat_add(2 + (block_type < 14 ? block_type : 13), 1);
             info->t = curr_t;
             v3 diff = normalize3(vsub(p, pi));
             float dv[3] = {diff.x, diff.y, diff.z};
@@ -969,6 +991,8 @@ static int grid_march(Ray ray, Isect* info, int scene, int* iters_out)
             return block_type;
         }
     }
+    stat_add(1, 125);
+    stat_add(2, 1);
     if (iters_out) *iters_out = 125;
     return 0;
 }
