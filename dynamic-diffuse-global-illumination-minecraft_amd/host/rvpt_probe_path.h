@@ -1,0 +1,114 @@
+// rvpt_probe_path.h — C++ host-side mirror of the probe path of the reference's `class RVPT`
+// (src/rvpt/rvpt.h:33-92), header-only, over the C ABI of include/ddgi_probe.h.
+//
+// Same member names, argument meaning and call order as the reference for this path:
+//   RVPT rvpt(window);                 ->  RVPTProbePath rvpt;
+//   rvpt.generate_probe_rays();            rvpt.generate_probe_rays();      (main.cpp:47)
+//   rvpt.initialize();                     rvpt.initialize();               (main.cpp:48)
+//   loop: rvpt.update(); rvpt.draw();      rvpt.update(); rvpt.draw();      (main.cpp:93-95)
+//   rvpt.shutdown();                       rvpt.shutdown();
+// `ir` and `render_settings` are the public data members the UI code of the reference writes
+// (rvpt.cpp:327-364); recreate_probe_textures() is the "Recalculate Probes" button (rvpt.cpp:361).
+// Error behaviour: like the reference's initialize()/update() the calls return bool and print the
+// reason to stderr (rvpt.cpp:499-592); nothing throws.
+#pragma once
+
+#include <cstdio>
+#include <vector>
+
+#include "../../include/ddgi_probe.h"
+
+class RVPTProbePath
+{
+public:
+    // RVPT::RenderSettings / RVPT::IrradianceField with the reference's defaults (rvpt.h:72-89)
+    ddgi_render_settings render_settings{1600, 900, 8, 0, 0, 0, 0.f, 0};
+    ddgi_irradiance_field ir{{9, 7, 9}, 11, 0.9f, 20, {0, 0}, {1.4f, 0.f, 1.f}, 1, {0, 0, 0}};
+
+    explicit RVPTProbePath(int device = 0) : device_(device) {}
+    ~RVPTProbePath() { shutdown(); }
+    RVPTProbePath(const RVPTProbePath&) = delete;
+    RVPTProbePath& operator=(const RVPTProbePath&) = delete;
+
+    // rvpt.cpp:1177-1224.  Before initialize() it only remembers that rays are wanted (the
+    // reference sizes its SSBO from this call, main.cpp:47); afterwards it regenerates + uploads.
+    void generate_probe_rays()
+    {
+        need_generate_probe_rays_ = true;
+        if (handle_) (void)flush_rays();
+    }
+
+    // rvpt.cpp:231-264 (probe resources only)
+    bool initialize()
+    {
+        if (handle_) return true;
+        if (!ok(ddgi_create(&ir, &render_settings, device_, &handle_), "ddgi_create")) return false;
+        return flush_rays();
+    }
+
+    // rvpt.cpp:265-290: advance time, make the per-frame uploads current
+    bool update()
+    {
+        render_settings.time += 2;  // rvpt.cpp:281
+        if (need_change_probe_texture_) return recreate_probe_textures();
+        return flush_rays();
+    }
+
+    // probe half of rvpt.cpp:372-431 (record_compute_command_buffer 1096-1129 + submit)
+    bool draw() { return handle_ && ok(ddgi_probe_update(handle_, &render_settings), "ddgi_probe_update"); }
+
+    // rvpt.cpp:661-755
+    bool recreate_probe_textures()
+    {
+        need_change_probe_texture_ = false;
+        if (!handle_) return initialize();
+        if (!ok(ddgi_configure(handle_, &ir, &render_settings), "ddgi_configure")) return false;
+        need_generate_probe_rays_ = true;
+        return flush_rays();
+    }
+    void request_probe_texture_change() { need_change_probe_texture_ = true; }  // the UI sliders, rvpt.cpp:334-357
+
+    // rvpt.cpp:433-468
+    void shutdown()
+    {
+        if (handle_) (void)ddgi_destroy(handle_);
+        handle_ = nullptr;
+    }
+
+    // what the render pass reads through bindings 3/4 (rvpt.cpp:783-786), here copied to the host
+    bool read_probe_textures(std::vector<uint8_t>& albedo, std::vector<uint8_t>& distance)
+    {
+        int w = 0, h = 0;
+        ddgi_texture_size(&ir, &w, &h);
+        albedo.resize(static_cast<size_t>(w) * h * 4);
+        distance.resize(albedo.size());
+        return handle_ && ok(ddgi_read_textures(handle_, albedo.data(), distance.data()), "ddgi_read_textures");
+    }
+
+    // get_diffuse_gi for a batch of shading points (intersection.glsl:1306-1409)
+    bool sample(const float* pos_xyz, const float* nrm_xyz, size_t n, float* rgb_out, int32_t* cage_idx8_out = nullptr)
+    {
+        return handle_ && ok(ddgi_sample(handle_, pos_xyz, nrm_xyz, n, rgb_out, cage_idx8_out), "ddgi_sample");
+    }
+
+    bool wait() { return handle_ && ok(ddgi_synchronize(handle_), "ddgi_synchronize"); }
+    ddgi_handle native_handle() const { return handle_; }
+
+private:
+    bool flush_rays()
+    {
+        if (!need_generate_probe_rays_) return true;
+        need_generate_probe_rays_ = false;
+        return ok(ddgi_generate_probe_rays(handle_, 1u, 0), "ddgi_generate_probe_rays");
+    }
+    static bool ok(int rc, const char* what)
+    {
+        if (rc != DDGI_OK) std::fprintf(stderr, "%s failed (%d): %s\n", what, rc, ddgi_last_error());
+        return rc == DDGI_OK;
+    }
+
+    int device_ = 0;
+    ddgi_handle handle_ = nullptr;
+    bool need_generate_probe_rays_ = true;    // rvpt.h:96
+    bool need_change_probe_texture_ = false;  // rvpt.h:95
+};
