@@ -73,8 +73,14 @@ def cpu_baseline(n_probes=96):
     st = O.make_settings(w["scene"], w["max_bounces"])
     rays = O.generate_probe_rays(f, O.new_rand_state(w["seed"]))
     total = w["counts"][0] * w["counts"][1] * w["counts"][2]
-    probes = np.linspace(0, total - 1, n_probes).astype(np.int32)
-    O.probe_update_probes(f, st, rays, probes[:8])  # warm
+    # calibrate on a small spread sample, then size the timed sample for ~12 s of wall time
+    # (bounded by the whole grid)
+    calib = np.linspace(0, total - 1, max(n_probes, 2 * O.num_threads())).astype(np.int32)
+    t0 = time.perf_counter()
+    O.probe_update_probes(f, st, rays, calib)
+    rate = len(calib) / max(time.perf_counter() - t0, 1e-6)
+    n = int(min(total, max(len(calib), rate * 12.0)))
+    probes = np.linspace(0, total - 1, n).astype(np.int32)
     t0 = time.perf_counter()
     O.probe_update_probes(f, st, rays, probes)
     dt = time.perf_counter() - t0
@@ -182,7 +188,7 @@ def main():
             "parallelism": f"zslab{world}" + ("+allgather" if world > 1 else ""),
         },
         "roofline": {
-            "kernel": "k_probe_trace_ref",
+            "kernel": "k_probe_trace_ref" if os.environ.get("DDGI_TRACE_KERNEL") == "lane" else "k_probe_trace_wf",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -191,7 +197,7 @@ def main():
             "traffic": _traffic_from_profiles(),
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_RAY * local_rays,
             "kernel_ms": kernel_ms,
-            "note": "the trace kernel is VALU-issue bound (dependent voxel steps), not HBM bound; see DESIGN.md",
+            "note": "the trace kernel is VALU-issue bound (dependent voxel steps + hit shading), not HBM bound: see DESIGN.md section 4 and profiles/",
         },
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
