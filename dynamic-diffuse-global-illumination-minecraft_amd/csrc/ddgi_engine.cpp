@@ -19,8 +19,10 @@ namespace ddgi {
 hipError_t launch_probe_trace_ref(const TraceArgs& args, int grid_blocks, hipStream_t stream);
 hipError_t launch_probe_sample_ref(const SampleArgs& args, hipStream_t stream);
 hipError_t trace_kernel_occupancy(int* blocks_per_cu, size_t lds_bytes);
-int wf_pool_size(int nwords, bool multi_light, size_t lds_limit);
-hipError_t launch_probe_trace_wf(const TraceArgs& args, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream);
+int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads);
+hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream);
+hipError_t launch_probe_blend(const BlendArgs& args, int grid_blocks, hipStream_t stream);
+hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream);
 }  // namespace ddgi
 
 using namespace ddgi;
@@ -104,6 +106,9 @@ struct ddgi_engine
     unsigned long long updates = 0;
     int wait_threshold = 64;
     uint32_t* d_work = nullptr;             // chunk counter of the wavefront trace kernel
+    float4* d_radiance = nullptr;           // DDGI mode: per local ray (radiance rgb, first-hit distance)
+    size_t d_radiance_capacity = 0;         // in rays
+    uint32_t frame = 0;                     // DDGI mode: updates done so far (seeds the ray rotation)
     unsigned long long* d_stats = nullptr;  // profiling aid, allocated on first ddgi_trace_stats(enable)
 };
 
@@ -149,7 +154,14 @@ static int alloc_textures(ddgi_engine* e)
     }
     const size_t probes = static_cast<size_t>(e->field.probe_count[0]) * e->field.probe_count[1] * e->field.probe_count[2];
     const size_t s2 = static_cast<size_t>(e->field.sqrt_rays_per_probe) * e->field.sqrt_rays_per_probe;
-    e->tex_bytes[0] = e->tex_bytes[1] = probes * s2 * 4;
+    if (e->mode == DDGI_MODE_DDGI)
+    {
+        e->tex_bytes[0] = probes * 8 * 8 * 4 * sizeof(float);    // irradiance tiles
+        e->tex_bytes[1] = probes * 16 * 16 * 2 * sizeof(float);  // depth-moment tiles
+    }
+    else
+        e->tex_bytes[0] = e->tex_bytes[1] = probes * s2 * 4;
+    e->frame = 0;
     for (int i = 0; i < 2; ++i)
     {
         HIP_TRY(hipMalloc(&e->own_tex[i], e->tex_bytes[i]));
@@ -308,6 +320,7 @@ int ddgi_destroy(ddgi_handle e)
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->d_work) (void)hipFree(e->d_work);
+    if (e->d_radiance) (void)hipFree(e->d_radiance);
     for (auto& p : e->d_noise)
         if (p) (void)hipFree(p);
     for (auto& d : e->dev_scene)
@@ -340,9 +353,14 @@ int ddgi_configure(ddgi_handle e, const ddgi_irradiance_field* field, const ddgi
 int ddgi_set_mode(ddgi_handle e, int mode)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
-    if (mode != DDGI_MODE_REF) return fail(DDGI_ERR_UNSUPPORTED, "mode %d not available in this build", mode);
+    if (mode != DDGI_MODE_REF && mode != DDGI_MODE_DDGI) return fail(DDGI_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
+    if (mode == e->mode) return DDGI_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->tex[0] != e->own_tex[0]) return fail(DDGI_ERR_INVALID_ARGUMENT, "unbind caller textures before changing the mode");
     e->mode = mode;
-    return DDGI_OK;
+    e->updates = 0;
+    return alloc_textures(e);  // the two modes keep differently shaped textures; both start zeroed
 }
 
 int ddgi_set_lights(ddgi_handle e, int scene, const ddgi_light* lights, int n)
@@ -414,7 +432,8 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         if (settings->scene < 0 || settings->scene > 2) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2}", settings->scene);
         e->settings = *settings;
     }
-    if (e->n_local_rays == 0) return fail(DDGI_ERR_NOT_READY, "ddgi_probe_update before any probe rays were generated/uploaded");
+    const bool ddgi_mode = e->mode == DDGI_MODE_DDGI;
+    if (!ddgi_mode && e->n_local_rays == 0) return fail(DDGI_ERR_NOT_READY, "ddgi_probe_update before any probe rays were generated/uploaded");
     HIP_TRY(hipSetDevice(e->device));
     const int scene = e->settings.scene;
     if (int rc = ensure_scene(e, scene)) return rc;
@@ -429,6 +448,26 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     for (int i = 0; i < a.nl; ++i) a.lights[i] = e->lights[scene][i];
     a.rays = e->d_rays;
     a.n_rays = e->n_local_rays;
+    if (ddgi_mode)
+    {
+        // rays are generated in the kernel; lights follow update_lights(time) (probe_pass.comp:217-251)
+        const size_t local_rays = static_cast<size_t>(a.grid.cx) * a.grid.cy * a.grid.czl * a.grid.s * a.grid.s;
+        if (local_rays > e->d_radiance_capacity)
+        {
+            if (e->d_radiance) (void)hipFree(e->d_radiance);
+            e->d_radiance = nullptr;
+            e->d_radiance_capacity = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_radiance), local_rays * sizeof(float4)));
+            e->d_radiance_capacity = local_rays;
+        }
+        animate_lights(scene, e->settings.time, e->lights[scene], a.nl, a.lights);
+        a.ddgi = 1;
+        a.frame_key = frame_key(e->frame);
+        frame_rotation(e->frame, a.rot);
+        a.radiance = e->d_radiance;
+        a.rays = nullptr;
+        a.n_rays = static_cast<uint32_t>(local_rays);
+    }
     a.albedo = static_cast<uint32_t*>(e->tex[0]);
     a.distance = static_cast<uint32_t*>(e->tex[1]);
     a.wait_threshold = e->wait_threshold;
@@ -444,18 +483,22 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     // (or when DDGI_TRACE_KERNEL=lane asks for it, e.g. to cross-check the two).
     const char* kernel_env = std::getenv("DDGI_TRACE_KERNEL");
     const bool force_lane = kernel_env && std::strcmp(kernel_env, "lane") == 0;
-    int pool = (force_lane || a.max_bounces < 1) ? 0 : wf_pool_size(a.scene.nwords, a.nl > 1, 160 * 1024);
-    if (const char* v = std::getenv("DDGI_WF_POOL")) pool = pool ? std::min(pool, std::max(1024, std::atoi(v) / 64 * 64)) : 0;
+    if (ddgi_mode && (force_lane || a.max_bounces < 1)) return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode needs the wavefront trace kernel and max_bounces >= 1");
+    int wf_threads = 1024;
+    if (const char* v = std::getenv("DDGI_WF_THREADS")) wf_threads = std::atoi(v) == 512 ? 512 : 1024;
+    const int wf_blocks_per_cu = 1024 / wf_threads;
+    int pool = (force_lane || a.max_bounces < 1) ? 0 : wf_pool_size(a.scene.nwords, a.nl > 1, 160 * 1024 / wf_blocks_per_cu, wf_threads);
+    if (const char* v = std::getenv("DDGI_WF_POOL")) pool = pool ? std::min(pool, std::max(wf_threads, std::atoi(v) / 64 * 64)) : 0;
 
     hipEvent_t* ev = e->ev[e->updates % ddgi_engine::kRing];
     if (pool > 0)
     {
         if (!e->d_work) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_work), sizeof(uint32_t)));
         const uint32_t chunks = (a.n_rays + 4095u) / 4096u;
-        uint32_t grid = static_cast<uint32_t>(e->num_cus);
+        uint32_t grid = static_cast<uint32_t>(e->num_cus * wf_blocks_per_cu);
         if (grid > chunks) grid = chunks;
         HIP_TRY(hipEventRecord(ev[0], e->stream));
-        HIP_TRY(launch_probe_trace_wf(a, pool, static_cast<int>(grid), e->d_work, e->stream));
+        HIP_TRY(launch_probe_trace_wf(a, wf_threads, pool, static_cast<int>(grid), e->d_work, e->stream));
     }
     else
     {
@@ -470,6 +513,20 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         HIP_TRY(launch_probe_trace_ref(a, static_cast<int>(grid), e->stream));
     }
     HIP_TRY(hipEventRecord(ev[1], e->stream));
+    if (ddgi_mode)
+    {
+        if (pool <= 0) return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode: the ray pool does not fit in LDS next to the scene bitmap");
+        BlendArgs b{};
+        b.grid = a.grid;
+        for (int i = 0; i < 9; ++i) b.rot[i] = a.rot[i];
+        b.radiance = e->d_radiance;
+        b.irradiance = static_cast<float*>(e->tex[0]);
+        b.depth = static_cast<float*>(e->tex[1]);
+        b.n_local_probes = static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.czl;
+        const uint32_t blend_grid = std::min<uint32_t>(b.n_local_probes, static_cast<uint32_t>(e->num_cus) * 8u);
+        HIP_TRY(launch_probe_blend(b, static_cast<int>(blend_grid), e->stream));
+        e->frame += 1;
+    }
     HIP_TRY(hipEventRecord(ev[2], e->stream));
     e->updates += 1;
     return DDGI_OK;
@@ -571,10 +628,38 @@ int ddgi_read_textures(ddgi_handle e, uint8_t* albedo, uint8_t* distance)
     return DDGI_OK;
 }
 
-int ddgi_read_tiles(ddgi_handle e, float*, float*)
+int ddgi_read_tiles(ddgi_handle e, float* irradiance, float* depth)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
-    return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode is not available in this build");
+    if (e->mode != DDGI_MODE_DDGI) return fail(DDGI_ERR_UNSUPPORTED, "ddgi_read_tiles is DDGI-mode only; use ddgi_read_textures");
+    HIP_TRY(hipSetDevice(e->device));
+    const GridK g = make_grid(e);
+    float* outs[2] = {irradiance, depth};
+    const size_t per_probe[2] = {8 * 8 * 4, 16 * 16 * 2};
+    for (int t = 0; t < 2; ++t)
+    {
+        if (!outs[t]) continue;
+        std::vector<float> slab(e->tex_bytes[t] / sizeof(float));
+        HIP_TRY(hipMemcpyAsync(slab.data(), e->tex[t], e->tex_bytes[t], hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        // slab-major [z][y][x] -> reference probe order p = y*cx*cz + z*cx + x
+        for (int z = 0; z < g.cz; ++z)
+            for (int y = 0; y < g.cy; ++y)
+                for (int x = 0; x < g.cx; ++x)
+                {
+                    const size_t q = (static_cast<size_t>(z) * g.cy + y) * g.cx + x;
+                    const size_t p = static_cast<size_t>(y) * g.cx * g.cz + static_cast<size_t>(z) * g.cx + x;
+                    std::memcpy(outs[t] + p * per_probe[t], slab.data() + q * per_probe[t], per_probe[t] * sizeof(float));
+                }
+    }
+    return DDGI_OK;
+}
+
+int ddgi_set_frame(ddgi_handle e, uint32_t frame)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->frame = frame;
+    return DDGI_OK;
 }
 
 int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, size_t n, float* d_rgb, int32_t* d_cage)
@@ -593,6 +678,13 @@ int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, si
     a.rgb = d_rgb;
     a.cage = d_cage;
     a.n = static_cast<uint32_t>(n);
+    if (e->mode == DDGI_MODE_DDGI)
+    {
+        a.irradiance = static_cast<const float*>(e->tex[0]);
+        a.depth = static_cast<const float*>(e->tex[1]);
+        HIP_TRY(launch_probe_sample_ddgi(a, e->stream));
+        return DDGI_OK;
+    }
     HIP_TRY(launch_probe_sample_ref(a, e->stream));
     return DDGI_OK;
 }

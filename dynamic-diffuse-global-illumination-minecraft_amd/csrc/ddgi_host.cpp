@@ -237,4 +237,82 @@ void shipped_lights(int scene, LightK* out, int* n)
     *n = cnt;
 }
 
+// ---- DDGI mode ------------------------------------------------------------------------------------
+
+static uint32_t host_wang_hash(uint32_t seed)  // probe_pass.comp:45-53
+{
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed *= 9u;
+    seed = seed ^ (seed >> 4);
+    seed *= 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return seed;
+}
+
+static float host_rand(uint32_t& s)  // probe_pass.comp:59-71
+{
+    s ^= (s << 13);
+    s ^= (s >> 17);
+    s ^= (s << 5);
+    return static_cast<float>(s) * 0x1.0p-32f;
+}
+
+uint32_t frame_key(uint32_t frame) { return host_wang_hash(frame); }
+
+void frame_rotation(uint32_t frame, float* m)
+{
+    // Shoemake's uniform random unit quaternion from three draws of the reference's own RNG
+    const float kTwoPi = 6.2831853071795864769252867665590057683943f;
+    uint32_t rng = host_wang_hash(0x9E3779B9u ^ frame);
+    const float u1 = host_rand(rng), u2 = host_rand(rng), u3 = host_rand(rng);
+    const float a = sqrtf(1.0f - u1), b = sqrtf(u1);
+    const pm::SinCos s2 = pm::sincos_core(kTwoPi * u2), s3 = pm::sincos_core(kTwoPi * u3);
+    const float qx = a * static_cast<float>(s2.s), qy = a * static_cast<float>(s2.c);
+    const float qz = b * static_cast<float>(s3.s), qw = b * static_cast<float>(s3.c);
+    m[0] = 1.0f - 2.0f * (qy * qy + qz * qz);
+    m[1] = 2.0f * (qx * qy - qz * qw);
+    m[2] = 2.0f * (qx * qz + qy * qw);
+    m[3] = 2.0f * (qx * qy + qz * qw);
+    m[4] = 1.0f - 2.0f * (qx * qx + qz * qz);
+    m[5] = 2.0f * (qy * qz - qx * qw);
+    m[6] = 2.0f * (qx * qz - qy * qw);
+    m[7] = 2.0f * (qy * qz + qx * qw);
+    m[8] = 1.0f - 2.0f * (qx * qx + qy * qy);
+}
+
+void animate_lights(int scene, float time, const LightK* base, int n, LightK* out)
+{
+    for (int i = 0; i < n; ++i)
+    {
+        out[i] = base[i];
+        float x = base[i].pos[0], y = base[i].pos[1], z = base[i].pos[2];
+        if (scene == 0)
+        {
+            const float t = 0.05f * time;
+            if (i == 0)
+                z = z + 10 * pm::cosf_pinned(t * 0.1f);
+            else
+            {
+                const float sn = pm::sinf_pinned(t * 0.5f), cs = pm::cosf_pinned(t * 0.5f);
+                x = x + static_cast<float>((i + 1) * 2) * sn;
+                y = y + static_cast<float>((i / 2) * 4) * sn;
+                z = z + static_cast<float>((i + 1) * 2) * cs;
+            }
+        }
+        else if (scene == 1)
+        {
+            const float t = 0.005f * time;
+            x = x + static_cast<float>(i + 1) * pm::sinf_pinned(t);
+            y = y + static_cast<float>((i / 2) * 4) * pm::sinf_pinned(t);
+            z = z + static_cast<float>(i + 1) * pm::cosf_pinned(t);
+        }
+        else if (scene == 2)
+        {
+            const float d = 0.00005f * time;
+            x += d, y += d, z += d;
+        }
+        out[i].pos[0] = x, out[i].pos[1] = y, out[i].pos[2] = z;
+    }
+}
+
 }  // namespace ddgi

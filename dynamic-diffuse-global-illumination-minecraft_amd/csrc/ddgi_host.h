@@ -50,4 +50,12 @@ const NoiseLutHost& noise_lut_host();  // cached, thread-safe
 // Default light tables (assets/shaders/structs.glsl:61-89, the shipped ones).
 void shipped_lights(int scene, LightK* out, int* n);
 
+// DDGI mode host pieces -------------------------------------------------------------------------
+// update_lights (assets/shaders/probe_pass.comp:217-251, dormant): light positions as a function
+// of RenderSettings::time, applied to the base table.
+void animate_lights(int scene, float time, const LightK* base, int n, LightK* out);
+// the frame's random rotation of the ray set (row-major 3x3) and its RNG key
+void frame_rotation(uint32_t frame, float* m9);
+uint32_t frame_key(uint32_t frame);
+
 }  // namespace ddgi

@@ -24,12 +24,10 @@
 //              store and slot release)
 // ------------------------------------------------------------------------------------------------
 #include "ddgi_device.h"
+#include "ddgi_oct.h"
 
 namespace ddgi {
 
-constexpr int kWfThreads = 1024;  // 16 wave64 = 4 per SIMD
-constexpr int kWfWaves = kWfThreads / 64;
-constexpr int kWfMaxPool = 2 * kWfThreads;
 constexpr int kWfTailSteps = 16;     // straggler steps after the march list is drained
 constexpr int kWfFetchLanes = 16;    // pull new march tasks once this many lanes are idle
 constexpr uint32_t kWfChunk = 4096;  // rays a workgroup claims at a time from the global counter
@@ -137,10 +135,17 @@ DDGI_D void wf_post_march(const WfPool& P, uint32_t slot, f3 o, f3 d, bool feele
 DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, const TraceArgs& A)
 {
     const f3 c = div3(color, static_cast<float>(A.max_bounces));  // Q14: always /max_bounces
-    const uint32_t texel = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
     const uint32_t dst = P.dst[slot];
-    A.albedo[dst] = texel;
-    A.distance[dst] = 0u;  // `distances` is never assigned (probe_pass.comp:276,302)
+    if (A.ddgi)
+    {
+        float* rec = reinterpret_cast<float*>(A.radiance + dst);  // .w (first-hit distance) was written at bounce 0
+        rec[0] = c.x, rec[1] = c.y, rec[2] = c.z;
+    }
+    else
+    {
+        A.albedo[dst] = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
+        A.distance[dst] = 0u;  // `distances` is never assigned (probe_pass.comp:276,302)
+    }
     P.flags[slot] = kSlotEmpty;
 }
 
@@ -163,7 +168,9 @@ DDGI_D void wf_lighting_done(const WfPool& P, uint32_t slot, f3 contribution, f3
         wf_finish_ray(P, slot, color, A);
 }
 
-__global__ __launch_bounds__(kWfThreads) void k_probe_trace_wf(const TraceArgs A, const int pool_size, uint32_t* __restrict__ work_counter)
+// T lanes per workgroup, kBlocksPerCU workgroups resident per CU (T * kBlocksPerCU = 1024 lanes = 4 waves/SIMD)
+template <int T, int kBlocksPerCU>
+__global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(const TraceArgs A, const int pool_size, uint32_t* __restrict__ work_counter)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t wf_lds[];
     const int tid = threadIdx.x;
@@ -196,8 +203,8 @@ __global__ __launch_bounds__(kWfThreads) void k_probe_trace_wf(const TraceArgs A
     for (int a = 0; a < 3; ++a) P.dir[a] = multi_light ? takef() : nullptr;
     P.list = reinterpret_cast<uint16_t*>(cursor);
 
-    for (int i = tid; i < A.scene.nwords; i += kWfThreads) s_bits[i] = A.scene.bits[i];
-    for (uint32_t i = tid; i < PS; i += kWfThreads) P.flags[i] = kSlotEmpty;
+    for (int i = tid; i < A.scene.nwords; i += T) s_bits[i] = A.scene.bits[i];
+    for (uint32_t i = tid; i < PS; i += T) P.flags[i] = kSlotEmpty;
     const uint32_t n_chunks = (A.n_rays + kWfChunk - 1) / kWfChunk;
     if (tid == 0)
     {
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(kWfThreads) void k_probe_trace_wf(const TraceArgs A
         // ================= A: refill free slots, list the marches =================
         const long long c0 = A.stats ? clock64() : 0;
         bool any_live = false;
-        for (uint32_t slot = tid; slot < PS; slot += kWfThreads)
+        for (uint32_t slot = tid; slot < PS; slot += T)
         {
             uint32_t fl = P.flags[slot];
             // claim a new ray for an empty slot (wave-aggregated claim on the workgroup's range)
@@ -245,14 +252,29 @@ __global__ __launch_bounds__(kWfThreads) void k_probe_trace_wf(const TraceArgs A
                     const int rem = pl - y * slab_row;
                     const int p = y * G.cx * G.cz + G.z0 * G.cx + rem;
                     const uint32_t global_ray = static_cast<uint32_t>(p) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i);
-                    const float4* rec = A.rays + 3 * static_cast<size_t>(r);
-                    const float4 ra = rec[0], rb = rec[1], rc = rec[2];
-                    const int dst_probe = static_cast<int>(rc.x);  // int(probe_info.x), probe_pass.comp:269
-                    P.dst[slot] = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.s + static_cast<int>(rc.y);
-                    P.rng[slot] = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
+                    f3 ray_o, ray_d;
+                    if (A.ddgi)
+                    {
+                        // in-kernel ray generation: probe position + rotated spherical Fibonacci direction
+                        const int pxz = p - y * G.cx * G.cz;
+                        ray_o = probe_position(G, pxz % G.cx, y, pxz / G.cx);
+                        ray_d = fibonacci_dir(i, rays_per_probe, A.rot);
+                        P.dst[slot] = r;
+                        P.rng[slot] = wang_hash(global_ray ^ A.frame_key);
+                    }
+                    else
+                    {
+                        const float4* rec = A.rays + 3 * static_cast<size_t>(r);
+                        const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+                        ray_o = mk3(ra.x, ra.y, ra.z);
+                        ray_d = mk3(rb.x, rb.y, rb.z);
+                        const int dst_probe = static_cast<int>(rc.x);  // int(probe_info.x), probe_pass.comp:269
+                        P.dst[slot] = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.s + static_cast<int>(rc.y);
+                        P.rng[slot] = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
+                    }
                     P.cnt[slot] = 0u;
                     st3(P.col, slot, mk3(0, 0, 0));
-                    wf_post_march(P, slot, mk3(ra.x, ra.y, ra.z), mk3(rb.x, rb.y, rb.z), false, A);
+                    wf_post_march(P, slot, ray_o, ray_d, false, A);
                     fl = kSlotMarch;
                 }
             }
@@ -350,7 +372,7 @@ __global__ __launch_bounds__(kWfThreads) void k_probe_trace_wf(const TraceArgs A
         uint32_t my_bucket[2], my_rank[2];
         {
             int k = 0;
-            for (uint32_t slot = tid; slot < PS; slot += kWfThreads, ++k)
+            for (uint32_t slot = tid; slot < PS; slot += T, ++k)
             {
                 const uint32_t fl = P.flags[slot];
                 const uint32_t st = fl & 3u;
@@ -383,7 +405,7 @@ __global__ __launch_bounds__(kWfThreads) void k_probe_trace_wf(const TraceArgs A
         __syncthreads();
         {
             int k = 0;
-            for (uint32_t slot = tid; slot < PS; slot += kWfThreads, ++k)
+            for (uint32_t slot = tid; slot < PS; slot += T, ++k)
                 if (my_bucket[k] < kWfBuckets) P.list[sh->bucket_base[my_bucket[k]] + my_rank[k]] = static_cast<uint16_t>(slot);
         }
         __syncthreads();
@@ -417,8 +439,10 @@ __global__ __launch_bounds__(kWfThreads) void k_probe_trace_wf(const TraceArgs A
             const bool any_hit = block_wins || (tl < inf);       // closest_t < INF
             if (b != kBucketFeeler)
             {
+                const bool first_bounce = A.ddgi && (P.cnt[slot] & 255u) == 0u;
                 if (!any_hit)
                 {
+                    if (first_bounce) reinterpret_cast<float*>(A.radiance + P.dst[slot])[3] = kMissDistance;
                     wf_finish_ray(P, slot, ld3(P.col, slot), A);  // probe_pass.comp:288-290 break
                     continue;
                 }
@@ -451,6 +475,7 @@ __global__ __launch_bounds__(kWfThreads) void k_probe_trace_wf(const TraceArgs A
                     nraw = ray_at((ro - lp) * 10.0f, rd * 10.0f, th);  // sphere-space position
                     hcol = mk3(0, 0, 0);  // Q12: unassigned Material, pinned to zero
                 }
+                if (first_bounce) reinterpret_cast<float*>(A.radiance + P.dst[slot])[3] = th;  // Isect.t of the probe ray
                 const f3 hnrm = normalize3(nraw);
                 const f3 hpos = ray_at(ro, rd, th) + hnrm * 0.001f;
                 st3(P.hn, slot, hnrm);
@@ -551,27 +576,35 @@ static size_t wf_lds_bytes(int nwords, int pool, bool multi_light)
 
 // Largest pool (multiple of 64, at most 2 per lane) that fits in `lds_limit` bytes; 0 if not even
 // one ray per lane fits (then the caller uses k_probe_trace_ref).
-int wf_pool_size(int nwords, bool multi_light, size_t lds_limit)
+int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads)
 {
-    int pool = kWfMaxPool;
-    while (pool >= kWfThreads && wf_lds_bytes(nwords, pool, multi_light) > lds_limit) pool -= 64;
-    return pool >= kWfThreads ? pool : 0;
+    int pool = 2 * threads;  // at most 2 slots per lane (the bucket pass keeps 2 ranks in registers)
+    while (pool >= threads && wf_lds_bytes(nwords, pool, multi_light) > lds_limit) pool -= 64;
+    return pool >= threads ? pool : 0;
 }
 
-hipError_t launch_probe_trace_wf(const TraceArgs& args, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream)
+template <int T, int B>
+static hipError_t launch_wf(const TraceArgs& args, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream)
 {
     const size_t lds = wf_lds_bytes(args.scene.nwords, pool, args.nl > 1);
     static bool attr_set = false;
     if (!attr_set)
     {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_wf), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_wf<T, B>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / B);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_probe_trace_wf, dim3(grid_blocks), dim3(kWfThreads), lds, stream, args, pool, work_counter);
+    hipLaunchKernelGGL((k_probe_trace_wf<T, B>), dim3(grid_blocks), dim3(T), lds, stream, args, pool, work_counter);
     return hipGetLastError();
+}
+
+// threads: 1024 (one workgroup per CU) or 512 (two per CU, each with half the LDS)
+hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream)
+{
+    if (threads == 512) return launch_wf<512, 2>(args, pool, grid_blocks, work_counter, stream);
+    return launch_wf<1024, 1>(args, pool, grid_blocks, work_counter, stream);
 }
 
 }  // namespace ddgi

@@ -66,6 +66,24 @@ struct TraceArgs
     int wf_tail;          // wavefront kernel: straggler steps after the march list is drained (0 = default)
     int wf_fetch;         // wavefront kernel: idle lanes that trigger a task fetch (0 = default)
     int ablate;           // profiling ablations (DDGI_ABLATE env, default 0 = exact): 1 constant albedo, 2 constant bounce direction
+    // DDGI mode (ddgi != 0): rays are generated in the kernel (spherical Fibonacci set rotated by
+    // rot, origin = probe position), the RNG seed is ray index ^ frame_key, and each ray writes
+    // (radiance rgb, first-hit distance) to radiance[local ray] instead of an rgba8 texel
+    int ddgi;
+    uint32_t frame_key;
+    float rot[9];
+    float4* radiance;
+};
+
+// k_probe_blend: per-probe update of the octahedral irradiance / depth-moment tiles
+struct BlendArgs
+{
+    GridK grid;
+    float rot[9];
+    const float4* radiance;  // local slab, [probe in slab (y, zl, x) order][ray]
+    float* irradiance;       // full-grid slab-major [cz][cy][cx][8][8][4]
+    float* depth;            // full-grid slab-major [cz][cy][cx][16][16][2]
+    uint32_t n_local_probes;
 };
 
 struct SampleArgs
@@ -78,6 +96,8 @@ struct SampleArgs
     float* rgb;        // n*3
     int32_t* cage;     // n*8 or null
     uint32_t n;
+    const float* irradiance;  // DDGI mode tiles (slab-major), else null
+    const float* depth;
 };
 
 }  // namespace ddgi

@@ -105,6 +105,7 @@ _SIGNATURES = {
     "ddgi_trace_stats": (C.c_int, [_VP, C.c_int, _VP]),
     "ddgi_read_textures": (C.c_int, [_VP, _VP, _VP]),
     "ddgi_read_tiles": (C.c_int, [_VP, _VP, _VP]),
+    "ddgi_set_frame": (C.c_int, [_VP, C.c_uint32]),
     "ddgi_sample": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP, _VP]),
     "ddgi_set_stream": (C.c_int, [_VP, _VP]),
     "ddgi_device_textures": (C.c_int, [_VP] + [C.POINTER(_VP), C.POINTER(C.c_size_t)] * 2 + [C.POINTER(C.c_size_t)] * 4),
@@ -292,6 +293,16 @@ class ProbeEngine:
         distance = np.empty((h, w, 4), dtype=np.uint8)
         _check(self._lib.ddgi_read_textures(self._h, _ptr(albedo), _ptr(distance)))
         return albedo, distance
+
+    def read_tiles(self):
+        """DDGI mode: (irradiance [P,8,8,4], depth moments [P,16,16,2]) float32, reference probe order."""
+        irr = np.empty((self.num_probes, 8, 8, 4), dtype=np.float32)
+        dep = np.empty((self.num_probes, 16, 16, 2), dtype=np.float32)
+        _check(self._lib.ddgi_read_tiles(self._h, _ptr(irr), _ptr(dep)))
+        return irr, dep
+
+    def set_frame(self, frame):
+        _check(self._lib.ddgi_set_frame(self._h, frame))
 
     def sample(self, pos, nrm, want_cage=True):
         """get_diffuse_gi (intersection.glsl:1306-1409) for a batch: -> (rgb [n,3], cage [n,8])."""

@@ -194,6 +194,10 @@ int ddgi_read_textures(ddgi_handle h, uint8_t* albedo_rgba8, uint8_t* distance_r
  * Either pointer may be NULL.  Synchronises. */
 int ddgi_read_tiles(ddgi_handle h, float* irradiance, float* depth);
 
+/* DDGI mode: the frame index that seeds the next update's ray-set rotation and per-ray RNG
+ * (starts at 0 after create/configure/set_mode and advances by one per ddgi_probe_update). */
+int ddgi_set_frame(ddgi_handle h, uint32_t frame);
+
 /* Replaces get_diffuse_gi (assets/shaders/intersection.glsl:1306-1409) as called from
  * integrator_DDGI / integrator_indirect (integrators.glsl:67,205) for a batch of n shading
  * points: pos_xyz/nrm_xyz are n*3 floats (Isect.pos / Isect.normal), rgb_out n*3 floats,

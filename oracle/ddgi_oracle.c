@@ -1455,3 +1455,391 @@ void oracle_sample_texel(const o_field* f, const float* dir, int* rx_out, int* r
     *rx_out = rx;
     *ry_out = gint((o_acos(id.x / sqrt_z) / (2.0f * PI_F)) * (float)s);
 }
+
+/* =========================================================================================== */
+/* DDGI mode — the pieces the reference leaves dormant, switched on. */
+/* Where the reference has dormant code it is followed and cited; where it has none (Fibonacci    */
+/* rays, octahedral tile update) the DDGI paper it cites (README.md:45; Majercik et al., JCGT 8(2)*/
+/* 2019, and its supplemental shaders) is restated.  Validated GPU-vs-oracle only.               */
+/* =========================================================================================== */
+
+#define DDGI_IRR_TILE 8   /* 6x6 interior + 1 texel border */
+#define DDGI_DEP_TILE 16  /* 14x14 interior + border */
+
+/* a19 — update_lights, probe_pass.comp:217-251 (dormant: the call at :254 is commented out).
+ * GLSL globals are re-initialised per invocation, so the offsets apply once to the base table. */
+void oracle_update_lights(int scene, float time, const o_light* base, int n, o_light* out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        out[i] = base[i];
+        float x = base[i].pos[0], y = base[i].pos[1], z = base[i].pos[2];
+        if (scene == 0)
+        {
+            float t = 0.05f * time;
+            if (i == 0)
+                z = z + 10 * o_cos(t * 0.1f);
+            else
+            {
+                x = x + (float)((i + 1) * 2) * o_sin(t * 0.5f);
+                y = y + (float)((i / 2) * 4) * o_sin(t * 0.5f);
+                z = z + (float)((i + 1) * 2) * o_cos(t * 0.5f);
+            }
+        }
+        else if (scene == 1)
+        {
+            float t = 0.005f * time;
+            x = x + (float)(i + 1) * o_sin(t);
+            y = y + (float)((i / 2) * 4) * o_sin(t);
+            z = z + (float)(i + 1) * o_cos(t);
+        }
+        else if (scene == 2)
+        {
+            float d = 0.00005f * time;
+            x += d, y += d, z += d;
+        }
+        out[i].pos[0] = x, out[i].pos[1] = y, out[i].pos[2] = z;
+    }
+}
+
+void oracle_shipped_lights(int scene, o_light* out, int* n)
+{
+    *n = 0;
+    if (scene < 0 || scene > 2) return;
+    *n = k_shipped_lights.n[scene];
+    memcpy(out, k_shipped_lights.l[scene], sizeof(o_light) * (size_t)*n);
+}
+
+/* Per-frame random rotation of the ray set (DDGI paper §4.2: "randomly rotated each frame"):
+ * Shoemake's uniform random unit quaternion from three draws of the reference's own RNG
+ * (probe_pass.comp:45-71) seeded by the frame index; row-major 3x3 out. */
+void oracle_frame_rotation(uint32_t frame, float* m9)
+{
+    const float TWO_PI_F = 6.2831853071795864769252867665590057683943f;
+    uint32_t rng = oracle_wang_hash(0x9E3779B9u ^ frame);
+    float u1 = rng_rand(&rng), u2 = rng_rand(&rng), u3 = rng_rand(&rng);
+    float a = sqrtf(1.0f - u1), b = sqrtf(u1);
+    float qx = a * o_sin(TWO_PI_F * u2), qy = a * o_cos(TWO_PI_F * u2);
+    float qz = b * o_sin(TWO_PI_F * u3), qw = b * o_cos(TWO_PI_F * u3);
+    m9[0] = 1.0f - 2.0f * (qy * qy + qz * qz);
+    m9[1] = 2.0f * (qx * qy - qz * qw);
+    m9[2] = 2.0f * (qx * qz + qy * qw);
+    m9[3] = 2.0f * (qx * qy + qz * qw);
+    m9[4] = 1.0f - 2.0f * (qx * qx + qz * qz);
+    m9[5] = 2.0f * (qy * qz - qx * qw);
+    m9[6] = 2.0f * (qx * qz - qy * qw);
+    m9[7] = 2.0f * (qy * qz + qx * qw);
+    m9[8] = 1.0f - 2.0f * (qx * qx + qy * qy);
+}
+
+/* sphericalFibonacci(i, n) (DDGI supplemental; Keinert et al. 2015) rotated by m9 */
+static v3 fibonacci_dir(int i, int n, const float* m9)
+{
+    const float TWO_PI_F = 6.2831853071795864769252867665590057683943f;
+    const float PHI_M1 = 0.6180339887498948482045868343656381f;
+    float fi = (float)i;
+    float fr = fmaf(fi, PHI_M1, -floorf(fi * PHI_M1)); /* madfrac(i, PHI-1) */
+    float phi = TWO_PI_F * fr;
+    float cos_t = 1.0f - (2.0f * fi + 1.0f) / (float)n;
+    float sin_t = sqrtf(gclamp(1.0f - cos_t * cos_t, 0.0f, 1.0f));
+    v3 d = V3(o_cos(phi) * sin_t, o_sin(phi) * sin_t, cos_t);
+    return V3(dot3(V3(m9[0], m9[1], m9[2]), d), dot3(V3(m9[3], m9[4], m9[5]), d), dot3(V3(m9[6], m9[7], m9[8]), d));
+}
+
+/* a20 — octahedral.glsl:13-34 (never included by the reference; needs g3d's signNotZero) */
+static inline float sign_not_zero(float v) { return v >= 0.0f ? 1.0f : -1.0f; }
+static v2 oct_encode(v3 v)
+{
+    float l1 = fabsf(v.x) + fabsf(v.y) + fabsf(v.z);
+    float inv = 1.0f / l1;
+    v2 r = {v.x * inv, v.y * inv};
+    if (v.z < 0.0f)
+    {
+        v2 q = {(1.0f - fabsf(r.y)) * sign_not_zero(r.x), (1.0f - fabsf(r.x)) * sign_not_zero(r.y)};
+        r = q;
+    }
+    return r;
+}
+static v3 oct_decode(v2 o)
+{
+    v3 v = V3(o.x, o.y, 1.0f - fabsf(o.x) - fabsf(o.y));
+    if (v.z < 0.0f)
+    {
+        float nx = (1.0f - fabsf(v.y)) * sign_not_zero(v.x);
+        float ny = (1.0f - fabsf(v.x)) * sign_not_zero(v.y);
+        v.x = nx, v.y = ny;
+    }
+    return normalize3(v);
+}
+
+/* direction of interior texel (x, y) in [1, side-2]^2 of a side x side tile */
+static v3 texel_dir(int x, int y, int side)
+{
+    float inner = (float)(side - 2);
+    v2 uv = {((float)(x - 1) + 0.5f) / inner * 2.0f - 1.0f, ((float)(y - 1) + 0.5f) / inner * 2.0f - 1.0f};
+    return oct_decode(uv);
+}
+
+/* where border texel (x, y) of a side x side tile copies from (the octahedral wrap of the DDGI
+ * supplemental "copy border texels" pass) */
+static void border_source(int x, int y, int side, int* sx, int* sy)
+{
+    int last = side - 1;
+    int cx = (x == 0 || x == last), cy = (y == 0 || y == last);
+    if (cx && cy)
+    {
+        *sx = x == 0 ? last - 1 : 1;
+        *sy = y == 0 ? last - 1 : 1;
+    }
+    else if (cy)
+    {
+        *sx = last - x;
+        *sy = y == 0 ? 1 : last - 1;
+    }
+    else
+    {
+        *sx = x == 0 ? 1 : last - 1;
+        *sy = last - y;
+    }
+}
+
+/* One DDGI-mode trace of a probe ray: radiance estimate (the reference's multi-bounce direct-light
+ * estimate, probe_pass.comp:283-295) + the distance of the first hit (1e27 for a miss). */
+static void ddgi_trace_ray(const TraceCtx* cx, v3 origin, v3 dir, uint32_t seed, float* rgbd)
+{
+    uint32_t rng = oracle_wang_hash(seed);
+    Ray ray;
+    ray.o = origin;
+    ray.d = dir;
+    v3 color = V3(0, 0, 0);
+    float first = 1e27f;
+    Isect hit;
+    for (int i = 0; i < cx->max_bounces; i++)
+    {
+        if (intersect_scene(cx, ray, &hit))
+        {
+            if (i == 0) first = hit.t;
+            color = vadd(color, get_direct_lighting(cx, &hit));
+        }
+        else
+            break;
+        ray.o = vadd(hit.pos, vscale(hit.normal, 0.0001f));
+        ray.d = random_dir_hemisphere(hit.normal, &rng);
+    }
+    color = vdivs(color, (float)cx->max_bounces);
+    rgbd[0] = color.x, rgbd[1] = color.y, rgbd[2] = color.z, rgbd[3] = first;
+}
+
+static inline float pow50(float x)
+{
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16;
+    return (x32 * x16) * x2;
+}
+
+/* One DDGI-mode probe update (frame `frame`): trace n = s*s Fibonacci rays per probe with the
+ * animated light table, then blend each probe's irradiance (8x8 rgba f32) and depth-moment
+ * (16x16 rg f32) tiles in place with the reference's dormant hysteresis line
+ * (probe_pass.comp:298-299: color = mix(old, new, hysteresis)).  Tiles are probe-major in the
+ * reference probe order p.  radiance_out (optional) receives the per-ray (rgb, distance). */
+void oracle_ddgi_update(const o_field* f, const o_settings* st, const o_light* base_lights, int nl, uint32_t frame,
+                        float* irradiance, float* depth, float* radiance_out, int first_probe, int n_probes, int nthreads)
+{
+    TraceCtx cx;
+    o_light base[O_MAX_LIGHTS], lights[O_MAX_LIGHTS];
+    if (base_lights)
+        memcpy(base, base_lights, sizeof(o_light) * (size_t)nl);
+    else
+        oracle_shipped_lights(st->scene, base, &nl);
+    oracle_update_lights(st->scene, st->time, base, nl, lights);
+    make_ctx(&cx, st, lights, nl);
+    float rot[9];
+    oracle_frame_rotation(frame, rot);
+    int cxn = f->probe_count[0], cyn = f->probe_count[1], czn = f->probe_count[2];
+    int s = f->sqrt_rays_per_probe, n = s * s;
+    float hyst = f->hysteresis;
+    float max_dist = (float)f->side_length * 1.5f;
+    uint32_t frame_key = oracle_wang_hash(frame);
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int pp = 0; pp < n_probes; pp++)
+    {
+        int p = first_probe + pp;
+        int py = p / (cxn * czn);
+        int rem = p - py * cxn * czn;
+        int pz = rem / cxn;
+        int px = rem - pz * cxn;
+        v3 origin = V3((float)(px - (cxn - 1) / 2), (float)(py - (cyn - 1) / 2), (float)(pz - (czn - 1) / 2));
+        origin = vscale(origin, (float)f->side_length);
+        origin = vadd(origin, V3(f->field_origin[0], f->field_origin[1], f->field_origin[2]));
+        float* rad = (float*)malloc(sizeof(float) * 4 * (size_t)n);
+        v3* dirs = (v3*)malloc(sizeof(v3) * (size_t)n);
+        for (int i = 0; i < n; i++)
+        {
+            dirs[i] = fibonacci_dir(i, n, rot);
+            uint32_t gi = (uint32_t)p * (uint32_t)n + (uint32_t)i;
+            ddgi_trace_ray(&cx, origin, dirs[i], gi ^ frame_key, rad + 4 * i);
+        }
+        if (radiance_out) memcpy(radiance_out + (size_t)p * n * 4, rad, sizeof(float) * 4 * (size_t)n);
+        /* irradiance: cosine-weighted mean of the ray radiances per texel direction */
+        float* it = irradiance + (size_t)p * DDGI_IRR_TILE * DDGI_IRR_TILE * 4;
+        for (int y = 1; y < DDGI_IRR_TILE - 1; y++)
+            for (int x = 1; x < DDGI_IRR_TILE - 1; x++)
+            {
+                v3 td = texel_dir(x, y, DDGI_IRR_TILE);
+                float sw = 0, sr = 0, sg = 0, sb = 0;
+                for (int i = 0; i < n; i++)
+                {
+                    float w = gmax(0.0f, dot3(td, dirs[i]));
+                    sr += rad[4 * i] * w, sg += rad[4 * i + 1] * w, sb += rad[4 * i + 2] * w;
+                    sw += w;
+                }
+                float res[3] = {0, 0, 0};
+                if (sw > 1e-6f) res[0] = sr / sw, res[1] = sg / sw, res[2] = sb / sw;
+                float* o = it + (y * DDGI_IRR_TILE + x) * 4;
+                for (int c = 0; c < 3; c++) o[c] = gmix(o[c], res[c], hyst);
+                o[3] = 1.0f;
+            }
+        for (int y = 0; y < DDGI_IRR_TILE; y++)
+            for (int x = 0; x < DDGI_IRR_TILE; x++)
+                if (x == 0 || y == 0 || x == DDGI_IRR_TILE - 1 || y == DDGI_IRR_TILE - 1)
+                {
+                    int sx, sy;
+                    border_source(x, y, DDGI_IRR_TILE, &sx, &sy);
+                    memcpy(it + (y * DDGI_IRR_TILE + x) * 4, it + (sy * DDGI_IRR_TILE + sx) * 4, sizeof(float) * 4);
+                }
+        /* depth moments: sharpened-cosine-weighted mean of min(d, 1.5*spacing) and its square */
+        float* dt = depth + (size_t)p * DDGI_DEP_TILE * DDGI_DEP_TILE * 2;
+        for (int y = 1; y < DDGI_DEP_TILE - 1; y++)
+            for (int x = 1; x < DDGI_DEP_TILE - 1; x++)
+            {
+                v3 td = texel_dir(x, y, DDGI_DEP_TILE);
+                float sw = 0, s1 = 0, s2 = 0;
+                for (int i = 0; i < n; i++)
+                {
+                    float w = pow50(gmax(0.0f, dot3(td, dirs[i])));
+                    float d = gmin(rad[4 * i + 3], max_dist);
+                    s1 += d * w, s2 += (d * d) * w;
+                    sw += w;
+                }
+                float r1 = 0, r2 = 0;
+                if (sw > 1e-6f) r1 = s1 / sw, r2 = s2 / sw;
+                float* o = dt + (y * DDGI_DEP_TILE + x) * 2;
+                o[0] = gmix(o[0], r1, hyst);
+                o[1] = gmix(o[1], r2, hyst);
+            }
+        for (int y = 0; y < DDGI_DEP_TILE; y++)
+            for (int x = 0; x < DDGI_DEP_TILE; x++)
+                if (x == 0 || y == 0 || x == DDGI_DEP_TILE - 1 || y == DDGI_DEP_TILE - 1)
+                {
+                    int sx, sy;
+                    border_source(x, y, DDGI_DEP_TILE, &sx, &sy);
+                    memcpy(dt + (y * DDGI_DEP_TILE + x) * 2, dt + (sy * DDGI_DEP_TILE + sx) * 2, sizeof(float) * 2);
+                }
+        free(rad);
+        free(dirs);
+    }
+}
+
+/* bilinear fetch of a side x side tile (nc channels) in direction dir */
+static void tile_fetch(const float* tile, int side, int nc, v3 dir, float* out)
+{
+    v2 uv = oct_encode(normalize3(dir));
+    float inner = (float)(side - 2);
+    float fx = (uv.x * 0.5f + 0.5f) * inner + 0.5f; /* texel-centre coordinate inside the bordered tile */
+    float fy = (uv.y * 0.5f + 0.5f) * inner + 0.5f;
+    float bx = floorf(fx), by = floorf(fy);
+    float tx = fx - bx, ty = fy - by;
+    int x0 = gint(bx), y0 = gint(by);
+    int x1 = x0 + 1, y1 = y0 + 1;
+    if (x0 < 0) x0 = 0;
+    if (y0 < 0) y0 = 0;
+    if (x1 > side - 1) x1 = side - 1;
+    if (y1 > side - 1) y1 = side - 1;
+    for (int c = 0; c < nc; c++)
+    {
+        float a = tile[(y0 * side + x0) * nc + c], b = tile[(y0 * side + x1) * nc + c];
+        float cc = tile[(y1 * side + x0) * nc + c], d = tile[(y1 * side + x1) * nc + c];
+        out[c] = gmix(gmix(a, b, tx), gmix(cc, d, tx), ty);
+    }
+}
+
+/* get_diffuse_gi (intersection.glsl:1306-1409) with its dormant Chebyshev lines (1363-1383)
+ * switched on and sample_probe replaced by octahedral bilinear fetches of the blended tiles. */
+void oracle_ddgi_sample(const o_field* f, const float* irradiance, const float* depth, const float* pos_a,
+                        const float* nrm_a, uint64_t npts, float* rgb, int32_t* cage8)
+{
+    int cxn = f->probe_count[0], cyn = f->probe_count[1], czn = f->probe_count[2];
+    float side = (float)f->side_length;
+    v3 origin = V3(f->field_origin[0], f->field_origin[1], f->field_origin[2]);
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < (int64_t)npts; k++)
+    {
+        v3 pos = V3(pos_a[3 * k], pos_a[3 * k + 1], pos_a[3 * k + 2]);
+        v3 N = normalize3(V3(nrm_a[3 * k], nrm_a[3 * k + 1], nrm_a[3 * k + 2]));
+        int32_t cage[8];
+        for (int i = 0; i < 8; i++) cage[i] = -1;
+        v3 out = V3(1, 0, 1);
+        v3 rel = vdivs(vsub(pos, origin), side);
+        int base[3] = {gint(floorf(rel.x)), gint(floorf(rel.y)), gint(floorf(rel.z))};
+        int lo = gint(-floorf((float)cxn / 2.0f));
+        int hi = gint(floorf((float)cxn / 2.0f) - 1);
+        int ok = 1;
+        for (int i = 0; i < 3; i++)
+            if (base[i] < lo || base[i] > hi) ok = 0;
+        if (ok)
+        {
+            v3 base_world = vadd(V3((float)(base[0] * f->side_length), (float)(base[1] * f->side_length),
+                                    (float)(base[2] * f->side_length)), origin);
+            v3 a = vdivs(vsub(pos, base_world), side);
+            v3 alpha = V3(gclamp(a.x, 0, 1), gclamp(a.y, 0, 1), gclamp(a.z, 0, 1));
+            v3 irr = V3(0, 0, 0);
+            float sum_w = 0.0f;
+            for (int i = 0; i < 8 && ok; i++)
+            {
+                int off[3] = {(i >> 2) & 1, (i >> 1) & 1, i & 1};
+                int sh[3] = {base[0] + off[0] + cxn / 2, base[1] + off[1] + cyn / 2, base[2] + off[2] + czn / 2};
+                int idx = sh[1] * cxn * czn + sh[2] * cxn + sh[0];
+                if (idx < 0 || idx >= cxn * cyn * czn)
+                {
+                    ok = 0;
+                    break;
+                }
+                cage[i] = idx;
+                v3 tri = V3(off[0] ? alpha.x : 1.0f - alpha.x, off[1] ? alpha.y : 1.0f - alpha.y, off[2] ? alpha.z : 1.0f - alpha.z);
+                v3 probe_pos = vadd(base_world, V3((float)(off[0] * f->side_length), (float)(off[1] * f->side_length),
+                                                   (float)(off[2] * f->side_length)));
+                v3 dir = normalize3(vsub(probe_pos, pos));
+                float temp = gmax(0.0001f, (dot3(dir, N) + 1.0f) * 0.5f);
+                float weight = temp * temp + 0.2f;
+                /* moment visibility test (:1363-1383) */
+                float dist = length3(vsub(pos, probe_pos));
+                float mms[2];
+                tile_fetch(depth + (size_t)idx * DDGI_DEP_TILE * DDGI_DEP_TILE * 2, DDGI_DEP_TILE, 2, V3(-dir.x, -dir.y, -dir.z), mms);
+                float mean = mms[0];
+                float variance = fabsf(mean * mean - mms[1]);
+                temp = gmax(dist - mean, 0.0f);
+                float cheb = variance / (variance + temp * temp);
+                cheb = gmax(cheb * cheb * cheb, 0.0f);
+                if (!(dist <= mean)) weight *= cheb;
+                weight = gmax(0.000001f, weight);
+                const float crush = 0.2f;
+                if (weight < crush) weight *= weight * weight * (1.f / (crush * crush));
+                weight *= tri.x * tri.y * tri.z;
+                float c4[4];
+                tile_fetch(irradiance + (size_t)idx * DDGI_IRR_TILE * DDGI_IRR_TILE * 4, DDGI_IRR_TILE, 4, N, c4);
+                irr = vadd(irr, vscale(V3(c4[0], c4[1], c4[2]), weight));
+                sum_w += weight;
+            }
+            if (ok) out = vdivs(irr, sum_w);
+        }
+        if (!ok)
+        {
+            out = V3(1, 0, 1);
+            for (int i = 0; i < 8; i++) cage[i] = -1;
+        }
+        rgb[3 * k] = out.x, rgb[3 * k + 1] = out.y, rgb[3 * k + 2] = out.z;
+        if (cage8) memcpy(cage8 + 8 * k, cage, sizeof(cage));
+    }
+}

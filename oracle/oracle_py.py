@@ -202,3 +202,62 @@ def rng_kat(p_idx):
 
 def num_threads():
     return lib().oracle_num_threads()
+
+
+# ---- DDGI mode ---------------------------------------------------------------------------------
+
+IRR_TILE, DEP_TILE = 8, 16
+
+
+def shipped_lights(scene):
+    out = np.zeros(8, dtype=LIGHT_DTYPE)
+    n = C.c_int(0)
+    lib().oracle_shipped_lights(scene, out.ctypes.data_as(C.c_void_p), C.byref(n))
+    return out[: n.value].copy()
+
+
+def update_lights(scene, time, base):
+    base = np.ascontiguousarray(base, dtype=LIGHT_DTYPE)
+    out = np.zeros(len(base), dtype=LIGHT_DTYPE)
+    lib().oracle_update_lights(scene, C.c_float(time), base.ctypes.data_as(C.c_void_p), len(base),
+                               out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def frame_rotation(frame):
+    m = np.zeros(9, dtype=np.float32)
+    lib().oracle_frame_rotation(C.c_uint32(frame), m.ctypes.data_as(C.c_void_p))
+    return m.reshape(3, 3)
+
+
+def new_tiles(field):
+    P = field.probe_count[0] * field.probe_count[1] * field.probe_count[2]
+    return (np.zeros((P, IRR_TILE, IRR_TILE, 4), dtype=np.float32), np.zeros((P, DEP_TILE, DEP_TILE, 2), dtype=np.float32))
+
+
+def ddgi_update(field, settings, frame, irradiance, depth, lights=None, probes=None, nthreads=0, want_radiance=False):
+    """One DDGI-mode probe update in place on (irradiance, depth) -> optional radiance [P*n, 4]."""
+    P = field.probe_count[0] * field.probe_count[1] * field.probe_count[2]
+    n = field.sqrt_rays_per_probe ** 2
+    rad = np.zeros((P * n, 4), dtype=np.float32) if want_radiance else None
+    lp, nl = None, 0
+    if lights is not None:
+        lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+        lp, nl = lights.ctypes.data_as(C.c_void_p), len(lights)
+    first, count = (0, P) if probes is None else probes
+    lib().oracle_ddgi_update(C.byref(field), C.byref(settings), lp, nl, C.c_uint32(frame),
+                             irradiance.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p),
+                             rad.ctypes.data_as(C.c_void_p) if want_radiance else None, first, count, nthreads)
+    return rad
+
+
+def ddgi_sample(field, irradiance, depth, pos, nrm):
+    pos = np.ascontiguousarray(pos, dtype=np.float32)
+    nrm = np.ascontiguousarray(nrm, dtype=np.float32)
+    n = pos.shape[0]
+    rgb = np.zeros((n, 3), dtype=np.float32)
+    cage = np.zeros((n, 8), dtype=np.int32)
+    lib().oracle_ddgi_sample(C.byref(field), irradiance.ctypes.data_as(C.c_void_p), depth.ctypes.data_as(C.c_void_p),
+                             pos.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p), C.c_uint64(n),
+                             rgb.ctypes.data_as(C.c_void_p), cage.ctypes.data_as(C.c_void_p))
+    return rgb, cage
