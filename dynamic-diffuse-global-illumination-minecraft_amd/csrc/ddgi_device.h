@@ -117,7 +117,7 @@ DDGI_D void start_march(March& m, f3 o, f3 d, const TraceArgs& A)
     m.lid = lid;
 }
 
-// Linear cell index of voxel id (x,y,z) clamped into the baked box.  Outside the box the world is
+// Raw linear cell index of voxel id (x,y,z) clamped into the baked box.  Outside the box the world is
 // the extrusion of the border layer (ddgi_scene_bake.cpp), so clamping is exact.
 DDGI_D int cell_index(const SceneK& S, int x, int y, int z)
 {
@@ -125,7 +125,7 @@ DDGI_D int cell_index(const SceneK& S, int x, int y, int z)
     y = min(max(y, S.lo[1]), S.hi[1]);
     z = min(max(z, S.lo[2]), S.hi[2]);
     // clamped coordinates and pitches fit 24 bits: v_mad_i32_i24 instead of quarter-rate v_mul_lo_u32
-    return __mul24(z, S.nxy) + __mul24(y, S.nx) + x - S.bias;
+    return __mul24(z, S.nxy) + __mul24(y, S.nx) + x;  // "raw" index; block-type index = raw - S.bias
 }
 
 // One grid_march iteration (intersection.glsl:1059-1069).  Returns true if the voxel reached is
@@ -143,7 +143,9 @@ DDGI_D bool march_step(March& m, const SceneK& S, const uint32_t* __restrict__ s
                                static_cast<int>(ceilf(m.p.z)));
     m.it += 1;
     m.cell = idx;
-    return (s_bits[idx >> 5] >> (idx & 31)) & 1u;
+    // the bitmap is stored so that the raw index addresses it directly (SceneK::bias32)
+    const uint32_t* __restrict__ base = s_bits - (S.bias32 >> 5);
+    return (base[idx >> 5] >> (idx & 31)) & 1u;
 }
 
 // True when the march can no longer hit a block: the position is outside the baked box on some

@@ -178,9 +178,17 @@ static int ensure_scene(ddgi_engine* e, int scene)
     ddgi_engine::DevScene& d = e->dev_scene[scene];
     if (d.ready) return DDGI_OK;
     const SceneBake& b = baked_scene(scene);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.bits), b.bits.size() * sizeof(uint32_t)));
+    // the kernels address the bitmap with the raw index z*nxy + y*nx + x: store it shifted so that the
+    // word boundary falls on a multiple of 32 of the raw index (SceneK::bias32)
+    const int bias = (b.lo[2] * b.dim[1] + b.lo[1]) * b.dim[0] + b.lo[0];
+    const int bias32 = (bias >= 0 ? bias / 32 : -((-bias + 31) / 32)) * 32;
+    const int shift = bias - bias32;  // 0..31
+    std::vector<uint32_t> shifted((b.types.size() + shift + 31) / 32, 0u);
+    for (size_t i = 0; i < b.types.size(); ++i)
+        if (b.types[i]) shifted[(i + shift) >> 5] |= 1u << ((i + shift) & 31);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.bits), shifted.size() * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.types), b.types.size()));
-    HIP_TRY(hipMemcpy(d.bits, b.bits.data(), b.bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.bits, shifted.data(), shifted.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d.types, b.types.data(), b.types.size(), hipMemcpyHostToDevice));
     for (int a = 0; a < 3; ++a)
     {
@@ -189,8 +197,9 @@ static int ensure_scene(ddgi_engine* e, int scene)
     }
     d.k.nx = b.dim[0];
     d.k.nxy = b.dim[0] * b.dim[1];
-    d.k.bias = (b.lo[2] * b.dim[1] + b.lo[1]) * b.dim[0] + b.lo[0];
-    d.k.nwords = static_cast<int>(b.bits.size());
+    d.k.bias = bias;
+    d.k.bias32 = bias32;
+    d.k.nwords = static_cast<int>(shifted.size());
     d.k.face_empty = b.face_empty;
     d.k.bits = d.bits;
     d.k.types = d.types;

@@ -11,17 +11,16 @@
 // Here rays are NOT bound to lanes.  A pool of P rays (P ~ 1.3 x the lane count) lives in LDS as a
 // structure of arrays (24 dwords/ray: the reference's Ray + Isect + accumulators) next to the
 // scene's occupancy bitmap, and the 16 waves run dense phases over compacted lists of pool slots:
-//   A  scan    refill free slots with new rays (48 B ProbeRay records), list the slots whose next
-//              action is a voxel march
+//   C  sort    pool slots are bucketed by what has to happen next: hit shading per block type (the
+//              procedural albedo is a switch over 13 block types), light hit / miss, light-feeler
+//              result, or - for a free slot while rays remain - taking a new ray
+//   D  events  waves claim 64-lane groups of ONE bucket, most expensive buckets first: hit
+//              shading (+ feeler set-up), light evaluation (+ bounce set-up, or texel store and
+//              slot release), refill (48 B ProbeRay record in, first march set up); every new
+//              march is appended to the round's march list
 //   B  march   every lane pulls march tasks from the list (wave-aggregated LDS atomic), steps them,
 //              and pulls another when its own finishes; once the list is drained the stragglers run
-//              kWfTailSteps more steps and are parked (t, iteration count) until the next round
-//   C  sort    finished marches are bucketed by what has to happen next: hit shading per block
-//              type (the procedural albedo is a switch over 13 block types), light hit / miss,
-//              light-feeler result
-//   D  events  waves claim 64-lane groups of ONE bucket, most expensive buckets first:
-//              hit shading (+ feeler set-up) or light evaluation (+ bounce set-up, or texel
-//              store and slot release)
+//              kWfTailSteps more steps and are parked (t, iteration count) on the NEXT round's list
 // ------------------------------------------------------------------------------------------------
 #include "ddgi_device.h"
 #include "ddgi_oct.h"
@@ -31,7 +30,7 @@ namespace ddgi {
 constexpr int kWfTailSteps = 16;     // straggler steps after the march list is drained
 constexpr int kWfFetchLanes = 16;    // pull new march tasks once this many lanes are idle
 constexpr uint32_t kWfChunk = 4096;  // rays a workgroup claims at a time from the global counter
-constexpr int kWfBuckets = 9;
+constexpr int kWfBuckets = 10;
 
 enum : uint32_t
 {
@@ -47,11 +46,11 @@ enum : uint32_t
 
 struct WfShared  // control block at the start of dynamic LDS (32 dwords)
 {
-    uint32_t n_march, head_march, cur, end;
-    uint32_t live, group_head, n_groups, pad;
-    uint32_t bucket_count[kWfBuckets + 1];  // entries per bucket
-    uint32_t bucket_base[kWfBuckets + 1];   // first list index of each bucket
-    uint32_t pad2[4];
+    uint32_t n_march[2];  // fill counts of the two march lists (this round's / next round's)
+    uint32_t head_march, cur, end, live, group_head, n_groups;
+    uint32_t bucket_count[kWfBuckets + 1];  // entries per event bucket
+    uint32_t bucket_base[kWfBuckets + 1];   // first event-list index of each bucket
+    uint32_t pad[2];
 };
 static_assert(sizeof(WfShared) == 32 * 4, "control block is 32 dwords");
 
@@ -70,7 +69,8 @@ struct WfPool
     uint32_t* cnt;  // [7:0] bounce, [11:8] light index, [15:12] visible lights
     uint32_t* dst;
     float* dir[3];  // accumulated direct light; only when there is more than one light
-    uint16_t* list;
+    uint16_t* march_list[2];  // double buffered: stragglers and new marches are appended for the next round
+    uint16_t* event_list;
 };
 
 constexpr int wf_dwords_per_ray(bool multi_light) { return multi_light ? 27 : 24; }
@@ -114,6 +114,7 @@ DDGI_D uint32_t shade_bucket(int type)
 }
 constexpr uint32_t kBucketNoBlock = 7;  // primary march that ended on a light sphere or missed
 constexpr uint32_t kBucketFeeler = 8;
+constexpr uint32_t kBucketRefill = 9;  // an empty slot that can take a new ray
 
 // A new voxel march for pool slot `slot` (intersect_scene's set-up, intersection.glsl:1253-1279 +
 // grid_march's, 1053-1058): origin, normalised direction and its reciprocal, light spheres.
@@ -150,7 +151,7 @@ DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, const TraceA
 }
 
 // End of get_direct_lighting for one hit: accumulate, then bounce or finish (probe_pass.comp:286-292).
-DDGI_D void wf_lighting_done(const WfPool& P, uint32_t slot, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A)
+DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A)
 {
     const f3 color = ld3(P.col, slot) + contribution;
     const uint32_t bounce = (cnt & 255u) + 1u;
@@ -163,13 +164,14 @@ DDGI_D void wf_lighting_done(const WfPool& P, uint32_t slot, f3 contribution, f3
         const f3 nd = (A.ablate & 2) ? normalize3(hnrm + mk3(0.3f, 0.2f, 0.1f)) : hemisphere_dir(hnrm, rng);
         P.rng[slot] = rng;
         wf_post_march(P, slot, no, nd, false, A);
+        return true;
     }
-    else
-        wf_finish_ray(P, slot, color, A);
+    wf_finish_ray(P, slot, color, A);
+    return false;
 }
 
 // T lanes per workgroup, kBlocksPerCU workgroups resident per CU (T * kBlocksPerCU = 1024 lanes = 4 waves/SIMD)
-template <int T, int kBlocksPerCU>
+template <int T, int kBlocksPerCU, bool kStats>
 __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(const TraceArgs A, const int pool_size, uint32_t* __restrict__ work_counter)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t wf_lds[];
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
     const int tail_steps = A.wf_tail > 0 ? A.wf_tail : kWfTailSteps;
     const int fetch_lanes = A.wf_fetch > 0 ? A.wf_fetch : kWfFetchLanes;
 
-    // ---- carve LDS: control block | occupancy bitmap | pool arrays | slot list ----
+    // ---- carve LDS: control block | occupancy bitmap | pool arrays | slot lists ----
     WfShared* sh = reinterpret_cast<WfShared*>(wf_lds);
     uint32_t* s_bits = wf_lds + 32;
     uint32_t* cursor = s_bits + ((A.scene.nwords + 3) & ~3);
@@ -201,14 +203,16 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
     P.cnt = takeu();
     P.dst = takeu();
     for (int a = 0; a < 3; ++a) P.dir[a] = multi_light ? takef() : nullptr;
-    P.list = reinterpret_cast<uint16_t*>(cursor);
+    P.march_list[0] = reinterpret_cast<uint16_t*>(cursor);
+    P.march_list[1] = P.march_list[0] + PS;
+    P.event_list = P.march_list[1] + PS;
 
     for (int i = tid; i < A.scene.nwords; i += T) s_bits[i] = A.scene.bits[i];
     for (uint32_t i = tid; i < PS; i += T) P.flags[i] = kSlotEmpty;
     const uint32_t n_chunks = (A.n_rays + kWfChunk - 1) / kWfChunk;
     if (tid == 0)
     {
-        sh->n_march = sh->head_march = 0;
+        sh->n_march[0] = sh->n_march[1] = sh->head_march = 0;
         sh->live = 0;
         sh->group_head = sh->n_groups = 0;
         const uint32_t c = atomicAdd(work_counter, 1u);
@@ -224,81 +228,271 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
     unsigned long long st_trips = 0, st_lane_steps = 0, st_groups = 0, st_lane_events = 0, st_iters = 0, st_fetches = 0;
     long long cy[6] = {0, 0, 0, 0, 0, 0};
 
-    for (;;)
+    for (uint32_t round = 0;; ++round)
     {
-        // ================= A: refill free slots, list the marches =================
-        const long long c0 = A.stats ? clock64() : 0;
-        bool any_live = false;
-        for (uint32_t slot = tid; slot < PS; slot += T)
+        const uint32_t cur_list = round & 1u, next_list = cur_list ^ 1u;
+        // ================= C: bucket every slot by its next action =================
+        const long long c0 = kStats ? clock64() : 0;
+        const uint32_t ray_cur = sh->cur, ray_end = sh->end;
+        const bool have_rays = ray_cur < ray_end;
+        uint32_t my_bucket[2], my_rank[2];
         {
-            uint32_t fl = P.flags[slot];
-            // claim a new ray for an empty slot (wave-aggregated claim on the workgroup's range)
-            const bool want = (fl & 3u) == kSlotEmpty;
-            const unsigned long long wm = __ballot(want);
-            if (wm != 0ull)
+            bool any_live = false;
+            int k = 0;
+            for (uint32_t slot = tid; slot < PS; slot += T, ++k)
             {
-                uint32_t base = 0;
-                const int leader = __ffsll(static_cast<long long>(wm)) - 1;
-                if (lane == leader) base = atomicAdd(&sh->cur, static_cast<uint32_t>(__popcll(wm)));
-                base = __shfl(base, leader);
-                const uint32_t r = base + static_cast<uint32_t>(__popcll(wm & ((1ull << lane) - 1ull)));
-                if (want && r < sh->end)
+                const uint32_t fl = P.flags[slot];
+                const uint32_t st = fl & 3u;
+                uint32_t b = kWfBuckets;  // none (a march in flight)
+                if (st == kSlotEvFeeler) b = kBucketFeeler;
+                else if (st == kSlotEvPrimary)
                 {
-                    // local (y, zl, x) probe enumeration -> reference probe index p -> global ray index
-                    const int pl = static_cast<int>(r / static_cast<uint32_t>(rays_per_probe));
-                    const int i = static_cast<int>(r) - pl * rays_per_probe;
-                    const int slab_row = G.czl * G.cx;
-                    const int y = pl / slab_row;
-                    const int rem = pl - y * slab_row;
-                    const int p = y * G.cx * G.cz + G.z0 * G.cx + rem;
-                    const uint32_t global_ray = static_cast<uint32_t>(p) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i);
-                    f3 ray_o, ray_d;
-                    if (A.ddgi)
-                    {
-                        // in-kernel ray generation: probe position + rotated spherical Fibonacci direction
-                        const int pxz = p - y * G.cx * G.cz;
-                        ray_o = probe_position(G, pxz % G.cx, y, pxz / G.cx);
-                        ray_d = fibonacci_dir(i, rays_per_probe, A.rot);
-                        P.dst[slot] = r;
-                        P.rng[slot] = wang_hash(global_ray ^ A.frame_key);
-                    }
-                    else
-                    {
-                        const float4* rec = A.rays + 3 * static_cast<size_t>(r);
-                        const float4 ra = rec[0], rb = rec[1], rc = rec[2];
-                        ray_o = mk3(ra.x, ra.y, ra.z);
-                        ray_d = mk3(rb.x, rb.y, rb.z);
-                        const int dst_probe = static_cast<int>(rc.x);  // int(probe_info.x), probe_pass.comp:269
-                        P.dst[slot] = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.s + static_cast<int>(rc.y);
-                        P.rng[slot] = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
-                    }
-                    P.cnt[slot] = 0u;
-                    st3(P.col, slot, mk3(0, 0, 0));
-                    wf_post_march(P, slot, ray_o, ray_d, false, A);
-                    fl = kSlotMarch;
+                    const bool block_wins = (fl & kFlagHit) && (P.t[slot] < P.tl[slot]);
+                    b = block_wins ? shade_bucket(static_cast<int>((fl >> 16) & 15u)) : kBucketNoBlock;
                 }
+                else if (st == kSlotEmpty && have_rays) b = kBucketRefill;
+                my_bucket[k] = b;
+                my_rank[k] = (b < kWfBuckets) ? atomicAdd(&sh->bucket_count[b], 1u) : 0u;
+                any_live |= (st != kSlotEmpty) || have_rays;
             }
-            const bool is_march = (fl & 3u) == kSlotMarch;
-            const uint32_t idx = wave_append(is_march, &sh->n_march, lane);
-            if (is_march) P.list[idx] = static_cast<uint16_t>(slot);
-            any_live |= (fl & 3u) != kSlotEmpty;
+            if (__ballot(any_live) != 0ull && lane == 0) sh->live = 1u;
         }
-        if (__ballot(any_live) != 0ull && lane == 0) sh->live = 1u;
         __syncthreads();
         if (sh->live == 0u) break;  // nothing in flight and no ray left to claim
         st_iters += 1;
         if (st_iters > (1ull << 20)) break;  // safety net: never spin forever on the GPU
+        if (tid == 0)
+        {
+            uint32_t base = 0, groups = 0;
+            for (int b = 0; b < kWfBuckets; ++b)
+            {
+                sh->bucket_base[b] = base;
+                base += sh->bucket_count[b];
+                groups += (sh->bucket_count[b] + 63u) / 64u;
+            }
+            sh->n_groups = groups;
+            sh->group_head = 0;
+            sh->n_march[next_list] = 0;  // last round's list is consumed; it now collects next round's marches
+            sh->head_march = 0;
+        }
+        __syncthreads();
+        {
+            int k = 0;
+            for (uint32_t slot = tid; slot < PS; slot += T, ++k)
+                if (my_bucket[k] < kWfBuckets) P.event_list[sh->bucket_base[my_bucket[k]] + my_rank[k]] = static_cast<uint16_t>(slot);
+        }
+        __syncthreads();
+
+        // ================= D: events, in 64-lane groups of one bucket =================
+        const long long c1 = kStats ? clock64() : 0;
+        for (;;)
+        {
+            uint32_t g = 0;
+            if (lane == 0) g = atomicAdd(&sh->group_head, 1u);
+            g = __shfl(g, 0);
+            if (g >= sh->n_groups) break;
+            // locate the group: bucket b, 64-entry window inside it
+            uint32_t b = 0, first = 0;
+            for (; b < kWfBuckets; ++b)
+            {
+                const uint32_t gb = (sh->bucket_count[b] + 63u) / 64u;
+                if (g < first + gb) break;
+                first += gb;
+            }
+            const uint32_t e = (g - first) * 64u + lane;
+            const bool valid = e < sh->bucket_count[b];
+            if (kStats)
+            {
+                st_groups += 1;
+                st_lane_events += __popcll(__ballot(valid));
+            }
+            uint32_t slot = 0;
+            bool posted = false;  // this lane set up a new voxel march for its slot
+            if (valid)
+            {
+                slot = P.event_list[sh->bucket_base[b] + e];
+                if (b == kBucketRefill)
+                {
+                    const uint32_t r = ray_cur + e;  // local ray index
+                    if (r < ray_end)
+                    {
+                        // local (y, zl, x) probe enumeration -> reference probe index p -> global ray index
+                        const int pl = static_cast<int>(r / static_cast<uint32_t>(rays_per_probe));
+                        const int i = static_cast<int>(r) - pl * rays_per_probe;
+                        const int slab_row = G.czl * G.cx;
+                        const int y = pl / slab_row;
+                        const int rem = pl - y * slab_row;
+                        const int p = y * G.cx * G.cz + G.z0 * G.cx + rem;
+                        const uint32_t global_ray = static_cast<uint32_t>(p) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i);
+                        f3 ray_o, ray_d;
+                        if (A.ddgi)
+                        {
+                            // in-kernel ray generation: probe position + rotated spherical Fibonacci direction
+                            const int pxz = p - y * G.cx * G.cz;
+                            ray_o = probe_position(G, pxz % G.cx, y, pxz / G.cx);
+                            ray_d = fibonacci_dir(i, rays_per_probe, A.rot);
+                            P.dst[slot] = r;
+                            P.rng[slot] = wang_hash(global_ray ^ A.frame_key);
+                        }
+                        else
+                        {
+                            const float4* rec = A.rays + 3 * static_cast<size_t>(r);
+                            const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+                            ray_o = mk3(ra.x, ra.y, ra.z);
+                            ray_d = mk3(rb.x, rb.y, rb.z);
+                            const int dst_probe = static_cast<int>(rc.x);  // int(probe_info.x), probe_pass.comp:269
+                            P.dst[slot] = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.s + static_cast<int>(rc.y);
+                            P.rng[slot] = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
+                        }
+                        P.cnt[slot] = 0u;
+                        st3(P.col, slot, mk3(0, 0, 0));
+                        wf_post_march(P, slot, ray_o, ray_d, false, A);
+                        posted = true;
+                    }
+                }
+                else
+                {
+                    const uint32_t fl = P.flags[slot];
+                    const float t = P.t[slot], tl = P.tl[slot];
+                    const f3 ro = ld3(P.ro, slot);
+                    const bool block_wins = (fl & kFlagHit) && (t < tl);  // temp_isect.t < closest_t
+                    const bool any_hit = block_wins || (tl < inf);       // closest_t < INF
+                    if (b != kBucketFeeler)
+                    {
+                        const bool first_bounce = A.ddgi && (P.cnt[slot] & 255u) == 0u;
+                        if (!any_hit)
+                        {
+                            if (first_bounce) reinterpret_cast<float*>(A.radiance + P.dst[slot])[3] = kMissDistance;
+                            wf_finish_ray(P, slot, ld3(P.col, slot), A);  // probe_pass.comp:288-290 break
+                        }
+                        else
+                        {
+                            const f3 rd = ld3(P.hc, slot);  // the ray direction as given (see WfPool::hc)
+                            f3 nraw, hcol;
+                            float th;
+                            bool axis_normal = false;
+                            if (block_wins)
+                            {
+                                th = t;
+                                const f3 p = ray_at(ro, ld3(P.dn, slot), t);  // the march position at the hit
+                                const f3 cell = cell_id(p);
+                                const f3 centre = f3{cell.x - 0.5f, cell.y - 0.5f, cell.z - 0.5f};
+                                const f3 diff = normalize3(p - centre);
+                                // axis of the largest |component|, first wins on ties (:1075-1086)
+                                f3 n = mk3(0, 0, 0);
+                                float best = 0.0f;
+                                if (fabsf(diff.x) > best) { best = fabsf(diff.x); n = mk3(gl_sign(diff.x), 0, 0); }
+                                if (fabsf(diff.y) > best) { best = fabsf(diff.y); n = mk3(0, gl_sign(diff.y), 0); }
+                                if (fabsf(diff.z) > best) { best = fabsf(diff.z); n = mk3(0, 0, gl_sign(diff.z)); }
+                                // normalize(n) of a unit axis vector is n itself (1*(1/sqrt(1)) = 1, 0*1 = 0);
+                                // n stays (0,0,0) only if diff is NaN, where the reference yields NaN as well
+                                const f3 nn = best > 0.0f ? n : normalize3(n);
+                                const int type = static_cast<int>((fl >> 16) & 15u);
+                                hcol = (A.ablate & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
+                                nraw = nn;
+                                axis_normal = best > 0.0f;
+                            }
+                            else
+                            {
+                                th = tl;
+                                const LightK& L = A.lights[static_cast<int>((fl >> 12) & 15u) - 1];
+                                const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
+                                nraw = ray_at((ro - lp) * 10.0f, rd * 10.0f, th);  // sphere-space position
+                                hcol = mk3(0, 0, 0);  // Q12: unassigned Material, pinned to zero
+                            }
+                            if (first_bounce) reinterpret_cast<float*>(A.radiance + P.dst[slot])[3] = th;  // Isect.t of the probe ray
+                            const f3 hnrm = axis_normal ? nraw : normalize3(nraw);
+                            const f3 hpos = ray_at(ro, rd, th) + hnrm * 0.001f;
+                            st3(P.hn, slot, hnrm);
+                            const uint32_t cnt = P.cnt[slot] & 255u;  // light index 0, no visible light yet
+                            if (A.nl > 0)
+                            {
+                                P.cnt[slot] = cnt;
+                                if (multi_light) st3(P.dir, slot, mk3(0, 0, 0));
+                                const LightK& L = A.lights[0];
+                                wf_post_march(P, slot, hpos, normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos), true, A);
+                                st3(P.hc, slot, hcol);
+                                posted = true;
+                            }
+                            else
+                            {
+                                st3(P.hc, slot, hcol);
+                                posted = wf_lighting_done(P, slot, mk3(0, 0, 0), hpos, hnrm, cnt, A);
+                            }
+                        }
+                    }
+                    else  // a light feeler came back: get_direct_lighting's loop body (probe_pass.comp:186-207)
+                    {
+                        const f3 hpos = ro;  // a feeler starts at the hit position
+                        const f3 hnrm = ld3(P.hn, slot), hcol = ld3(P.hc, slot);
+                        const uint32_t cnt = P.cnt[slot];
+                        int li = static_cast<int>((cnt >> 8) & 15u);
+                        int nvis = static_cast<int>((cnt >> 12) & 15u);
+                        f3 direct = multi_light ? ld3(P.dir, slot) : mk3(0, 0, 0);
+                        const LightK& L = A.lights[li];
+                        const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
+                        f3 contribution = mk3(0, 0, 0);
+                        bool early = false;
+                        if (any_hit)
+                        {
+                            const bool is_axis = (fabsf(hnrm.x) + fabsf(hnrm.y) + fabsf(hnrm.z) == 1.0f) &&
+                                                 (fabsf(hnrm.x) == 1.0f || fabsf(hnrm.y) == 1.0f || fabsf(hnrm.z) == 1.0f);
+                            const f3 nh = is_axis ? hnrm : normalize3(hnrm);  // identity for a unit axis vector
+                            const float lambert = gl_clamp(dot3(nh, normalize3(lp - hpos)), 0.0f, 1.0f);
+                            if (!block_wins)
+                            {
+                                const float dist = length3(lp - hpos);
+                                const f3 lc{L.col[0], L.col[1], L.col[2]};
+                                direct = direct + div3((lc * lambert) * L.intensity, dist);
+                                nvis += 1;
+                            }
+                            else
+                            {
+                                contribution = (hcol * 0.2f) * lambert;  // Q10 early return
+                                early = true;
+                            }
+                        }
+                        li += 1;
+                        if (!early && li < A.nl)
+                        {
+                            P.cnt[slot] = (cnt & 255u) | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
+                            if (multi_light) st3(P.dir, slot, direct);
+                            const LightK& Ln = A.lights[li];
+                            wf_post_march(P, slot, hpos, normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos), true, A);
+                            posted = true;
+                        }
+                        else
+                        {
+                            if (!early && nvis != 0) contribution = div3(hcol * direct, static_cast<float>(nvis));
+                            posted = wf_lighting_done(P, slot, contribution, hpos, hnrm, cnt, A);
+                        }
+                    }
+                }
+            }
+            const uint32_t at = wave_append(posted, &sh->n_march[cur_list], lane);
+            if (posted) (P.march_list[0] + cur_list * PS)[at] = static_cast<uint16_t>(slot);
+        }
+        const long long c2 = kStats ? clock64() : 0;
+        __syncthreads();
 
         // ================= B: march =================
-        const long long c1 = A.stats ? clock64() : 0;
-        if (tid == 0 && sh->cur >= sh->end)  // range used up: claim the next chunk for the following round
+        const long long c3 = kStats ? clock64() : 0;
+        if (tid == 0)
         {
-            const uint32_t c = atomicAdd(work_counter, 1u);
-            sh->cur = c < n_chunks ? c * kWfChunk : 0u;
-            sh->end = c < n_chunks ? min(c * kWfChunk + kWfChunk, A.n_rays) : 0u;
+            sh->live = 0;
+            const uint32_t taken = sh->cur + sh->bucket_count[kBucketRefill];
+            sh->cur = taken;
+            if (taken >= sh->end)  // range used up: claim the next chunk
+            {
+                const uint32_t c = atomicAdd(work_counter, 1u);
+                sh->cur = c < n_chunks ? c * kWfChunk : 0u;
+                sh->end = c < n_chunks ? min(c * kWfChunk + kWfChunk, A.n_rays) : 0u;
+            }
+            for (int b = 0; b <= kWfBuckets; ++b) sh->bucket_count[b] = 0u;  // next read after this phase's barrier
         }
         {
-            const uint32_t n_list = sh->n_march;
+            const uint32_t n_list = sh->n_march[cur_list];
+            const uint16_t* list = P.march_list[0] + cur_list * PS;
             March m;
             m.ro = m.rd = m.dn = m.inv = m.cc = m.p = mk3(0, 0, 0);
             m.t = 0.0f, m.tl = inf, m.it = 0, m.lid = -1, m.cell = 0;
@@ -310,12 +504,12 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                 const unsigned long long idle_mask = __ballot(!have);
                 if (!exhausted && (__popcll(idle_mask) >= fetch_lanes))
                 {
-                    st_fetches += 1;
+                    if (kStats) st_fetches += 1;
                     const uint32_t idx = wave_append(!have, &sh->head_march, lane);
                     const uint32_t top = __shfl(idx, 63 - __builtin_clzll(idle_mask)) + 1u;  // one past the wave's last claim
                     if (!have && idx < n_list)
                     {
-                        slot = P.list[idx];
+                        slot = list[idx];
                         fl = P.flags[slot];
                         m.ro = ld3(P.ro, slot);
                         m.dn = ld3(P.dn, slot);
@@ -336,8 +530,11 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                     if (exhausted) break;
                     continue;
                 }
-                st_trips += 1;
-                st_lane_steps += __popcll(hb);
+                if (kStats)
+                {
+                    st_trips += 1;
+                    st_lane_steps += __popcll(hb);
+                }
                 if (have)
                 {
                     const bool occ = march_step(m, A.scene, s_bits);
@@ -345,7 +542,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                     if (!fin && ((trips & 7) == 7)) fin = march_escaped(m, A.scene);
                     if (fin)
                     {
-                        const uint32_t type = occ ? static_cast<uint32_t>(A.scene.types[m.cell]) : 0u;
+                        const uint32_t type = occ ? static_cast<uint32_t>(A.scene.types[m.cell - A.scene.bias]) : 0u;
                         P.t[slot] = m.t;
                         P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) |
                                         (occ ? kFlagHit : 0u) | (type << 16);
@@ -360,199 +557,27 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                         P.t[slot] = m.t;
                         P.flags[slot] = (fl & ~0xff0u) | (static_cast<uint32_t>(m.it) << 4);
                     }
+                    const uint32_t at = wave_append(have, &sh->n_march[next_list], lane);
+                    if (have) (P.march_list[0] + next_list * PS)[at] = static_cast<uint16_t>(slot);
                     break;
                 }
             }
         }
-        const long long c1b = A.stats ? clock64() : 0;
+        const long long c4 = kStats ? clock64() : 0;
         __syncthreads();
-
-        // ================= C: bucket the finished marches =================
-        const long long c2 = A.stats ? clock64() : 0;
-        uint32_t my_bucket[2], my_rank[2];
-        {
-            int k = 0;
-            for (uint32_t slot = tid; slot < PS; slot += T, ++k)
-            {
-                const uint32_t fl = P.flags[slot];
-                const uint32_t st = fl & 3u;
-                uint32_t b = kWfBuckets;  // none
-                if (st == kSlotEvFeeler) b = kBucketFeeler;
-                else if (st == kSlotEvPrimary)
-                {
-                    const bool block_wins = (fl & kFlagHit) && (P.t[slot] < P.tl[slot]);
-                    b = block_wins ? shade_bucket(static_cast<int>((fl >> 16) & 15u)) : kBucketNoBlock;
-                }
-                my_bucket[k] = b;
-                my_rank[k] = (b < kWfBuckets) ? atomicAdd(&sh->bucket_count[b], 1u) : 0u;
-            }
-        }
-        __syncthreads();
-        if (tid == 0)
-        {
-            uint32_t base = 0, groups = 0;
-            for (int b = 0; b < kWfBuckets; ++b)
-            {
-                sh->bucket_base[b] = base;
-                base += sh->bucket_count[b];
-                groups += (sh->bucket_count[b] + 63u) / 64u;
-            }
-            sh->n_groups = groups;
-            sh->group_head = 0;
-            sh->n_march = sh->head_march = 0;
-            sh->live = 0;
-        }
-        __syncthreads();
-        {
-            int k = 0;
-            for (uint32_t slot = tid; slot < PS; slot += T, ++k)
-                if (my_bucket[k] < kWfBuckets) P.list[sh->bucket_base[my_bucket[k]] + my_rank[k]] = static_cast<uint16_t>(slot);
-        }
-        __syncthreads();
-
-        // ================= D: events, in 64-lane groups of one bucket =================
-        const long long c3 = A.stats ? clock64() : 0;
-        for (;;)
-        {
-            uint32_t g = 0;
-            if (lane == 0) g = atomicAdd(&sh->group_head, 1u);
-            g = __shfl(g, 0);
-            if (g >= sh->n_groups) break;
-            // locate the group: bucket b, 64-entry window w inside it
-            uint32_t b = 0, first = 0;
-            for (; b < kWfBuckets; ++b)
-            {
-                const uint32_t gb = (sh->bucket_count[b] + 63u) / 64u;
-                if (g < first + gb) break;
-                first += gb;
-            }
-            const uint32_t e = (g - first) * 64u + lane;
-            const bool valid = e < sh->bucket_count[b];
-            st_groups += 1;
-            st_lane_events += __popcll(__ballot(valid));
-            if (!valid) continue;
-            const uint32_t slot = P.list[sh->bucket_base[b] + e];
-            const uint32_t fl = P.flags[slot];
-            const float t = P.t[slot], tl = P.tl[slot];
-            const f3 ro = ld3(P.ro, slot);
-            const bool block_wins = (fl & kFlagHit) && (t < tl);  // temp_isect.t < closest_t
-            const bool any_hit = block_wins || (tl < inf);       // closest_t < INF
-            if (b != kBucketFeeler)
-            {
-                const bool first_bounce = A.ddgi && (P.cnt[slot] & 255u) == 0u;
-                if (!any_hit)
-                {
-                    if (first_bounce) reinterpret_cast<float*>(A.radiance + P.dst[slot])[3] = kMissDistance;
-                    wf_finish_ray(P, slot, ld3(P.col, slot), A);  // probe_pass.comp:288-290 break
-                    continue;
-                }
-                const f3 rd = ld3(P.hc, slot);  // the ray direction as given (see WfPool::hc)
-                f3 nraw, hcol;
-                float th;
-                if (block_wins)
-                {
-                    th = t;
-                    const f3 p = ray_at(ro, ld3(P.dn, slot), t);  // the march position at the hit
-                    const f3 cell = cell_id(p);
-                    const f3 centre = f3{cell.x - 0.5f, cell.y - 0.5f, cell.z - 0.5f};
-                    const f3 diff = normalize3(p - centre);
-                    // axis of the largest |component|, first wins on ties (:1075-1086)
-                    f3 n = mk3(0, 0, 0);
-                    float best = 0.0f;
-                    if (fabsf(diff.x) > best) { best = fabsf(diff.x); n = mk3(gl_sign(diff.x), 0, 0); }
-                    if (fabsf(diff.y) > best) { best = fabsf(diff.y); n = mk3(0, gl_sign(diff.y), 0); }
-                    if (fabsf(diff.z) > best) { best = fabsf(diff.z); n = mk3(0, 0, gl_sign(diff.z)); }
-                    const f3 nn = normalize3(n);
-                    const int type = static_cast<int>((fl >> 16) & 15u);
-                    hcol = (A.ablate & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
-                    nraw = nn;
-                }
-                else
-                {
-                    th = tl;
-                    const LightK& L = A.lights[static_cast<int>((fl >> 12) & 15u) - 1];
-                    const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
-                    nraw = ray_at((ro - lp) * 10.0f, rd * 10.0f, th);  // sphere-space position
-                    hcol = mk3(0, 0, 0);  // Q12: unassigned Material, pinned to zero
-                }
-                if (first_bounce) reinterpret_cast<float*>(A.radiance + P.dst[slot])[3] = th;  // Isect.t of the probe ray
-                const f3 hnrm = normalize3(nraw);
-                const f3 hpos = ray_at(ro, rd, th) + hnrm * 0.001f;
-                st3(P.hn, slot, hnrm);
-                const uint32_t cnt = P.cnt[slot] & 255u;  // light index 0, no visible light yet
-                if (A.nl > 0)
-                {
-                    P.cnt[slot] = cnt;
-                    if (multi_light) st3(P.dir, slot, mk3(0, 0, 0));
-                    const LightK& L = A.lights[0];
-                    wf_post_march(P, slot, hpos, normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos), true, A);
-                    st3(P.hc, slot, hcol);
-                }
-                else
-                {
-                    st3(P.hc, slot, hcol);
-                    wf_lighting_done(P, slot, mk3(0, 0, 0), hpos, hnrm, cnt, A);
-                }
-            }
-            else  // a light feeler came back: get_direct_lighting's loop body (probe_pass.comp:186-207)
-            {
-                const f3 hpos = ro;  // a feeler starts at the hit position
-                const f3 hnrm = ld3(P.hn, slot), hcol = ld3(P.hc, slot);
-                const uint32_t cnt = P.cnt[slot];
-                int li = static_cast<int>((cnt >> 8) & 15u);
-                int nvis = static_cast<int>((cnt >> 12) & 15u);
-                f3 direct = multi_light ? ld3(P.dir, slot) : mk3(0, 0, 0);
-                const LightK& L = A.lights[li];
-                const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
-                f3 contribution = mk3(0, 0, 0);
-                bool early = false;
-                if (any_hit)
-                {
-                    const float lambert = gl_clamp(dot3(normalize3(hnrm), normalize3(lp - hpos)), 0.0f, 1.0f);
-                    if (!block_wins)
-                    {
-                        const float dist = length3(lp - hpos);
-                        const f3 lc{L.col[0], L.col[1], L.col[2]};
-                        direct = direct + div3((lc * lambert) * L.intensity, dist);
-                        nvis += 1;
-                    }
-                    else
-                    {
-                        contribution = (hcol * 0.2f) * lambert;  // Q10 early return
-                        early = true;
-                    }
-                }
-                li += 1;
-                if (!early && li < A.nl)
-                {
-                    P.cnt[slot] = (cnt & 255u) | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
-                    if (multi_light) st3(P.dir, slot, direct);
-                    const LightK& Ln = A.lights[li];
-                    wf_post_march(P, slot, hpos, normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos), true, A);
-                }
-                else
-                {
-                    if (!early && nvis != 0) contribution = div3(hcol * direct, static_cast<float>(nvis));
-                    wf_lighting_done(P, slot, contribution, hpos, hnrm, cnt, A);
-                }
-            }
-        }
-        const long long c4 = A.stats ? clock64() : 0;
-        __syncthreads();
-        if (tid <= kWfBuckets) sh->bucket_count[tid] = 0u;  // read again only after the next barrier
-        if (A.stats)
+        if (kStats)
         {
             const long long c5 = clock64();
-            cy[0] += c1 - c0;   // A incl. its barrier
-            cy[1] += c1b - c1;  // B work
-            cy[2] += c2 - c1b;  // B barrier wait
-            cy[3] += c3 - c2;   // C incl. barriers
-            cy[4] += c4 - c3;   // D work
-            cy[5] += c5 - c4;   // D barrier wait
+            cy[0] += c1 - c0;  // C (sort) incl. its barriers
+            cy[1] += c4 - c3;  // B work
+            cy[2] += c5 - c4;  // B barrier wait
+            cy[3] += 0;
+            cy[4] += c2 - c1;  // D work
+            cy[5] += c3 - c2;  // D barrier wait
         }
     }
 
-    if (A.stats && lane == 0)
+    if (kStats && A.stats && lane == 0)
     {
         atomicAdd(&A.stats[0], st_trips);
         atomicAdd(&A.stats[1], st_lane_steps);
@@ -571,7 +596,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
 static size_t wf_lds_bytes(int nwords, int pool, bool multi_light)
 {
     return (32 + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * wf_dwords_per_ray(multi_light) * 4 +
-           static_cast<size_t>(pool) * 2 + 16;
+           static_cast<size_t>(pool) * 6 + 16;  // three 16-bit slot lists
 }
 
 // Largest pool (multiple of 64, at most 2 per lane) that fits in `lds_limit` bytes; 0 if not even
@@ -583,28 +608,29 @@ int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads)
     return pool >= threads ? pool : 0;
 }
 
-template <int T, int B>
+template <int T, int B, bool kStats>
 static hipError_t launch_wf(const TraceArgs& args, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream)
 {
     const size_t lds = wf_lds_bytes(args.scene.nwords, pool, args.nl > 1);
     static bool attr_set = false;
     if (!attr_set)
     {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_wf<T, B>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / B);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_wf<T, B, kStats>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / B);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_probe_trace_wf<T, B>), dim3(grid_blocks), dim3(T), lds, stream, args, pool, work_counter);
+    hipLaunchKernelGGL((k_probe_trace_wf<T, B, kStats>), dim3(grid_blocks), dim3(T), lds, stream, args, pool, work_counter);
     return hipGetLastError();
 }
 
 // threads: 1024 (one workgroup per CU) or 512 (two per CU, each with half the LDS)
 hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream)
 {
-    if (threads == 512) return launch_wf<512, 2>(args, pool, grid_blocks, work_counter, stream);
-    return launch_wf<1024, 1>(args, pool, grid_blocks, work_counter, stream);
+    if (threads == 512) return launch_wf<512, 2, false>(args, pool, grid_blocks, work_counter, stream);
+    if (args.stats) return launch_wf<1024, 1, true>(args, pool, grid_blocks, work_counter, stream);
+    return launch_wf<1024, 1, false>(args, pool, grid_blocks, work_counter, stream);
 }
 
 }  // namespace ddgi

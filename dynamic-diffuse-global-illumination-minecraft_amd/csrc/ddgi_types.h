@@ -30,7 +30,9 @@ struct SceneK
     int hi[3];
     int nx;   // cells per row (x extent)
     int nxy;  // cells per z-slice (x extent * y extent)
-    int bias; // (lo.z*ny + lo.y)*nx + lo.x : linear index = z*nxy + y*nx + x - bias
+    int bias;    // (lo.z*ny + lo.y)*nx + lo.x : block-type index = z*nxy + y*nx + x - bias
+    int bias32;  // bias rounded down to a multiple of 32; the occupancy bitmap is stored shifted by
+                 // (bias - bias32) bits so that bit (raw & 31) of word (raw >> 5) - (bias32 >> 5) is voxel raw
     int nwords;            // 32-bit words in the occupancy bitmap
     unsigned face_empty;   // bit (2*axis + side): that border layer is entirely empty
     const uint32_t* bits;  // device

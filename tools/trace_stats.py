@@ -17,7 +17,7 @@ rays = eng.num_rays
 print(st, "kernel_ms", ms)
 cyc = [st[k] for k in ("cyc_scan", "cyc_march", "cyc_march_wait", "cyc_list", "cyc_events", "cyc_events_wait")]
 if sum(cyc):
-    print("phase share of wave time: scan %.3f march %.3f march-barrier %.3f list %.3f events %.3f events-barrier %.3f | fetches/wave %.0f rounds %d" % (
+    print("phase share of wave time: sort %.3f march %.3f march-barrier %.3f (unused %.3f) events %.3f events-barrier %.3f | fetches/wave %.0f rounds %d" % (
         *[c / sum(cyc) for c in cyc], st["fetches"] / st["waves"], st["rounds"]))
 print("steps/ray %.1f  march-lane-utilisation %.3f  events/ray %.2f  lanes/event-round %.1f  trips/wave %.0f rounds/wave %.0f" % (
     st["lane_steps"] / rays, st["lane_steps"] / (64.0 * st["trips"]), st["lane_events"] / rays,
