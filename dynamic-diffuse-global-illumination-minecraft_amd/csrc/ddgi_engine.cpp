@@ -197,6 +197,13 @@ static int ensure_scene(ddgi_engine* e, int scene)
     }
     d.k.nx = b.dim[0];
     d.k.nxy = b.dim[0] * b.dim[1];
+    for (int a = 0; a < 3; ++a)
+    {
+        d.k.lo_f[a] = static_cast<float>(b.lo[a]);
+        d.k.hi_f[a] = static_cast<float>(b.hi[a]);
+    }
+    d.k.nx_f = static_cast<float>(d.k.nx);
+    d.k.nxy_f = static_cast<float>(d.k.nxy);
     d.k.bias = bias;
     d.k.bias32 = bias32;
     d.k.nwords = static_cast<int>(shifted.size());

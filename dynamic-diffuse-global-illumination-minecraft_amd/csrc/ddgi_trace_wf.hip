@@ -30,7 +30,7 @@ namespace ddgi {
 constexpr int kWfTailSteps = 16;     // straggler steps after the march list is drained
 constexpr int kWfFetchLanes = 16;    // pull new march tasks once this many lanes are idle
 constexpr uint32_t kWfChunk = 4096;  // rays a workgroup claims at a time from the global counter
-constexpr int kWfBuckets = 10;
+constexpr int kWfBuckets = 7;
 
 enum : uint32_t
 {
@@ -50,7 +50,7 @@ struct WfShared  // control block at the start of dynamic LDS (32 dwords)
     uint32_t head_march, cur, end, live, group_head, n_groups;
     uint32_t bucket_count[kWfBuckets + 1];  // entries per event bucket
     uint32_t bucket_base[kWfBuckets + 1];   // first event-list index of each bucket
-    uint32_t pad[2];
+    uint32_t pad[32 - 8 - 2 * (kWfBuckets + 1)];
 };
 static_assert(sizeof(WfShared) == 32 * 4, "control block is 32 dwords");
 
@@ -101,20 +101,15 @@ DDGI_D uint32_t wave_append(bool pred, uint32_t* counter, int lane)
 // most expensive first (ddgi_scene.h: block_albedo).
 DDGI_D uint32_t shade_bucket(int type)
 {
-    switch (type)
-    {
-        case 9: return 0;             // mushroom stem: two fbm's, lattice mostly outside the LUT
-        case 10: return 1;            // cave wall
-        case 11: return 2;            // cave ground
-        case 12: case 13: return 3;   // moss / mold
-        case 6: case 7: return 4;     // worley caps
-        case 8: return 5;             // dotted cap
-        default: return 6;            // flat colours
-    }
+    // few, well filled buckets: every bucket ends in one partially filled 64-lane group per round
+    if (type == 9) return 0;                 // mushroom stem: two fbm's, lattice mostly outside the LUT
+    if (type == 10) return 1;                // cave wall (72 % of the cave's hits)
+    if (type >= 11 && type <= 13) return 2;  // cave ground, moss, mold: lattice-noise lookups
+    return 3;                                // mushroom caps (worley, dots) and the flat colours
 }
-constexpr uint32_t kBucketNoBlock = 7;  // primary march that ended on a light sphere or missed
-constexpr uint32_t kBucketFeeler = 8;
-constexpr uint32_t kBucketRefill = 9;  // an empty slot that can take a new ray
+constexpr uint32_t kBucketNoBlock = 4;  // primary march that ended on a light sphere or missed
+constexpr uint32_t kBucketFeeler = 5;
+constexpr uint32_t kBucketRefill = 6;  // an empty slot that can take a new ray
 
 // A new voxel march for pool slot `slot` (intersect_scene's set-up, intersection.glsl:1253-1279 +
 // grid_march's, 1053-1058): origin, normalised direction and its reciprocal, light spheres.
@@ -407,12 +402,27 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                             const uint32_t cnt = P.cnt[slot] & 255u;  // light index 0, no visible light yet
                             if (A.nl > 0)
                             {
-                                P.cnt[slot] = cnt;
-                                if (multi_light) st3(P.dir, slot, mk3(0, 0, 0));
                                 const LightK& L = A.lights[0];
-                                wf_post_march(P, slot, hpos, normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos), true, A);
-                                st3(P.hc, slot, hcol);
-                                posted = true;
+                                const f3 to_light = normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos);
+                                // Dead-feeler elimination (single light): whatever the feeler finds, the hit's
+                                // direct light is scaled by lambert = clamp(dot(n, to_light), 0, 1)
+                                // (probe_pass.comp:194-204), so for lambert == 0 and a finite albedo every
+                                // outcome adds exactly +0 to the colour: skip the march and its event.
+                                const f3 nh = axis_normal ? hnrm : normalize3(hnrm);
+                                const bool finite_albedo = fabsf(hcol.x) < inf && fabsf(hcol.y) < inf && fabsf(hcol.z) < inf;
+                                if (A.nl == 1 && finite_albedo && dot3(nh, to_light) <= 0.0f && !(A.ablate & 4))
+                                {
+                                    st3(P.hc, slot, hcol);
+                                    posted = wf_lighting_done(P, slot, mk3(0, 0, 0), hpos, hnrm, cnt, A);
+                                }
+                                else
+                                {
+                                    P.cnt[slot] = cnt;
+                                    if (multi_light) st3(P.dir, slot, mk3(0, 0, 0));
+                                    wf_post_march(P, slot, hpos, to_light, true, A);
+                                    st3(P.hc, slot, hcol);
+                                    posted = true;
+                                }
                             }
                             else
                             {

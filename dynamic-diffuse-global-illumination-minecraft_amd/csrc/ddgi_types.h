@@ -33,6 +33,7 @@ struct SceneK
     int bias;    // (lo.z*ny + lo.y)*nx + lo.x : block-type index = z*nxy + y*nx + x - bias
     int bias32;  // bias rounded down to a multiple of 32; the occupancy bitmap is stored shifted by
                  // (bias - bias32) bits so that bit (raw & 31) of word (raw >> 5) - (bias32 >> 5) is voxel raw
+    float lo_f[3], hi_f[3], nx_f, nxy_f;  // lo, hi, nx, nxy as floats (exact small integers) for march_step
     int nwords;            // 32-bit words in the occupancy bitmap
     unsigned face_empty;   // bit (2*axis + side): that border layer is entirely empty
     const uint32_t* bits;  // device

@@ -137,6 +137,12 @@ def load_library(build=True):
                     raise
         if not os.path.exists(library_path()):
             raise DDGIError(-2, f"{library_path()} is missing: build it with __graft_entry__.build()")
+        # PyTorch wheels bundle their own libamdhip64; a process must hold ONE HIP runtime, so when
+        # torch is installed let it load its runtime first and our library binds to that one.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = C.CDLL(library_path())
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(lib, name)

@@ -175,3 +175,41 @@ def test_full_size_c3_properties_and_sampled_oracle_check(ddgi, oracle):
     for p in probes:
         x0, y0 = ddgi.probe_tile_origin(ddgi.make_field(counts, side, s, origin), int(p))
         assert np.array_equal(a1[y0:y0 + 16, x0:x0 + 16], want[y0:y0 + 16, x0:x0 + 16]), f"probe {p}"
+
+
+def test_torch_owned_textures_and_stream(ddgi, oracle):
+    """The multi-GPU plumbing at world size 1: textures allocated by torch and bound into the
+    engine (ddgi_bind_textures), kernels on torch's current stream (ddgi_set_stream), the in-place
+    all-gather a no-op.  Same bytes as the engine-owned path."""
+    import torch
+
+    from ddgi_amd import distributed as dd
+
+    name = "cave_small"
+    counts, side, s, origin, scene = CONFIGS[name]
+    (want_a, _), _, _ = _oracle_textures(oracle, name)
+    with _engine(ddgi, name) as eng:
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            eng.set_stream(stream.cuda_stream)
+            tex = dd.ShardedTextures(eng, torch.device("cuda", 0))
+            eng.generate_probe_rays(seed=1)
+            eng.probe_update()
+            tex.all_gather()
+            stream.synchronize()
+            slab = tex.tex0.cpu().numpy().view(np.uint8)
+            raster = dd.slab_major_to_raster(slab, counts, s, (4,))
+            assert np.array_equal(raster, want_a)
+            albedo, _ = eng.read_textures()          # the C ABI reads the bound buffers too
+            assert np.array_equal(albedo, want_a)
+            pos, nrm = shading_points(np.random.default_rng(2), counts, side, origin, 512)
+            d_pos = torch.from_numpy(pos).cuda()
+            d_nrm = torch.from_numpy(nrm).cuda()
+            d_rgb = torch.empty((512, 3), dtype=torch.float32, device="cuda")
+            d_cage = torch.empty((512, 8), dtype=torch.int32, device="cuda")
+            eng.sample_device(d_pos.data_ptr(), d_nrm.data_ptr(), 512, d_rgb.data_ptr(), d_cage.data_ptr())
+            stream.synchronize()
+            want_rgb, want_cage = oracle.sample(oracle.make_field(counts, side, s, origin), want_a, np.zeros_like(want_a), pos, nrm)
+            assert np.array_equal(d_cage.cpu().numpy(), want_cage)
+            assert np.array_equal(d_rgb.cpu().numpy().view(np.uint32), want_rgb.view(np.uint32))
+            tex.close()
