@@ -106,6 +106,9 @@ struct ddgi_engine
     unsigned long long updates = 0;
     int wait_threshold = 64;
     uint32_t* d_work = nullptr;             // chunk counter of the wavefront trace kernel
+    void* d_wf_cold = nullptr;              // wavefront kernel scratch: per-slot shading state
+    float4* d_wf_dir = nullptr;
+    size_t wf_cold_slots = 0, wf_dir_slots = 0;
     float4* d_radiance = nullptr;           // DDGI mode: per local ray (radiance rgb, first-hit distance)
     size_t d_radiance_capacity = 0;         // in rays
     uint32_t frame = 0;                     // DDGI mode: updates done so far (seeds the ray rotation)
@@ -336,6 +339,8 @@ int ddgi_destroy(ddgi_handle e)
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->d_work) (void)hipFree(e->d_work);
+    if (e->d_wf_cold) (void)hipFree(e->d_wf_cold);
+    if (e->d_wf_dir) (void)hipFree(e->d_wf_dir);
     if (e->d_radiance) (void)hipFree(e->d_radiance);
     for (auto& p : e->d_noise)
         if (p) (void)hipFree(p);
@@ -513,6 +518,25 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         const uint32_t chunks = (a.n_rays + 4095u) / 4096u;
         uint32_t grid = static_cast<uint32_t>(e->num_cus * wf_blocks_per_cu);
         if (grid > chunks) grid = chunks;
+        const size_t slots = static_cast<size_t>(grid) * pool;
+        if (slots > e->wf_cold_slots)
+        {
+            if (e->d_wf_cold) (void)hipFree(e->d_wf_cold);
+            e->d_wf_cold = nullptr;
+            e->wf_cold_slots = 0;
+            HIP_TRY(hipMalloc(&e->d_wf_cold, slots * 48));
+            e->wf_cold_slots = slots;
+        }
+        if (a.nl > 1 && slots > e->wf_dir_slots)
+        {
+            if (e->d_wf_dir) (void)hipFree(e->d_wf_dir);
+            e->d_wf_dir = nullptr;
+            e->wf_dir_slots = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_wf_dir), slots * sizeof(float4)));
+            e->wf_dir_slots = slots;
+        }
+        a.wf_cold = e->d_wf_cold;
+        a.wf_dir = e->d_wf_dir;
         HIP_TRY(hipEventRecord(ev[0], e->stream));
         HIP_TRY(launch_probe_trace_wf(a, wf_threads, pool, static_cast<int>(grid), e->d_work, e->stream));
     }

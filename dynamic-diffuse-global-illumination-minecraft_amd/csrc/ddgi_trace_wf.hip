@@ -22,13 +22,16 @@
 //              and pulls another when its own finishes; once the list is drained the stragglers run
 //              kWfTailSteps more steps and are parked (t, iteration count) on the NEXT round's list
 // ------------------------------------------------------------------------------------------------
+#include <algorithm>
+#include <cstdlib>
+
 #include "ddgi_device.h"
 #include "ddgi_oct.h"
 
 namespace ddgi {
 
 constexpr int kWfTailSteps = 16;     // straggler steps after the march list is drained
-constexpr int kWfFetchLanes = 16;    // pull new march tasks once this many lanes are idle
+constexpr int kWfFetchLanes = 8;     // pull new march tasks once this many lanes are idle
 constexpr uint32_t kWfChunk = 4096;  // rays a workgroup claims at a time from the global counter
 constexpr int kWfBuckets = 7;
 
@@ -54,26 +57,52 @@ struct WfShared  // control block at the start of dynamic LDS (32 dwords)
 };
 static_assert(sizeof(WfShared) == 32 * 4, "control block is 32 dwords");
 
+// Shading state of a pool slot: touched only by event groups (phase D), never by the march loop, so
+// it lives in global memory (one 48-byte record per slot, 3 x dwordx4; 256 workgroups x 2048 slots
+// = 25 MB, L2 / Infinity-Cache resident) and LDS holds only what the march needs.  That buys a
+// pool of 2 rays per lane instead of 1.3.
+struct WfCold
+{
+    float hn[3];   // hit normal (live while the feelers of a hit are in flight)
+    float hc[3];   // hit albedo; during a PRIMARY march: the ray direction exactly as given
+    float col[3];  // accumulated radiance
+    uint32_t rng;
+    uint32_t cnt;  // [7:0] bounce, [11:8] light index, [15:12] visible lights
+    uint32_t dst;  // REF: texel index; DDGI: local ray index
+};
+static_assert(sizeof(WfCold) == 48, "3 x 16 bytes");
+
+DDGI_D WfCold load_cold(const WfCold* p)
+{
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    union { uint4 v[3]; WfCold c; } u;
+    u.v[0] = q[0], u.v[1] = q[1], u.v[2] = q[2];
+    return u.c;
+}
+DDGI_D void store_cold(WfCold* p, const WfCold& c)
+{
+    union { uint4 v[3]; WfCold c; } u;
+    u.c = c;
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = u.v[0], q[1] = u.v[1], q[2] = u.v[2];
+}
+DDGI_D f3 v3of(const float* a) { return f3{a[0], a[1], a[2]}; }
+DDGI_D void set3(float* a, f3 v) { a[0] = v.x, a[1] = v.y, a[2] = v.z; }
+
 struct WfPool
 {
     float* ro[3];   // march origin (for a light feeler: the hit position)
     float* dn[3];   // normalize(direction): the direction the march steps along
-    float* inv[3];  // 1/dn (+inf where dn == 0)
     float* t;
     float* tl;
     uint32_t* flags;
-    float* hn[3];   // hit normal (live while the feelers of a hit are in flight)
-    float* hc[3];   // hit albedo; during a PRIMARY march: the ray direction exactly as given
-    float* col[3];
-    uint32_t* rng;
-    uint32_t* cnt;  // [7:0] bounce, [11:8] light index, [15:12] visible lights
-    uint32_t* dst;
-    float* dir[3];  // accumulated direct light; only when there is more than one light
+    struct WfCold* cold;  // per-slot shading state, in global memory (see WfCold)
+    float4* dirbuf;       // accumulated direct light per slot; only when there is more than one light
     uint16_t* march_list[2];  // double buffered: stragglers and new marches are appended for the next round
     uint16_t* event_list;
 };
 
-constexpr int wf_dwords_per_ray(bool multi_light) { return multi_light ? 27 : 24; }
+constexpr int wf_dwords_per_ray(bool) { return 9; }  // LDS part: ro, dn, t, tl, flags
 
 DDGI_D f3 ld3(float* const* a, uint32_t i) { return f3{a[0][i], a[1][i], a[2][i]}; }
 DDGI_D void st3(float* const* a, uint32_t i, f3 v)
@@ -113,7 +142,7 @@ constexpr uint32_t kBucketRefill = 6;  // an empty slot that can take a new ray
 
 // A new voxel march for pool slot `slot` (intersect_scene's set-up, intersection.glsl:1253-1279 +
 // grid_march's, 1053-1058): origin, normalised direction and its reciprocal, light spheres.
-DDGI_D void wf_post_march(const WfPool& P, uint32_t slot, f3 o, f3 d, bool feeler, const TraceArgs& A)
+DDGI_D void wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, bool feeler, const TraceArgs& A)
 {
     float tl;
     int lid;
@@ -121,17 +150,15 @@ DDGI_D void wf_post_march(const WfPool& P, uint32_t slot, f3 o, f3 d, bool feele
     const f3 dn = normalize3(d);
     st3(P.ro, slot, o);
     st3(P.dn, slot, dn);
-    st3(P.inv, slot, f3{axis_inv(dn.x), axis_inv(dn.y), axis_inv(dn.z)});
-    if (!feeler) st3(P.hc, slot, d);  // the hit albedo is dead until this march is shaded
+    if (!feeler) set3(c.hc, d);  // the hit albedo is dead until this march is shaded
     P.t[slot] = 0.0f;
     P.tl[slot] = tl;
     P.flags[slot] = kSlotMarch | (feeler ? kFlagFeeler : 0u) | (static_cast<uint32_t>(lid + 1) << 12);
 }
 
-DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, const TraceArgs& A)
+DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst, const TraceArgs& A)
 {
     const f3 c = div3(color, static_cast<float>(A.max_bounces));  // Q14: always /max_bounces
-    const uint32_t dst = P.dst[slot];
     if (A.ddgi)
     {
         float* rec = reinterpret_cast<float*>(A.radiance + dst);  // .w (first-hit distance) was written at bounce 0
@@ -146,22 +173,20 @@ DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, const TraceA
 }
 
 // End of get_direct_lighting for one hit: accumulate, then bounce or finish (probe_pass.comp:286-292).
-DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A)
+DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A)
 {
-    const f3 color = ld3(P.col, slot) + contribution;
+    const f3 color = v3of(c.col) + contribution;
     const uint32_t bounce = (cnt & 255u) + 1u;
     if (static_cast<int>(bounce) < A.max_bounces)
     {
-        st3(P.col, slot, color);
-        P.cnt[slot] = bounce;
-        uint32_t rng = P.rng[slot];
+        set3(c.col, color);
+        c.cnt = bounce;
         const f3 no = hpos + hnrm * 0.0001f;
-        const f3 nd = (A.ablate & 2) ? normalize3(hnrm + mk3(0.3f, 0.2f, 0.1f)) : hemisphere_dir(hnrm, rng);
-        P.rng[slot] = rng;
-        wf_post_march(P, slot, no, nd, false, A);
+        const f3 nd = (A.ablate & 2) ? normalize3(hnrm + mk3(0.3f, 0.2f, 0.1f)) : hemisphere_dir(hnrm, c.rng);
+        wf_post_march(P, slot, c, no, nd, false, A);
         return true;
     }
-    wf_finish_ray(P, slot, color, A);
+    wf_finish_ray(P, slot, color, c.dst, A);
     return false;
 }
 
@@ -187,17 +212,11 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
     auto takeu = [&]() { uint32_t* p = cursor; cursor += PS; return p; };
     for (int a = 0; a < 3; ++a) P.ro[a] = takef();
     for (int a = 0; a < 3; ++a) P.dn[a] = takef();
-    for (int a = 0; a < 3; ++a) P.inv[a] = takef();
     P.t = takef();
     P.tl = takef();
     P.flags = takeu();
-    for (int a = 0; a < 3; ++a) P.hn[a] = takef();
-    for (int a = 0; a < 3; ++a) P.hc[a] = takef();
-    for (int a = 0; a < 3; ++a) P.col[a] = takef();
-    P.rng = takeu();
-    P.cnt = takeu();
-    P.dst = takeu();
-    for (int a = 0; a < 3; ++a) P.dir[a] = multi_light ? takef() : nullptr;
+    P.cold = static_cast<WfCold*>(A.wf_cold) + static_cast<size_t>(blockIdx.x) * PS;
+    P.dirbuf = multi_light ? A.wf_dir + static_cast<size_t>(blockIdx.x) * PS : nullptr;
     P.march_list[0] = reinterpret_cast<uint16_t*>(cursor);
     P.march_list[1] = P.march_list[0] + PS;
     P.event_list = P.march_list[1] + PS;
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
         const long long c0 = kStats ? clock64() : 0;
         const uint32_t ray_cur = sh->cur, ray_end = sh->end;
         const bool have_rays = ray_cur < ray_end;
-        uint32_t my_bucket[2], my_rank[2];
+        uint32_t my_bucket[3], my_rank[3];  // a lane looks after at most 3 pool slots
         {
             bool any_live = false;
             int k = 0;
@@ -320,14 +339,15 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                         const int p = y * G.cx * G.cz + G.z0 * G.cx + rem;
                         const uint32_t global_ray = static_cast<uint32_t>(p) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i);
                         f3 ray_o, ray_d;
+                        WfCold c;
                         if (A.ddgi)
                         {
                             // in-kernel ray generation: probe position + rotated spherical Fibonacci direction
                             const int pxz = p - y * G.cx * G.cz;
                             ray_o = probe_position(G, pxz % G.cx, y, pxz / G.cx);
                             ray_d = fibonacci_dir(i, rays_per_probe, A.rot);
-                            P.dst[slot] = r;
-                            P.rng[slot] = wang_hash(global_ray ^ A.frame_key);
+                            c.dst = r;
+                            c.rng = wang_hash(global_ray ^ A.frame_key);
                         }
                         else
                         {
@@ -336,17 +356,20 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                             ray_o = mk3(ra.x, ra.y, ra.z);
                             ray_d = mk3(rb.x, rb.y, rb.z);
                             const int dst_probe = static_cast<int>(rc.x);  // int(probe_info.x), probe_pass.comp:269
-                            P.dst[slot] = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.s + static_cast<int>(rc.y);
-                            P.rng[slot] = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
+                            c.dst = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.s + static_cast<int>(rc.y);
+                            c.rng = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
                         }
-                        P.cnt[slot] = 0u;
-                        st3(P.col, slot, mk3(0, 0, 0));
-                        wf_post_march(P, slot, ray_o, ray_d, false, A);
+                        c.cnt = 0u;
+                        set3(c.col, mk3(0, 0, 0));
+                        set3(c.hn, mk3(0, 0, 0));
+                        wf_post_march(P, slot, c, ray_o, ray_d, false, A);
+                        store_cold(P.cold + slot, c);
                         posted = true;
                     }
                 }
                 else
                 {
+                    WfCold c = load_cold(P.cold + slot);
                     const uint32_t fl = P.flags[slot];
                     const float t = P.t[slot], tl = P.tl[slot];
                     const f3 ro = ld3(P.ro, slot);
@@ -354,15 +377,15 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                     const bool any_hit = block_wins || (tl < inf);       // closest_t < INF
                     if (b != kBucketFeeler)
                     {
-                        const bool first_bounce = A.ddgi && (P.cnt[slot] & 255u) == 0u;
+                        const bool first_bounce = A.ddgi && (c.cnt & 255u) == 0u;
                         if (!any_hit)
                         {
-                            if (first_bounce) reinterpret_cast<float*>(A.radiance + P.dst[slot])[3] = kMissDistance;
-                            wf_finish_ray(P, slot, ld3(P.col, slot), A);  // probe_pass.comp:288-290 break
+                            if (first_bounce) reinterpret_cast<float*>(A.radiance + c.dst)[3] = kMissDistance;
+                            wf_finish_ray(P, slot, v3of(c.col), c.dst, A);  // probe_pass.comp:288-290 break
                         }
                         else
                         {
-                            const f3 rd = ld3(P.hc, slot);  // the ray direction as given (see WfPool::hc)
+                            const f3 rd = v3of(c.hc);  // the ray direction as given (see WfCold::hc)
                             f3 nraw, hcol;
                             float th;
                             bool axis_normal = false;
@@ -395,11 +418,11 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                                 nraw = ray_at((ro - lp) * 10.0f, rd * 10.0f, th);  // sphere-space position
                                 hcol = mk3(0, 0, 0);  // Q12: unassigned Material, pinned to zero
                             }
-                            if (first_bounce) reinterpret_cast<float*>(A.radiance + P.dst[slot])[3] = th;  // Isect.t of the probe ray
+                            if (first_bounce) reinterpret_cast<float*>(A.radiance + c.dst)[3] = th;  // Isect.t of the probe ray
                             const f3 hnrm = axis_normal ? nraw : normalize3(nraw);
                             const f3 hpos = ray_at(ro, rd, th) + hnrm * 0.001f;
-                            st3(P.hn, slot, hnrm);
-                            const uint32_t cnt = P.cnt[slot] & 255u;  // light index 0, no visible light yet
+                            set3(c.hn, hnrm);
+                            const uint32_t cnt = c.cnt & 255u;  // light index 0, no visible light yet
                             if (A.nl > 0)
                             {
                                 const LightK& L = A.lights[0];
@@ -412,33 +435,38 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                                 const bool finite_albedo = fabsf(hcol.x) < inf && fabsf(hcol.y) < inf && fabsf(hcol.z) < inf;
                                 if (A.nl == 1 && finite_albedo && dot3(nh, to_light) <= 0.0f && !(A.ablate & 4))
                                 {
-                                    st3(P.hc, slot, hcol);
-                                    posted = wf_lighting_done(P, slot, mk3(0, 0, 0), hpos, hnrm, cnt, A);
+                                    set3(c.hc, hcol);
+                                    posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A);
                                 }
                                 else
                                 {
-                                    P.cnt[slot] = cnt;
-                                    if (multi_light) st3(P.dir, slot, mk3(0, 0, 0));
-                                    wf_post_march(P, slot, hpos, to_light, true, A);
-                                    st3(P.hc, slot, hcol);
+                                    c.cnt = cnt;
+                                    if (multi_light) P.dirbuf[slot] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+                                    wf_post_march(P, slot, c, hpos, to_light, true, A);
+                                    set3(c.hc, hcol);
                                     posted = true;
                                 }
                             }
                             else
                             {
-                                st3(P.hc, slot, hcol);
-                                posted = wf_lighting_done(P, slot, mk3(0, 0, 0), hpos, hnrm, cnt, A);
+                                set3(c.hc, hcol);
+                                posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A);
                             }
                         }
                     }
                     else  // a light feeler came back: get_direct_lighting's loop body (probe_pass.comp:186-207)
                     {
                         const f3 hpos = ro;  // a feeler starts at the hit position
-                        const f3 hnrm = ld3(P.hn, slot), hcol = ld3(P.hc, slot);
-                        const uint32_t cnt = P.cnt[slot];
+                        const f3 hnrm = v3of(c.hn), hcol = v3of(c.hc);
+                        const uint32_t cnt = c.cnt;
                         int li = static_cast<int>((cnt >> 8) & 15u);
                         int nvis = static_cast<int>((cnt >> 12) & 15u);
-                        f3 direct = multi_light ? ld3(P.dir, slot) : mk3(0, 0, 0);
+                        f3 direct = mk3(0, 0, 0);
+                        if (multi_light)
+                        {
+                            const float4 dv = P.dirbuf[slot];
+                            direct = mk3(dv.x, dv.y, dv.z);
+                        }
                         const LightK& L = A.lights[li];
                         const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
                         f3 contribution = mk3(0, 0, 0);
@@ -465,18 +493,19 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                         li += 1;
                         if (!early && li < A.nl)
                         {
-                            P.cnt[slot] = (cnt & 255u) | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
-                            if (multi_light) st3(P.dir, slot, direct);
+                            c.cnt = (cnt & 255u) | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
+                            if (multi_light) P.dirbuf[slot] = float4{direct.x, direct.y, direct.z, 0.0f};
                             const LightK& Ln = A.lights[li];
-                            wf_post_march(P, slot, hpos, normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos), true, A);
+                            wf_post_march(P, slot, c, hpos, normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos), true, A);
                             posted = true;
                         }
                         else
                         {
                             if (!early && nvis != 0) contribution = div3(hcol * direct, static_cast<float>(nvis));
-                            posted = wf_lighting_done(P, slot, contribution, hpos, hnrm, cnt, A);
+                            posted = wf_lighting_done(P, slot, c, contribution, hpos, hnrm, cnt, A);
                         }
                     }
+                    if (posted) store_cold(P.cold + slot, c);  // the slot lives on: write its shading state back
                 }
             }
             const uint32_t at = wave_append(posted, &sh->n_march[cur_list], lane);
@@ -523,12 +552,11 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                         fl = P.flags[slot];
                         m.ro = ld3(P.ro, slot);
                         m.dn = ld3(P.dn, slot);
-                        m.inv = ld3(P.inv, slot);
+                        m.inv = f3{axis_inv(m.dn.x), axis_inv(m.dn.y), axis_inv(m.dn.z)};  // P5; recomputed, not stored
                         m.t = P.t[slot];
                         m.tl = P.tl[slot];
                         m.it = static_cast<int>((fl >> 4) & 255u);
-                        // inv is +inf for dn == +-0, so (inv > 0) == (dn >= 0)
-                        m.cc = f3{m.inv.x > 0.0f ? 1.0f : 0.0f, m.inv.y > 0.0f ? 1.0f : 0.0f, m.inv.z > 0.0f ? 1.0f : 0.0f};
+                        m.cc = f3{m.dn.x >= 0.0f ? 1.0f : 0.0f, m.dn.y >= 0.0f ? 1.0f : 0.0f, m.dn.z >= 0.0f ? 1.0f : 0.0f};
                         m.p = ray_at(m.ro, m.dn, m.t);
                         have = true;
                     }
@@ -613,7 +641,8 @@ static size_t wf_lds_bytes(int nwords, int pool, bool multi_light)
 // one ray per lane fits (then the caller uses k_probe_trace_ref).
 int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads)
 {
-    int pool = 2 * threads;  // at most 2 slots per lane (the bucket pass keeps 2 ranks in registers)
+    int pool = 3 * threads;  // at most 3 slots per lane (the bucket pass keeps that many ranks in registers)
+    if (const char* v = std::getenv("DDGI_WF_MAXPOOL")) pool = std::min(pool, std::max(threads, std::atoi(v) / 64 * 64));
     while (pool >= threads && wf_lds_bytes(nwords, pool, multi_light) > lds_limit) pool -= 64;
     return pool >= threads ? pool : 0;
 }
