@@ -30,7 +30,7 @@
 
 namespace ddgi {
 
-constexpr int kWfTailSteps = 16;     // straggler steps after the march list is drained
+constexpr int kWfTailSteps = 24;     // straggler steps after the march list is drained
 constexpr int kWfFetchLanes = 8;     // pull new march tasks once this many lanes are idle
 constexpr uint32_t kWfChunk = 4096;  // rays a workgroup claims at a time from the global counter
 constexpr int kWfBuckets = 7;
