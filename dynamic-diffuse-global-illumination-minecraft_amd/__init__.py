@@ -10,6 +10,7 @@ multi-GPU path.  It never imports anything from oracle/.
 """
 from .build import build_library, library_path  # noqa: F401
 from .probe_engine import (  # noqa: F401
+    Camera,
     DDGIError,
     IrradianceField,
     Light,
@@ -21,6 +22,7 @@ from .probe_engine import (  # noqa: F401
     MODE_DDGI,
     generate_probe_rays_host,
     load_library,
+    make_camera,
     make_field,
     make_settings,
     probe_tile_origin,

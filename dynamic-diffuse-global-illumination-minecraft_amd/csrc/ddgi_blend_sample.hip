@@ -6,6 +6,7 @@
 //                        lines (1363-1383) enabled and octahedral bilinear tile fetches
 #include "ddgi_device.h"
 #include "ddgi_oct.h"
+#include "ddgi_sampler.h"
 
 namespace ddgi {
 
@@ -120,97 +121,13 @@ __global__ __launch_bounds__(kBlendBlock) void k_probe_blend(const BlendArgs A)
 // k_probe_sample_ddgi — one lane per shading point
 // ------------------------------------------------------------------------------------------------
 
-template <int kSide, int kCh>
-DDGI_D void tile_fetch(const float* tile, f3 dir, float* out)
-{
-    const f2 uv = oct_encode(normalize3(dir));
-    const float inner = static_cast<float>(kSide - 2);
-    const float fx = (uv.x * 0.5f + 0.5f) * inner + 0.5f;  // texel-centre coordinate inside the bordered tile
-    const float fy = (uv.y * 0.5f + 0.5f) * inner + 0.5f;
-    const float bx = floorf(fx), by = floorf(fy);
-    const float tx = fx - bx, ty = fy - by;
-    int x0 = gl_int(bx), y0 = gl_int(by);
-    int x1 = x0 + 1, y1 = y0 + 1;
-    x0 = max(x0, 0), y0 = max(y0, 0);
-    x1 = min(x1, kSide - 1), y1 = min(y1, kSide - 1);
-    for (int c = 0; c < kCh; ++c)
-    {
-        const float a = tile[(y0 * kSide + x0) * kCh + c], b = tile[(y0 * kSide + x1) * kCh + c];
-        const float cc = tile[(y1 * kSide + x0) * kCh + c], d = tile[(y1 * kSide + x1) * kCh + c];
-        out[c] = gl_mix(gl_mix(a, b, tx), gl_mix(cc, d, tx), ty);
-    }
-}
-
 __global__ __launch_bounds__(256) void k_probe_sample_ddgi(const SampleArgs A)
 {
-    const GridK& G = A.grid;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
-    const f3 pos{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]};
-    const f3 N = normalize3(f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]});
-    const f3 origin{G.origin[0], G.origin[1], G.origin[2]};
-    const float side = static_cast<float>(G.side);
-
     int cage[8];
-    for (int k = 0; k < 8; ++k) cage[k] = -1;
-    f3 out = mk3(1, 0, 1);
-    bool ok = true;
-    const f3 rel = div3(pos - origin, side);
-    const int bx = gl_int(floorf(rel.x)), by = gl_int(floorf(rel.y)), bz = gl_int(floorf(rel.z));
-    const int lo = gl_int(-floorf(static_cast<float>(G.cx) / 2.0f));  // Q6: x count for every axis
-    const int hi = gl_int(floorf(static_cast<float>(G.cx) / 2.0f) - 1.0f);
-    if (bx < lo || bx > hi || by < lo || by > hi || bz < lo || bz > hi) ok = false;
-    if (ok)
-    {
-        const f3 base_world = f3{static_cast<float>(bx * G.side), static_cast<float>(by * G.side), static_cast<float>(bz * G.side)} + origin;
-        const f3 a = div3(pos - base_world, side);
-        const f3 alpha{gl_clamp(a.x, 0.0f, 1.0f), gl_clamp(a.y, 0.0f, 1.0f), gl_clamp(a.z, 0.0f, 1.0f)};
-        f3 irr = mk3(0, 0, 0);
-        float sum_w = 0.0f;
-        const int n_probes = G.cx * G.cy * G.cz;
-        for (int k = 0; k < 8; ++k)
-        {
-            const int ox = (k >> 2) & 1, oy = (k >> 1) & 1, oz = k & 1;                            // Q7
-            const int sx = bx + ox + G.cx / 2, sy = by + oy + G.cy / 2, sz = bz + oz + G.cz / 2;  // Q4
-            const int idx = sy * G.cx * G.cz + sz * G.cx + sx;
-            if (idx < 0 || idx >= n_probes)
-            {
-                ok = false;
-                break;
-            }
-            cage[k] = idx;
-            const f3 tri{ox ? alpha.x : 1.0f - alpha.x, oy ? alpha.y : 1.0f - alpha.y, oz ? alpha.z : 1.0f - alpha.z};
-            const f3 probe_pos = base_world + f3{static_cast<float>(ox * G.side), static_cast<float>(oy * G.side), static_cast<float>(oz * G.side)};
-            const f3 dir = normalize3(probe_pos - pos);
-            float tmp = gl_max(0.0001f, (dot3(dir, N) + 1.0f) * 0.5f);
-            float weight = tmp * tmp + 0.2f;
-            const size_t slot = static_cast<size_t>(slab_slot(G, idx));
-            // moment visibility test (intersection.glsl:1363-1383, enabled)
-            const float dist = length3(pos - probe_pos);
-            float mms[2];
-            tile_fetch<kDepTile, 2>(A.depth + slot * (kDepTile * kDepTile * 2), f3{-dir.x, -dir.y, -dir.z}, mms);
-            const float mean = mms[0];
-            const float variance = fabsf(mean * mean - mms[1]);
-            tmp = gl_max(dist - mean, 0.0f);
-            float cheb = variance / (variance + tmp * tmp);
-            cheb = gl_max(cheb * cheb * cheb, 0.0f);
-            if (!(dist <= mean)) weight *= cheb;
-            weight = gl_max(0.000001f, weight);
-            const float crush = 0.2f;
-            if (weight < crush) weight *= weight * weight * (1.f / (crush * crush));
-            weight *= tri.x * tri.y * tri.z;
-            float c4[4];
-            tile_fetch<kIrrTile, 4>(A.irradiance + slot * (kIrrTile * kIrrTile * 4), N, c4);
-            irr = irr + f3{c4[0], c4[1], c4[2]} * weight;
-            sum_w += weight;
-        }
-        if (ok) out = div3(irr, sum_w);
-    }
-    if (!ok)
-    {
-        out = mk3(1, 0, 1);
-        for (int k = 0; k < 8; ++k) cage[k] = -1;
-    }
+    const f3 out = diffuse_gi_ddgi(A.grid, A.irradiance, A.depth, f3{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]},
+                                   f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]}, cage);
     A.rgb[3 * i] = out.x, A.rgb[3 * i + 1] = out.y, A.rgb[3 * i + 2] = out.z;
     if (A.cage)
         for (int k = 0; k < 8; ++k) A.cage[8 * i + k] = cage[k];

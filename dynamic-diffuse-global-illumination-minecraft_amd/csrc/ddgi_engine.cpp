@@ -23,6 +23,7 @@ int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads);
 hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream);
 hipError_t launch_probe_blend(const BlendArgs& args, int grid_blocks, hipStream_t stream);
 hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream);
+hipError_t launch_render_primary(const RenderArgs& args, hipStream_t stream);
 }  // namespace ddgi
 
 using namespace ddgi;
@@ -772,6 +773,74 @@ int ddgi_sample(ddgi_handle e, const float* pos, const float* nrm, size_t n, flo
     TRY_OR_CLEAN(hipStreamSynchronize(e->stream));
 #undef TRY_OR_CLEAN
     cleanup();
+    return DDGI_OK;
+}
+
+int ddgi_render_device(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_settings* st, uint32_t* d_rgba8, float* d_rgb_f32)
+{
+    if (!e || !cam || !st || !d_rgba8) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/camera/settings/output");
+    if (st->scene < 0 || st->scene > 2) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2}", st->scene);
+    if (st->screen_width < 1 || st->screen_height < 1 || 1ll * st->screen_width * st->screen_height > 0x7fffffffll)
+        return fail(DDGI_ERR_INVALID_ARGUMENT, "bad image size %d x %d", st->screen_width, st->screen_height);
+    if (st->camera_mode != 0 && st->camera_mode != 1) return fail(DDGI_ERR_UNSUPPORTED, "camera_mode %d (only 0 pinhole, 1 ortho)", st->camera_mode);
+    HIP_TRY(hipSetDevice(e->device));
+    const int scene = st->scene;
+    if (int rc = ensure_scene(e, scene)) return rc;
+    if (int rc = ensure_noise(e)) return rc;
+    RenderArgs r{};
+    r.trace.grid = make_grid(e);
+    r.trace.scene = e->dev_scene[scene].k;
+    r.trace.scene_id = scene;
+    r.trace.max_bounces = st->max_bounces;
+    r.trace.nl = e->n_lights[scene];
+    if (e->mode == DDGI_MODE_DDGI) animate_lights(scene, st->time, e->lights[scene], r.trace.nl, r.trace.lights);
+    else
+        for (int i = 0; i < r.trace.nl; ++i) r.trace.lights[i] = e->lights[scene][i];
+    r.trace.noise = e->noise;
+    for (int i = 0; i < 16; ++i) r.cam_matrix[i] = cam->matrix[i];
+    for (int i = 0; i < 4; ++i) r.cam_params[i] = cam->params[i];
+    const float half = 0.5f * cam->params[1];
+    r.pinhole_w = 1.0f / (pm::sinf_pinned(half) / pm::cosf_pinned(half));  // P6: tan := sin / cos
+    r.camera_mode = st->camera_mode;
+    r.render_mode = st->render_mode;
+    r.width = st->screen_width;
+    r.height = st->screen_height;
+    if (e->mode == DDGI_MODE_DDGI)
+    {
+        r.irradiance = static_cast<const float*>(e->tex[0]);
+        r.depth = static_cast<const float*>(e->tex[1]);
+    }
+    else
+        r.albedo = static_cast<const uint32_t*>(e->tex[0]);
+    r.rgba8 = d_rgba8;
+    r.rgb_f32 = d_rgb_f32;
+    HIP_TRY(launch_render_primary(r, e->stream));
+    return DDGI_OK;
+}
+
+int ddgi_render(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_settings* st, uint8_t* rgba8, float* rgb_f32)
+{
+    if (!e || !cam || !st || !rgba8) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/camera/settings/output");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t n = static_cast<size_t>(st->screen_width > 0 ? st->screen_width : 0) * (st->screen_height > 0 ? st->screen_height : 0);
+    uint32_t* d_img = nullptr;
+    float* d_f = nullptr;
+    if (n == 0) return fail(DDGI_ERR_INVALID_ARGUMENT, "bad image size");
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_img), n * 4));
+    if (rgb_f32 && hipMalloc(reinterpret_cast<void**>(&d_f), n * 12) != hipSuccess)
+    {
+        (void)hipFree(d_img);
+        return fail(DDGI_ERR_OUT_OF_MEMORY, "hipMalloc failed");
+    }
+    int rc = ddgi_render_device(e, cam, st, d_img, d_f);
+    hipError_t he = hipSuccess;
+    if (rc == DDGI_OK) he = hipMemcpyAsync(rgba8, d_img, n * 4, hipMemcpyDeviceToHost, e->stream);
+    if (rc == DDGI_OK && he == hipSuccess && rgb_f32) he = hipMemcpyAsync(rgb_f32, d_f, n * 12, hipMemcpyDeviceToHost, e->stream);
+    if (rc == DDGI_OK && he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    (void)hipFree(d_img);
+    if (d_f) (void)hipFree(d_f);
+    if (rc != DDGI_OK) return rc;
+    if (he != hipSuccess) return fail(DDGI_ERR_HIP, "render readback failed: %s", hipGetErrorString(he));
     return DDGI_OK;
 }
 

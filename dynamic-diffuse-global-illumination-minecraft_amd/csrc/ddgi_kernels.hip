@@ -9,6 +9,7 @@
 // All arithmetic is the engine's pinned binary32 arithmetic (DESIGN.md "Arithmetic pinning");
 // this file is compiled with -ffp-contract=off so that only the fmaf() written in the source fuse.
 #include "ddgi_device.h"
+#include "ddgi_sampler.h"
 
 namespace ddgi {
 
@@ -253,105 +254,16 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
 // k_probe_sample_ref — one lane per shading point
 // ------------------------------------------------------------------------------------------------
 
-DDGI_D f3 load_rgb(const uint32_t* tex, size_t i)
-{
-    const uint32_t v = tex[i];
-    return f3{static_cast<float>(v & 255u) / 255.0f, static_cast<float>((v >> 8) & 255u) / 255.0f,
-              static_cast<float>((v >> 16) & 255u) / 255.0f};
-}
-
-// sample_probe (intersection.glsl:1176-1240) against the slab-major texel buffer
-DDGI_D f3 sample_probe_ref(const GridK& G, const uint32_t* albedo, const uint32_t* tex, int probe, f3 dir)
-{
-    const int cxz = G.cx * G.cz;
-    // get_text_coord_from_probe_number (:1152-1174): out of range -> magenta
-    if (probe >= cxz * G.cy || probe < 0) return mk3(1, 0, 1);
-    const int s = G.s;
-    const f3 id = normalize3(dir);
-    int rx = gl_int(((-1.0f * (id.z - 1.0f)) / 2.0f) * static_cast<float>(s));
-    if (rx == s) rx = 0;
-    const float sqrt_z = sqrtf(1.0f - (id.z * id.z));
-    const float kPi = 3.1415926535897932384626433832795f;
-    const int ry = gl_int((pm::acosf_pinned(id.x / sqrt_z) / (2.0f * kPi)) * static_cast<float>(s));
-    const size_t base = static_cast<size_t>(slab_slot(G, probe)) * s * s;
-    f3 result = load_rgb(albedo, base + ry * s + rx);
-    int count = 0;
-    for (int dx = -2; dx <= 2; ++dx)
-    {
-        const int x = rx + dx;
-        if (x < 0 || x >= s) continue;
-        for (int dy = -2; dy <= 2; ++dy)
-        {
-            const int y = ry + dy;
-            if (y < 0 || y >= s) continue;
-            count += 1;
-            result = result + load_rgb(tex, base + y * s + x);
-        }
-    }
-    return div3(result, static_cast<float>(count));
-}
-
 __global__ __launch_bounds__(256) void k_probe_sample_ref(const SampleArgs A)
 {
-    const GridK& G = A.grid;
+    __shared__ float s_unorm[256];
+    s_unorm[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;  // blockDim.x == 256
+    __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
-    const f3 pos{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]};
-    const f3 N = normalize3(f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]});
-    const f3 origin{G.origin[0], G.origin[1], G.origin[2]};
-    const float side = static_cast<float>(G.side);
-
     int cage[8];
-    for (int k = 0; k < 8; ++k) cage[k] = -1;
-    f3 out = mk3(1, 0, 1);
-    bool ok = true;
-
-    const f3 rel = div3(pos - origin, side);
-    const int bx = gl_int(floorf(rel.x)), by = gl_int(floorf(rel.y)), bz = gl_int(floorf(rel.z));
-    // Q6: every axis is bounds-checked against probe_count.x
-    const int lo = gl_int(-floorf(static_cast<float>(G.cx) / 2.0f));
-    const int hi = gl_int(floorf(static_cast<float>(G.cx) / 2.0f) - 1.0f);
-    if (bx < lo || bx > hi || by < lo || by > hi || bz < lo || bz > hi) ok = false;
-
-    if (ok)
-    {
-        const f3 base_world = f3{static_cast<float>(bx * G.side), static_cast<float>(by * G.side), static_cast<float>(bz * G.side)} + origin;
-        const f3 a = div3(pos - base_world, side);
-        const f3 alpha{gl_clamp(a.x, 0.0f, 1.0f), gl_clamp(a.y, 0.0f, 1.0f), gl_clamp(a.z, 0.0f, 1.0f)};
-        f3 irradiance = mk3(0, 0, 0);
-        float sum_weight = 0.0f;
-        const int n_probes = G.cx * G.cy * G.cz;
-        for (int k = 0; k < 8 && ok; ++k)
-        {
-            const int ox = (k >> 2) & 1, oy = (k >> 1) & 1, oz = k & 1;  // Q7 corner order
-            const int sx = bx + ox + G.cx / 2, sy = by + oy + G.cy / 2, sz = bz + oz + G.cz / 2;  // Q4
-            const int idx = sy * G.cx * G.cz + sz * G.cx + sx;
-            if (idx < 0 || idx >= n_probes)
-            {
-                ok = false;
-                break;
-            }
-            cage[k] = idx;
-            const f3 tri{ox ? alpha.x : 1.0f - alpha.x, oy ? alpha.y : 1.0f - alpha.y, oz ? alpha.z : 1.0f - alpha.z};
-            const f3 probe_pos = base_world + f3{static_cast<float>(ox * G.side), static_cast<float>(oy * G.side), static_cast<float>(oz * G.side)};
-            const f3 dir = normalize3(probe_pos - pos);
-            const float tmp = gl_max(0.0001f, (dot3(dir, N) + 1.0f) * 0.5f);
-            float weight = tmp * tmp + 0.2f;
-            weight = gl_max(0.000001f, weight);
-            const float crush = 0.2f;
-            if (weight < crush) weight *= weight * weight * (1.f / (crush * crush));  // unreachable (Q11)
-            weight *= tri.x * tri.y * tri.z;
-            const f3 smp = sample_probe_ref(G, A.albedo, A.albedo, idx, N);
-            irradiance = irradiance + smp * weight;
-            sum_weight += weight;
-        }
-        if (ok) out = div3(irradiance, sum_weight);
-    }
-    if (!ok)
-    {
-        out = mk3(1, 0, 1);
-        for (int k = 0; k < 8; ++k) cage[k] = -1;
-    }
+    const f3 out = diffuse_gi_ref(A.grid, A.albedo, f3{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]},
+                                  f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]}, s_unorm, cage);
     A.rgb[3 * i] = out.x;
     A.rgb[3 * i + 1] = out.y;
     A.rgb[3 * i + 2] = out.z;

@@ -105,4 +105,21 @@ struct SampleArgs
     const float* depth;
 };
 
+// k_render_primary: camera rays + integrators over the probe field
+struct RenderArgs
+{
+    TraceArgs trace;       // scene, lights, noise, grid (rays/textures of the trace kernels unused)
+    float cam_matrix[16];  // Camera UBO: mat4, column-major (compute_pass.comp:30-35)
+    float cam_params[4];   // aspect, hfov, ortho scale, 0
+    float pinhole_w;       // 1 / tan(hfov / 2), pinned tan = sin / cos, evaluated on the host
+    int camera_mode;       // 0 pinhole, 1 ortho
+    int render_mode;       // integrator index, compute_pass.comp:58-87
+    int width, height;
+    const uint32_t* albedo;   // REF mode probe texture (slab-major)
+    const float* irradiance;  // DDGI mode tiles; null in REF mode
+    const float* depth;
+    uint32_t* rgba8;  // width*height
+    float* rgb_f32;   // optional, width*height*3
+};
+
 }  // namespace ddgi

@@ -51,6 +51,31 @@ class RenderSettings(C.Structure):
     ]
 
 
+class Camera(C.Structure):
+    """Camera UBO of the render pass (compute_pass.comp:30-35): column-major mat4 + params."""
+    _fields_ = [("matrix", C.c_float * 16), ("params", C.c_float * 4)]
+
+
+def make_camera(origin, rotation_deg=(0.0, 0.0, 0.0), fov_deg=75.0, aspect=16.0 / 9.0, scale=4.0):
+    """Camera::recalculate_values + get_data (src/rvpt/camera.cpp:18-26, 76-110): translate, then
+    rotate about UP (y) by rotation.x, RIGHT (x) by rotation.y, FORWARD (z) by rotation.z."""
+    def rot(axis, deg):
+        a = np.deg2rad(deg)
+        c, s = np.cos(a), np.sin(a)
+        x, y, z = axis
+        return np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s, 0],
+                         [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s, 0],
+                         [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c), 0],
+                         [0, 0, 0, 1]], dtype=np.float64)
+    m = np.eye(4)
+    m[:3, 3] = origin
+    m = m @ rot((0, 1, 0), rotation_deg[0]) @ rot((1, 0, 0), rotation_deg[1]) @ rot((0, 0, 1), rotation_deg[2])
+    cam = Camera()
+    cam.matrix[:] = [float(v) for v in m.T.reshape(-1).astype(np.float32)]  # column-major
+    cam.params[:] = [float(np.float32(aspect)), float(np.float32(np.deg2rad(fov_deg))), float(scale), 0.0]
+    return cam
+
+
 class Light(C.Structure):
     """struct Light (assets/shaders/structs.glsl:54-59)."""
     _fields_ = [("intensity", C.c_float), ("col", C.c_float * 3), ("pos", C.c_float * 3)]
@@ -107,6 +132,8 @@ _SIGNATURES = {
     "ddgi_read_tiles": (C.c_int, [_VP, _VP, _VP]),
     "ddgi_set_frame": (C.c_int, [_VP, C.c_uint32]),
     "ddgi_sample": (C.c_int, [_VP, _VP, _VP, C.c_size_t, _VP, _VP]),
+    "ddgi_render": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "ddgi_render_device": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
     "ddgi_set_stream": (C.c_int, [_VP, _VP]),
     "ddgi_device_textures": (C.c_int, [_VP] + [C.POINTER(_VP), C.POINTER(C.c_size_t)] * 2 + [C.POINTER(C.c_size_t)] * 4),
     "ddgi_bind_textures": (C.c_int, [_VP, _VP, _VP]),
@@ -319,6 +346,14 @@ class ProbeEngine:
         cage = np.empty((n, 8), dtype=np.int32) if want_cage else None
         _check(self._lib.ddgi_sample(self._h, _ptr(pos), _ptr(nrm), n, _ptr(rgb), _ptr(cage)))
         return rgb, cage
+
+    def render(self, camera, settings, want_float=False):
+        """compute_pass.comp:main for the probe-consuming integrators -> rgba8 [H, W, 4] (+ rgb f32)."""
+        w, h = settings.screen_width, settings.screen_height
+        img = np.empty((h, w, 4), dtype=np.uint8)
+        rgb = np.empty((h, w, 3), dtype=np.float32) if want_float else None
+        _check(self._lib.ddgi_render(self._h, C.byref(camera), C.byref(settings), _ptr(img), _ptr(rgb)))
+        return (img, rgb) if want_float else img
 
     # -- device-pointer level ------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr):

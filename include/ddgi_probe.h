@@ -207,6 +207,30 @@ int ddgi_set_frame(ddgi_handle h, uint32_t frame);
 int ddgi_sample(ddgi_handle h, const float* pos_xyz, const float* nrm_xyz, size_t n,
                 float* rgb_out, int32_t* cage_idx8_out);
 
+/* ---- the primary-visibility consumer ------------------------------------ */
+
+/* The Camera UBO of the render pass (assets/shaders/compute_pass.comp:30-35; filled by
+ * Camera::get_data, src/rvpt/camera.cpp:100-110): column-major mat4 + (aspect, hfov in radians,
+ * ortho scale, 0).  80 bytes. */
+typedef struct ddgi_camera
+{
+    float matrix[16];
+    float params[4];
+} ddgi_camera;
+
+/* Replaces the render half of record_compute_command_buffer (rvpt.cpp:1131-1140) for the
+ * integrators that consume the probe field: compute_pass.comp:main 162-191 = camera ray
+ * (camera.glsl:29-74; settings->camera_mode 0 pinhole, 1 ortho) + eval_integrator
+ * (compute_pass.comp:58-87; settings->render_mode 0 DDGI, 1 direct, 2 indirect, 3 colour, 4 normal,
+ * 5 depth) over a screen_width x screen_height image, using the handle's current probe textures in
+ * its current mode.  Output: rgba8 (the reference's result_image format), row 0 = top; optional
+ * unquantised rgb (3 floats per pixel).  Probe visualisation is not implemented.  Synchronises. */
+int ddgi_render(ddgi_handle h, const ddgi_camera* camera, const ddgi_render_settings* settings,
+                uint8_t* rgba8_out, float* rgb_f32_out);
+/* Same on device pointers, asynchronous on the handle's stream. */
+int ddgi_render_device(ddgi_handle h, const ddgi_camera* camera, const ddgi_render_settings* settings,
+                       uint32_t* d_rgba8_out, float* d_rgb_f32_out);
+
 /* ---- device-pointer level (for hosts that own device memory / streams, e.g. PyTorch) ---------- */
 
 /* Uses `hip_stream` (a hipStream_t) for all subsequent work of this handle; NULL = default. */

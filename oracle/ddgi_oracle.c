@@ -849,6 +849,7 @@ typedef struct
     v3 normal;
     v3 base_color; /* mat.base_color = albedo.xyz */
     int type;      /* 2 light, 3 block */
+    int lid;       /* which light (info.mat.emissive = its colour, intersection.glsl:1275) */
 } Isect;
 
 typedef struct
@@ -1032,6 +1033,7 @@ static int intersect_scene(const TraceCtx* cx, Ray ray, Isect* info)
                pinned to zero here (base_color = 0) */
             info->base_color = V3(0, 0, 0);
             info->type = 2;
+            info->lid = i;
         }
         closest_t = gmin(tmp.t, closest_t);
     }
@@ -1841,5 +1843,182 @@ void oracle_ddgi_sample(const o_field* f, const float* irradiance, const float* 
         }
         rgb[3 * k] = out.x, rgb[3 * k + 1] = out.y, rgb[3 * k + 2] = out.z;
         if (cage8) memcpy(cage8 + 8 * k, cage, sizeof(cage));
+    }
+}
+
+/* =========================================================================================== */
+/* SURVEY.md §8(f) row 1 — the primary-visibility consumer of the probe field: camera rays        */
+/* (assets/shaders/camera.glsl:29-74) + the integrators that call get_diffuse_gi                  */
+/* (assets/shaders/integrators.glsl:27-271) + compute_pass.comp:main 162-191.                     */
+/* Probe visualisation (intersect_probes, render_settings.visualize_probes) is not restated.      */
+/* =========================================================================================== */
+
+typedef struct
+{
+    float matrix[16]; /* mat4, column-major: matrix[4*c + r] */
+    float params[4];  /* aspect, hfov (radians), ortho scale, 0  (camera.cpp:100-110) */
+} o_camera;
+
+/* P6 extension: tan(x) := sin(x) / cos(x) in PINNED mode */
+static inline float o_tan(float x) { return g_pinned ? o_sin(x) / o_cos(x) : tanf(x); }
+
+/* mat4 * vec4(x, y, z, w) restricted to xyz, columns accumulated left to right */
+static v3 cam_mul(const o_camera* cam, float x, float y, float z, float w)
+{
+    const float* m = cam->matrix;
+    v3 r;
+    r.x = ((m[0] * x + m[4] * y) + m[8] * z) + m[12] * w;
+    r.y = ((m[1] * x + m[5] * y) + m[9] * z) + m[13] * w;
+    r.z = ((m[2] * x + m[6] * y) + m[10] * z) + m[14] * w;
+    return r;
+}
+
+/* get_camera_ray, compute_pass.comp:89-103: 0 pinhole (camera.glsl:29-51), 1 ortho (:55-74) */
+static Ray camera_ray(const o_camera* cam, int camera_mode, float x, float y)
+{
+    Ray r;
+    float aspect = cam->params[0];
+    float u = aspect * (2.0f * x - 1.0f);
+    float v = 2.0f * y - 1.0f;
+    if (camera_mode == 1)
+    {
+        float s = cam->params[2];
+        r.o = cam_mul(cam, s * u, s * v, 0.0f, 1.0f);
+        r.d = V3(cam->matrix[8], cam->matrix[9], cam->matrix[10]);
+        return r;
+    }
+    float w = 1.0f / o_tan(0.5f * cam->params[1]);
+    r.o = V3(cam->matrix[12], cam->matrix[13], cam->matrix[14]);
+    r.d = normalize3(cam_mul(cam, u, v, w, 0.0f));
+    return r;
+}
+
+typedef struct
+{
+    const o_field* f;
+    int ddgi_mode;
+    const uint8_t* albedo;   /* REF */
+    const uint8_t* distance; /* REF */
+    const float* irradiance; /* DDGI */
+    const float* depth;      /* DDGI */
+} RenderProbes;
+
+void oracle_ddgi_sample(const o_field* f, const float* irradiance, const float* depth, const float* pos_a,
+                        const float* nrm_a, uint64_t npts, float* rgb, int32_t* cage8);
+
+static v3 probe_field_gi(const RenderProbes* rp, v3 pos, v3 nrm)
+{
+    if (rp->ddgi_mode)
+    {
+        float p[3] = {pos.x, pos.y, pos.z}, n[3] = {nrm.x, nrm.y, nrm.z}, out[3];
+        oracle_ddgi_sample(rp->f, rp->irradiance, rp->depth, p, n, 1, out, NULL);
+        return V3(out[0], out[1], out[2]);
+    }
+    SampleCtx sc;
+    sc.f = rp->f;
+    sc.albedo = rp->albedo;
+    sc.distance = rp->distance;
+    sc.W = rp->f->probe_count[0] * rp->f->probe_count[2] * rp->f->sqrt_rays_per_probe;
+    sc.H = rp->f->probe_count[1] * rp->f->sqrt_rays_per_probe;
+    int32_t cage[8];
+    return get_diffuse_gi(&sc, pos, nrm, cage);
+}
+
+/* the direct-light loop shared by integrator_DDGI (:77-96) and integrator_direct (:131-149): only
+ * feelers that END ON A LIGHT contribute; returns the number of visible lights */
+static int render_direct(const TraceCtx* cx, const Isect* info, v3* direct)
+{
+    *direct = V3(0, 0, 0);
+    int nvis = 0;
+    for (int i = 0; i < cx->nl; i++)
+    {
+        const o_light* l = &cx->lights[i];
+        v3 lp = V3(l->pos[0], l->pos[1], l->pos[2]);
+        Ray feeler;
+        feeler.o = info->pos;
+        feeler.d = normalize3(vsub(lp, info->pos));
+        Isect tmp;
+        if (intersect_scene(cx, feeler, &tmp) && tmp.type == 2)
+        {
+            float lambert = gclamp(dot3(normalize3(info->normal), normalize3(vsub(lp, info->pos))), 0.0f, 1.0f);
+            float dist = length3(vsub(lp, info->pos));
+            v3 c = vscale(V3(l->col[0], l->col[1], l->col[2]), lambert);
+            c = vscale(c, l->intensity);
+            c = vdivs(c, dist);
+            *direct = vadd(*direct, c);
+            nvis++;
+        }
+    }
+    return nvis;
+}
+
+/* eval_integrator, compute_pass.comp:58-87 */
+static v3 eval_integrator(const TraceCtx* cx, const RenderProbes* rp, int idx, Ray ray)
+{
+    Isect info;
+    int hit = intersect_scene(cx, ray, &info);
+    v3 direct;
+    switch (idx)
+    {
+        case 1: /* integrator_direct :108-158 */
+        {
+            if (!hit) return V3(0, 0, 0);
+            int nvis = render_direct(cx, &info, &direct);
+            if (nvis != 0) return vmul(vscale(info.base_color, 0.5f), vdivs(direct, (float)nvis));
+            return V3(0, 0, 0);
+        }
+        case 2: /* integrator_indirect :162-207 */
+            if (!hit) return V3(0, 0, 0);
+            return vscale(probe_field_gi(rp, info.pos, info.normal), 0.5f);
+        case 3: /* integrator_color */
+            return hit ? info.base_color : V3(0, 0, 0);
+        case 4: /* integrator_normal: 0.5*normal + 0.5*float(hit); normal is (0,0,0) on a miss */
+        {
+            float h = hit ? 1.0f : 0.0f;
+            return V3(0.5f * info.normal.x + 0.5f * h, 0.5f * info.normal.y + 0.5f * h, 0.5f * info.normal.z + 0.5f * h);
+        }
+        case 5: /* integrator_depth: 1 / (|d| * t); t = INF on a miss */
+        {
+            float inv = 1.0f / (length3(ray.d) * info.t);
+            return V3(inv, inv, inv);
+        }
+        default: /* 0: integrator_DDGI :27-106 */
+        {
+            if (!hit) return V3(0.898f, 0.968f, 1.0f);
+            if (info.type == 2)
+            { /* returns the light colour: info.mat.emissive = get_light(scene, i).col (intersection.glsl:1275) */
+                const o_light* l = &cx->lights[info.lid];
+                return V3(l->col[0], l->col[1], l->col[2]);
+            }
+            v3 indirect = probe_field_gi(rp, info.pos, info.normal);
+            int nvis = render_direct(cx, &info, &direct);
+            v3 half_base = vscale(info.base_color, 0.5f);
+            if (nvis != 0) return vadd(vmul(half_base, vdivs(direct, (float)nvis)), vmul(half_base, indirect));
+            return vmul(vscale(indirect, 0.5f), info.base_color);
+        }
+    }
+}
+
+/* compute_pass.comp:main 162-191 for a width x height image -> rgba8 (+ optional float rgb) */
+void oracle_render(const o_field* f, const o_settings* st, const o_camera* cam, const o_light* lights_in, int nl,
+                   int ddgi_mode, const void* tex0, const void* tex1, int width, int height, uint8_t* rgba8, float* rgb_f32)
+{
+    TraceCtx cx;
+    make_ctx(&cx, st, lights_in, nl);
+    RenderProbes rp;
+    rp.f = f;
+    rp.ddgi_mode = ddgi_mode;
+    rp.albedo = (const uint8_t*)tex0, rp.distance = (const uint8_t*)tex1;
+    rp.irradiance = (const float*)tex0, rp.depth = (const float*)tex1;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t k = 0; k < (int64_t)width * height; k++)
+    {
+        int px = (int)(k % width), py = (int)(k / width);
+        float cxn = (float)px / (float)width;
+        float cyn = 1.0f - (float)py / (float)height; /* flip image vertically */
+        Ray ray = camera_ray(cam, st->camera_mode, cxn, cyn);
+        v3 c = eval_integrator(&cx, &rp, st->render_mode, ray);
+        if (rgb_f32) rgb_f32[3 * k] = c.x, rgb_f32[3 * k + 1] = c.y, rgb_f32[3 * k + 2] = c.z;
+        rgba8[4 * k] = unorm8(c.x), rgba8[4 * k + 1] = unorm8(c.y), rgba8[4 * k + 2] = unorm8(c.z), rgba8[4 * k + 3] = 255;
     }
 }

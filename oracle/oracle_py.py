@@ -261,3 +261,27 @@ def ddgi_sample(field, irradiance, depth, pos, nrm):
                              pos.ctypes.data_as(C.c_void_p), nrm.ctypes.data_as(C.c_void_p), C.c_uint64(n),
                              rgb.ctypes.data_as(C.c_void_p), cage.ctypes.data_as(C.c_void_p))
     return rgb, cage
+
+
+# ---- camera rays + integrators -----------------------------------------
+
+class OCamera(C.Structure):
+    _fields_ = [("matrix", C.c_float * 16), ("params", C.c_float * 4)]
+
+
+def render(field, settings, camera, tex0, tex1, ddgi_mode=False, lights=None, want_float=False):
+    """compute_pass.comp:main -> rgba8 [H, W, 4] (+ rgb f32).  tex0/tex1: REF rasters (u8) or DDGI tiles (f32).
+    `camera` is any ctypes struct with the 80-byte Camera UBO layout."""
+    w, h = settings.screen_width, settings.screen_height
+    img = np.zeros((h, w, 4), dtype=np.uint8)
+    rgb = np.zeros((h, w, 3), dtype=np.float32) if want_float else None
+    lp, nl = None, 0
+    if lights is not None:
+        lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+        lp, nl = lights.ctypes.data_as(C.c_void_p), len(lights)
+    tex0 = np.ascontiguousarray(tex0)
+    tex1 = np.ascontiguousarray(tex1)
+    lib().oracle_render(C.byref(field), C.byref(settings), C.byref(camera), lp, nl, 1 if ddgi_mode else 0,
+                        tex0.ctypes.data_as(C.c_void_p), tex1.ctypes.data_as(C.c_void_p), w, h,
+                        img.ctypes.data_as(C.c_void_p), rgb.ctypes.data_as(C.c_void_p) if want_float else None)
+    return (img, rgb) if want_float else img
