@@ -153,6 +153,19 @@ DDGI_D bool march_step(March& m, const SceneK& S, const uint32_t* __restrict__ s
     return (base[idx >> 5] >> (idx & 31)) & 1u;
 }
 
+// Block type of the voxel a march ended in (its id `cell` = ceil(p), raw linear index `raw`).  The
+// baked table is exact inside the box and for everything that is an extrusion of its border layer;
+// the one exception is the cave's floor band (y < -15): there getBlockAt decides 11/12/13 from an
+// fbm of (x, z) BEFORE it looks at the hollow (intersection.glsl:726-742), so it continues under the
+// solid rock outside the box.  No ray can reach those voxels from the hollow, but a probe placed in
+// the rock there starts inside one — evaluate the rule itself for them.
+DDGI_D int hit_block_type(const SceneK& S, int scene_id, f3 cell, int raw)
+{
+    if (scene_id == 0 && cell.y < -15.0f && (cell.x < S.lo_f[0] || cell.x > S.hi_f[0] || cell.z < S.lo_f[2] || cell.z > S.hi_f[2]))
+        return block_at(cell, 0);
+    return S.types[raw - S.bias];
+}
+
 // True when the march can no longer hit a block: the position is outside the baked box on some
 // axis, moving away from it, and the border layer it left through is entirely empty (so the whole
 // half space beyond is empty).  Skipping the remaining iterations does not change any result.

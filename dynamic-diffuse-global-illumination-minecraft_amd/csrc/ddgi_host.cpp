@@ -83,6 +83,9 @@ static SceneBake bake_scene(int scene)
 
 int SceneBake::block_at(int x, int y, int z) const
 {
+    // the cave's fbm floor band continues outside the box (see hit_block_type in ddgi_device.h)
+    if (scene == 0 && y < -15 && (x < lo[0] || x > hi[0] || z < lo[2] || z > hi[2]))
+        return ddgi::block_at(mk3(static_cast<float>(x), static_cast<float>(y), static_cast<float>(z)), 0);
     x = x < lo[0] ? lo[0] : (x > hi[0] ? hi[0] : x);
     y = y < lo[1] ? lo[1] : (y > hi[1] ? hi[1] : y);
     z = z < lo[2] ? lo[2] : (z > hi[2] ? hi[2] : z);

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
                             if (fabsf(diff.z) > best) { best = fabsf(diff.z); n = mk3(0, 0, gl_sign(diff.z)); }
                             const f3 nn = normalize3(n);
                             const int idx = cell_index(A.scene, static_cast<int>(cell.x), static_cast<int>(cell.y), static_cast<int>(cell.z));
-                            const int type = A.scene.types[idx - A.scene.bias];
+                            const int type = hit_block_type(A.scene, A.scene_id, cell, idx);
                             hcol = (A.ablate & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(m.p, type, nn, A.noise);
                             nraw = nn;
                         }

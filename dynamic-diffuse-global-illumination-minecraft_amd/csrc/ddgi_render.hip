@@ -52,7 +52,7 @@ DDGI_D Hit intersect_scene_dev(f3 o, f3 d, const TraceArgs& T, const uint32_t* s
         if (fabsf(diff.y) > best) { best = fabsf(diff.y); n = mk3(0, gl_sign(diff.y), 0); }
         if (fabsf(diff.z) > best) { best = fabsf(diff.z); n = mk3(0, 0, gl_sign(diff.z)); }
         const f3 nn = normalize3(n);
-        if (want_albedo) h.base = block_albedo(m.p, T.scene.types[m.cell - T.scene.bias], nn, T.noise);
+        if (want_albedo) h.base = block_albedo(m.p, hit_block_type(T.scene, T.scene_id, cell, m.cell), nn, T.noise);
         nraw = nn;
     }
     else

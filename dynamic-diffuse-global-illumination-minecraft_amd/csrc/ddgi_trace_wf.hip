@@ -580,7 +580,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                     if (!fin && ((trips & 7) == 7)) fin = march_escaped(m, A.scene);
                     if (fin)
                     {
-                        const uint32_t type = occ ? static_cast<uint32_t>(A.scene.types[m.cell - A.scene.bias]) : 0u;
+                        const uint32_t type = occ ? static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)) : 0u;
                         P.t[slot] = m.t;
                         P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) |
                                         (occ ? kFlagHit : 0u) | (type << 16);

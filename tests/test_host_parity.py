@@ -62,12 +62,11 @@ def test_pinned_acos_product_equals_oracle_bitwise_and_tracks_libm(ddgi, oracle)
 @pytest.mark.parametrize("scene,box", [
     (1, ((-16, 16), (-16, 16), (-2, 32))),
     (2, ((-32, 32), (-10, 10), (-22, 22))),
-    (0, ((-50, 40), (-30, 24), (-46, 40))),
+    (0, ((-56, 46), (-30, 24), (-50, 44))),
 ])
 def test_scene_bake_equals_procedural_getBlockAt(ddgi, oracle, scene, box):
     """The clamped lookup into the bake (what the kernels traverse) against the oracle's
-    procedural getBlockAt on a box well beyond the bake: block types must agree everywhere a ray
-    can arrive (any voxel with an empty face-neighbour), occupancy must agree everywhere."""
+    procedural getBlockAt on a box well beyond the bake."""
     g = oracle.lib().oracle_get_block_at
     (x0, x1), (y0, y1), (z0, z1) = box
     shape = (x1 - x0 + 1, y1 - y0 + 1, z1 - z0 + 1)
@@ -79,17 +78,9 @@ def test_scene_bake_equals_procedural_getBlockAt(ddgi, oracle, scene, box):
                 want[ix, iy, iz] = g(x, y, z, scene)
                 got[ix, iy, iz] = ddgi.scene_block_at(scene, x, y, z)
     assert np.array_equal(want > 0, got > 0), "occupancy differs"
-    empty = want == 0
-    reachable = np.zeros(shape, dtype=bool)
-    for axis in range(3):
-        lo = [slice(None)] * 3
-        hi = [slice(None)] * 3
-        lo[axis], hi[axis] = slice(0, -1), slice(1, None)
-        reachable[tuple(lo)] |= empty[tuple(hi)]
-        reachable[tuple(hi)] |= empty[tuple(lo)]
-    reachable &= want > 0
-    assert np.array_equal(want[reachable], got[reachable]), "a hittable voxel has a different block type"
-    assert reachable.sum() > 100
+    # block types must agree EVERYWHERE, not only on voxels a ray can arrive at from empty space: a
+    # probe placed inside solid rock starts its rays inside a voxel and is shaded with that type
+    assert np.array_equal(want, got), f"{(want != got).sum()} voxels have a different block type"
 
 
 @pytest.mark.parametrize("name", ["c1_cornell", "cave_small", "cave_odd", "c2_cornell"])
