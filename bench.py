@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-probes", type=int, default=96)
+    ap.add_argument("--mode", choices=["ref", "ddgi"], default="ref",
+                    help="ref (default): the reference's live behaviour, the headline metric; ddgi: in-kernel Fibonacci rays + "
+                         "octahedral irradiance/depth blend with hysteresis (trace + blend per step)")
     args = ap.parse_args()
 
     import torch
@@ -125,7 +128,11 @@ def main():
     eng = ddgi_amd.ProbeEngine(field, settings, device=local_rank, rank=rank, world=world)
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)          # kernels + collectives share torch's stream
-    eng.generate_probe_rays(seed=w["seed"])     # ray buffer resident in HBM from here on
+    ddgi_mode = args.mode == "ddgi"
+    if ddgi_mode:
+        eng.set_mode(ddgi_amd.MODE_DDGI)        # rays are generated in the kernel; tiles start zeroed
+    else:
+        eng.generate_probe_rays(seed=w["seed"])  # ray buffer resident in HBM from here on
 
     tex = None
     if world > 1:
@@ -133,8 +140,15 @@ def main():
 
         tex = ddist.ShardedTextures(eng, torch.device("cuda", local_rank))
 
+    frame_time = [0.0]
+
     def step():
-        eng.probe_update()
+        if ddgi_mode:
+            frame_time[0] += 2.0                # RVPT::update: render_settings.time += 2 (rvpt.cpp:281)
+            settings.time = frame_time[0]
+            eng.probe_update(settings)
+        else:
+            eng.probe_update()
         if tex is not None:
             tex.all_gather()
 
@@ -157,13 +171,15 @@ def main():
         elapsed = float(t.item())
 
     # kernel durations of the timed steps: HIP events recorded on the launch stream by the engine
-    trace_ms, _ = eng.update_history_ms(min(args.steps, 64))
+    trace_ms, blend_ms = eng.update_history_ms(min(args.steps, 64))
     kernel_ms = float(np.mean(trace_ms)) if len(trace_ms) else float("nan")
 
     total_rays = eng.num_rays
     local_rays = total_rays // world
     ms_per_step = elapsed / args.steps * 1e3
-    achieved = ALGO_BYTES_PER_RAY * local_rays / (kernel_ms * 1e-3) / 1e9
+    # REF: 48 B ProbeRay in + two 4 B texels out; DDGI: rays are generated in the kernel, 16 B (rgb, distance) record out
+    algo_bytes_per_ray = 16 if ddgi_mode else ALGO_BYTES_PER_RAY
+    achieved = algo_bytes_per_ray * local_rays / (kernel_ms * 1e-3) / 1e9
     out = {
         "metric": "probe_rays_per_sec",
         "value": total_rays / (elapsed / args.steps),
@@ -184,7 +200,7 @@ def main():
             "probe_rays": total_rays,
             "scene": "minecraft_cave",
             "max_bounces": w["max_bounces"],
-            "mode": "REF",
+            "mode": "DDGI" if ddgi_mode else "REF",
             "parallelism": f"zslab{world}" + ("+allgather" if world > 1 else ""),
         },
         "roofline": {
@@ -194,13 +210,21 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": _traffic_from_profiles(),
-            "algorithmic_bytes_per_launch": ALGO_BYTES_PER_RAY * local_rays,
+            "traffic": None if ddgi_mode else _traffic_from_profiles(),
+            "algorithmic_bytes_per_launch": algo_bytes_per_ray * local_rays,
             "kernel_ms": kernel_ms,
             "note": "the trace kernel is VALU-issue bound (dependent voxel steps + hit shading), not HBM bound: see DESIGN.md section 4 and profiles/",
         },
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if ddgi_mode:
+        # the blend kernel: 16 B ray record per ray in, 3 KB old tiles in + 3 KB new tiles out per probe
+        bms = float(np.mean(blend_ms)) if len(blend_ms) else float("nan")
+        probes_local = eng.num_probes // world
+        bbytes = 16 * local_rays + 6144 * probes_local
+        out["config"]["workload"] = w["name"].replace("_ref", "_ddgi")
+        out["blend"] = {"kernel": "k_probe_blend", "kernel_ms": bms, "algorithmic_bytes_per_launch": bbytes,
+                        "achieved_GBps": bbytes / (bms * 1e-3) / 1e9, "frac_of_hbm_peak": bbytes / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not ddgi_mode:
         out["cpu_baseline"] = cpu_baseline(args.cpu_probes)
     eng.close()
     if world > 1:
