@@ -26,6 +26,8 @@ from .probe_engine import (  # noqa: F401
     make_field,
     make_settings,
     probe_tile_origin,
+    read_scene_file,
     scene_block_at,
+    scene_save,
     texture_size,
 )

@@ -13,6 +13,7 @@
 
 #include "ddgi_host.h"
 #include "ddgi_pinned_math.h"
+#include "ddgi_scene.h"
 #include "ddgi_types.h"
 
 namespace ddgi {
@@ -73,8 +74,9 @@ struct ddgi_engine
     int num_cus = 256;
 
     // lights per scene
-    LightK lights[3][kMaxLights];
-    int n_lights[3] = {0, 0, 0};
+    LightK lights[4][kMaxLights];  // [3] = the user scene (DDGI_SCENE_USER)
+    int n_lights[4] = {0, 0, 0, 0};
+    SceneBake user_scene;          // host copy of the loaded user scene (scene id 3); empty until loaded
 
     // baked scene on device (per scene id, uploaded lazily)
     struct DevScene
@@ -83,7 +85,7 @@ struct ddgi_engine
         uint8_t* types = nullptr;
         SceneK k{};
         bool ready = false;
-    } dev_scene[3];
+    } dev_scene[4];
 
     // memoised lattice hashes on device
     float* d_noise[3] = {nullptr, nullptr, nullptr};
@@ -143,7 +145,7 @@ static int validate_config(const ddgi_irradiance_field* f, const ddgi_render_set
     if (probes >= (1ull << 24)) return fail(DDGI_ERR_UNSUPPORTED, "more than 2^24 probes: probe_info.x (float) cannot index them");
     const unsigned long long rays = probes * f->sqrt_rays_per_probe * f->sqrt_rays_per_probe;
     if (rays >= (1ull << 32)) return fail(DDGI_ERR_UNSUPPORTED, "more than 2^32 probe rays: the reference's uint RNG seed wraps");
-    if (s->scene < 0 || s->scene > 2) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2}", s->scene);
+    if (s->scene < 0 || s->scene > 3) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2,3}", s->scene);
     if (world < 1 || f->probe_count[2] % world != 0)
         return fail(DDGI_ERR_INVALID_ARGUMENT, "probe_count.z = %d is not divisible by world = %d", f->probe_count[2], world);
     return DDGI_OK;
@@ -181,7 +183,8 @@ static int ensure_scene(ddgi_engine* e, int scene)
 {
     ddgi_engine::DevScene& d = e->dev_scene[scene];
     if (d.ready) return DDGI_OK;
-    const SceneBake& b = baked_scene(scene);
+    if (scene == 3 && e->user_scene.types.empty()) return fail(DDGI_ERR_NOT_READY, "scene 3 selected but no user scene loaded (ddgi_scene_load / ddgi_scene_set_grid)");
+    const SceneBake& b = scene == 3 ? e->user_scene : baked_scene(scene);
     // the kernels address the bitmap with the raw index z*nxy + y*nx + x: store it shifted so that the
     // word boundary falls on a multiple of 32 of the raw index (SceneK::bias32)
     const int bias = (b.lo[2] * b.dim[1] + b.lo[1]) * b.dim[0] + b.lo[0];
@@ -388,7 +391,7 @@ int ddgi_set_mode(ddgi_handle e, int mode)
 int ddgi_set_lights(ddgi_handle e, int scene, const ddgi_light* lights, int n)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
-    if (scene < 0 || scene > 2 || n < 0 || n > kMaxLights || (n > 0 && !lights))
+    if (scene < 0 || scene > 3 || n < 0 || n > kMaxLights || (n > 0 && !lights))
         return fail(DDGI_ERR_INVALID_ARGUMENT, "bad light table (scene %d, n %d)", scene, n);
     for (int i = 0; i < n; ++i)
     {
@@ -451,7 +454,7 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     if (settings)
     {
-        if (settings->scene < 0 || settings->scene > 2) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2}", settings->scene);
+        if (settings->scene < 0 || settings->scene > 3) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2,3}", settings->scene);
         e->settings = *settings;
     }
     const bool ddgi_mode = e->mode == DDGI_MODE_DDGI;
@@ -779,7 +782,7 @@ int ddgi_sample(ddgi_handle e, const float* pos, const float* nrm, size_t n, flo
 int ddgi_render_device(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_settings* st, uint32_t* d_rgba8, float* d_rgb_f32)
 {
     if (!e || !cam || !st || !d_rgba8) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/camera/settings/output");
-    if (st->scene < 0 || st->scene > 2) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2}", st->scene);
+    if (st->scene < 0 || st->scene > 3) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2,3}", st->scene);
     if (st->screen_width < 1 || st->screen_height < 1 || 1ll * st->screen_width * st->screen_height > 0x7fffffffll)
         return fail(DDGI_ERR_INVALID_ARGUMENT, "bad image size %d x %d", st->screen_width, st->screen_height);
     if (st->camera_mode != 0 && st->camera_mode != 1) return fail(DDGI_ERR_UNSUPPORTED, "camera_mode %d (only 0 pinhole, 1 ortho)", st->camera_mode);
@@ -918,6 +921,121 @@ int ddgi_generate_probe_rays_host(const ddgi_irradiance_field* f, uint32_t seed,
     generate_probe_rays(*f, rng, tmp);
     std::memcpy(rays, tmp.data(), tmp.size() * sizeof(ddgi_probe_ray));
     return DDGI_OK;
+}
+
+// ---- baked scenes on disk, user scenes -------------------------------------------
+// File: "DDGIVOX1" | int32 version (1) | int32 source scene (-1 = user made) | int32 lo[3] | int32 dim[3] |
+//       uint32 noise id | dim.x*dim.y*dim.z bytes of block types, x fastest, then y, then z.
+// noise id = bits of the pinned noise2D(1,1): a bake of the cave depends on the pinned sine
+// (its floor is an fbm), so a file made with another arithmetic is refused.
+
+static uint32_t noise_id()
+{
+    const float v = noise2D(1.0f, 1.0f);
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    return u;
+}
+
+static int fill_user_scene(ddgi_engine* e, const int lo[3], const int dim[3], const uint8_t* types)
+{
+    for (int a = 0; a < 3; ++a)
+        if (dim[a] < 1 || dim[a] > 4096 || lo[a] < -(1 << 20) || lo[a] > (1 << 20)) return fail(DDGI_ERR_INVALID_ARGUMENT, "bad scene box");
+    const size_t n = static_cast<size_t>(dim[0]) * dim[1] * dim[2];
+    // the kernels linearise voxel ids as z*nxy + y*nx + x in float / 24-bit integer arithmetic
+    {
+        long long bound = 0;
+        const long long pitch[3] = {1, dim[0], 1ll * dim[0] * dim[1]};
+        for (int a = 0; a < 3; ++a)
+        {
+            const long long m = std::max(std::llabs(static_cast<long long>(lo[a])), std::llabs(static_cast<long long>(lo[a]) + dim[a] - 1));
+            bound += m * pitch[a];
+        }
+        if (n > (size_t(1) << 23) || bound >= (1ll << 23))
+            return fail(DDGI_ERR_UNSUPPORTED, "scene box too large or too far from the origin: |z*nx*ny + y*nx + x| must stay below 2^23");
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (types[i] > 13) return fail(DDGI_ERR_INVALID_ARGUMENT, "voxel %zu: block type %d not in 0..13", i, types[i]);
+    SceneBake b;
+    b.scene = 3;
+    for (int a = 0; a < 3; ++a) b.lo[a] = lo[a], b.dim[a] = dim[a], b.hi[a] = lo[a] + dim[a] - 1;
+    b.types.assign(types, types + n);
+    b.bits.clear();
+    unsigned fe = 0;  // which border layers are entirely empty (march_escaped)
+    for (int axis = 0; axis < 3; ++axis)
+        for (int side = 0; side < 2; ++side)
+        {
+            bool empty = true;
+            int c[3];
+            const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+            c[axis] = side ? b.hi[axis] : b.lo[axis];
+            for (c[a1] = b.lo[a1]; c[a1] <= b.hi[a1] && empty; ++c[a1])
+                for (c[a2] = b.lo[a2]; c[a2] <= b.hi[a2]; ++c[a2])
+                    if (b.block_at(c[0], c[1], c[2]) > 0)
+                    {
+                        empty = false;
+                        break;
+                    }
+            if (empty) fe |= 1u << (2 * axis + side);
+        }
+    b.face_empty = fe;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    ddgi_engine::DevScene& d = e->dev_scene[3];
+    if (d.bits) (void)hipFree(d.bits);
+    if (d.types) (void)hipFree(d.types);
+    d = ddgi_engine::DevScene{};
+    e->user_scene = std::move(b);
+    return DDGI_OK;
+}
+
+int ddgi_scene_set_grid(ddgi_handle e, const int32_t lo[3], const int32_t dim[3], const uint8_t* types)
+{
+    if (!e || !lo || !dim || !types) return fail(DDGI_ERR_INVALID_ARGUMENT, "null argument");
+    const int l[3] = {lo[0], lo[1], lo[2]}, d[3] = {dim[0], dim[1], dim[2]};
+    return fill_user_scene(e, l, d, types);
+}
+
+int ddgi_scene_save(int scene, const char* path)
+{
+    if (scene < 0 || scene > 2 || !path) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2} or null path", scene);
+    const SceneBake& b = baked_scene(scene);
+    FILE* fh = std::fopen(path, "wb");
+    if (!fh) return fail(DDGI_ERR_INVALID_ARGUMENT, "cannot open %s for writing", path);
+    const int32_t hdr[8] = {1, scene, b.lo[0], b.lo[1], b.lo[2], b.dim[0], b.dim[1], b.dim[2]};
+    const uint32_t nid = noise_id();
+    bool ok = std::fwrite("DDGIVOX1", 1, 8, fh) == 8 && std::fwrite(hdr, 4, 8, fh) == 8 && std::fwrite(&nid, 4, 1, fh) == 1 &&
+              std::fwrite(b.types.data(), 1, b.types.size(), fh) == b.types.size();
+    ok = (std::fclose(fh) == 0) && ok;
+    return ok ? DDGI_OK : fail(DDGI_ERR_INVALID_ARGUMENT, "short write to %s", path);
+}
+
+int ddgi_scene_load(ddgi_handle e, const char* path)
+{
+    if (!e || !path) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/path");
+    FILE* fh = std::fopen(path, "rb");
+    if (!fh) return fail(DDGI_ERR_INVALID_ARGUMENT, "cannot open %s", path);
+    char magic[8];
+    int32_t hdr[8];
+    uint32_t nid = 0;
+    std::vector<uint8_t> types;
+    int rc = DDGI_OK;
+    if (std::fread(magic, 1, 8, fh) != 8 || std::memcmp(magic, "DDGIVOX1", 8) != 0 || std::fread(hdr, 4, 8, fh) != 8 || std::fread(&nid, 4, 1, fh) != 1 ||
+        hdr[0] != 1)
+        rc = fail(DDGI_ERR_INVALID_ARGUMENT, "%s is not a DDGIVOX1 version-1 file", path);
+    else if (hdr[1] == 0 && nid != noise_id())
+        rc = fail(DDGI_ERR_INVALID_ARGUMENT, "%s was baked with a different noise arithmetic (id %08x, this build %08x)", path, nid, noise_id());
+    else if (hdr[5] < 1 || hdr[6] < 1 || hdr[7] < 1 || 1ll * hdr[5] * hdr[6] * hdr[7] > (1ll << 23))
+        rc = fail(DDGI_ERR_INVALID_ARGUMENT, "%s: bad dimensions", path);
+    else
+    {
+        types.resize(static_cast<size_t>(hdr[5]) * hdr[6] * hdr[7]);
+        if (std::fread(types.data(), 1, types.size(), fh) != types.size()) rc = fail(DDGI_ERR_INVALID_ARGUMENT, "%s is truncated", path);
+    }
+    std::fclose(fh);
+    if (rc) return rc;
+    const int lo[3] = {hdr[2], hdr[3], hdr[4]}, dim[3] = {hdr[5], hdr[6], hdr[7]};
+    return fill_user_scene(e, lo, dim, types.data());
 }
 
 int ddgi_scene_block_at(int scene, int x, int y, int z)

@@ -24,7 +24,7 @@ namespace ddgi {
 //   Cornell walls at |x|,|y| = 10, z = 25, open front: box x,y[-11,11] z[4,26]; all layers empty.
 //   house   walls |x| = 25, |z| = 15, roof y = 5, unbounded floor plane y = -5:
 //           box x[-26,26] y[-6,6] z[-16,16]; the floor row of each side layer extrudes to the plane.
-// tests/test_scene_bake.py checks the clamped lookup against the oracle's procedural getBlockAt on
+// tests/test_host_parity.py checks the clamped lookup against the oracle's procedural getBlockAt on
 // a box far larger than the bake.
 
 static void scene_box(int scene, int lo[3], int hi[3])

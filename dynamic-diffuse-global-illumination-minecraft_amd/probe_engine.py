@@ -143,6 +143,9 @@ _SIGNATURES = {
     "ddgi_texture_size": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ddgi_probe_tile_origin": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ddgi_generate_probe_rays_host": (C.c_int, [_VP, C.c_uint32, C.c_int, _VP, C.c_size_t]),
+    "ddgi_scene_save": (C.c_int, [C.c_int, C.c_char_p]),
+    "ddgi_scene_load": (C.c_int, [_VP, C.c_char_p]),
+    "ddgi_scene_set_grid": (C.c_int, [_VP, _VP, _VP, _VP]),
     "ddgi_scene_block_at": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ddgi_pinned_sinf": (C.c_float, [C.c_float]),
     "ddgi_pinned_cosf": (C.c_float, [C.c_float]),
@@ -206,6 +209,22 @@ def generate_probe_rays_host(field, seed=1, skip_calls=0):
     return rays
 
 
+def scene_save(scene, path):
+    """Bake of a built-in scene -> DDGIVOX1 file (host only)."""
+    _check(load_library().ddgi_scene_save(scene, os.fsencode(path)))
+
+
+def read_scene_file(path):
+    """(lo, dim, types[z, y, x]) of a DDGIVOX1 file."""
+    raw = open(path, "rb").read()
+    if raw[:8] != b"DDGIVOX1":
+        raise ValueError("not a DDGIVOX1 file")
+    hdr = np.frombuffer(raw, dtype="<i4", count=8, offset=8)
+    lo, dim = tuple(int(v) for v in hdr[2:5]), tuple(int(v) for v in hdr[5:8])
+    types = np.frombuffer(raw, dtype=np.uint8, count=dim[0] * dim[1] * dim[2], offset=8 + 32 + 4)
+    return lo, dim, types.reshape(dim[2], dim[1], dim[0]).copy()
+
+
 def scene_block_at(scene, x, y, z):
     return load_library().ddgi_scene_block_at(scene, x, y, z)
 
@@ -259,6 +278,17 @@ class ProbeEngine:
 
     def set_mode(self, mode):
         _check(self._lib.ddgi_set_mode(self._h, mode))
+
+    def load_scene(self, path):
+        """User scene (scene id 3) from a DDGIVOX1 file."""
+        _check(self._lib.ddgi_scene_load(self._h, os.fsencode(path)))
+
+    def set_scene_grid(self, lo, types_zyx):
+        """User scene (scene id 3) from a uint8 array [z, y, x] of block types 0..13 at voxel-id origin lo."""
+        t = np.ascontiguousarray(types_zyx, dtype=np.uint8)
+        lo_a = (C.c_int32 * 3)(*[int(v) for v in lo])
+        dim_a = (C.c_int32 * 3)(t.shape[2], t.shape[1], t.shape[0])
+        _check(self._lib.ddgi_scene_set_grid(self._h, lo_a, dim_a, _ptr(t)))
 
     def set_lights(self, scene, lights):
         arr = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)

@@ -273,6 +273,22 @@ int ddgi_probe_tile_origin(const ddgi_irradiance_field* field, int probe_index, 
 int ddgi_generate_probe_rays_host(const ddgi_irradiance_field* field, uint32_t seed, int skip_calls,
                                   ddgi_probe_ray* rays, size_t n);
 
+/* ---- baked scenes on disk, user scenes ------------------------------------ */
+
+#define DDGI_SCENE_USER 3 /* RenderSettings::scene value that selects the loaded user scene */
+
+/* Writes the bake of a built-in scene (0 cave, 1 Cornell, 2 house: getBlockAt evaluated over the
+ * scene's box, intersection.glsl:699-826) to a versioned file: "DDGIVOX1", version, source scene,
+ * lo[3], dim[3], noise id, then dim.x*dim.y*dim.z block-type bytes (x fastest).  Host only. */
+int ddgi_scene_save(int scene, const char* path);
+
+/* Loads such a file, or takes a caller-made grid, as the handle's user scene (scene id 3).  Block
+ * types 0..13 keep the reference's meaning (0 empty; albedo per getColorAt, intersection.glsl:872-
+ * 1047); outside the box the world is the axis-wise extrusion of the box's outermost layer.  The
+ * scene's lights are set with ddgi_set_lights(h, 3, ...) (default: none). */
+int ddgi_scene_load(ddgi_handle h, const char* path);
+int ddgi_scene_set_grid(ddgi_handle h, const int32_t lo[3], const int32_t dim[3], const uint8_t* block_types);
+
 /* Host evaluation of the baked scene the kernels traverse (block type 0..13 at integer voxel
  * id; replaces getBlockAt, intersection.glsl:699-826, which the reference evaluates per march
  * step on the GPU).  Usable without a GPU; exists so the bake can be checked against the

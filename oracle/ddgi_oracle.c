@@ -583,9 +583,37 @@ static int all_mushrooms(v3 c)
     return 0;
 }
 
+/* SURVEY.md §8(f) row 3 — a user scene (scene id 3): block types on a box of voxel ids; outside the
+ * box the world is the axis-wise extrusion of its outermost layer.  Not in the reference. */
+static struct
+{
+    int lo[3], dim[3];
+    const uint8_t* types; /* x fastest, then y, then z; owned by the caller */
+} g_user_scene;
+
+void oracle_set_user_scene(const int32_t* lo, const int32_t* dim, const uint8_t* types)
+{
+    for (int a = 0; a < 3; a++) g_user_scene.lo[a] = lo[a], g_user_scene.dim[a] = dim[a];
+    g_user_scene.types = types;
+}
+
+static int user_block_at(v3 c)
+{
+    int q[3] = {gint(c.x), gint(c.y), gint(c.z)};
+    for (int a = 0; a < 3; a++)
+    {
+        int hi = g_user_scene.lo[a] + g_user_scene.dim[a] - 1;
+        if (q[a] < g_user_scene.lo[a]) q[a] = g_user_scene.lo[a];
+        if (q[a] > hi) q[a] = hi;
+        q[a] -= g_user_scene.lo[a];
+    }
+    return g_user_scene.types[((size_t)q[2] * g_user_scene.dim[1] + q[1]) * g_user_scene.dim[0] + q[0]];
+}
+
 /* :699-826 */
 static int getBlockAt(v3 c, int scene)
 {
+    if (scene == 3) return g_user_scene.types ? user_block_at(c) : 0;
     if (scene == 0)
     {
         if (c.y > 17.0f) return 0;
