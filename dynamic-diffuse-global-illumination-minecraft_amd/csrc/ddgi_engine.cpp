@@ -88,7 +88,7 @@ struct ddgi_engine
     } dev_scene[4];
 
     // memoised lattice hashes on device
-    float* d_noise[3] = {nullptr, nullptr, nullptr};
+    float* d_noise[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     NoiseLut noise{};
 
     // rays
@@ -225,8 +225,8 @@ static int ensure_noise(ddgi_engine* e)
 {
     if (e->noise.n2 || std::getenv("DDGI_NO_NOISE_LUT")) return DDGI_OK;
     const NoiseLutHost& h = noise_lut_host();
-    const std::vector<float>* src[3] = {&h.n2, &h.n1, &h.wp};
-    for (int i = 0; i < 3; ++i)
+    const std::vector<float>* src[5] = {&h.n2, &h.n1, &h.wp, &h.wall, &h.r1};
+    for (int i = 0; i < 5; ++i)
     {
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_noise[i]), src[i]->size() * sizeof(float)));
         HIP_TRY(hipMemcpy(e->d_noise[i], src[i]->data(), src[i]->size() * sizeof(float), hipMemcpyHostToDevice));
@@ -236,6 +236,14 @@ static int ensure_noise(ddgi_engine* e)
     e->noise.n1 = e->d_noise[1];
     e->noise.n1_i0 = h.n1_i0, e->noise.n1_n = h.n1_n;
     e->noise.wp = e->d_noise[2];
+    e->noise.wall = e->d_noise[3];
+    e->noise.r1 = e->d_noise[4];
+    for (int a = 0; a < 3; ++a) e->noise.r1_lo[a] = h.r1_lo[a], e->noise.r1_n[a] = h.r1_n[a];
+    if (const char* v = std::getenv("DDGI_LUT_OFF"))  // profiling: 1 = no wall table, 2 = no random1 table
+    {
+        if (std::atoi(v) & 1) e->noise.wall = nullptr;
+        if (std::atoi(v) & 2) e->noise.r1 = nullptr;
+    }
     e->noise.wp_c0 = h.wp_c0, e->noise.wp_n = h.wp_n;
     return DDGI_OK;
 }
@@ -621,18 +629,18 @@ int ddgi_update_history_ms(ddgi_handle e, float* trace_ms, float* blend_ms, int 
     return DDGI_OK;
 }
 
-int ddgi_trace_stats(ddgi_handle e, int enable, unsigned long long* out8)
+int ddgi_trace_stats(ddgi_handle e, int enable, unsigned long long* out64)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (out8)
+    if (out64)
     {
-        std::memset(out8, 0, 16 * sizeof(unsigned long long));
-        if (e->d_stats) HIP_TRY(hipMemcpy(out8, e->d_stats, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::memset(out64, 0, 64 * sizeof(unsigned long long));
+        if (e->d_stats) HIP_TRY(hipMemcpy(out64, e->d_stats, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
-    if (enable && !e->d_stats) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_stats), 16 * sizeof(unsigned long long)));
-    if (e->d_stats) HIP_TRY(hipMemset(e->d_stats, 0, 16 * sizeof(unsigned long long)));
+    if (enable && !e->d_stats) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_stats), 64 * sizeof(unsigned long long)));
+    if (e->d_stats) HIP_TRY(hipMemset(e->d_stats, 0, 64 * sizeof(unsigned long long)));
     if (!enable && e->d_stats)
     {
         (void)hipFree(e->d_stats);

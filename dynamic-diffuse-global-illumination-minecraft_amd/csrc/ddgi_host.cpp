@@ -120,6 +120,30 @@ static NoiseLutHost build_noise_lut()
     for (int ix = 0; ix < t.n2_nx; ++ix)
         for (int iy = 0; iy < t.n2_ny; ++iy)
             t.n2[static_cast<size_t>(ix) * t.n2_ny + iy] = noise2D(static_cast<float>(ix + t.n2_x0), static_cast<float>(iy + t.n2_y0));
+    t.wall.resize(static_cast<size_t>(8) * t.n2_ny);
+    {
+        float freq = 1.0f;
+        for (int o = 0; o < 8; ++o)
+        {
+            freq *= 2.0f;
+            const float xo = kWallFbmX * freq;
+            const size_t ux = static_cast<size_t>(gl_int(floorf(xo)) - t.n2_x0);
+            const float tx = gl_fract(xo);
+            for (int iy = 0; iy < t.n2_ny; ++iy)
+                t.wall[static_cast<size_t>(o) * t.n2_ny + iy] = gl_mix(t.n2[ux * t.n2_ny + iy], t.n2[(ux + 1) * t.n2_ny + iy], tx);
+        }
+    }
+    // random1 over the cave's bake box (cave wall and ground colours hash the voxel id)
+    {
+        const int lo[3] = {-42, -21, -38}, hi[3] = {32, 18, 31};
+        for (int a = 0; a < 3; ++a) t.r1_lo[a] = lo[a], t.r1_n[a] = hi[a] - lo[a] + 1;
+        t.r1.resize(static_cast<size_t>(t.r1_n[0]) * t.r1_n[1] * t.r1_n[2]);
+        size_t k = 0;
+        for (int z = 0; z < t.r1_n[2]; ++z)
+            for (int y = 0; y < t.r1_n[1]; ++y)
+                for (int x = 0; x < t.r1_n[0]; ++x)
+                    t.r1[k++] = random1(mk3(static_cast<float>(x + lo[0]), static_cast<float>(y + lo[1]), static_cast<float>(z + lo[2])));
+    }
     t.n1.resize(t.n1_n);
     for (int i = 0; i < t.n1_n; ++i) t.n1[i] = noise1(static_cast<float>(i + t.n1_i0));
     t.wp.resize(static_cast<size_t>(t.wp_n) * t.wp_n * 2);

@@ -43,7 +43,8 @@ struct NoiseLutHost
     int n2_x0, n2_nx, n2_y0, n2_ny;
     int n1_i0, n1_n;
     int wp_c0, wp_n;
-    std::vector<float> n2, n1, wp;
+    int r1_lo[3], r1_n[3];
+    std::vector<float> n2, n1, wp, wall, r1;
 };
 const NoiseLutHost& noise_lut_host();  // cached, thread-safe
 

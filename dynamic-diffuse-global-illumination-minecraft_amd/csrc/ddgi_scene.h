@@ -88,6 +88,8 @@ DDGI_HD float random1(f3 p)  // :400
 {
     return gl_fract(hash_sin(hash_dot3(p, mk3(127.1f, 311.7f, 191.999f))) * 43758.5453f);
 }
+struct NoiseLut;
+DDGI_HD float random1_at(f3 cell, const NoiseLut& L);
 DDGI_HD float noise2D(float px, float py)  // :402
 {
     return gl_fract(hash_sin(hash_dot2(f2{px, py}, f2{127.1f, 311.7f})) * 43758.5453f);
@@ -108,7 +110,23 @@ struct NoiseLut
     // worley_point(cx, cy) for cx, cy in [wp_c0, wp_c0+wp_n): 2 floats each, index ((cx-c0)*n + (cy-c0))*2
     const float* wp = nullptr;
     int wp_c0 = 0, wp_n = 0;
+    // cave wall: fbm2(kWallFbmX, y) has a constant x, so each octave's two x-interpolations
+    // mix(noise2D(ix,iy), noise2D(ix+1,iy), fract(x*freq)) depend on iy alone:
+    // wall[o*n2_ny + (iy-n2_y0)] for octave o = 0..7 (freq 2..256) holds that value
+    const float* wall = nullptr;
+    // random1(cell) for cell ids in [r1_lo, r1_lo + r1_n) per axis (the cave's bake box); x fastest
+    const float* r1 = nullptr;
+    int r1_lo[3] = {0, 0, 0}, r1_n[3] = {0, 0, 0};
 };
+constexpr float kWallFbmX = 0.05f;
+DDGI_HD float random1_at(f3 cell, const NoiseLut& L)  // random1 of a voxel id (integer-valued floats)
+{
+    const unsigned ux = static_cast<unsigned>(gl_int(cell.x) - L.r1_lo[0]), uy = static_cast<unsigned>(gl_int(cell.y) - L.r1_lo[1]),
+                   uz = static_cast<unsigned>(gl_int(cell.z) - L.r1_lo[2]);
+    if (L.r1 && ux < static_cast<unsigned>(L.r1_n[0]) && uy < static_cast<unsigned>(L.r1_n[1]) && uz < static_cast<unsigned>(L.r1_n[2]))
+        return L.r1[(uz * static_cast<unsigned>(L.r1_n[1]) + uy) * static_cast<unsigned>(L.r1_n[0]) + ux];
+    return random1(cell);
+}
 
 DDGI_HD float interp_noise2D(float x, float y, const NoiseLut& L = NoiseLut())  // :404-419
 {
@@ -142,6 +160,28 @@ DDGI_HD float fbm2(float x, float y, const NoiseLut& L = NoiseLut())
         total += interp_noise2D(x * freq, y * freq, L) * amp;
     }
     return total;
+}
+// fbm2(kWallFbmX, y, L): the same operations in the same order, with the x-interpolations of every
+// octave read from L.wall (each entry was computed by the very expression it replaces)
+DDGI_HD float fbm2_wall(float y, const NoiseLut& L = NoiseLut())
+{
+    if (L.wall && fabsf(y) < 7.9f)  // 7.9 * 256 < 2047: every octave's iy, iy+1 are inside the table
+    {
+        float total = 0.0f;
+        float freq = 1.0f, amp = 1.0f;
+        const float* row = L.wall - L.n2_y0;
+        for (int i = 1; i <= 8; ++i)
+        {
+            freq *= 2.0f;
+            amp *= 0.5f;
+            const float yo = y * freq;
+            const float* q = row + gl_int(floorf(yo));
+            total += gl_mix(q[0], q[1], gl_fract(yo)) * amp;
+            row += L.n2_ny;
+        }
+        return total;
+    }
+    return fbm2(kWallFbmX, y, L);
 }
 DDGI_HD float noise1(float i) { return gl_fract(hash_sin(203.311f * i)); }  // :437-439 (.x only)
 DDGI_HD float noise1_at(float i, const NoiseLut& L)
@@ -426,18 +466,18 @@ DDGI_HD f3 block_albedo(f3 p, int type, f3 n, const NoiseLut& L = NoiseLut())
             else if (p.y < 6.0f) band = mk3(0.368f, 0.203f, 0.415f);
             else if (p.y < 11.0f) band = mk3(0.470f, 0.270f, 0.729f);
             const f2 g = face_uv(p, n);
-            const float r = fbm2(0.05f, (g.y + p.y) * 0.3f, L);
+            const float r = fbm2_wall((g.y + p.y) * 0.3f, L);
             const f3 blue = mk3(0.0f, 0.666f, 1.0f), red = mk3(0.294f, 0.007f, 0.152f);
             f3 wall = blue;
             if (p.x < -1.0f) wall = red;
             else if (p.x < 6.0f && p.x >= -1.0f)
-                wall = (random1(cell_id(p)) < p.x / 7.0f) ? blue : red;
+                wall = (random1_at(cell_id(p), L) < p.x / 7.0f) ? blue : red;
             return gl_mix3(wall, band, r);
         }
         case 11:  // :1007-1021 — cave ground
         {
             const f3 base = mk3(0.294f, 0.007f, 0.152f);
-            float r = random1(cell_id(p)) / 3.0f;
+            float r = random1_at(cell_id(p), L) / 3.0f;
             f3 c = gl_mix3(base, mk3(0.901f, 0.992f, 0.427f), r);
             const f2 g = face_uv(p, n);
             r = fbm2(g.x * 2.0f, g.y * 2.0f, L);

@@ -174,7 +174,9 @@ DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst
 }
 
 // End of get_direct_lighting for one hit: accumulate, then bounce or finish (probe_pass.comp:286-292).
-DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A)
+// Returns true when the ray bounces; the caller then posts the march (o, d) — every path of an event
+// group shares ONE wf_post_march call site, so divergent lanes do not run its code twice.
+DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A, f3& o, f3& d)
 {
     const f3 color = v3of(c.col) + contribution;
     const uint32_t bounce = (cnt & 255u) + 1u;
@@ -182,9 +184,8 @@ DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contr
     {
         set3(c.col, color);
         c.cnt = bounce;
-        const f3 no = hpos + hnrm * 0.0001f;
-        const f3 nd = (A.ablate & 2) ? normalize3(hnrm + mk3(0.3f, 0.2f, 0.1f)) : hemisphere_dir(hnrm, c.rng);
-        wf_post_march(P, slot, c, no, nd, false, A);
+        o = hpos + hnrm * 0.0001f;
+        d = (A.ablate & 2) ? normalize3(hnrm + mk3(0.3f, 0.2f, 0.1f)) : hemisphere_dir(hnrm, c.rng);
         return true;
     }
     wf_finish_ray(P, slot, color, c.dst, A);
@@ -242,6 +243,17 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
     const float inf = __builtin_inff();
     unsigned long long st_trips = 0, st_lane_steps = 0, st_groups = 0, st_lane_events = 0, st_iters = 0, st_fetches = 0;
     long long cy[6] = {0, 0, 0, 0, 0, 0};
+    long long cy_bucket[kWfBuckets] = {};
+    long long cy_sec[12] = {};
+    long long sec_last = 0;
+#define WF_MARK(k)                                 \
+    if (kStats)                                    \
+    {                                              \
+        const long long now_ = clock64();          \
+        cy_sec[k] += now_ - sec_last;              \
+        sec_last = now_;                           \
+    }
+    unsigned long long n_bucket[kWfBuckets] = {};
 
     for (uint32_t round = 0;; ++round)
     {
@@ -316,6 +328,8 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
             }
             const uint32_t e = (g - first) * 64u + lane;
             const bool valid = e < sh->bucket_count[b];
+            const long long cg0 = kStats ? clock64() : 0;
+            sec_last = cg0;
             if (kStats)
             {
                 st_groups += 1;
@@ -371,11 +385,14 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                 else
                 {
                     WfCold c = load_cold(P.cold + slot);
+                    f3 mo = mk3(0, 0, 0), md = mk3(0, 0, 0);  // the march this event posts, if any
+                    bool as_feeler = false;
                     const uint32_t fl = P.flags[slot];
                     const float t = P.t[slot], tl = P.tl[slot];
                     const f3 ro = ld3(P.ro, slot);
                     const bool block_wins = (fl & kFlagHit) && (t < tl);  // temp_isect.t < closest_t
                     const bool any_hit = block_wins || (tl < inf);       // closest_t < INF
+                    WF_MARK(0)  // state loads
                     if (b != kBucketFeeler)
                     {
                         const bool first_bounce = A.ddgi && (c.cnt & 255u) == 0u;
@@ -407,9 +424,11 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                                 // n stays (0,0,0) only if diff is NaN, where the reference yields NaN as well
                                 const f3 nn = best > 0.0f ? n : normalize3(n);
                                 const int type = static_cast<int>((fl >> 16) & 15u);
+                                WF_MARK(1)  // block normal
                                 hcol = (A.ablate & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
                                 nraw = nn;
                                 axis_normal = best > 0.0f;
+                                WF_MARK(2)  // albedo
                             }
                             else
                             {
@@ -434,24 +453,22 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                                 // outcome adds exactly +0 to the colour: skip the march and its event.
                                 const f3 nh = axis_normal ? hnrm : normalize3(hnrm);
                                 const bool finite_albedo = fabsf(hcol.x) < inf && fabsf(hcol.y) < inf && fabsf(hcol.z) < inf;
+                                WF_MARK(3)  // hit position, direction to the light
+                                set3(c.hc, hcol);
                                 if (A.nl == 1 && finite_albedo && dot3(nh, to_light) <= 0.0f && !(A.ablate & 4))
-                                {
-                                    set3(c.hc, hcol);
-                                    posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A);
-                                }
+                                    posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
                                 else
                                 {
                                     c.cnt = cnt;
                                     if (multi_light) P.dirbuf[slot] = float4{0.0f, 0.0f, 0.0f, 0.0f};
-                                    wf_post_march(P, slot, c, hpos, to_light, true, A);
-                                    set3(c.hc, hcol);
-                                    posted = true;
+                                    mo = hpos, md = to_light;
+                                    as_feeler = posted = true;
                                 }
                             }
                             else
                             {
                                 set3(c.hc, hcol);
-                                posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A);
+                                posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
                             }
                         }
                     }
@@ -492,25 +509,40 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                             }
                         }
                         li += 1;
+                        WF_MARK(5)  // feeler result
                         if (!early && li < A.nl)
                         {
                             c.cnt = (cnt & 255u) | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
                             if (multi_light) P.dirbuf[slot] = float4{direct.x, direct.y, direct.z, 0.0f};
                             const LightK& Ln = A.lights[li];
-                            wf_post_march(P, slot, c, hpos, normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos), true, A);
-                            posted = true;
+                            mo = hpos, md = normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos);
+                            as_feeler = posted = true;
                         }
                         else
                         {
                             if (!early && nvis != 0) contribution = div3(hcol * direct, static_cast<float>(nvis));
-                            posted = wf_lighting_done(P, slot, c, contribution, hpos, hnrm, cnt, A);
+                            posted = wf_lighting_done(P, slot, c, contribution, hpos, hnrm, cnt, A, mo, md);
                         }
                     }
-                    if (posted) store_cold(P.cold + slot, c);  // the slot lives on: write its shading state back
+                    WF_MARK(4)  // bounce: accumulate, hemisphere direction
+                    if (posted)
+                    {
+                        wf_post_march(P, slot, c, mo, md, as_feeler, A);
+                        WF_MARK(6)  // march set-up
+                        store_cold(P.cold + slot, c);  // the slot lives on: write its shading state back
+                    }
                 }
             }
             const uint32_t at = wave_append(posted, &sh->n_march[cur_list], lane);
             if (posted) (P.march_list[0] + cur_list * PS)[at] = static_cast<uint16_t>(slot);
+            WF_MARK(7)  // record store, list append
+            if (kStats)
+            {
+                const long long dt = clock64() - cg0;
+#pragma unroll
+                for (int k = 0; k < kWfBuckets; ++k)
+                    if (static_cast<uint32_t>(k) == b) cy_bucket[k] += dt, n_bucket[k] += 1;
+            }
         }
         const long long c2 = kStats ? clock64() : 0;
         __syncthreads();
@@ -638,6 +670,12 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
         if (wave == 0) atomicAdd(&A.stats[5], st_iters);
         atomicAdd(&A.stats[6], st_fetches);
         for (int k = 0; k < 6; ++k) atomicAdd(&A.stats[8 + k], static_cast<unsigned long long>(cy[k]));
+        for (int k = 0; k < 12; ++k) atomicAdd(&A.stats[32 + k], static_cast<unsigned long long>(cy_sec[k]));
+        for (int k = 0; k < kWfBuckets; ++k)
+        {
+            atomicAdd(&A.stats[16 + k], static_cast<unsigned long long>(cy_bucket[k]));
+            atomicAdd(&A.stats[24 + k], n_bucket[k]);
+        }
     }
 }
 

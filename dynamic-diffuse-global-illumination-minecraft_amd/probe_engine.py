@@ -342,11 +342,15 @@ class ProbeEngine:
 
     def trace_stats(self, enable=True):
         """Profiling aid: utilisation counters of the trace kernel since the last call."""
-        out = np.zeros(16, dtype=np.uint64)
+        out = np.zeros(64, dtype=np.uint64)
         _check(self._lib.ddgi_trace_stats(self._h, 1 if enable else 0, _ptr(out)))
         keys = ("trips", "lane_steps", "event_rounds", "lane_events", "waves", "rounds", "fetches", "_7",
                 "cyc_scan", "cyc_march", "cyc_march_wait", "cyc_list", "cyc_events", "cyc_events_wait")
-        return dict(zip(keys, (int(v) for v in out[:14])))
+        st = dict(zip(keys, (int(v) for v in out[:14])))
+        st["bucket_cycles"] = [int(v) for v in out[16:23]]   # event groups by bucket (ddgi_trace_wf.hip: shade_bucket)
+        st["bucket_groups"] = [int(v) for v in out[24:31]]
+        st["section_cycles"] = [int(v) for v in out[32:44]]  # event code sections (WF_MARK in ddgi_trace_wf.hip)
+        return st
 
     # -- outputs -------------------------------------------------------------------------------
     def read_textures(self):
