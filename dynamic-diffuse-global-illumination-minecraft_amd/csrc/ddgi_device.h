@@ -153,6 +153,29 @@ DDGI_D bool march_step(March& m, const SceneK& S, const uint32_t* __restrict__ s
     return (base[idx >> 5] >> (idx & 31)) & 1u;
 }
 
+// march_step for the wavefront kernel's unrolled bursts: the box's upper corner comes in VGPRs (a VALU
+// instruction can read only one SGPR, so with S.hi_f in SGPRs every v_med3 costs an extra v_mov), the
+// iteration counter is left to the caller (one add per burst instead of one per step) and the
+// occupancy bit is extracted with v_bfe_u32 (which takes the bit offset modulo 32 by itself).
+typedef float f2v __attribute__((ext_vector_type(2)));
+DDGI_D bool march_step_burst(March& m, const SceneK& S, const uint32_t* __restrict__ s_bits, f3 hi)
+{
+    const float fx = gl_fract(m.p.x), fy = gl_fract(m.p.y), fz = gl_fract(m.p.z);
+    const float tx = (m.cc.x - fx) * m.inv.x;
+    // y and z as a packed pair: v_pk_add_f32 / v_pk_mul_f32 are the same IEEE operations, two per issue
+    const f2v tyz = (f2v{m.cc.y, m.cc.z} - f2v{fy, fz}) * f2v{m.inv.y, m.inv.z};
+    const float step = fminf(fminf(tx, tyz.x), tyz.y) + 0.0001f;
+    m.t += step;
+    m.p = ray_at(m.ro, m.dn, m.t);
+    const float kx = __builtin_amdgcn_fmed3f(ceilf(m.p.x), S.lo_f[0], hi.x);
+    const float ky = __builtin_amdgcn_fmed3f(ceilf(m.p.y), S.lo_f[1], hi.y);
+    const float kz = __builtin_amdgcn_fmed3f(ceilf(m.p.z), S.lo_f[2], hi.z);
+    const int idx = static_cast<int>(fmaf(kz, S.nxy_f, fmaf(ky, S.nx_f, kx)));
+    m.cell = idx;
+    const uint32_t* __restrict__ base = s_bits - (S.bias32 >> 5);
+    return __builtin_amdgcn_ubfe(base[idx >> 5], static_cast<uint32_t>(idx), 1u) != 0u;
+}
+
 // Block type of the voxel a march ended in (its id `cell` = ceil(p), raw linear index `raw`).  The
 // baked table is exact inside the box and for everything that is an extrusion of its border layer;
 // the one exception is the cave's floor band (y < -15): there getBlockAt decides 11/12/13 from an

@@ -569,6 +569,8 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
             m.ro = m.rd = m.dn = m.inv = m.cc = m.p = mk3(0, 0, 0);
             m.t = 0.0f, m.tl = inf, m.it = 0, m.lid = -1, m.cell = 0;
             uint32_t slot = 0, fl = 0;
+            f3 hi_v = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
+            asm volatile("" : "+v"(hi_v.x), "+v"(hi_v.y), "+v"(hi_v.z));  // keep the clamp bound in VGPRs (see march_step_burst)
             bool have = false, exhausted = false;
             int tail = 0, trips = 0;
             for (;;)
@@ -613,15 +615,17 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                     // of once per step, and no branch breaks the burst's instruction stream; a march that
                     // ends early sits out the rest of the burst (measured: 1 step/trip 5.15 ms, 2: 4.73,
                     // 4: 4.37, 8: 4.08, 16: 4.00 on C3; a per-step wave-wide early exit costs more than it saves)
-                    bool occ = march_step(m, A.scene, s_bits);
-                    bool fin = occ | (m.t >= m.tl) | (m.it >= kMarchIters);
+                    const int left = kMarchIters - m.it;  // >= 1: a march that used up its iterations is not in flight
+                    bool occ = march_step_burst(m, A.scene, s_bits, hi_v);
+                    bool fin = occ | (m.t >= m.tl) | (left <= 1);
 #pragma unroll
                     for (int sub = 1; sub < kWfStepsPerTrip; ++sub)
                         if (!fin)
                         {
-                            occ = march_step(m, A.scene, s_bits);
-                            fin = occ | (m.t >= m.tl) | (m.it >= kMarchIters);
+                            occ = march_step_burst(m, A.scene, s_bits, hi_v);
+                            fin = occ | (m.t >= m.tl) | (left <= sub + 1);
                         }
+                    m.it += kWfStepsPerTrip;  // only read again for a march that is still going (then all steps ran)
                     if (!fin && ((trips & 3) == 3)) fin = march_escaped(m, A.scene);
                     if (fin)
                     {

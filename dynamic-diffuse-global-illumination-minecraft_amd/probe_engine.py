@@ -159,6 +159,16 @@ def load_library(build=True):
     """Loads (building first if stale and `build`) libddgi_probe.so; raises if it is missing."""
     global _lib
     if _lib is None:
+        alt = os.environ.get("DDGI_LIB")  # profiling aid: an alternative build of the same sources (make alt) for A/B runs
+        if alt:
+            import torch  # noqa: F401
+            lib = C.CDLL(alt)
+            for name, (res, args) in _SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+            return _lib
         if build and os.environ.get("DDGI_NO_BUILD", "0") != "1":
             try:
                 build_library()
