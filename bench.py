@@ -178,7 +178,7 @@ def main():
     local_rays = total_rays // world
     ms_per_step = elapsed / args.steps * 1e3
     # REF: 48 B ProbeRay in + two 4 B texels out; DDGI: rays are generated in the kernel, 16 B (rgb, distance) record out
-    algo_bytes_per_ray = 16 if ddgi_mode else ALGO_BYTES_PER_RAY
+    algo_bytes_per_ray = 20 if ddgi_mode else ALGO_BYTES_PER_RAY  # DDGI: the (r, g, b, d, d*d) ray record out, no ray buffer in
     achieved = algo_bytes_per_ray * local_rays / (kernel_ms * 1e-3) / 1e9
     out = {
         "metric": "probe_rays_per_sec",
@@ -217,12 +217,13 @@ def main():
         },
     }
     if ddgi_mode:
-        # the blend kernel: 16 B ray record per ray in, 3 KB old tiles in + 3 KB new tiles out per probe
+        # the blend kernels (k_blend_weights + k_probe_blend_s): 20 B ray record per ray in (rgb, d, d*d),
+        # 3 KB old tiles in + 3 KB new tiles out per probe
         bms = float(np.mean(blend_ms)) if len(blend_ms) else float("nan")
         probes_local = eng.num_probes // world
-        bbytes = 16 * local_rays + 6144 * probes_local
+        bbytes = 20 * local_rays + 6144 * probes_local
         out["config"]["workload"] = w["name"].replace("_ref", "_ddgi")
-        out["blend"] = {"kernel": "k_probe_blend", "kernel_ms": bms, "algorithmic_bytes_per_launch": bbytes,
+        out["blend"] = {"kernel": "k_blend_weights+k_probe_blend_s", "kernel_ms": bms, "algorithmic_bytes_per_launch": bbytes,
                         "achieved_GBps": bbytes / (bms * 1e-3) / 1e9, "frac_of_hbm_peak": bbytes / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not ddgi_mode:
         out["cpu_baseline"] = cpu_baseline(args.cpu_probes)

@@ -22,7 +22,9 @@ hipError_t launch_probe_sample_ref(const SampleArgs& args, hipStream_t stream);
 hipError_t trace_kernel_occupancy(int* blocks_per_cu, size_t lds_bytes);
 int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads);
 hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream);
-hipError_t launch_probe_blend(const BlendArgs& args, int grid_blocks, hipStream_t stream);
+hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t stream);
+size_t blend_weights_floats(int n);
+size_t blend_record_groups(uint32_t n_local_probes);
 hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream);
 hipError_t launch_render_primary(const RenderArgs& args, hipStream_t stream);
 }  // namespace ddgi
@@ -112,9 +114,11 @@ struct ddgi_engine
     void* d_wf_cold = nullptr;              // wavefront kernel scratch: per-slot shading state
     float4* d_wf_dir = nullptr;
     size_t wf_cold_slots = 0, wf_dir_slots = 0;
-    float4* d_radiance = nullptr;           // DDGI mode: per local ray (radiance rgb, first-hit distance)
-    size_t d_radiance_capacity = 0;         // in rays
+    float* d_radiance = nullptr;            // DDGI mode ray records: rgb part then (d, d*d) part (ddgi_types.h: kRecGroup)
+    size_t d_radiance_capacity = 0;         // in (record group, ray) pairs
     uint32_t frame = 0;                     // DDGI mode: updates done so far (seeds the ray rotation)
+    float* d_blend_w = nullptr;  // k_blend_weights output: [256 sums][n][256]
+    size_t d_blend_w_floats = 0;
     unsigned long long* d_stats = nullptr;  // profiling aid, allocated on first ddgi_trace_stats(enable)
 };
 
@@ -350,6 +354,7 @@ int ddgi_destroy(ddgi_handle e)
         if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_stats) (void)hipFree(e->d_stats);
+    if (e->d_blend_w) (void)hipFree(e->d_blend_w);
     if (e->d_work) (void)hipFree(e->d_work);
     if (e->d_wf_cold) (void)hipFree(e->d_wf_cold);
     if (e->d_wf_dir) (void)hipFree(e->d_wf_dir);
@@ -485,19 +490,22 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     {
         // rays are generated in the kernel; lights follow update_lights(time) (probe_pass.comp:217-251)
         const size_t local_rays = static_cast<size_t>(a.grid.cx) * a.grid.cy * a.grid.czl * a.grid.s * a.grid.s;
-        if (local_rays > e->d_radiance_capacity)
+        const size_t rec_pairs = blend_record_groups(static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.czl) * a.grid.s * a.grid.s;
+        if (rec_pairs > e->d_radiance_capacity)
         {
             if (e->d_radiance) (void)hipFree(e->d_radiance);
             e->d_radiance = nullptr;
             e->d_radiance_capacity = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_radiance), local_rays * sizeof(float4)));
-            e->d_radiance_capacity = local_rays;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_radiance), rec_pairs * 40 * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(e->d_radiance, 0, rec_pairs * 40 * sizeof(float), e->stream));
+            e->d_radiance_capacity = rec_pairs;
         }
         animate_lights(scene, e->settings.time, e->lights[scene], a.nl, a.lights);
         a.ddgi = 1;
         a.frame_key = frame_key(e->frame);
         frame_rotation(e->frame, a.rot);
-        a.radiance = e->d_radiance;
+        a.rad_rgb = e->d_radiance;
+        a.rad_dd = e->d_radiance + rec_pairs * 24;
         a.rays = nullptr;
         a.n_rays = static_cast<uint32_t>(local_rays);
     }
@@ -571,12 +579,25 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         BlendArgs b{};
         b.grid = a.grid;
         for (int i = 0; i < 9; ++i) b.rot[i] = a.rot[i];
-        b.radiance = e->d_radiance;
+        b.rad_rgb = a.rad_rgb;
+        b.rad_dd = a.rad_dd;
         b.irradiance = static_cast<float*>(e->tex[0]);
         b.depth = static_cast<float*>(e->tex[1]);
         b.n_local_probes = static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.czl;
-        const uint32_t blend_grid = std::min<uint32_t>(b.n_local_probes, static_cast<uint32_t>(e->num_cus) * 8u);
-        HIP_TRY(launch_probe_blend(b, static_cast<int>(blend_grid), e->stream));
+        {
+            const size_t need = blend_weights_floats(a.grid.s * a.grid.s) + 256;
+            if (need > e->d_blend_w_floats)
+            {
+                if (e->d_blend_w) (void)hipFree(e->d_blend_w);
+                e->d_blend_w = nullptr, e->d_blend_w_floats = 0;
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_blend_w), need * sizeof(float)));
+                e->d_blend_w_floats = need;
+            }
+            b.w_sum = e->d_blend_w;
+            b.w = e->d_blend_w + 256;
+            if (std::getenv("DDGI_BLEND_KERNEL")) b.w = b.w_sum = nullptr;  // "probe": one probe per workgroup, weights in place
+        }
+        HIP_TRY(launch_probe_blend(b, e->num_cus, e->stream));
         e->frame += 1;
     }
     HIP_TRY(hipEventRecord(ev[2], e->stream));

@@ -69,7 +69,7 @@ struct WfCold
     float col[3];  // accumulated radiance
     uint32_t rng;
     uint32_t cnt;  // [7:0] bounce, [11:8] light index, [15:12] visible lights
-    uint32_t dst;  // REF: texel index; DDGI: local ray index
+    uint32_t dst;  // REF: texel index; DDGI: ray record id (ddgi_types.h: kRecGroup)
 };
 static_assert(sizeof(WfCold) == 48, "3 x 16 bytes");
 
@@ -157,13 +157,21 @@ DDGI_D void wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d,
     P.flags[slot] = kSlotMarch | (feeler ? kFlagFeeler : 0u) | (static_cast<uint32_t>(lid + 1) << 12);
 }
 
+// DDGI mode, bounce 0: the probe ray's hit distance, clamped as the depth blend wants it, and its square
+DDGI_D void wf_store_distance(const TraceArgs& A, uint32_t dst, float t)
+{
+    const float d = gl_min(t, static_cast<float>(A.grid.side) * 1.5f);
+    float* rec = A.rad_dd + static_cast<size_t>(dst >> 3) * 16 + (dst & 7u);
+    rec[0] = d, rec[8] = d * d;
+}
+
 DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst, const TraceArgs& A)
 {
     const f3 c = div3(color, static_cast<float>(A.max_bounces));  // Q14: always /max_bounces
     if (A.ddgi)
     {
-        float* rec = reinterpret_cast<float*>(A.radiance + dst);  // .w (first-hit distance) was written at bounce 0
-        rec[0] = c.x, rec[1] = c.y, rec[2] = c.z;
+        float* rec = A.rad_rgb + static_cast<size_t>(dst >> 3) * 24 + (dst & 7u);  // (the distance was written at bounce 0)
+        rec[0] = c.x, rec[8] = c.y, rec[16] = c.z;
     }
     else
     {
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                             const int pxz = p - y * G.cx * G.cz;
                             ray_o = probe_position(G, pxz % G.cx, y, pxz / G.cx);
                             ray_d = fibonacci_dir(i, rays_per_probe, A.rot);
-                            c.dst = r;
+                            c.dst = ((static_cast<uint32_t>(pl) >> 3) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i)) * 8u + (static_cast<uint32_t>(pl) & 7u);  // record id (kRecGroup)
                             c.rng = wang_hash(global_ray ^ A.frame_key);
                         }
                         else
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                         const bool first_bounce = A.ddgi && (c.cnt & 255u) == 0u;
                         if (!any_hit)
                         {
-                            if (first_bounce) reinterpret_cast<float*>(A.radiance + c.dst)[3] = kMissDistance;
+                            if (first_bounce) wf_store_distance(A, c.dst, kMissDistance);
                             wf_finish_ray(P, slot, v3of(c.col), c.dst, A);  // probe_pass.comp:288-290 break
                         }
                         else
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                                 nraw = ray_at((ro - lp) * 10.0f, rd * 10.0f, th);  // sphere-space position
                                 hcol = mk3(0, 0, 0);  // Q12: unassigned Material, pinned to zero
                             }
-                            if (first_bounce) reinterpret_cast<float*>(A.radiance + c.dst)[3] = th;  // Isect.t of the probe ray
+                            if (first_bounce) wf_store_distance(A, c.dst, th);  // Isect.t of the probe ray
                             const f3 hnrm = axis_normal ? nraw : normalize3(nraw);
                             const f3 hpos = ray_at(ro, rd, th) + hnrm * 0.001f;
                             set3(c.hn, hnrm);

@@ -73,22 +73,33 @@ struct TraceArgs
     int ablate;           // profiling ablations (DDGI_ABLATE env, default 0 = exact): 1 constant albedo, 2 constant bounce direction
     // DDGI mode (ddgi != 0): rays are generated in the kernel (spherical Fibonacci set rotated by
     // rot, origin = probe position), the RNG seed is ray index ^ frame_key, and each ray writes
-    // (radiance rgb, first-hit distance) to radiance[local ray] instead of an rgba8 texel
+    // its radiance and clamped first-hit distance to the ray records (below) instead of an rgba8 texel
     int ddgi;
     uint32_t frame_key;
     float rot[9];
-    float4* radiance;
+    float* rad_rgb;  // ray records, see RayRecords
+    float* rad_dd;
 };
+
+// DDGI-mode ray records, laid out for the blend kernel: local probes in groups of 8; for group g and
+// ray i   rad_rgb[(g*n + i)*24 + {0,8,16} + j] = r, g, b   and   rad_dd[(g*n + i)*16 + {0,8} + j] = d, d*d
+// of probe 8g + j, with d = min(first-hit distance, 1.5 * spacing).  One ray's values for 8 probes
+// are contiguous, so the blend reads them with scalar loads (they are uniform across its texel lanes).
+// A ray's record id is  (g*n + i)*8 + j.
+constexpr int kRecGroup = 8;
 
 // k_probe_blend: per-probe update of the octahedral irradiance / depth-moment tiles
 struct BlendArgs
 {
     GridK grid;
     float rot[9];
-    const float4* radiance;  // local slab, [probe in slab (y, zl, x) order][ray]
+    const float* rad_rgb;  // ray records of the local slab (probes in (y, zl, x) order), see kRecGroup
+    const float* rad_dd;
     float* irradiance;       // full-grid slab-major [cz][cy][cx][8][8][4]
     float* depth;            // full-grid slab-major [cz][cy][cx][16][16][2]
     uint32_t n_local_probes;
+    float* w;      // per-update texel weights [ray][256 texel columns] (k_blend_weights), or null
+    float* w_sum;  // [256] weight sum per texel column
 };
 
 struct SampleArgs

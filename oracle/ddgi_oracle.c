@@ -1722,7 +1722,8 @@ void oracle_ddgi_update(const o_field* f, const o_settings* st, const o_light* b
                 for (int i = 0; i < n; i++)
                 {
                     float w = gmax(0.0f, dot3(td, dirs[i]));
-                    sr += rad[4 * i] * w, sg += rad[4 * i + 1] * w, sb += rad[4 * i + 2] * w;
+                    /* sums of products are fma chains */
+                    sr = fmaf(rad[4 * i], w, sr), sg = fmaf(rad[4 * i + 1], w, sg), sb = fmaf(rad[4 * i + 2], w, sb);
                     sw += w;
                 }
                 float res[3] = {0, 0, 0};
@@ -1750,7 +1751,7 @@ void oracle_ddgi_update(const o_field* f, const o_settings* st, const o_light* b
                 {
                     float w = pow50(gmax(0.0f, dot3(td, dirs[i])));
                     float d = gmin(rad[4 * i + 3], max_dist);
-                    s1 += d * w, s2 += (d * d) * w;
+                    s1 = fmaf(d, w, s1), s2 = fmaf(d * d, w, s2);
                     sw += w;
                 }
                 float r1 = 0, r2 = 0;

@@ -15,7 +15,7 @@ tr, bl = eng.update_history_ms(8)
 print("trace ms", np.round(tr, 3), "blend ms", np.round(bl, 3))
 P = eng.num_probes
 print("blend: %.1f MB algorithmic (2 x 3 KB tiles/probe) + %.1f MB ray records -> %.0f GB/s" % (
-    P * 6144 / 1e6, eng.num_rays * 16 / 1e6, (P * 6144 + eng.num_rays * 16) / (bl[-1] * 1e-3) / 1e9))
+    P * 6144 / 1e6, eng.num_rays * 20 / 1e6, (P * 6144 + eng.num_rays * 20) / (bl[-1] * 1e-3) / 1e9))
 rng = np.random.default_rng(0)
 import time
 n = 1 << 20

@@ -1,0 +1,22 @@
+#!/bin/bash
+# SQ PMC passes for the DDGI-mode blend kernel (GPU box); prints per-launch means
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_blend
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $GRAFT_REPO_ROOT/bench.py --mode ddgi --steps 3 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU -d $OUT -o sq1 --output-format csv -- $BENCH > $OUT/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SMEM SQ_WAVES SQ_INST_CYCLES_VMEM -d $OUT -o sq2 --output-format csv -- $BENCH > $OUT/sq2.log 2>&1
+python3 - <<PY
+import csv, collections
+for f in ["sq1","sq2"]:
+    agg=collections.defaultdict(list)
+    try:
+        rows = list(csv.DictReader(open("$OUT/"+f+"_counter_collection.csv")))
+    except Exception as e:
+        print(f, "no data", e); continue
+    for r in rows:
+        if "blend_s" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k,v in sorted(agg.items()): print(f,k,"%.4g"%(sum(v)/len(v)))
+PY
+tail -3 $OUT/sq2.log

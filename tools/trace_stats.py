@@ -7,7 +7,10 @@ from bench import WORKLOAD as w
 
 eng = ddgi_amd.ProbeEngine(ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"]),
                            ddgi_amd.make_settings(w["scene"], w["max_bounces"]))
-eng.generate_probe_rays(seed=1)
+if len(sys.argv) > 1 and sys.argv[1] == "ddgi":
+    eng.set_mode(ddgi_amd.MODE_DDGI)
+else:
+    eng.generate_probe_rays(seed=1)
 eng.probe_update(); eng.synchronize()
 eng.trace_stats(True)
 eng.probe_update(); eng.synchronize()
