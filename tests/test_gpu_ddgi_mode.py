@@ -87,3 +87,35 @@ def test_ddgi_sharded_slabs(ddgi, oracle):
         mine = np.array([(p % (cx * cz)) // cx // (cz // 2) == rank for p in range(cx * cy * cz)])
         assert np.array_equal(_bits(g_irr[mine]), _bits(irr[mine])) and not g_irr[~mine].any()
         assert np.array_equal(_bits(g_dep[mine]), _bits(dep[mine])) and not g_dep[~mine].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("counts,s", [((3, 3, 3), 5), ((2, 1, 3), 3), ((5, 2, 2), 8), ((1, 1, 1), 1)])
+def test_blend_kernels_agree_on_ragged_shapes(ddgi, oracle, counts, s):
+    """Probe counts that are not a multiple of the 8-probe record group and odd ray counts: the
+    scalar-operand blend (k_blend_weights + k_probe_blend_s), the one-probe-per-workgroup blend
+    (DDGI_BLEND_KERNEL=probe) and the oracle give the same tiles, bit for bit, over three frames."""
+    import os
+    side, origin, scene = 6, (0.0, 0.0, 15.0), 1
+    f = oracle.make_field(counts, side, s, origin, hysteresis=0.7)
+    st = oracle.make_settings(scene, 4)
+    n_probes = counts[0] * counts[1] * counts[2]
+    o_irr = np.zeros((n_probes, 8, 8, 4), dtype=np.float32)
+    o_dep = np.zeros((n_probes, 16, 16, 2), dtype=np.float32)
+    results = {}
+    for kernel in ("scalar", "probe"):
+        if kernel == "probe":
+            os.environ["DDGI_BLEND_KERNEL"] = "probe"
+        try:
+            with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin, hysteresis=0.7), ddgi.make_settings(scene, 4)) as eng:
+                eng.set_mode(ddgi.MODE_DDGI)
+                for _ in range(3):
+                    eng.probe_update()
+                results[kernel] = eng.read_tiles()
+        finally:
+            os.environ.pop("DDGI_BLEND_KERNEL", None)
+    for frame in range(3):
+        oracle.ddgi_update(f, st, frame, o_irr, o_dep)
+    for kernel, (irr, dep) in results.items():
+        assert np.array_equal(_bits(irr), _bits(o_irr)), kernel
+        assert np.array_equal(_bits(dep), _bits(o_dep)), kernel
