@@ -25,6 +25,7 @@ hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, i
 hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t stream);
 size_t blend_weights_floats(int n);
 size_t blend_record_groups(uint32_t n_local_probes);
+hipError_t launch_carry_tiles(void* dst, const void* src, const int32_t* map, uint32_t n_probes, uint32_t words_per_tile, hipStream_t stream);
 hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream);
 hipError_t launch_render_primary(const RenderArgs& args, hipStream_t stream);
 }  // namespace ddgi
@@ -386,6 +387,77 @@ int ddgi_configure(ddgi_handle e, const ddgi_irradiance_field* field, const ddgi
     e->n_local_rays = 0;
     e->updates = 0;
     return alloc_textures(e);
+}
+
+// Probe coordinate along one axis: RVPT::generate_probe_rays, src/rvpt/rvpt.cpp:1199-1205 (ddgi_oct.h: probe_position)
+static float probe_axis_position(int idx, int count, int side, float origin)
+{
+    return static_cast<float>(idx - (count - 1) / 2) * static_cast<float>(side) + origin;
+}
+
+int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const ddgi_render_settings* settings, int carry_over)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (!carry_over) return ddgi_configure(e, field, settings);
+    if (int rc = validate_config(field, settings, e->world)) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const ddgi_irradiance_field old = e->field;
+    // a tile can be carried over only if it has the same size: always in DDGI mode (8x8 / 16x16
+    // octahedral tiles), in REF mode when the rays per probe did not change
+    const bool same_tiles = e->mode == DDGI_MODE_DDGI || old.sqrt_rays_per_probe == field->sqrt_rays_per_probe;
+    // per axis: which old probe index has exactly the new probe's coordinate (-1: none)
+    std::vector<int> axis_map[3];
+    for (int a = 0; a < 3; ++a)
+    {
+        axis_map[a].assign(field->probe_count[a], -1);
+        for (int i = 0; i < field->probe_count[a]; ++i)
+        {
+            const float x = probe_axis_position(i, field->probe_count[a], field->side_length, field->field_origin[a]);
+            for (int j = 0; j < old.probe_count[a]; ++j)
+                if (probe_axis_position(j, old.probe_count[a], old.side_length, old.field_origin[a]) == x) axis_map[a][i] = j;
+        }
+    }
+    const int cx = field->probe_count[0], cy = field->probe_count[1], cz = field->probe_count[2];
+    std::vector<int32_t> map(static_cast<size_t>(cx) * cy * cz, -1);  // slab-major slots (z*cy + y)*cx + x
+    size_t carried = 0;
+    if (same_tiles)
+        for (int z = 0; z < cz; ++z)
+            for (int y = 0; y < cy; ++y)
+                for (int x = 0; x < cx; ++x)
+                {
+                    const int ox = axis_map[0][x], oy = axis_map[1][y], oz = axis_map[2][z];
+                    if (ox < 0 || oy < 0 || oz < 0) continue;
+                    map[(static_cast<size_t>(z) * cy + y) * cx + x] = (oz * old.probe_count[1] + oy) * old.probe_count[0] + ox;
+                    carried += 1;
+                }
+    // keep the old textures alive across the re-allocation
+    void* old_own[2] = {e->own_tex[0], e->own_tex[1]};
+    const void* old_tex[2] = {e->tex[0], e->tex[1]};
+    const size_t old_words[2] = {e->tex_bytes[0] / 4 / (static_cast<size_t>(old.probe_count[0]) * old.probe_count[1] * old.probe_count[2]),
+                                 e->tex_bytes[1] / 4 / (static_cast<size_t>(old.probe_count[0]) * old.probe_count[1] * old.probe_count[2])};
+    e->own_tex[0] = e->own_tex[1] = nullptr;
+    const uint32_t frame = e->frame;
+    e->field = *field;
+    e->settings = *settings;
+    e->host_rays.clear();
+    e->n_local_rays = 0;
+    e->updates = 0;
+    int rc = alloc_textures(e);
+    e->frame = frame;  // the temporal sequence (ray rotation, RNG keys) goes on
+    if (rc == DDGI_OK && carried > 0)
+    {
+        int32_t* d_map = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_map), map.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpyAsync(d_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
+        for (int i = 0; i < 2; ++i)
+            HIP_TRY(launch_carry_tiles(e->tex[i], old_tex[i], d_map, static_cast<uint32_t>(map.size()), static_cast<uint32_t>(old_words[i]), e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        (void)hipFree(d_map);
+    }
+    for (void* p : old_own)
+        if (p) (void)hipFree(p);
+    return rc;
 }
 
 int ddgi_set_mode(ddgi_handle e, int mode)

@@ -11,6 +11,8 @@
 #include "ddgi_device.h"
 #include "ddgi_sampler.h"
 
+#include <algorithm>
+
 namespace ddgi {
 
 enum : int
@@ -291,6 +293,34 @@ hipError_t launch_probe_sample_ref(const SampleArgs& args, hipStream_t stream)
 hipError_t trace_kernel_occupancy(int* blocks_per_cu, size_t lds_bytes)
 {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_probe_trace_ref, kTraceBlock, lds_bytes);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_carry_tiles — reconfiguration with carry-over: the tile of every new probe
+// that stands exactly where an old probe stood is copied from the old textures; map[new slot] = old
+// slot or -1.  One 64-lane wave per probe tile, 4-byte words.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_carry_tiles(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, const int32_t* __restrict__ map, uint32_t n_probes,
+                                                     uint32_t words_per_tile)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t p = wave; p < n_probes; p += n_waves)
+    {
+        const int32_t from = map[p];
+        if (from < 0) continue;
+        const uint32_t* s = src + static_cast<size_t>(from) * words_per_tile;
+        uint32_t* d = dst + static_cast<size_t>(p) * words_per_tile;
+        for (uint32_t w = lane; w < words_per_tile; w += 64u) d[w] = s[w];
+    }
+}
+
+hipError_t launch_carry_tiles(void* dst, const void* src, const int32_t* map, uint32_t n_probes, uint32_t words_per_tile, hipStream_t stream)
+{
+    if (n_probes == 0) return hipSuccess;
+    const unsigned blocks = std::min<unsigned>((n_probes + 3u) / 4u, 4096u);
+    hipLaunchKernelGGL(k_carry_tiles, dim3(blocks), dim3(256), 0, stream, static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), map, n_probes, words_per_tile);
+    return hipGetLastError();
 }
 
 }  // namespace ddgi

@@ -57,12 +57,13 @@ public:
     // probe half of rvpt.cpp:372-431 (record_compute_command_buffer 1096-1129 + submit)
     bool draw() { return handle_ && ok(ddgi_probe_update(handle_, &render_settings), "ddgi_probe_update"); }
 
-    // rvpt.cpp:661-755
-    bool recreate_probe_textures()
+    // rvpt.cpp:661-755; keep_surviving_probes: probes that stand where an old probe stood keep their tiles
+    // (ddgi_reconfigure) — the reference itself drops every texture
+    bool recreate_probe_textures(bool keep_surviving_probes = false)
     {
         need_change_probe_texture_ = false;
         if (!handle_) return initialize();
-        if (!ok(ddgi_configure(handle_, &ir, &render_settings), "ddgi_configure")) return false;
+        if (!ok(ddgi_reconfigure(handle_, &ir, &render_settings, keep_surviving_probes ? 1 : 0), "ddgi_reconfigure")) return false;
         need_generate_probe_rays_ = true;
         return flush_rays();
     }

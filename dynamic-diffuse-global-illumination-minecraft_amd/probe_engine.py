@@ -118,6 +118,7 @@ _SIGNATURES = {
     "ddgi_create_sharded": (C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
     "ddgi_destroy": (C.c_int, [_VP]),
     "ddgi_configure": (C.c_int, [_VP, _VP, _VP]),
+    "ddgi_reconfigure": (C.c_int, [_VP, _VP, _VP, C.c_int]),
     "ddgi_set_mode": (C.c_int, [_VP, C.c_int]),
     "ddgi_set_lights": (C.c_int, [_VP, C.c_int, _VP, C.c_int]),
     "ddgi_generate_probe_rays": (C.c_int, [_VP, C.c_uint32, C.c_int]),
@@ -285,6 +286,15 @@ class ProbeEngine:
         _check(self._lib.ddgi_configure(self._h, C.byref(self.ir), C.byref(self.render_settings)))
 
     recreate_probe_textures = configure
+
+    def reconfigure(self, field=None, settings=None, carry_over=True):
+        """configure() that keeps the tiles of every probe whose world position survives the change
+        (include/ddgi_probe.h: ddgi_reconfigure)."""
+        if field is not None:
+            self.ir = field
+        if settings is not None:
+            self.render_settings = settings
+        _check(self._lib.ddgi_reconfigure(self._h, C.byref(self.ir), C.byref(self.render_settings), 1 if carry_over else 0))
 
     def set_mode(self, mode):
         _check(self._lib.ddgi_set_mode(self._h, mode))

@@ -126,6 +126,15 @@ int ddgi_destroy(ddgi_handle h);
 int ddgi_configure(ddgi_handle h, const ddgi_irradiance_field* field,
                    const ddgi_render_settings* settings);
 
+/* ddgi_configure with carry-over (no reference counterpart — the reference
+ * drops its textures, rvpt.cpp:661-755): with carry_over != 0 every new probe that stands exactly
+ * where an old probe stood (same world position; REF mode additionally: same rays per probe) keeps
+ * that probe's tiles, all others start zeroed, and in DDGI mode the frame sequence continues.
+ * The handle uses its own textures afterwards (re-bind external ones with ddgi_bind_textures).
+ * carry_over == 0 is ddgi_configure. */
+int ddgi_reconfigure(ddgi_handle h, const ddgi_irradiance_field* field,
+                     const ddgi_render_settings* settings, int carry_over);
+
 int ddgi_set_mode(ddgi_handle h, int mode /* ddgi_mode */);
 
 /* Overrides the light table of one scene (the reference compiles them into the shader,
