@@ -119,8 +119,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # DDGI_BENCH_FORCE_DIST=1: run the N > 1 code path (RCCL group, torch-owned textures, pipelined
+    # exchange) with a single rank — a smoke test of that path on a one-GPU box
+    sharded = world > 1 or os.environ.get("DDGI_BENCH_FORCE_DIST") == "1"
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     w = WORKLOAD
     field = ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"])
@@ -135,14 +140,17 @@ def main():
         eng.generate_probe_rays(seed=w["seed"])  # ray buffer resident in HBM from here on
 
     tex = None
-    if world > 1:
+    if sharded:
         from ddgi_amd import distributed as ddist
 
-        tex = ddist.ShardedTextures(eng, torch.device("cuda", local_rank))
+        # REF mode: the exchange of update k overlaps the kernel of update k+1 (two buffer pairs)
+        tex = ddist.ShardedTextures(eng, torch.device("cuda", local_rank), pipelined=not ddgi_mode, ddgi_mode=ddgi_mode)
 
     frame_time = [0.0]
 
     def step():
+        if tex is not None:
+            tex.begin_step()
         if ddgi_mode:
             frame_time[0] += 2.0                # RVPT::update: render_settings.time += 2 (rvpt.cpp:281)
             settings.time = frame_time[0]
@@ -153,7 +161,9 @@ def main():
             tex.all_gather()
 
     def fence():
-        if world > 1:
+        if tex is not None:
+            tex.finish()                        # every exchange issued so far has completed on this stream
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +175,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -227,8 +237,10 @@ def main():
                         "achieved_GBps": bbytes / (bms * 1e-3) / 1e9, "frac_of_hbm_peak": bbytes / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not ddgi_mode:
         out["cpu_baseline"] = cpu_baseline(args.cpu_probes)
+    if tex is not None:
+        tex.close()
     eng.close()
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -65,24 +65,103 @@ def raster_to_slab_major(raster, counts, s, texel_shape=()):
 
 
 class ShardedTextures:
-    """Torch-owned full-grid texture buffers bound into a sharded ProbeEngine + their all-gather."""
+    """Torch-owned full-grid texture buffers bound into a sharded ProbeEngine + their all-gather.
 
-    def __init__(self, engine, device, group=None):
+    Usage per update:   tex.begin_step(); engine.probe_update(); tex.all_gather()
+    and once before the textures are consumed / timed:   tex.finish()
+
+    pipelined=False: one buffer pair; the collectives run in order with the kernels on the current
+    stream (update k+1 starts after update k's exchange).
+    pipelined=True (REF mode: an update rewrites the rank's whole slab and reads nothing back): two
+    buffer pairs used alternately and a communication stream — update k+1 writes pair (k+1)&1 while
+    pair k&1 is still being exchanged, so the exchange hides behind the next update's kernel (the
+    probe rays of different updates are independent; only the consumer needs the gathered field).
+    `latest()` is the pair holding the most recent update; it is complete after `finish()` (or, on the
+    consumer's stream, after waiting for `ready_event()`).
+
+    `skip_constant` (default on): in REF mode the reference never assigns its `distances` image
+    (probe_pass.comp:276,302 — every rank writes zeros into its slab of zero-initialised buffers), so
+    exchanging it moves no information; it is left out.
+    """
+
+    def __init__(self, engine, device, group=None, pipelined=False, ddgi_mode=False, skip_constant=True):
         import torch
 
+        if pipelined and ddgi_mode:
+            raise ValueError("pipelined exchange needs an update that does not read its own previous output: REF mode only")
         self.engine = engine
         self.group = group
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.pipelined = bool(pipelined)
+        self.gather_tex1 = bool(ddgi_mode) or not skip_constant
         info = engine.device_textures()
-        self.tex0 = torch.zeros(info["tex0_bytes"], dtype=torch.uint8, device=device)
-        self.tex1 = torch.zeros(info["tex1_bytes"], dtype=torch.uint8, device=device)
+        nbuf = 2 if self.pipelined else 1
+        self.bufs = [(torch.zeros(info["tex0_bytes"], dtype=torch.uint8, device=self.device),
+                      torch.zeros(info["tex1_bytes"], dtype=torch.uint8, device=self.device)) for _ in range(nbuf)]
+        self.comm = torch.cuda.Stream(self.device) if (self.pipelined and self.cuda) else None
+        self.sent = [None] * nbuf   # event on the comm stream: buffer i's last exchange is over
+        self.k = 0                  # updates exchanged so far
+        self.cur = 0
+        self.tex0, self.tex1 = self.bufs[0]
         engine.bind_textures(self.tex0.data_ptr(), self.tex1.data_ptr())
 
-    def all_gather(self):
-        """One collective per texture, on the current torch stream (= the engine's stream)."""
-        if self.engine.world == 1:
+    def begin_step(self):
+        """Selects (and binds) the buffer pair the next probe_update writes."""
+        if not self.pipelined:
             return
-        all_gather_slabs(self.tex0, self.engine.rank, self.engine.world, self.group)
-        all_gather_slabs(self.tex1, self.engine.rank, self.engine.world, self.group)
+        import torch
+
+        self.cur = self.k % 2
+        if self.cuda and self.sent[self.cur] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.sent[self.cur])  # its previous exchange has left the buffer
+        self.tex0, self.tex1 = self.bufs[self.cur]
+        self.engine.bind_textures(self.tex0.data_ptr(), self.tex1.data_ptr())
+
+    def _exchange(self, pair):
+        all_gather_slabs(pair[0], self.engine.rank, self.engine.world, self.group)
+        if self.gather_tex1:
+            all_gather_slabs(pair[1], self.engine.rank, self.engine.world, self.group)
+
+    def all_gather(self):
+        """One collective per texture that carries information; on the current stream, or (pipelined)
+        on the communication stream once the update just issued on the current stream is done."""
+        import torch.distributed as dist
+
+        if self.engine.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            self.k += 1  # single process without a process group: nothing to exchange
+            return
+        pair = self.bufs[self.cur]
+        if self.comm is None:
+            self._exchange(pair)
+        else:
+            import torch
+
+            written = torch.cuda.Event()
+            written.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(written)
+                self._exchange(pair)
+                ev = torch.cuda.Event()
+                ev.record(self.comm)
+                self.sent[self.cur] = ev
+        self.k += 1
+
+    def latest(self):
+        """(tex0, tex1) of the most recent update (complete after finish())."""
+        return self.bufs[self.cur]
+
+    def ready_event(self):
+        """Pipelined + CUDA: the event after which latest() is complete; else None."""
+        return self.sent[self.cur] if self.comm is not None else None
+
+    def finish(self):
+        """Makes the current stream wait for every exchange issued so far."""
+        if self.comm is not None:
+            import torch
+
+            torch.cuda.current_stream(self.device).wait_stream(self.comm)
 
     def close(self):
+        self.finish()
         self.engine.bind_textures(None, None)

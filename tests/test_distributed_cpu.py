@@ -80,3 +80,60 @@ def test_layout_conversions_roundtrip():
     assert dd.slab_range(8, 3, 4) == (6, 8)
     with pytest.raises(ValueError):
         dd.slab_range(9, 0, 2)
+
+
+class _FakeEngine:
+    """Stands in for a sharded ProbeEngine: records which buffers are bound."""
+
+    def __init__(self, rank, world, nbytes):
+        self.rank, self.world, self.nbytes = rank, world, nbytes
+        self.bound = None
+
+    def device_textures(self):
+        return {"tex0_bytes": self.nbytes, "tex1_bytes": self.nbytes}
+
+    def bind_textures(self, p0, p1):
+        self.bound = (p0, p1)
+
+
+def _pipelined_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ddgi_amd import distributed as dd
+
+        nbytes = 4096
+        per = nbytes // world
+        eng = _FakeEngine(rank, world, nbytes)
+        tex = dd.ShardedTextures(eng, torch.device("cpu"), pipelined=True)
+        seen = []
+        for k in range(5):
+            tex.begin_step()
+            t0, t1 = tex.latest()
+            assert eng.bound == (t0.data_ptr(), t1.data_ptr())          # the update writes the pair that was just bound
+            t0[rank * per:(rank + 1) * per] = (k + 1) * 10 + rank          # "probe_update k": this rank's slab only
+            tex.all_gather()
+            seen.append(t0.data_ptr())
+        tex.finish()
+        assert seen[0] == seen[2] == seen[4] and seen[1] == seen[3] and seen[0] != seen[1]   # two pairs, alternating
+        t0, t1 = tex.latest()
+        np.save(os.path.join(out_dir, f"p{rank}_last.npy"), t0.numpy())
+        np.save(os.path.join(out_dir, f"p{rank}_prev.npy"), tex.bufs[1 - tex.cur][0].numpy())
+        assert not t1.any()                                              # the constant image is not exchanged (and stays zero)
+        tex.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_exchange_world2_gloo(tmp_path):
+    """Double-buffered exchange (REF mode): update k is gathered from pair k&1 while k+1 writes the other."""
+    world = 2
+    mp.spawn(_pipelined_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    per = 4096 // world
+    for r in range(world):
+        last = np.load(tmp_path / f"p{r}_last.npy")
+        prev = np.load(tmp_path / f"p{r}_prev.npy")
+        for q in range(world):
+            assert (last[q * per:(q + 1) * per] == 50 + q).all()     # update 4 (k+1 = 5) of every rank
+            assert (prev[q * per:(q + 1) * per] == 40 + q).all()     # update 3 in the other pair

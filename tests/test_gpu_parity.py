@@ -213,3 +213,47 @@ def test_torch_owned_textures_and_stream(ddgi, oracle):
             assert np.array_equal(d_cage.cpu().numpy(), want_cage)
             assert np.array_equal(d_rgb.cpu().numpy().view(np.uint32), want_rgb.view(np.uint32))
             tex.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_exchange_on_a_one_rank_rccl_group(ddgi):
+    """The pipelined (double-buffered, side-stream) exchange with a real RCCL communicator of one
+    rank: bind alternation, stream/event ordering and the collective on the communication stream.
+    Update k must end up in pair k&1, identical to what a plain engine produces for the same rays."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from ddgi_amd import distributed as dd
+
+    name = "c1_cornell"
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        want = []
+        with _engine(ddgi, name) as ref:
+            for seed in (1, 2, 3):
+                ref.generate_probe_rays(seed=seed)
+                ref.probe_update()
+                want.append(ref.read_textures()[0])
+        counts, side, s, origin, scene = CONFIGS[name]
+        with _engine(ddgi, name) as eng:
+            eng.set_stream(torch.cuda.current_stream().cuda_stream)
+            tex = dd.ShardedTextures(eng, torch.device("cuda", 0), pipelined=True)
+            for seed in (1, 2, 3):
+                eng.generate_probe_rays(seed=seed)
+                tex.begin_step()
+                eng.probe_update()
+                tex.all_gather()
+            tex.finish()
+            torch.cuda.synchronize()
+            last = dd.slab_major_to_raster(tex.latest()[0].cpu().numpy(), counts, s, (4,))
+            prev = dd.slab_major_to_raster(tex.bufs[1 - tex.cur][0].cpu().numpy(), counts, s, (4,))
+            assert np.array_equal(last, want[2]) and np.array_equal(prev, want[1])
+            assert not np.array_equal(want[1], want[2])
+            tex.close()
+    finally:
+        dist.destroy_process_group()
