@@ -590,6 +590,8 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     if (const char* v = std::getenv("DDGI_ABLATE")) a.ablate = std::atoi(v);
     if (const char* v = std::getenv("DDGI_WF_TAIL")) a.wf_tail = std::atoi(v);
     if (const char* v = std::getenv("DDGI_WF_FETCH")) a.wf_fetch = std::atoi(v);
+    if (const char* v = std::getenv("DDGI_WF_CHUNK")) a.wf_chunk = std::atoi(v);
+    if (const char* v = std::getenv("DDGI_WF_DRAIN")) a.wf_drain = std::atoi(v);
 
     // Kernel choice: the wavefront kernel (one persistent 1024-lane workgroup per CU, ray pool in
     // LDS) whenever its pool fits next to the scene bitmap; the ray-per-lane kernel otherwise
@@ -607,7 +609,9 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     if (pool > 0)
     {
         if (!e->d_work) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_work), sizeof(uint32_t)));
-        const uint32_t chunks = (a.n_rays + 4095u) / 4096u;
+        // one persistent workgroup per CU unless the launch is tiny (the launcher sizes the ray claims
+        // so that every workgroup gets several: launch_probe_trace_wf)
+        const uint32_t chunks = (a.n_rays + 255u) / 256u;
         uint32_t grid = static_cast<uint32_t>(e->num_cus * wf_blocks_per_cu);
         if (grid > chunks) grid = chunks;
         const size_t slots = static_cast<size_t>(grid) * pool;

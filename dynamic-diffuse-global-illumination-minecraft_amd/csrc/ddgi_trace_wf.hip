@@ -32,8 +32,9 @@ namespace ddgi {
 
 constexpr int kWfStepsPerTrip = 16;  // voxel steps per march-loop trip (burst)
 constexpr int kWfTailSteps = 1;          // straggler trips (bursts) after the march list is drained
+constexpr int kWfDrainTail = 8;      // straggler trips once no new ray can be claimed (8 x 16 steps >= kMarchIters)
 constexpr int kWfFetchLanes = 8;     // pull new march tasks once this many lanes are idle
-constexpr uint32_t kWfChunk = 4096;  // rays a workgroup claims at a time from the global counter
+constexpr uint32_t kWfChunk = 4096;  // rays a workgroup claims at a time from the global counter (upper bound, see wf_chunk)
 constexpr int kWfBuckets = 7;
 
 enum : uint32_t
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
     const uint32_t PS = static_cast<uint32_t>(pool_size);
     const bool multi_light = A.nl > 1;
     const int tail_steps = A.wf_tail > 0 ? A.wf_tail : kWfTailSteps;
+    const int drain_tail = A.wf_drain > 0 ? A.wf_drain : kWfDrainTail;
     const int fetch_lanes = A.wf_fetch > 0 ? A.wf_fetch : kWfFetchLanes;
 
     // ---- carve LDS: control block | occupancy bitmap | pool arrays | slot lists ----
@@ -233,15 +235,16 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
 
     for (int i = tid; i < A.scene.nwords; i += T) s_bits[i] = A.scene.bits[i];
     for (uint32_t i = tid; i < PS; i += T) P.flags[i] = kSlotEmpty;
-    const uint32_t n_chunks = (A.n_rays + kWfChunk - 1) / kWfChunk;
+    const uint32_t chunk = static_cast<uint32_t>(A.wf_chunk);
+    const uint32_t n_chunks = (A.n_rays + chunk - 1) / chunk;
     if (tid == 0)
     {
         sh->n_march[0] = sh->n_march[1] = sh->head_march = 0;
         sh->live = 0;
         sh->group_head = sh->n_groups = 0;
         const uint32_t c = atomicAdd(work_counter, 1u);
-        sh->cur = c < n_chunks ? c * kWfChunk : 0u;
-        sh->end = c < n_chunks ? min(c * kWfChunk + kWfChunk, A.n_rays) : 0u;
+        sh->cur = c < n_chunks ? c * chunk : 0u;
+        sh->end = c < n_chunks ? min(c * chunk + chunk, A.n_rays) : 0u;
     }
     if (tid <= kWfBuckets) sh->bucket_count[tid] = 0u;
     __syncthreads();
@@ -565,8 +568,8 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
             if (taken >= sh->end)  // range used up: claim the next chunk
             {
                 const uint32_t c = atomicAdd(work_counter, 1u);
-                sh->cur = c < n_chunks ? c * kWfChunk : 0u;
-                sh->end = c < n_chunks ? min(c * kWfChunk + kWfChunk, A.n_rays) : 0u;
+                sh->cur = c < n_chunks ? c * chunk : 0u;
+                sh->end = c < n_chunks ? min(c * chunk + chunk, A.n_rays) : 0u;
             }
             for (int b = 0; b <= kWfBuckets; ++b) sh->bucket_count[b] = 0u;  // next read after this phase's barrier
         }
@@ -645,7 +648,11 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                     }
                 }
                 ++trips;
-                if (exhausted && ++tail >= tail_steps)
+                // While new rays can still be claimed a straggler is parked after tail_steps trips (the
+                // other waves have events to run).  Once the workgroup is draining its pool there is
+                // nothing to overlap with: marches run to their end, so that a ray's remaining bounces
+                // cost one round each instead of one round per parked trip.
+                if (exhausted && ++tail >= (have_rays ? tail_steps : drain_tail))
                 {
                     if (have)  // park the straggler: it resumes from (t, it) next round
                     {
@@ -728,8 +735,16 @@ static hipError_t launch_wf(const TraceArgs& args, int pool, int grid_blocks, ui
 }
 
 // threads: 1024 (one workgroup per CU) or 512 (two per CU, each with half the LDS)
-hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream)
+hipError_t launch_probe_trace_wf(const TraceArgs& args_in, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream)
 {
+    // rays per claim: small enough that a short launch (one rank's slab of a sharded grid) still gives
+    // every workgroup several claims, at most kWfChunk
+    TraceArgs args = args_in;
+    if (args.wf_chunk <= 0)
+    {
+        const uint32_t per_claim = args.n_rays / (static_cast<uint32_t>(grid_blocks > 0 ? grid_blocks : 1) * 8u);
+        args.wf_chunk = static_cast<int>(std::min<uint32_t>(kWfChunk, std::max<uint32_t>(256u, (per_claim + 63u) & ~63u)));
+    }
     if (threads == 512) return launch_wf<512, 2, false>(args, pool, grid_blocks, work_counter, stream);
     if (args.stats) return launch_wf<1024, 1, true>(args, pool, grid_blocks, work_counter, stream);
     return launch_wf<1024, 1, false>(args, pool, grid_blocks, work_counter, stream);

@@ -70,6 +70,8 @@ struct TraceArgs
     float4* wf_dir;       // wavefront kernel: per-slot accumulated direct light (only with > 1 light)
     int wf_tail;          // wavefront kernel: straggler steps after the march list is drained (0 = default)
     int wf_fetch;         // wavefront kernel: idle lanes that trigger a task fetch (0 = default)
+    int wf_drain;         // wavefront kernel: straggler trips while the pool drains (0 = default)
+    int wf_chunk;         // wavefront kernel: rays a workgroup claims at a time (set by the launcher)
     int ablate;           // profiling ablations (DDGI_ABLATE env, default 0 = exact): 1 constant albedo, 2 constant bounce direction
     // DDGI mode (ddgi != 0): rays are generated in the kernel (spherical Fibonacci set rotated by
     // rot, origin = probe position), the RNG seed is ray index ^ frame_key, and each ray writes

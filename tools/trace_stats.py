@@ -5,8 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ddgi_amd
 from bench import WORKLOAD as w
 
+world = int(os.environ.get("STATS_WORLD", "1"))   # STATS_WORLD=8: one rank's slab of the sharded grid
 eng = ddgi_amd.ProbeEngine(ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"]),
-                           ddgi_amd.make_settings(w["scene"], w["max_bounces"]))
+                           ddgi_amd.make_settings(w["scene"], w["max_bounces"]), rank=world // 2, world=world)
 if len(sys.argv) > 1 and sys.argv[1] == "ddgi":
     eng.set_mode(ddgi_amd.MODE_DDGI)
 else:
@@ -16,7 +17,7 @@ eng.trace_stats(True)
 eng.probe_update(); eng.synchronize()
 st = eng.trace_stats(False)
 ms = eng.last_update_ms()["trace_ms"]
-rays = eng.num_rays
+rays = eng.num_rays // world
 print(st, "kernel_ms", ms)
 cyc = [st[k] for k in ("cyc_scan", "cyc_march", "cyc_march_wait", "cyc_list", "cyc_events", "cyc_events_wait")]
 if sum(cyc):
