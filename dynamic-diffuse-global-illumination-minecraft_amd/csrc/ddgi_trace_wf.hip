@@ -201,6 +201,204 @@ DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contr
     return false;
 }
 
+// One event of pool slot `slot` in bucket b (ddgi_trace_wf.hip: shade_bucket): shades a finished march /
+// starts local ray r in an empty slot (b == kBucketRefill).  Returns true when the slot has a new march
+// posted (its state is in the pool arrays, its shading record stored); a finished ray has written its
+// output and left the slot empty.
+DDGI_D bool wf_event(const TraceArgs& A, const WfPool& P, uint32_t b, uint32_t slot, uint32_t r, bool r_valid)
+{
+    const GridK& G = A.grid;
+    const int rays_per_probe = G.s * G.s;
+    const float inf = __builtin_inff();
+    const bool multi_light = A.nl > 1;
+    bool posted = false;
+    if (b == kBucketRefill)
+    {
+        if (r_valid)
+        {
+            // local (y, zl, x) probe enumeration -> reference probe index p -> global ray index
+            const int pl = static_cast<int>(r / static_cast<uint32_t>(rays_per_probe));
+            const int i = static_cast<int>(r) - pl * rays_per_probe;
+            const int slab_row = G.czl * G.cx;
+            const int y = pl / slab_row;
+            const int rem = pl - y * slab_row;
+            const int p = y * G.cx * G.cz + G.z0 * G.cx + rem;
+            const uint32_t global_ray = static_cast<uint32_t>(p) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i);
+            f3 ray_o, ray_d;
+            WfCold c;
+            if (A.ddgi)
+            {
+                // in-kernel ray generation: probe position + rotated spherical Fibonacci direction
+                const int pxz = p - y * G.cx * G.cz;
+                ray_o = probe_position(G, pxz % G.cx, y, pxz / G.cx);
+                ray_d = fibonacci_dir(i, rays_per_probe, A.rot);
+                c.dst = ((static_cast<uint32_t>(pl) >> 3) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i)) * 8u + (static_cast<uint32_t>(pl) & 7u);  // record id (kRecGroup)
+                c.rng = wang_hash(global_ray ^ A.frame_key);
+            }
+            else
+            {
+                const float4* rec = A.rays + 3 * static_cast<size_t>(r);
+                const float4 ra = rec[0], rb = rec[1], rc = rec[2];
+                ray_o = mk3(ra.x, ra.y, ra.z);
+                ray_d = mk3(rb.x, rb.y, rb.z);
+                const int dst_probe = static_cast<int>(rc.x);  // int(probe_info.x), probe_pass.comp:269
+                c.dst = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.s + static_cast<int>(rc.y);
+                c.rng = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
+            }
+            c.cnt = 0u;
+            set3(c.col, mk3(0, 0, 0));
+            set3(c.hn, mk3(0, 0, 0));
+            wf_post_march(P, slot, c, ray_o, ray_d, false, A);
+            store_cold(P.cold + slot, c);
+            posted = true;
+        }
+    }
+    else
+    {
+        WfCold c = load_cold(P.cold + slot);
+        f3 mo = mk3(0, 0, 0), md = mk3(0, 0, 0);  // the march this event posts, if any
+        bool as_feeler = false;
+        const uint32_t fl = P.flags[slot];
+        const float t = P.t[slot], tl = P.tl[slot];
+        const f3 ro = ld3(P.ro, slot);
+        const bool block_wins = (fl & kFlagHit) && (t < tl);  // temp_isect.t < closest_t
+        const bool any_hit = block_wins || (tl < inf);       // closest_t < INF
+        if (b != kBucketFeeler)
+        {
+            const bool first_bounce = A.ddgi && (c.cnt & 255u) == 0u;
+            if (!any_hit)
+            {
+                if (first_bounce) wf_store_distance(A, c.dst, kMissDistance);
+                wf_finish_ray(P, slot, v3of(c.col), c.dst, A);  // probe_pass.comp:288-290 break
+            }
+            else
+            {
+                const f3 rd = v3of(c.hc);  // the ray direction as given (see WfCold::hc)
+                f3 nraw, hcol;
+                float th;
+                bool axis_normal = false;
+                if (block_wins)
+                {
+                    th = t;
+                    const f3 p = ray_at(ro, ld3(P.dn, slot), t);  // the march position at the hit
+                    const f3 cell = cell_id(p);
+                    const f3 centre = f3{cell.x - 0.5f, cell.y - 0.5f, cell.z - 0.5f};
+                    const f3 diff = normalize3(p - centre);
+                    // axis of the largest |component|, first wins on ties (:1075-1086)
+                    f3 n = mk3(0, 0, 0);
+                    float best = 0.0f;
+                    if (fabsf(diff.x) > best) { best = fabsf(diff.x); n = mk3(gl_sign(diff.x), 0, 0); }
+                    if (fabsf(diff.y) > best) { best = fabsf(diff.y); n = mk3(0, gl_sign(diff.y), 0); }
+                    if (fabsf(diff.z) > best) { best = fabsf(diff.z); n = mk3(0, 0, gl_sign(diff.z)); }
+                    // normalize(n) of a unit axis vector is n itself (1*(1/sqrt(1)) = 1, 0*1 = 0);
+                    // n stays (0,0,0) only if diff is NaN, where the reference yields NaN as well
+                    const f3 nn = best > 0.0f ? n : normalize3(n);
+                    const int type = static_cast<int>((fl >> 16) & 15u);
+                    hcol = (A.ablate & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
+                    nraw = nn;
+                    axis_normal = best > 0.0f;
+                }
+                else
+                {
+                    th = tl;
+                    const LightK& L = A.lights[static_cast<int>((fl >> 12) & 15u) - 1];
+                    const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
+                    nraw = ray_at((ro - lp) * 10.0f, rd * 10.0f, th);  // sphere-space position
+                    hcol = mk3(0, 0, 0);  // Q12: unassigned Material, pinned to zero
+                }
+                if (first_bounce) wf_store_distance(A, c.dst, th);  // Isect.t of the probe ray
+                const f3 hnrm = axis_normal ? nraw : normalize3(nraw);
+                const f3 hpos = ray_at(ro, rd, th) + hnrm * 0.001f;
+                set3(c.hn, hnrm);
+                const uint32_t cnt = c.cnt & 255u;  // light index 0, no visible light yet
+                if (A.nl > 0)
+                {
+                    const LightK& L = A.lights[0];
+                    const f3 to_light = normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos);
+                    // Dead-feeler elimination (single light): whatever the feeler finds, the hit's
+                    // direct light is scaled by lambert = clamp(dot(n, to_light), 0, 1)
+                    // (probe_pass.comp:194-204), so for lambert == 0 and a finite albedo every
+                    // outcome adds exactly +0 to the colour: skip the march and its event.
+                    const f3 nh = axis_normal ? hnrm : normalize3(hnrm);
+                    const bool finite_albedo = fabsf(hcol.x) < inf && fabsf(hcol.y) < inf && fabsf(hcol.z) < inf;
+                    set3(c.hc, hcol);
+                    if (A.nl == 1 && finite_albedo && dot3(nh, to_light) <= 0.0f && !(A.ablate & 4))
+                        posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
+                    else
+                    {
+                        c.cnt = cnt;
+                        if (multi_light) P.dirbuf[slot] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+                        mo = hpos, md = to_light;
+                        as_feeler = posted = true;
+                    }
+                }
+                else
+                {
+                    set3(c.hc, hcol);
+                    posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
+                }
+            }
+        }
+        else  // a light feeler came back: get_direct_lighting's loop body (probe_pass.comp:186-207)
+        {
+            const f3 hpos = ro;  // a feeler starts at the hit position
+            const f3 hnrm = v3of(c.hn), hcol = v3of(c.hc);
+            const uint32_t cnt = c.cnt;
+            int li = static_cast<int>((cnt >> 8) & 15u);
+            int nvis = static_cast<int>((cnt >> 12) & 15u);
+            f3 direct = mk3(0, 0, 0);
+            if (multi_light)
+            {
+                const float4 dv = P.dirbuf[slot];
+                direct = mk3(dv.x, dv.y, dv.z);
+            }
+            const LightK& L = A.lights[li];
+            const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
+            f3 contribution = mk3(0, 0, 0);
+            bool early = false;
+            if (any_hit)
+            {
+                const bool is_axis = (fabsf(hnrm.x) + fabsf(hnrm.y) + fabsf(hnrm.z) == 1.0f) &&
+                                     (fabsf(hnrm.x) == 1.0f || fabsf(hnrm.y) == 1.0f || fabsf(hnrm.z) == 1.0f);
+                const f3 nh = is_axis ? hnrm : normalize3(hnrm);  // identity for a unit axis vector
+                const float lambert = gl_clamp(dot3(nh, normalize3(lp - hpos)), 0.0f, 1.0f);
+                if (!block_wins)
+                {
+                    const float dist = length3(lp - hpos);
+                    const f3 lc{L.col[0], L.col[1], L.col[2]};
+                    direct = direct + div3((lc * lambert) * L.intensity, dist);
+                    nvis += 1;
+                }
+                else
+                {
+                    contribution = (hcol * 0.2f) * lambert;  // Q10 early return
+                    early = true;
+                }
+            }
+            li += 1;
+            if (!early && li < A.nl)
+            {
+                c.cnt = (cnt & 255u) | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
+                if (multi_light) P.dirbuf[slot] = float4{direct.x, direct.y, direct.z, 0.0f};
+                const LightK& Ln = A.lights[li];
+                mo = hpos, md = normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos);
+                as_feeler = posted = true;
+            }
+            else
+            {
+                if (!early && nvis != 0) contribution = div3(hcol * direct, static_cast<float>(nvis));
+                posted = wf_lighting_done(P, slot, c, contribution, hpos, hnrm, cnt, A, mo, md);
+            }
+        }
+        if (posted)
+        {
+            wf_post_march(P, slot, c, mo, md, as_feeler, A);
+            store_cold(P.cold + slot, c);  // the slot lives on: write its shading state back
+        }
+    }
+    return posted;
+}
+
 // T lanes per workgroup, kBlocksPerCU workgroups resident per CU (T * kBlocksPerCU = 1024 lanes = 4 waves/SIMD)
 template <int T, int kBlocksPerCU, bool kStats>
 __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(const TraceArgs A, const int pool_size, uint32_t* __restrict__ work_counter)
@@ -255,15 +453,6 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
     unsigned long long st_trips = 0, st_lane_steps = 0, st_groups = 0, st_lane_events = 0, st_iters = 0, st_fetches = 0;
     long long cy[6] = {0, 0, 0, 0, 0, 0};
     long long cy_bucket[kWfBuckets] = {};
-    long long cy_sec[12] = {};
-    long long sec_last = 0;
-#define WF_MARK(k)                                 \
-    if (kStats)                                    \
-    {                                              \
-        const long long now_ = clock64();          \
-        cy_sec[k] += now_ - sec_last;              \
-        sec_last = now_;                           \
-    }
     unsigned long long n_bucket[kWfBuckets] = {};
 
     for (uint32_t round = 0;; ++round)
@@ -340,7 +529,6 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
             const uint32_t e = (g - first) * 64u + lane;
             const bool valid = e < sh->bucket_count[b];
             const long long cg0 = kStats ? clock64() : 0;
-            sec_last = cg0;
             if (kStats)
             {
                 st_groups += 1;
@@ -351,202 +539,10 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
             if (valid)
             {
                 slot = P.event_list[sh->bucket_base[b] + e];
-                if (b == kBucketRefill)
-                {
-                    const uint32_t r = ray_cur + e;  // local ray index
-                    if (r < ray_end)
-                    {
-                        // local (y, zl, x) probe enumeration -> reference probe index p -> global ray index
-                        const int pl = static_cast<int>(r / static_cast<uint32_t>(rays_per_probe));
-                        const int i = static_cast<int>(r) - pl * rays_per_probe;
-                        const int slab_row = G.czl * G.cx;
-                        const int y = pl / slab_row;
-                        const int rem = pl - y * slab_row;
-                        const int p = y * G.cx * G.cz + G.z0 * G.cx + rem;
-                        const uint32_t global_ray = static_cast<uint32_t>(p) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i);
-                        f3 ray_o, ray_d;
-                        WfCold c;
-                        if (A.ddgi)
-                        {
-                            // in-kernel ray generation: probe position + rotated spherical Fibonacci direction
-                            const int pxz = p - y * G.cx * G.cz;
-                            ray_o = probe_position(G, pxz % G.cx, y, pxz / G.cx);
-                            ray_d = fibonacci_dir(i, rays_per_probe, A.rot);
-                            c.dst = ((static_cast<uint32_t>(pl) >> 3) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i)) * 8u + (static_cast<uint32_t>(pl) & 7u);  // record id (kRecGroup)
-                            c.rng = wang_hash(global_ray ^ A.frame_key);
-                        }
-                        else
-                        {
-                            const float4* rec = A.rays + 3 * static_cast<size_t>(r);
-                            const float4 ra = rec[0], rb = rec[1], rc = rec[2];
-                            ray_o = mk3(ra.x, ra.y, ra.z);
-                            ray_d = mk3(rb.x, rb.y, rb.z);
-                            const int dst_probe = static_cast<int>(rc.x);  // int(probe_info.x), probe_pass.comp:269
-                            c.dst = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.s + static_cast<int>(rc.y);
-                            c.rng = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
-                        }
-                        c.cnt = 0u;
-                        set3(c.col, mk3(0, 0, 0));
-                        set3(c.hn, mk3(0, 0, 0));
-                        wf_post_march(P, slot, c, ray_o, ray_d, false, A);
-                        store_cold(P.cold + slot, c);
-                        posted = true;
-                    }
-                }
-                else
-                {
-                    WfCold c = load_cold(P.cold + slot);
-                    f3 mo = mk3(0, 0, 0), md = mk3(0, 0, 0);  // the march this event posts, if any
-                    bool as_feeler = false;
-                    const uint32_t fl = P.flags[slot];
-                    const float t = P.t[slot], tl = P.tl[slot];
-                    const f3 ro = ld3(P.ro, slot);
-                    const bool block_wins = (fl & kFlagHit) && (t < tl);  // temp_isect.t < closest_t
-                    const bool any_hit = block_wins || (tl < inf);       // closest_t < INF
-                    WF_MARK(0)  // state loads
-                    if (b != kBucketFeeler)
-                    {
-                        const bool first_bounce = A.ddgi && (c.cnt & 255u) == 0u;
-                        if (!any_hit)
-                        {
-                            if (first_bounce) wf_store_distance(A, c.dst, kMissDistance);
-                            wf_finish_ray(P, slot, v3of(c.col), c.dst, A);  // probe_pass.comp:288-290 break
-                        }
-                        else
-                        {
-                            const f3 rd = v3of(c.hc);  // the ray direction as given (see WfCold::hc)
-                            f3 nraw, hcol;
-                            float th;
-                            bool axis_normal = false;
-                            if (block_wins)
-                            {
-                                th = t;
-                                const f3 p = ray_at(ro, ld3(P.dn, slot), t);  // the march position at the hit
-                                const f3 cell = cell_id(p);
-                                const f3 centre = f3{cell.x - 0.5f, cell.y - 0.5f, cell.z - 0.5f};
-                                const f3 diff = normalize3(p - centre);
-                                // axis of the largest |component|, first wins on ties (:1075-1086)
-                                f3 n = mk3(0, 0, 0);
-                                float best = 0.0f;
-                                if (fabsf(diff.x) > best) { best = fabsf(diff.x); n = mk3(gl_sign(diff.x), 0, 0); }
-                                if (fabsf(diff.y) > best) { best = fabsf(diff.y); n = mk3(0, gl_sign(diff.y), 0); }
-                                if (fabsf(diff.z) > best) { best = fabsf(diff.z); n = mk3(0, 0, gl_sign(diff.z)); }
-                                // normalize(n) of a unit axis vector is n itself (1*(1/sqrt(1)) = 1, 0*1 = 0);
-                                // n stays (0,0,0) only if diff is NaN, where the reference yields NaN as well
-                                const f3 nn = best > 0.0f ? n : normalize3(n);
-                                const int type = static_cast<int>((fl >> 16) & 15u);
-                                WF_MARK(1)  // block normal
-                                hcol = (A.ablate & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
-                                nraw = nn;
-                                axis_normal = best > 0.0f;
-                                WF_MARK(2)  // albedo
-                            }
-                            else
-                            {
-                                th = tl;
-                                const LightK& L = A.lights[static_cast<int>((fl >> 12) & 15u) - 1];
-                                const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
-                                nraw = ray_at((ro - lp) * 10.0f, rd * 10.0f, th);  // sphere-space position
-                                hcol = mk3(0, 0, 0);  // Q12: unassigned Material, pinned to zero
-                            }
-                            if (first_bounce) wf_store_distance(A, c.dst, th);  // Isect.t of the probe ray
-                            const f3 hnrm = axis_normal ? nraw : normalize3(nraw);
-                            const f3 hpos = ray_at(ro, rd, th) + hnrm * 0.001f;
-                            set3(c.hn, hnrm);
-                            const uint32_t cnt = c.cnt & 255u;  // light index 0, no visible light yet
-                            if (A.nl > 0)
-                            {
-                                const LightK& L = A.lights[0];
-                                const f3 to_light = normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos);
-                                // Dead-feeler elimination (single light): whatever the feeler finds, the hit's
-                                // direct light is scaled by lambert = clamp(dot(n, to_light), 0, 1)
-                                // (probe_pass.comp:194-204), so for lambert == 0 and a finite albedo every
-                                // outcome adds exactly +0 to the colour: skip the march and its event.
-                                const f3 nh = axis_normal ? hnrm : normalize3(hnrm);
-                                const bool finite_albedo = fabsf(hcol.x) < inf && fabsf(hcol.y) < inf && fabsf(hcol.z) < inf;
-                                WF_MARK(3)  // hit position, direction to the light
-                                set3(c.hc, hcol);
-                                if (A.nl == 1 && finite_albedo && dot3(nh, to_light) <= 0.0f && !(A.ablate & 4))
-                                    posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
-                                else
-                                {
-                                    c.cnt = cnt;
-                                    if (multi_light) P.dirbuf[slot] = float4{0.0f, 0.0f, 0.0f, 0.0f};
-                                    mo = hpos, md = to_light;
-                                    as_feeler = posted = true;
-                                }
-                            }
-                            else
-                            {
-                                set3(c.hc, hcol);
-                                posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
-                            }
-                        }
-                    }
-                    else  // a light feeler came back: get_direct_lighting's loop body (probe_pass.comp:186-207)
-                    {
-                        const f3 hpos = ro;  // a feeler starts at the hit position
-                        const f3 hnrm = v3of(c.hn), hcol = v3of(c.hc);
-                        const uint32_t cnt = c.cnt;
-                        int li = static_cast<int>((cnt >> 8) & 15u);
-                        int nvis = static_cast<int>((cnt >> 12) & 15u);
-                        f3 direct = mk3(0, 0, 0);
-                        if (multi_light)
-                        {
-                            const float4 dv = P.dirbuf[slot];
-                            direct = mk3(dv.x, dv.y, dv.z);
-                        }
-                        const LightK& L = A.lights[li];
-                        const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
-                        f3 contribution = mk3(0, 0, 0);
-                        bool early = false;
-                        if (any_hit)
-                        {
-                            const bool is_axis = (fabsf(hnrm.x) + fabsf(hnrm.y) + fabsf(hnrm.z) == 1.0f) &&
-                                                 (fabsf(hnrm.x) == 1.0f || fabsf(hnrm.y) == 1.0f || fabsf(hnrm.z) == 1.0f);
-                            const f3 nh = is_axis ? hnrm : normalize3(hnrm);  // identity for a unit axis vector
-                            const float lambert = gl_clamp(dot3(nh, normalize3(lp - hpos)), 0.0f, 1.0f);
-                            if (!block_wins)
-                            {
-                                const float dist = length3(lp - hpos);
-                                const f3 lc{L.col[0], L.col[1], L.col[2]};
-                                direct = direct + div3((lc * lambert) * L.intensity, dist);
-                                nvis += 1;
-                            }
-                            else
-                            {
-                                contribution = (hcol * 0.2f) * lambert;  // Q10 early return
-                                early = true;
-                            }
-                        }
-                        li += 1;
-                        WF_MARK(5)  // feeler result
-                        if (!early && li < A.nl)
-                        {
-                            c.cnt = (cnt & 255u) | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
-                            if (multi_light) P.dirbuf[slot] = float4{direct.x, direct.y, direct.z, 0.0f};
-                            const LightK& Ln = A.lights[li];
-                            mo = hpos, md = normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos);
-                            as_feeler = posted = true;
-                        }
-                        else
-                        {
-                            if (!early && nvis != 0) contribution = div3(hcol * direct, static_cast<float>(nvis));
-                            posted = wf_lighting_done(P, slot, c, contribution, hpos, hnrm, cnt, A, mo, md);
-                        }
-                    }
-                    WF_MARK(4)  // bounce: accumulate, hemisphere direction
-                    if (posted)
-                    {
-                        wf_post_march(P, slot, c, mo, md, as_feeler, A);
-                        WF_MARK(6)  // march set-up
-                        store_cold(P.cold + slot, c);  // the slot lives on: write its shading state back
-                    }
-                }
+                posted = wf_event(A, P, b, slot, ray_cur + e, ray_cur + e < ray_end);
             }
             const uint32_t at = wave_append(posted, &sh->n_march[cur_list], lane);
             if (posted) (P.march_list[0] + cur_list * PS)[at] = static_cast<uint16_t>(slot);
-            WF_MARK(7)  // record store, list append
             if (kStats)
             {
                 const long long dt = clock64() - cg0;
@@ -689,7 +685,6 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
         if (wave == 0) atomicAdd(&A.stats[5], st_iters);
         atomicAdd(&A.stats[6], st_fetches);
         for (int k = 0; k < 6; ++k) atomicAdd(&A.stats[8 + k], static_cast<unsigned long long>(cy[k]));
-        for (int k = 0; k < 12; ++k) atomicAdd(&A.stats[32 + k], static_cast<unsigned long long>(cy_sec[k]));
         for (int k = 0; k < kWfBuckets; ++k)
         {
             atomicAdd(&A.stats[16 + k], static_cast<unsigned long long>(cy_bucket[k]));

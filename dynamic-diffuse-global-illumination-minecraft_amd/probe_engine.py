@@ -369,7 +369,6 @@ class ProbeEngine:
         st = dict(zip(keys, (int(v) for v in out[:14])))
         st["bucket_cycles"] = [int(v) for v in out[16:23]]   # event groups by bucket (ddgi_trace_wf.hip: shade_bucket)
         st["bucket_groups"] = [int(v) for v in out[24:31]]
-        st["section_cycles"] = [int(v) for v in out[32:44]]  # event code sections (WF_MARK in ddgi_trace_wf.hip)
         return st
 
     # -- outputs -------------------------------------------------------------------------------

@@ -186,8 +186,7 @@ int ddgi_update_history_ms(ddgi_handle h, float* trace_ms, float* blend_ms, int 
  * utilisation counters accumulated since the last call: out64 = {march-loop trips summed over
  * waves, lane-steps, event groups, lane-events, waves, rounds, task fetches, 0, shader-clock
  * cycles per phase (scan, march, march barrier, list, events, events barrier), 0, 0,
- * [16..22] cycles per event bucket, 0, [24..30] event groups per bucket, 0,
- * [32..43] cycles per event code section, 0 ...}.
+ * [16..22] cycles per event bucket, 0, [24..30] event groups per bucket, 0, reserved ...}.
  * Synchronises. */
 int ddgi_trace_stats(ddgi_handle h, int enable, unsigned long long* out64);
 

@@ -30,7 +30,3 @@ names = ("stem", "wall", "ground/moss/mold", "caps+flat", "light-or-miss", "feel
 tot = sum(st["bucket_cycles"]) or 1
 for nm, cyc, n in zip(names, st["bucket_cycles"], st["bucket_groups"]):
     print("  bucket %-18s groups %8d  cycles/group %8.0f  share of event time %.3f" % (nm, n, cyc / max(n, 1), cyc / tot))
-secs = ("state loads", "block normal", "albedo", "hit pos + to-light", "bounce (hemisphere)", "feeler result", "march set-up", "store + append")
-tot = sum(st["section_cycles"]) or 1
-for nm, cyc in zip(secs, st["section_cycles"]):
-    print("  section %-22s share of event time %.3f" % (nm, cyc / tot))
