@@ -23,6 +23,8 @@ hipError_t trace_kernel_occupancy(int* blocks_per_cu, size_t lds_bytes);
 int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads);
 hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream);
 hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t stream);
+int aq_pool_size(int nwords, size_t lds_limit);
+hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, hipStream_t stream);
 size_t blend_weights_floats(int n);
 size_t blend_record_groups(uint32_t n_local_probes);
 hipError_t launch_carry_tiles(void* dst, const void* src, const int32_t* map, uint32_t n_probes, uint32_t words_per_tile, hipStream_t stream);
@@ -604,6 +606,9 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     const int wf_blocks_per_cu = 1024 / wf_threads;
     int pool = (force_lane || a.max_bounces < 1) ? 0 : wf_pool_size(a.scene.nwords, a.nl > 1, 160 * 1024 / wf_blocks_per_cu, wf_threads);
     if (const char* v = std::getenv("DDGI_WF_POOL")) pool = pool ? std::min(pool, std::max(wf_threads, std::atoi(v) / 64 * 64)) : 0;
+    // DDGI_TRACE_KERNEL=async: the barrier-free queue variant (k_probe_trace_aq)
+    const bool use_async = pool > 0 && kernel_env && std::strcmp(kernel_env, "async") == 0 && aq_pool_size(a.scene.nwords, 160 * 1024) > 0;
+    if (use_async) pool = aq_pool_size(a.scene.nwords, 160 * 1024);
 
     hipEvent_t* ev = e->ev[e->updates % ddgi_engine::kRing];
     if (pool > 0)
@@ -634,7 +639,14 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         a.wf_cold = e->d_wf_cold;
         a.wf_dir = e->d_wf_dir;
         HIP_TRY(hipEventRecord(ev[0], e->stream));
-        HIP_TRY(launch_probe_trace_wf(a, wf_threads, pool, static_cast<int>(grid), e->d_work, e->stream));
+        if (use_async)
+        {
+            int march_waves = 8;
+            if (const char* v = std::getenv("DDGI_AQ_MARCH")) march_waves = std::min(15, std::max(1, std::atoi(v)));
+            HIP_TRY(launch_probe_trace_aq(a, pool, static_cast<int>(grid), march_waves, e->d_work, e->stream));
+        }
+        else
+            HIP_TRY(launch_probe_trace_wf(a, wf_threads, pool, static_cast<int>(grid), e->d_work, e->stream));
     }
     else
     {

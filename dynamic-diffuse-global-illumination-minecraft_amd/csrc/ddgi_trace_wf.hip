@@ -695,6 +695,318 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
 
 // ---- launchers (called from ddgi_engine.cpp) -----------------------------------------------------
 
+// =================================================================================================
+// k_probe_trace_aq — the same pool, marches and events WITHOUT rounds: no workgroup barrier after
+// start-up.  Slots travel through LDS queues (rings of 16-bit slot ids; a slot is in at most one
+// queue, every ring holds kAqCap >= pool entries, so a ring never overflows):
+//     FQ free slots -> (refill event) -> MQ marches -> (march waves) -> EQ[bucket] -> (event waves) -> MQ | FQ
+// The workgroup's first `march_waves` waves only march: a lane takes a march from MQ whenever it is
+// idle, runs it in 16-step bursts to its end (nothing is ever parked) and pushes the slot to the event
+// queue of its block-type bucket.  The other waves only run events: a full 64-lane group of one bucket
+// if any queue holds 64, else a refill (64 new rays into free slots), else the fullest partial group.
+// Every ray proceeds at its own pace: a round no longer lasts as long as its slowest member, and the
+// pool drains without barrier-bound near-empty rounds.
+// Ring protocol: producers reserve indices with one wave-aggregated atomic add on `tail` and then
+// write the entries; consumers claim indices below `tail` with a compare-and-swap on `head`, wait for
+// the entry to become valid (!= 0xffff) and invalidate it.
+// =================================================================================================
+constexpr uint32_t kAqCap = 2048, kAqMask = kAqCap - 1;
+constexpr int kAqEventQueues = 6;  // buckets 0..5 (kBucketRefill is served from FQ)
+
+struct AqShared  // control block at the start of dynamic LDS (32 dwords)
+{
+    uint32_t mq_head, mq_tail;
+    uint32_t fq_head, fq_tail;
+    uint32_t eq_head[kAqEventQueues], eq_tail[kAqEventQueues];
+    uint32_t live;     // rays in flight (claimed and not yet finished)
+    uint32_t no_more;  // the launch's ray counter is used up
+    uint32_t abort;    // safety net tripped: every wave leaves
+    uint32_t pad[32 - 4 - 2 * kAqEventQueues - 3];
+};
+static_assert(sizeof(AqShared) == 32 * 4, "control block is 32 dwords");
+
+DDGI_D uint32_t aq_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// One lane: claims up to `want` entries of a ring; returns the count, base = first claimed index.
+DDGI_D uint32_t aq_claim(uint32_t* head, const uint32_t* tail, uint32_t want, uint32_t& base)
+{
+    for (int tries = 0; tries < 1024; ++tries)
+    {
+        const uint32_t h = aq_load(head), t = aq_load(tail);
+        const uint32_t avail = t - h;
+        const uint32_t k = avail < want ? avail : want;
+        base = h;
+        if (k == 0u || static_cast<int32_t>(avail) < 0) return 0u;
+        if (atomicCAS(head, h, h + k) == h) return k;
+    }
+    return 0u;
+}
+
+// Reads (and invalidates) ring entry idx; waits until its producer has written it.
+DDGI_D uint32_t aq_take(uint16_t* ring, uint32_t idx, uint32_t* abort)
+{
+    volatile uint16_t* p = ring + (idx & kAqMask);
+    uint32_t v = *p;
+    for (int spins = 0; v == 0xffffu; ++spins)
+    {
+        if (spins > (1 << 22))
+        {
+            *abort = 1u;
+            return 0u;
+        }
+        v = *p;
+    }
+    *p = 0xffffu;
+    return v;
+}
+
+// Every lane with pred appends `value` to a ring.
+DDGI_D void aq_push(uint16_t* ring, uint32_t* tail, bool pred, uint32_t value, int lane)
+{
+    const uint32_t at = wave_append(pred, tail, lane);
+    if (pred) ring[at & kAqMask] = static_cast<uint16_t>(value);
+}
+
+__global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, const int pool_size, const int march_waves, uint32_t* __restrict__ work_counter)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t wf_lds[];
+    constexpr int T = 1024;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint32_t PS = static_cast<uint32_t>(pool_size);
+    const int fetch_lanes = A.wf_fetch > 0 ? A.wf_fetch : kWfFetchLanes;
+
+    // ---- carve LDS: control block | occupancy bitmap | pool arrays | rings ----
+    AqShared* sh = reinterpret_cast<AqShared*>(wf_lds);
+    uint32_t* s_bits = wf_lds + 32;
+    uint32_t* cursor = s_bits + ((A.scene.nwords + 3) & ~3);
+    WfPool P;
+    auto takef = [&]() { float* p = reinterpret_cast<float*>(cursor); cursor += PS; return p; };
+    auto takeu = [&]() { uint32_t* p = cursor; cursor += PS; return p; };
+    for (int a = 0; a < 3; ++a) P.ro[a] = takef();
+    for (int a = 0; a < 3; ++a) P.dn[a] = takef();
+    P.t = takef();
+    P.tl = takef();
+    P.flags = takeu();
+    P.cold = static_cast<WfCold*>(A.wf_cold) + static_cast<size_t>(blockIdx.x) * PS;
+    P.dirbuf = A.nl > 1 ? A.wf_dir + static_cast<size_t>(blockIdx.x) * PS : nullptr;
+    P.march_list[0] = P.march_list[1] = P.event_list = nullptr;
+    uint16_t* ring_mq = reinterpret_cast<uint16_t*>(cursor);
+    uint16_t* ring_fq = ring_mq + kAqCap;
+    uint16_t* ring_eq = ring_fq + kAqCap;  // kAqEventQueues rings
+
+    for (int i = tid; i < A.scene.nwords; i += T) s_bits[i] = A.scene.bits[i];
+    for (uint32_t i = tid; i < PS; i += T) P.flags[i] = kSlotEmpty;
+    for (uint32_t i = tid; i < kAqCap * (2 + kAqEventQueues); i += T) ring_mq[i] = 0xffffu;
+    __syncthreads();
+    for (uint32_t i = tid; i < PS; i += T) ring_fq[i] = static_cast<uint16_t>(i);  // every slot starts free
+    if (tid < 32) wf_lds[tid] = 0u;
+    __syncthreads();
+    if (tid == 0) sh->fq_tail = PS;
+    __syncthreads();
+
+    const float inf = __builtin_inff();
+    unsigned long long guard = 0;  // safety net: never spin forever on the GPU
+
+    if (wave < march_waves)
+    {
+        // ================= march waves =================
+        March m;
+        m.ro = m.rd = m.dn = m.inv = m.cc = m.p = mk3(0, 0, 0);
+        m.t = 0.0f, m.tl = inf, m.it = 0, m.lid = -1, m.cell = 0;
+        uint32_t slot = 0, fl = 0;
+        f3 hi_v = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
+        asm volatile("" : "+v"(hi_v.x), "+v"(hi_v.y), "+v"(hi_v.z));
+        bool have = false;
+        int trips = 0;
+        for (;;)
+        {
+            if (++guard > (1ull << 24)) sh->abort = 1u;
+            const unsigned long long idle_mask = __ballot(!have);
+            const int n_idle = __popcll(idle_mask);
+            if (n_idle >= fetch_lanes)
+            {
+                uint32_t base = 0, k = 0;
+                if (lane == 0) k = aq_claim(&sh->mq_head, &sh->mq_tail, static_cast<uint32_t>(n_idle), base);
+                k = __shfl(k, 0), base = __shfl(base, 0);
+                const uint32_t rank = static_cast<uint32_t>(__popcll(idle_mask & ((1ull << lane) - 1ull)));
+                if (!have && rank < k)
+                {
+                    slot = aq_take(ring_mq, base + rank, &sh->abort);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    fl = P.flags[slot];
+                    m.ro = ld3(P.ro, slot);
+                    m.dn = ld3(P.dn, slot);
+                    m.inv = f3{axis_inv(m.dn.x), axis_inv(m.dn.y), axis_inv(m.dn.z)};  // P5; recomputed, not stored
+                    m.t = P.t[slot];
+                    m.tl = P.tl[slot];
+                    m.it = static_cast<int>((fl >> 4) & 255u);
+                    m.cc = f3{m.dn.x >= 0.0f ? 1.0f : 0.0f, m.dn.y >= 0.0f ? 1.0f : 0.0f, m.dn.z >= 0.0f ? 1.0f : 0.0f};
+                    m.p = ray_at(m.ro, m.dn, m.t);
+                    have = true;
+                }
+            }
+            if (__ballot(have) == 0ull)
+            {
+                if ((aq_load(&sh->no_more) != 0u && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            bool finished = false;
+            uint32_t bucket = 0;
+            if (have)
+            {
+                const int left = kMarchIters - m.it;
+                bool occ = march_step_burst(m, A.scene, s_bits, hi_v);
+                bool fin = occ | (m.t >= m.tl) | (left <= 1);
+#pragma unroll
+                for (int sub = 1; sub < kWfStepsPerTrip; ++sub)
+                    if (!fin)
+                    {
+                        occ = march_step_burst(m, A.scene, s_bits, hi_v);
+                        fin = occ | (m.t >= m.tl) | (left <= sub + 1);
+                    }
+                m.it += kWfStepsPerTrip;
+                if (!fin && ((trips & 3) == 3)) fin = march_escaped(m, A.scene);
+                if (fin)
+                {
+                    const uint32_t type = occ ? static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)) : 0u;
+                    P.t[slot] = m.t;
+                    P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | (occ ? kFlagHit : 0u) | (type << 16);
+                    const bool block_wins = occ && (m.t < m.tl);
+                    bucket = (fl & kFlagFeeler) ? kBucketFeeler : (block_wins ? shade_bucket(static_cast<int>(type)) : kBucketNoBlock);
+                    have = false;
+                    finished = true;
+                }
+            }
+            ++trips;
+            if (__ballot(finished) != 0ull)
+            {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#pragma unroll
+                for (uint32_t b = 0; b < static_cast<uint32_t>(kAqEventQueues); ++b) aq_push(ring_eq + b * kAqCap, &sh->eq_tail[b], finished && bucket == b, slot, lane);
+            }
+        }
+    }
+    else
+    {
+        // ================= event waves =================
+        for (;;)
+        {
+            if (++guard > (1ull << 24)) sh->abort = 1u;
+            uint32_t b = 0, base = 0, k = 0;
+            if (lane == 0)
+            {
+                // 1) a full group, dearest bucket first
+                for (uint32_t bb = 0; bb < static_cast<uint32_t>(kAqEventQueues) && k == 0u; ++bb)
+                    if (aq_load(&sh->eq_tail[bb]) - aq_load(&sh->eq_head[bb]) >= 64u)
+                    {
+                        k = aq_claim(&sh->eq_head[bb], &sh->eq_tail[bb], 64u, base);
+                        b = bb;
+                    }
+                // 2) new rays into free slots
+                if (k == 0u && aq_load(&sh->no_more) == 0u)
+                {
+                    k = aq_claim(&sh->fq_head, &sh->fq_tail, 64u, base);
+                    b = kBucketRefill;
+                }
+                // 3) the fullest partial group
+                if (k == 0u)
+                {
+                    uint32_t best = 0, best_n = 0;
+                    for (uint32_t bb = 0; bb < static_cast<uint32_t>(kAqEventQueues); ++bb)
+                    {
+                        const uint32_t n = aq_load(&sh->eq_tail[bb]) - aq_load(&sh->eq_head[bb]);
+                        if (n > best_n && n <= kAqCap) best = bb, best_n = n;
+                    }
+                    if (best_n > 0u)
+                    {
+                        k = aq_claim(&sh->eq_head[best], &sh->eq_tail[best], 64u, base);
+                        b = best;
+                    }
+                }
+            }
+            k = __shfl(k, 0), b = __shfl(b, 0), base = __shfl(base, 0);
+            if (k == 0u)
+            {
+                if ((aq_load(&sh->no_more) != 0u && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            const bool valid = static_cast<uint32_t>(lane) < k;
+            uint32_t slot = 0;
+            bool posted = false, freed = false;
+            if (b == kBucketRefill)
+            {
+                // k free slots: claim k rays of the launch for them
+                uint32_t rbase = 0;
+                if (lane == 0)
+                {
+                    atomicAdd(&sh->live, k);  // counted before they exist, so that `live` never reads 0 early
+                    rbase = atomicAdd(work_counter, k);
+                }
+                rbase = __shfl(rbase, 0);
+                const uint32_t r = rbase + static_cast<uint32_t>(lane);
+                const bool r_valid = valid && r < A.n_rays;
+                if (valid) slot = aq_take(ring_fq, base + lane, &sh->abort);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (r_valid) posted = wf_event(A, P, kBucketRefill, slot, r, true);
+                freed = valid && !r_valid;  // more slots than rays left: hand them back
+                const uint32_t n_back = static_cast<uint32_t>(__popcll(__ballot(freed)));
+                if (lane == 0)
+                {
+                    if (n_back) atomicSub(&sh->live, n_back);
+                    if (rbase + k >= A.n_rays) __hip_atomic_store(&sh->no_more, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            else
+            {
+                if (valid)
+                {
+                    slot = aq_take(ring_eq + b * kAqCap, base + lane, &sh->abort);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    posted = wf_event(A, P, b, slot, 0u, false);
+                    freed = !posted;  // the ray is finished: its output is written, the slot is empty
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            aq_push(ring_mq, &sh->mq_tail, posted, slot, lane);
+            aq_push(ring_fq, &sh->fq_tail, freed, slot, lane);
+            if (b != kBucketRefill)
+            {
+                const uint32_t n_done = static_cast<uint32_t>(__popcll(__ballot(freed)));
+                if (lane == 0 && n_done) atomicSub(&sh->live, n_done);
+            }
+        }
+    }
+}
+
+static size_t aq_lds_bytes(int nwords, int pool) { return (32 + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * 9 * 4 + kAqCap * 2 * (2 + kAqEventQueues) + 16; }
+
+int aq_pool_size(int nwords, size_t lds_limit)
+{
+    int pool = static_cast<int>(kAqCap);
+    while (pool >= 1024 && aq_lds_bytes(nwords, pool) > lds_limit) pool -= 64;
+    return pool >= 1024 ? pool : 0;
+}
+
+hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, hipStream_t stream)
+{
+    const size_t lds = aq_lds_bytes(args.scene.nwords, pool);
+    static bool attr_set = false;
+    if (!attr_set)
+    {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_aq), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_probe_trace_aq, dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter);
+    return hipGetLastError();
+}
+
 // LDS bytes of k_probe_trace_wf for a pool of `pool` rays
 static size_t wf_lds_bytes(int nwords, int pool, bool multi_light)
 {
