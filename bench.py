@@ -214,7 +214,7 @@ def main():
             "parallelism": f"zslab{world}" + ("+allgather" if world > 1 else ""),
         },
         "roofline": {
-            "kernel": "k_probe_trace_ref" if os.environ.get("DDGI_TRACE_KERNEL") == "lane" else "k_probe_trace_wf",
+            "kernel": {"lane": "k_probe_trace_ref", "rounds": "k_probe_trace_wf"}.get(os.environ.get("DDGI_TRACE_KERNEL", ""), "k_probe_trace_aq"),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

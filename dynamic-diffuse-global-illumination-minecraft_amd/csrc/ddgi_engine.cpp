@@ -24,7 +24,7 @@ int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads);
 hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream);
 hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t stream);
 int aq_pool_size(int nwords, size_t lds_limit);
-hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, hipStream_t stream);
+hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream);
 size_t blend_weights_floats(int n);
 size_t blend_record_groups(uint32_t n_local_probes);
 hipError_t launch_carry_tiles(void* dst, const void* src, const int32_t* map, uint32_t n_probes, uint32_t words_per_tile, hipStream_t stream);
@@ -157,6 +157,8 @@ static int validate_config(const ddgi_irradiance_field* f, const ddgi_render_set
         return fail(DDGI_ERR_INVALID_ARGUMENT, "probe_count.z = %d is not divisible by world = %d", f->probe_count[2], world);
     return DDGI_OK;
 }
+
+static int check_kernel_status(ddgi_engine* e);
 
 static int alloc_textures(ddgi_engine* e)
 {
@@ -606,14 +608,20 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     const int wf_blocks_per_cu = 1024 / wf_threads;
     int pool = (force_lane || a.max_bounces < 1) ? 0 : wf_pool_size(a.scene.nwords, a.nl > 1, 160 * 1024 / wf_blocks_per_cu, wf_threads);
     if (const char* v = std::getenv("DDGI_WF_POOL")) pool = pool ? std::min(pool, std::max(wf_threads, std::atoi(v) / 64 * 64)) : 0;
-    // DDGI_TRACE_KERNEL=async: the barrier-free queue variant (k_probe_trace_aq)
-    const bool use_async = pool > 0 && kernel_env && std::strcmp(kernel_env, "async") == 0 && aq_pool_size(a.scene.nwords, 160 * 1024) > 0;
+    // the barrier-free queue kernel (k_probe_trace_aq) whenever its pool fits; DDGI_TRACE_KERNEL=rounds asks
+    // for the round-based k_probe_trace_wf (cross-check), which also serves the utilisation counters
+    const bool force_rounds = (kernel_env && std::strcmp(kernel_env, "rounds") == 0) || a.stats != nullptr || wf_threads != 1024;
+    const bool use_async = pool > 0 && !force_rounds && aq_pool_size(a.scene.nwords, 160 * 1024) > 0;
     if (use_async) pool = aq_pool_size(a.scene.nwords, 160 * 1024);
 
     hipEvent_t* ev = e->ev[e->updates % ddgi_engine::kRing];
     if (pool > 0)
     {
-        if (!e->d_work) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_work), sizeof(uint32_t)));
+        if (!e->d_work)
+        {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_work), 2 * sizeof(uint32_t)));  // [0] ray counter, [1] kernel status
+            HIP_TRY(hipMemsetAsync(e->d_work, 0, 2 * sizeof(uint32_t), e->stream));
+        }
         // one persistent workgroup per CU unless the launch is tiny (the launcher sizes the ray claims
         // so that every workgroup gets several: launch_probe_trace_wf)
         const uint32_t chunks = (a.n_rays + 255u) / 256u;
@@ -641,9 +649,9 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         HIP_TRY(hipEventRecord(ev[0], e->stream));
         if (use_async)
         {
-            int march_waves = 8;
+            int march_waves = 8;  // of 16: stepping and shading are about half of the work each (C3: 6: 4.17 ms, 7: 3.38, 8: 3.39, 9: 3.87)
             if (const char* v = std::getenv("DDGI_AQ_MARCH")) march_waves = std::min(15, std::max(1, std::atoi(v)));
-            HIP_TRY(launch_probe_trace_aq(a, pool, static_cast<int>(grid), march_waves, e->d_work, e->stream));
+            HIP_TRY(launch_probe_trace_aq(a, pool, static_cast<int>(grid), march_waves, e->d_work, e->d_work + 1, e->stream));
         }
         else
             HIP_TRY(launch_probe_trace_wf(a, wf_threads, pool, static_cast<int>(grid), e->d_work, e->stream));
@@ -693,12 +701,23 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     return DDGI_OK;
 }
 
+// After a stream synchronisation: did a trace kernel trip its safety net (k_probe_trace_aq: a queue wait
+// that never ended)?  Then the textures are not valid — say so instead of returning them.
+static int check_kernel_status(ddgi_engine* e)
+{
+    if (!e->d_work) return DDGI_OK;
+    uint32_t status = 0;
+    HIP_TRY(hipMemcpy(&status, e->d_work + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (status != 0) return fail(DDGI_ERR_HIP, "the trace kernel aborted (status %u): the probe textures are not valid", status);
+    return DDGI_OK;
+}
+
 int ddgi_synchronize(ddgi_handle e)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    return DDGI_OK;
+    return check_kernel_status(e);
 }
 
 int ddgi_last_update_ms(ddgi_handle e, float* trace_ms, float* blend_ms, float* total_ms)
@@ -773,6 +792,7 @@ int ddgi_read_textures(ddgi_handle e, uint8_t* albedo, uint8_t* distance)
         if (!outs[t]) continue;
         HIP_TRY(hipMemcpyAsync(slab.data(), e->tex[t], e->tex_bytes[t], hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
+        if (int rc = check_kernel_status(e)) return rc;
         uint32_t* raster = reinterpret_cast<uint32_t*>(outs[t]);
         // slab-major [z][y][x][ty][tx] -> reference raster: tile of probe p at ((p mod cx*cz)*s, (p div cx*cz)*s)
         for (int z = 0; z < g.cz; ++z)
@@ -803,6 +823,7 @@ int ddgi_read_tiles(ddgi_handle e, float* irradiance, float* depth)
         std::vector<float> slab(e->tex_bytes[t] / sizeof(float));
         HIP_TRY(hipMemcpyAsync(slab.data(), e->tex[t], e->tex_bytes[t], hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
+        if (int rc = check_kernel_status(e)) return rc;
         // slab-major [z][y][x] -> reference probe order p = y*cx*cz + z*cx + x
         for (int z = 0; z < g.cz; ++z)
             for (int y = 0; y < g.cy; ++y)

@@ -767,7 +767,8 @@ DDGI_D void aq_push(uint16_t* ring, uint32_t* tail, bool pred, uint32_t value, i
     if (pred) ring[at & kAqMask] = static_cast<uint16_t>(value);
 }
 
-__global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, const int pool_size, const int march_waves, uint32_t* __restrict__ work_counter)
+__global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, const int pool_size, const int march_waves, uint32_t* __restrict__ work_counter,
+                                                            uint32_t* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t wf_lds[];
     constexpr int T = 1024;
@@ -980,6 +981,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             }
         }
     }
+    if (status && lane == 0 && aq_load(&sh->abort) != 0u) atomicOr(status, 1u);  // the safety net tripped: the output is not valid
 }
 
 static size_t aq_lds_bytes(int nwords, int pool) { return (32 + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * 9 * 4 + kAqCap * 2 * (2 + kAqEventQueues) + 16; }
@@ -991,7 +993,7 @@ int aq_pool_size(int nwords, size_t lds_limit)
     return pool >= 1024 ? pool : 0;
 }
 
-hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, hipStream_t stream)
+hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
 {
     const size_t lds = aq_lds_bytes(args.scene.nwords, pool);
     static bool attr_set = false;
@@ -1003,7 +1005,7 @@ hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_block
     }
     hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_probe_trace_aq, dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter);
+    hipLaunchKernelGGL(k_probe_trace_aq, dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter, status);
     return hipGetLastError();
 }
 
