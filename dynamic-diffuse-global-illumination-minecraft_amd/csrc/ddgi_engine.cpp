@@ -612,7 +612,11 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     // for the round-based k_probe_trace_wf (cross-check), which also serves the utilisation counters
     const bool force_rounds = (kernel_env && std::strcmp(kernel_env, "rounds") == 0) || a.stats != nullptr || wf_threads != 1024;
     const bool use_async = pool > 0 && !force_rounds && aq_pool_size(a.scene.nwords, 160 * 1024) > 0;
-    if (use_async) pool = aq_pool_size(a.scene.nwords, 160 * 1024);
+    if (use_async)
+    {
+        pool = std::min(1536, aq_pool_size(a.scene.nwords, 160 * 1024));  // more slots than ~1300 buy nothing (C3: 1024: 3.64 ms, 1280: 3.36, 1536: 3.35, 2048: 3.39)
+        if (const char* v = std::getenv("DDGI_AQ_POOL")) pool = std::min(aq_pool_size(a.scene.nwords, 160 * 1024), std::max(1024, std::atoi(v) / 64 * 64));
+    }
 
     hipEvent_t* ev = e->ev[e->updates % ddgi_engine::kRing];
     if (pool > 0)

@@ -31,6 +31,10 @@
 namespace ddgi {
 
 constexpr int kWfStepsPerTrip = 16;  // voxel steps per march-loop trip (burst)
+#ifndef DDGI_AQ_STEPS
+#define DDGI_AQ_STEPS 16
+#endif
+constexpr int kAqStepsPerTrip = DDGI_AQ_STEPS;  // the same for k_probe_trace_aq
 constexpr int kWfTailSteps = 1;          // straggler trips (bursts) after the march list is drained
 constexpr int kWfDrainTail = 8;      // straggler trips once no new ray can be claimed (8 x 16 steps >= kMarchIters)
 constexpr int kWfFetchLanes = 8;     // pull new march tasks once this many lanes are idle
@@ -862,13 +866,13 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 bool occ = march_step_burst(m, A.scene, s_bits, hi_v);
                 bool fin = occ | (m.t >= m.tl) | (left <= 1);
 #pragma unroll
-                for (int sub = 1; sub < kWfStepsPerTrip; ++sub)
+                for (int sub = 1; sub < kAqStepsPerTrip; ++sub)
                     if (!fin)
                     {
                         occ = march_step_burst(m, A.scene, s_bits, hi_v);
                         fin = occ | (m.t >= m.tl) | (left <= sub + 1);
                     }
-                m.it += kWfStepsPerTrip;
+                m.it += kAqStepsPerTrip;
                 if (!fin && ((trips & 3) == 3)) fin = march_escaped(m, A.scene);
                 if (fin)
                 {
@@ -896,42 +900,51 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
         for (;;)
         {
             if (++guard > (1ull << 24)) sh->abort = 1u;
+            // Which group?  Lanes 0..5 look at one event queue each (polling is paid in VALU issue slots that
+            // the marching waves of the same SIMD want, so it is kept to a handful of instructions).
             uint32_t b = 0, base = 0, k = 0;
-            if (lane == 0)
+            uint32_t avail = 0;
+            if (lane < kAqEventQueues) avail = aq_load(&sh->eq_tail[lane]) - aq_load(&sh->eq_head[lane]);
+            if (avail > kAqCap) avail = 0;  // a claim in flight can make tail - head wrap for an instant
+            const unsigned long long full = __ballot(avail >= 64u);
+            const bool no_more = aq_load(&sh->no_more) != 0u;
+            if (full != 0ull)
             {
                 // 1) a full group, dearest bucket first
-                for (uint32_t bb = 0; bb < static_cast<uint32_t>(kAqEventQueues) && k == 0u; ++bb)
-                    if (aq_load(&sh->eq_tail[bb]) - aq_load(&sh->eq_head[bb]) >= 64u)
-                    {
-                        k = aq_claim(&sh->eq_head[bb], &sh->eq_tail[bb], 64u, base);
-                        b = bb;
-                    }
+                b = static_cast<uint32_t>(__ffsll(static_cast<long long>(full)) - 1);
+                if (lane == 0) k = aq_claim(&sh->eq_head[b], &sh->eq_tail[b], 64u, base);
+            }
+            else
+            {
                 // 2) new rays into free slots
-                if (k == 0u && aq_load(&sh->no_more) == 0u)
+                if (!no_more)
                 {
-                    k = aq_claim(&sh->fq_head, &sh->fq_tail, 64u, base);
                     b = kBucketRefill;
+                    if (lane == 0) k = aq_claim(&sh->fq_head, &sh->fq_tail, 64u, base);
                 }
-                // 3) the fullest partial group
-                if (k == 0u)
+                k = __shfl(k, 0);
+                // 3) the fullest partial group — unless the march side still has work queued: then a full
+                //    group is worth waiting for
+                if (k == 0u && (no_more || aq_load(&sh->mq_tail) - aq_load(&sh->mq_head) < 64u))
                 {
                     uint32_t best = 0, best_n = 0;
-                    for (uint32_t bb = 0; bb < static_cast<uint32_t>(kAqEventQueues); ++bb)
+#pragma unroll
+                    for (int bb = 0; bb < kAqEventQueues; ++bb)
                     {
-                        const uint32_t n = aq_load(&sh->eq_tail[bb]) - aq_load(&sh->eq_head[bb]);
-                        if (n > best_n && n <= kAqCap) best = bb, best_n = n;
+                        const uint32_t n = __shfl(avail, bb);
+                        if (n > best_n) best = static_cast<uint32_t>(bb), best_n = n;
                     }
                     if (best_n > 0u)
                     {
-                        k = aq_claim(&sh->eq_head[best], &sh->eq_tail[best], 64u, base);
                         b = best;
+                        if (lane == 0) k = aq_claim(&sh->eq_head[best], &sh->eq_tail[best], 64u, base);
                     }
                 }
             }
-            k = __shfl(k, 0), b = __shfl(b, 0), base = __shfl(base, 0);
+            k = __shfl(k, 0), base = __shfl(base, 0);
             if (k == 0u)
             {
-                if ((aq_load(&sh->no_more) != 0u && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
+                if ((no_more && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
                 __builtin_amdgcn_s_sleep(2);
                 continue;
             }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # instruction-cache / fetch counters of the trace kernel for the bench workload (GPU box)
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_icache
+OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_icache_${1:-x}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"

@@ -45,7 +45,7 @@ def main(tag, rnd="r01", workload="c3_cave_32x16x32_probes_x256_rays_ref"):
     txt = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{tag}.txt")
     open(txt, "w").write("\n".join(lines) + "\n")
     js = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{tag}.json")
-    json.dump({"workload": workload, "kernel": "k_probe_trace_wf", "fetch_size_bytes_raw": fetch_b,
+    json.dump({"workload": workload, "kernel": "k_probe_trace_aq", "fetch_size_bytes_raw": fetch_b,
                "fetch_size_bytes_corrected": 2 * fetch_b, "write_size_bytes": write_b,
                "hbm_bytes_per_launch": 2 * fetch_b + write_b,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; read side doubled per MI355X_MICROARCH.md"},
