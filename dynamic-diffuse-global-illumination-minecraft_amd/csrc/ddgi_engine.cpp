@@ -610,7 +610,8 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     if (const char* v = std::getenv("DDGI_WF_POOL")) pool = pool ? std::min(pool, std::max(wf_threads, std::atoi(v) / 64 * 64)) : 0;
     // the barrier-free queue kernel (k_probe_trace_aq) whenever its pool fits; DDGI_TRACE_KERNEL=rounds asks
     // for the round-based k_probe_trace_wf (cross-check), which also serves the utilisation counters
-    const bool force_rounds = (kernel_env && std::strcmp(kernel_env, "rounds") == 0) || a.stats != nullptr || wf_threads != 1024;
+    const bool ask_queues = kernel_env && std::strcmp(kernel_env, "queues") == 0;
+    const bool force_rounds = (kernel_env && std::strcmp(kernel_env, "rounds") == 0) || (a.stats != nullptr && !ask_queues) || wf_threads != 1024;
     const bool use_async = pool > 0 && !force_rounds && aq_pool_size(a.scene.nwords, 160 * 1024) > 0;
     if (use_async)
     {

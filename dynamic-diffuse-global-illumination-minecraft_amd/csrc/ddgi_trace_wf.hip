@@ -451,8 +451,6 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
     if (tid <= kWfBuckets) sh->bucket_count[tid] = 0u;
     __syncthreads();
 
-    const GridK& G = A.grid;
-    const int rays_per_probe = G.s * G.s;
     const float inf = __builtin_inff();
     unsigned long long st_trips = 0, st_lane_steps = 0, st_groups = 0, st_lane_events = 0, st_iters = 0, st_fetches = 0;
     long long cy[6] = {0, 0, 0, 0, 0, 0};
@@ -715,6 +713,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
 // the entry to become valid (!= 0xffff) and invalidate it.
 // =================================================================================================
 constexpr uint32_t kAqCap = 2048, kAqMask = kAqCap - 1;
+constexpr int kAqThinTrip = 32;     // a march wave with fewer lanes in flight (and nothing queued) yields for a moment
 constexpr int kAqEventQueues = 6;  // buckets 0..5 (kBucketRefill is served from FQ)
 
 struct AqShared  // control block at the start of dynamic LDS (32 dwords)
@@ -771,6 +770,7 @@ DDGI_D void aq_push(uint16_t* ring, uint32_t* tail, bool pred, uint32_t value, i
     if (pred) ring[at & kAqMask] = static_cast<uint16_t>(value);
 }
 
+template <bool kStats>
 __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, const int pool_size, const int march_waves, uint32_t* __restrict__ work_counter,
                                                             uint32_t* __restrict__ status)
 {
@@ -813,6 +813,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
 
     const float inf = __builtin_inff();
     unsigned long long guard = 0;  // safety net: never spin forever on the GPU
+    unsigned long long st_a = 0, st_b = 0;  // utilisation counters: trips / groups, and the lanes that had work in them
 
     if (wave < march_waves)
     {
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
         f3 hi_v = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
         asm volatile("" : "+v"(hi_v.x), "+v"(hi_v.y), "+v"(hi_v.z));
         bool have = false;
-        int trips = 0;
+        int trips = 0, thin_waits = 0;
         for (;;)
         {
             if (++guard > (1ull << 24)) sh->abort = 1u;
@@ -858,8 +859,18 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 __builtin_amdgcn_s_sleep(2);
                 continue;
             }
+            // a thin trip costs the SIMD as many issue slots as a full one: with few marches in flight and
+            // none queued, give the slots to the event waves for a moment and look again (bounded)
+            if (__popcll(__ballot(have)) < kAqThinTrip && thin_waits < 4)
+            {
+                ++thin_waits;
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            thin_waits = 0;
             bool finished = false;
             uint32_t bucket = 0;
+            if (kStats) st_a += 1, st_b += static_cast<unsigned long long>(__popcll(__ballot(have)));
             if (have)
             {
                 const int left = kMarchIters - m.it;
@@ -949,6 +960,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 continue;
             }
             const bool valid = static_cast<uint32_t>(lane) < k;
+            if (kStats) st_a += 1, st_b += k;
             uint32_t slot = 0;
             bool posted = false, freed = false;
             if (b == kBucketRefill)
@@ -994,6 +1006,12 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             }
         }
     }
+    if (kStats && A.stats && lane == 0)  // ddgi_trace_stats: [0] march trips, [1] lanes marching in them, [2] event groups, [3] lanes in them, [4] waves
+    {
+        atomicAdd(&A.stats[wave < march_waves ? 0 : 2], st_a);
+        atomicAdd(&A.stats[wave < march_waves ? 1 : 3], st_b);
+        atomicAdd(&A.stats[4], 1ull);
+    }
     if (status && lane == 0 && aq_load(&sh->abort) != 0u) atomicOr(status, 1u);  // the safety net tripped: the output is not valid
 }
 
@@ -1006,20 +1024,27 @@ int aq_pool_size(int nwords, size_t lds_limit)
     return pool >= 1024 ? pool : 0;
 }
 
-hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
+template <bool kStats>
+static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
 {
     const size_t lds = aq_lds_bytes(args.scene.nwords, pool);
     static bool attr_set = false;
     if (!attr_set)
     {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_aq), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_aq<kStats>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_probe_trace_aq, dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter, status);
+    hipLaunchKernelGGL(k_probe_trace_aq<kStats>, dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter, status);
     return hipGetLastError();
+}
+
+hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
+{
+    return args.stats ? launch_aq<true>(args, pool, grid_blocks, march_waves, work_counter, status, stream)
+                      : launch_aq<false>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
 }
 
 // LDS bytes of k_probe_trace_wf for a pool of `pool` rays

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Lane utilisation of k_probe_trace_aq's march trips and event groups on the bench workload (GPU box)."""
+import os, sys
+os.environ["DDGI_TRACE_KERNEL"] = "queues"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ddgi_amd
+from bench import WORKLOAD as w
+
+eng = ddgi_amd.ProbeEngine(ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"]), ddgi_amd.make_settings(w["scene"], w["max_bounces"]))
+eng.generate_probe_rays(seed=1)
+eng.probe_update(); eng.synchronize()
+eng.trace_stats(True)
+eng.probe_update(); eng.synchronize()
+st = eng.trace_stats(False)
+rays = eng.num_rays
+trips, lanes, groups, glanes = st["trips"], st["lane_steps"], st["event_rounds"], st["lane_events"]
+print("march: %.1f lane-trips/ray, %.1f of 64 lanes busy per trip;  events: %.2f per ray, %.1f of 64 lanes per group;  kernel %.3f ms" % (
+    lanes / rays, lanes / max(trips, 1), glanes / rays, glanes / max(groups, 1), eng.last_update_ms()["trace_ms"]))
