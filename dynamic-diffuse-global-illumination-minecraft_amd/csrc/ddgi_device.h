@@ -218,7 +218,6 @@ DDGI_D f3 hemisphere_dir(f3 n, uint32_t& rng)
     if (fabsf(n.x) < kSqrtThird) other = mk3(1, 0, 0);
     else if (fabsf(n.y) < kSqrtThird) other = mk3(0, 1, 0);
     else other = mk3(0, 0, 1);
-#if DDGI_ALT
     // For a unit axis normal both cross products are unit axis vectors (exact products of 0 and +-1)
     // and normalize() of one is the identity (x * (1/sqrt(1))): skip the two square roots and divisions.
     const bool axis = (fabsf(n.x) + fabsf(n.y) + fabsf(n.z) == 1.0f) && (fabsf(n.x) == 1.0f || fabsf(n.y) == 1.0f || fabsf(n.z) == 1.0f);
@@ -226,10 +225,6 @@ DDGI_D f3 hemisphere_dir(f3 n, uint32_t& rng)
     if (!axis) p1 = normalize3(p1);
     f3 p2 = cross3(n, p1);
     if (!axis) p2 = normalize3(p2);
-#else
-    const f3 p1 = normalize3(cross3(n, other));
-    const f3 p2 = normalize3(cross3(n, p1));
-#endif
     const pm::SinCos sc = pm::sincos_core(around);
     const float ca = static_cast<float>(sc.c) * over;
     const float sa = static_cast<float>(sc.s) * over;
