@@ -287,7 +287,18 @@ DDGI_D bool wf_event(const TraceArgs& A, const WfPool& P, uint32_t b, uint32_t s
                     const f3 p = ray_at(ro, ld3(P.dn, slot), t);  // the march position at the hit
                     const f3 cell = cell_id(p);
                     const f3 centre = f3{cell.x - 0.5f, cell.y - 0.5f, cell.z - 0.5f};
-                    const f3 diff = normalize3(p - centre);
+                    // The reference picks the axis of the largest |component| of normalize(p - centre).  The
+                    // normalisation multiplies all three by the same positive factor, so it can only change
+                    // the choice when the two largest are within rounding of each other: unless they are
+                    // (a hit on a voxel edge), compare the raw components and skip the square root and division.
+                    f3 diff = p - centre;
+                    {
+                        const float ax = fabsf(diff.x), ay = fabsf(diff.y), az = fabsf(diff.z);
+                        const float hi = fmaxf(ax, fmaxf(ay, az));
+                        const float mid = fmaxf(fminf(ax, ay), fminf(fmaxf(ax, ay), az));  // the second largest
+                        const bool clear = hi > 0x1.0p-60f && hi < 0x1.0p60f && mid < hi * (1.0f - 0x1.0p-21f);  // false for NaN too
+                        if (!clear) diff = normalize3(diff);
+                    }
                     // axis of the largest |component|, first wins on ties (:1075-1086)
                     f3 n = mk3(0, 0, 0);
                     float best = 0.0f;
