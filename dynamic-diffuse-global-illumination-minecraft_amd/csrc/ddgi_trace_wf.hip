@@ -1,26 +1,26 @@
-// ddgi_trace_wf.hip — k_probe_trace_wf: the REF-mode probe update (assets/shaders/probe_pass.comp:main
-// and everything it calls) scheduled as a wavefront path tracer inside ONE persistent 1024-lane
-// workgroup per CU.  Same per-ray arithmetic, in the same order, as k_probe_trace_ref
-// (ddgi_kernels.hip), hence bit-identical results; only the schedule differs.
+// ddgi_trace_wf.hip — the probe update (assets/shaders/probe_pass.comp:main and everything it calls)
+// scheduled as a wavefront path tracer inside ONE persistent 1024-lane workgroup per CU:
+//   k_probe_trace_aq  slots travel through LDS queues, 8 waves march, 8 waves shade, no barrier  (default)
+//   k_probe_trace_wf  the same work in synchronous rounds (sort / events / march) with barriers   (cross-check, counters)
+// Same per-ray arithmetic, in the same order, as the ray-per-lane k_probe_trace_ref (ddgi_kernels.hip),
+// hence bit-identical results; only the schedule differs.
 //
-// Why a different schedule: per ray the path alternates ~15 voxel marches (1..125 dependent steps
+// Why a different schedule: per ray the path alternates ~13 voxel marches (1..125 dependent steps
 // each, heavy tailed) with hit shading whose cost depends on the block type hit.  With one ray
 // bound to one lane, a wave spends ~3/4 of its march-loop issue slots on parked lanes and every
 // shading round pays for every block type present in the wave.
 //
-// Here rays are NOT bound to lanes.  A pool of P rays (P ~ 1.3 x the lane count) lives in LDS as a
-// structure of arrays (24 dwords/ray: the reference's Ray + Isect + accumulators) next to the
-// scene's occupancy bitmap, and the 16 waves run dense phases over compacted lists of pool slots:
-//   C  sort    pool slots are bucketed by what has to happen next: hit shading per block type (the
-//              procedural albedo is a switch over 13 block types), light hit / miss, light-feeler
-//              result, or - for a free slot while rays remain - taking a new ray
-//   D  events  waves claim 64-lane groups of ONE bucket, most expensive buckets first: hit
-//              shading (+ feeler set-up), light evaluation (+ bounce set-up, or texel store and
-//              slot release), refill (48 B ProbeRay record in, first march set up); every new
-//              march is appended to the round's march list
-//   B  march   every lane pulls march tasks from the list (wave-aggregated LDS atomic), steps them,
-//              and pulls another when its own finishes; once the list is drained the stragglers run
-//              kWfTailSteps more steps and are parked (t, iteration count) on the NEXT round's list
+// Here rays are NOT bound to lanes.  A pool of P rays lives in LDS as a structure of arrays (9 dwords
+// per ray: what a march needs; the shading state is a 48-byte record per slot in global memory) next
+// to the scene's occupancy bitmap.  Two kinds of work alternate on a slot:
+//   events  (wf_event) 64-lane groups of ONE bucket: hit shading per block-type class (the procedural
+//           albedo is a switch over 13 block types) + feeler set-up, light hit / miss, light-feeler
+//           result (+ bounce set-up, or texel store and slot release), refill (a new ray into a free
+//           slot: 48 B ProbeRay record in, first march set up)
+//   marches bursts of 16 predicated, fully unrolled voxel steps; a lane takes another march when its
+//           own ends
+// The round kernel alternates them in phases over compacted slot lists (C sort, D events, B march,
+// stragglers parked for the next round); the queue kernel lets every ray run at its own pace.
 // ------------------------------------------------------------------------------------------------
 #include <algorithm>
 #include <cstdlib>
