@@ -823,7 +823,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     __syncthreads();
 
     const float inf = __builtin_inff();
-    unsigned long long guard = 0;  // safety net: never spin forever on the GPU
+    unsigned int guard = 0;  // safety net: consecutive polls without work (about 1 s of them trips it); never spin forever on the GPU
     unsigned long long st_a = 0, st_b = 0;  // utilisation counters: trips / groups, and the lanes that had work in them
 
     if (wave < march_waves)
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
         int trips = 0, thin_waits = 0;
         for (;;)
         {
-            if (++guard > (1ull << 24)) sh->abort = 1u;
+            if (++guard > (1u << 23)) sh->abort = 1u;
             const unsigned long long idle_mask = __ballot(!have);
             const int n_idle = __popcll(idle_mask);
             if (n_idle >= fetch_lanes)
@@ -879,6 +879,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 continue;
             }
             thin_waits = 0;
+            guard = 0;
             bool finished = false;
             uint32_t bucket = 0;
             if (kStats) st_a += 1, st_b += static_cast<unsigned long long>(__popcll(__ballot(have)));
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
         // ================= event waves =================
         for (;;)
         {
-            if (++guard > (1ull << 24)) sh->abort = 1u;
+            if (++guard > (1u << 23)) sh->abort = 1u;
             // Which group?  Lanes 0..5 look at one event queue each (polling is paid in VALU issue slots that
             // the marching waves of the same SIMD want, so it is kept to a handful of instructions).
             uint32_t b = 0, base = 0, k = 0;
@@ -971,6 +972,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 continue;
             }
             const bool valid = static_cast<uint32_t>(lane) < k;
+            guard = 0;
             if (kStats) st_a += 1, st_b += k;
             uint32_t slot = 0;
             bool posted = false, freed = false;
@@ -1008,7 +1010,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            aq_push(ring_mq, &sh->mq_tail, posted, slot, lane);
+            aq_push(ring_mq, &sh->mq_tail, posted && !(A.ablate & 8), slot, lane);  // DDGI_ABLATE=8: fault injection for the safety-net test
             aq_push(ring_fq, &sh->fq_tail, freed, slot, lane);
             if (b != kBucketRefill)
             {

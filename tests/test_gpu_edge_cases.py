@@ -168,3 +168,18 @@ def test_large_ref_grid_beyond_the_bake_box(ddgi, oracle):
     for p in probes:
         x0, y0 = ddgi.probe_tile_origin(fld, int(p))
         assert np.array_equal(a[y0:y0 + s, x0:x0 + s], want[y0:y0 + s, x0:x0 + s]), f"probe {p}"
+
+
+@pytest.mark.gpu
+def test_queue_kernel_safety_net_reports_instead_of_hanging(ddgi, monkeypatch):
+    """Fault injection (DDGI_ABLATE=8: the queue kernel drops every march it posts, so rays never
+    finish): the kernel's bounded waits trip after about a second, every wave leaves, and the next
+    synchronising call returns an error instead of textures."""
+    counts, side, s, origin, scene = CONFIGS["c1_cornell"]
+    monkeypatch.setenv("DDGI_ABLATE", "8")
+    monkeypatch.setenv("DDGI_TRACE_KERNEL", "queues")
+    with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 4)) as eng:
+        eng.generate_probe_rays(seed=1)
+        eng.probe_update()
+        with pytest.raises(ddgi.DDGIError, match="aborted"):
+            eng.synchronize()
