@@ -401,7 +401,7 @@ DDGI_D bool wf_event(const TraceArgs& A, const WfPool& P, uint32_t b, uint32_t s
             }
             else
             {
-                if (!early && nvis != 0) contribution = div3(hcol * direct, static_cast<float>(nvis));
+                if (!early && nvis != 0) contribution = nvis == 1 ? hcol * direct : div3(hcol * direct, static_cast<float>(nvis));  // x / 1.0f == x
                 posted = wf_lighting_done(P, slot, c, contribution, hpos, hnrm, cnt, A, mo, md);
             }
         }
