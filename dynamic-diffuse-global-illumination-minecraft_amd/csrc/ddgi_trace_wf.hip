@@ -912,8 +912,13 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             if (__ballot(finished) != 0ull)
             {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-#pragma unroll
-                for (uint32_t b = 0; b < static_cast<uint32_t>(kAqEventQueues); ++b) aq_push(ring_eq + b * kAqCap, &sh->eq_tail[b], finished && bucket == b, slot, lane);
+                // a handful of lanes finish per trip, spread over six queues: one LDS atomic per lane is
+                // cheaper than six wave-aggregated appends
+                if (finished)
+                {
+                    const uint32_t at = atomicAdd(&sh->eq_tail[bucket], 1u);
+                    (ring_eq + bucket * kAqCap)[at & kAqMask] = static_cast<uint16_t>(slot);
+                }
             }
         }
     }
