@@ -1,6 +1,6 @@
+"""Queue kernel vs round kernel on two small scenes: same bytes? (GPU box)"""
 import os, sys, numpy as np
-sys.path.insert(0, "/root/repo")
-os.chdir("/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ddgi_amd
 from tests.common import CONFIGS
 def run(name, env):
@@ -13,6 +13,6 @@ def run(name, env):
         ms = eng.last_update_ms()["trace_ms"]
         return eng.read_textures()[0], ms
 for name in ("c1_cornell", "cave_small"):
-    a, t1 = run(name, {})
-    b, t2 = run(name, {"DDGI_TRACE_KERNEL": "async"})
+    a, t1 = run(name, {"DDGI_TRACE_KERNEL": "rounds"})
+    b, t2 = run(name, {"DDGI_TRACE_KERNEL": "queues"})
     print(name, "equal", np.array_equal(a, b), "diff texels", int((a != b).any(axis=-1).sum()), "nonzero", int(b.any(axis=-1).sum()), "ms %.3f %.3f" % (t1, t2))
