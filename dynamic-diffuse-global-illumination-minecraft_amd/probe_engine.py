@@ -408,6 +408,10 @@ class ProbeEngine:
         _check(self._lib.ddgi_render(self._h, C.byref(camera), C.byref(settings), _ptr(img), _ptr(rgb)))
         return (img, rgb) if want_float else img
 
+    def render_device(self, camera, settings, rgba8_ptr, rgb_f32_ptr=None):
+        """render() on device pointers, asynchronous on the handle's stream."""
+        _check(self._lib.ddgi_render_device(self._h, C.byref(camera), C.byref(settings), C.c_void_p(rgba8_ptr), C.c_void_p(rgb_f32_ptr)))
+
     # -- device-pointer level ------------------------------------------------------------------
     def set_stream(self, hip_stream_ptr):
         _check(self._lib.ddgi_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
