@@ -44,6 +44,27 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_RAY = 56        # 48 B ProbeRay read + two 4 B rgba8 texel writes
 
 
+def _issue_from_profiles():
+    """VALU occupancy of the trace kernel from the committed rocprofv3 --pmc passes
+    (profiles/*_issue.txt, tools/pmc_icache.sh): the bound the kernel actually sits at."""
+    import glob
+    import re
+
+    out = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_issue.txt"))):
+        try:
+            txt = open(path).read()
+            busy = re.search(r"VALU busy = .* = ([0-9.]+)", txt)
+            lanes = re.search(r"mean active lanes per VALU instruction = .* = ([0-9.]+)", txt)
+            insts = re.search(r"SQ_INSTS_VALU\s+([0-9.e+]+)", txt)
+            if busy and lanes:
+                out = {"valu_busy": float(busy.group(1)), "valu_lane_use": float(lanes.group(1)),
+                       "valu_wave_instructions_per_launch": float(insts.group(1)) if insts else None, "source": os.path.basename(path)}
+        except Exception:
+            pass
+    return out or None
+
+
 def _traffic_from_profiles():
     """Per-launch HBM bytes of k_probe_trace_ref from the committed rocprofv3 --pmc passes
     (profiles/*_traffic.json, written by tools/pmc_traffic.py); None if not collected."""
@@ -223,7 +244,8 @@ def main():
             "traffic": None if ddgi_mode else _traffic_from_profiles(),
             "algorithmic_bytes_per_launch": algo_bytes_per_ray * local_rays,
             "kernel_ms": kernel_ms,
-            "note": "the trace kernel is VALU-issue bound (dependent voxel steps + hit shading), not HBM bound: see DESIGN.md section 4 and profiles/",
+            "issue": None if ddgi_mode else _issue_from_profiles(),
+            "note": "the trace kernel is VALU-issue bound (dependent voxel steps + hit shading), not HBM bound: `issue` = the VALU's occupancy from profiles/ (rocprofv3 --pmc), see DESIGN.md section 4",
         },
     }
     if ddgi_mode:
