@@ -65,3 +65,34 @@ def test_random_user_scene_vs_oracle(ddgi, oracle):
     want, _ = oracle.probe_update(f, oracle.make_settings(3, 8), rays, lights=np.array(lights, dtype=oracle.LIGHT_DTYPE))
     assert np.array_equal(got, want)
     assert got[..., :3].any()
+
+
+@pytest.mark.gpu
+def test_large_user_scene_vs_oracle(ddgi, oracle):
+    """A 96x40x96 voxel scene (46 KB of occupancy bits next to the ray pool and the queues in LDS):
+    a rough terrain with pillars, three lights, probes in the open space above it."""
+    rng = np.random.default_rng(5)
+    nx, ny, nz = 96, 40, 96
+    lo = (-48, -20, -48)
+    types = np.zeros((nz, ny, nx), dtype=np.uint8)                   # [z, y, x]
+    height = (6 + 4 * np.sin(np.arange(nx)[None, :] / 9.0) + 3 * np.cos(np.arange(nz)[:, None] / 7.0)).astype(int)
+    for y in range(ny):
+        types[:, y, :][y < height] = 1 + (y % 13)
+    pillars = rng.integers(4, 92, size=(40, 2))
+    for px, pz in pillars:
+        types[pz, :30, px] = rng.integers(1, 14)
+    counts, side, s, origin = (4, 2, 4), 6, 6, (1.0, 8.0, 1.0)
+    lights = np.array([(14.0, (1.0, 0.9, 0.8), (0.5, 15.5, 0.5)), (9.0, (0.3, 0.5, 1.0), (-20.5, 12.5, 18.5)),
+                       (9.0, (1.0, 0.4, 0.3), (22.5, 10.5, -15.5))], dtype=ddgi.LIGHT_DTYPE)
+    with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(3, 6)) as eng:
+        eng.set_scene_grid(lo, types)
+        eng.set_lights(3, lights)
+        eng.generate_probe_rays(seed=1)
+        eng.probe_update()
+        got, _ = eng.read_textures()
+    oracle.lib().oracle_set_user_scene((C.c_int32 * 3)(*lo), (C.c_int32 * 3)(nx, ny, nz), types.ctypes.data_as(C.c_void_p))
+    f = oracle.make_field(counts, side, s, origin)
+    rays = oracle.generate_probe_rays(f, oracle.new_rand_state(1))
+    want, _ = oracle.probe_update(f, oracle.make_settings(3, 6), rays, lights=np.array(lights, dtype=oracle.LIGHT_DTYPE))
+    assert np.array_equal(got, want)
+    assert got[..., :3].any()
