@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -120,6 +121,8 @@ struct ddgi_engine
     float* d_radiance = nullptr;            // DDGI mode ray records: rgb part then (d, d*d) part (ddgi_types.h: kRecGroup)
     size_t d_radiance_capacity = 0;         // in (record group, ray) pairs
     uint32_t frame = 0;                     // DDGI mode: updates done so far (seeds the ray rotation)
+    unsigned long long aq_key = 0;  // configuration the march/event wave split was measured for
+    int aq_march = 0;               // that split (0: not measured yet)
     float* d_blend_w = nullptr;  // k_blend_weights output: [256 sums][n][256]
     size_t d_blend_w_floats = 0;
     unsigned long long* d_stats = nullptr;  // profiling aid, allocated on first ddgi_trace_stats(enable)
@@ -538,6 +541,25 @@ int ddgi_get_probe_rays(ddgi_handle e, ddgi_probe_ray* rays, size_t n)
     return DDGI_OK;
 }
 
+// What the march/event balance of the queue kernel depends on: grid, rays, scene, bounces, lights, mode, shard.
+static unsigned long long aq_config_key(const ddgi_engine* e, const TraceArgs& a, bool ddgi_mode)
+{
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](unsigned long long v) { h = (h ^ v) * 1099511628211ull; };
+    for (int i = 0; i < 3; ++i) mix(static_cast<unsigned>(e->field.probe_count[i]));
+    mix(static_cast<unsigned>(e->field.side_length));
+    mix(static_cast<unsigned>(e->field.sqrt_rays_per_probe));
+    for (int i = 0; i < 3; ++i)
+    {
+        unsigned u;
+        std::memcpy(&u, &e->field.field_origin[i], 4);
+        mix(u);
+    }
+    mix(static_cast<unsigned>(a.scene_id)), mix(static_cast<unsigned>(a.max_bounces)), mix(static_cast<unsigned>(a.nl));
+    mix(ddgi_mode ? 1u : 0u), mix(static_cast<unsigned>(e->rank)), mix(static_cast<unsigned>(e->world)), mix(a.n_rays);
+    return h | 1ull;
+}
+
 int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
@@ -651,13 +673,66 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         }
         a.wf_cold = e->d_wf_cold;
         a.wf_dir = e->d_wf_dir;
-        HIP_TRY(hipEventRecord(ev[0], e->stream));
+        int march_waves = 5;
         if (use_async)
         {
-            int march_waves = 8;  // of 16: stepping and shading are about half of the work each (C3: 6: 4.17 ms, 7: 3.38, 8: 3.39, 9: 3.87)
+            // How many of the 16 waves march (the rest run events) is the one knob the balance of a scene
+            // moves: C3 is fastest at 5 (4: 3.44 ms, 5: 2.96, 6: 3.14, 8: 3.7), Cornell and the house at 6,
+            // a sparser cave grid at 3.  The first update of a configuration measures it: a few extra
+            // launches of the same (idempotent) trace, hill-climbing from the last value.
+            const unsigned long long key = aq_config_key(e, a, ddgi_mode);
             if (const char* v = std::getenv("DDGI_AQ_MARCH")) march_waves = std::min(15, std::max(1, std::atoi(v)));
-            HIP_TRY(launch_probe_trace_aq(a, pool, static_cast<int>(grid), march_waves, e->d_work, e->d_work + 1, e->stream));
+            else if (e->aq_key == key && e->aq_march > 0) march_waves = e->aq_march;
+            else
+            {
+                const char* tune = std::getenv("DDGI_AUTOTUNE");
+                march_waves = e->aq_march > 0 ? e->aq_march : 5;
+                if (!(tune && std::atoi(tune) == 0) && a.ablate == 0)  // (not under the profiling / fault-injection switches)
+                {
+                    auto timed = [&](int mw, float* ms) -> int {  // the faster of two launches
+                        *ms = 0.0f;
+                        for (int rep = 0; rep < 2; ++rep)
+                        {
+                            float t = 0.0f;
+                            HIP_TRY(hipEventRecord(ev[0], e->stream));
+                            HIP_TRY(launch_probe_trace_aq(a, pool, static_cast<int>(grid), mw, e->d_work, e->d_work + 1, e->stream));
+                            HIP_TRY(hipEventRecord(ev[1], e->stream));
+                            HIP_TRY(hipEventSynchronize(ev[1]));
+                            HIP_TRY(hipEventElapsedTime(&t, ev[0], ev[1]));
+                            if (rep == 0 || t < *ms) *ms = t;
+                        }
+                        return DDGI_OK;
+                    };
+                    float best_ms = 0.0f, ms = 0.0f;
+                    // first touches, cold caches, clocks still low: repeat the starting point until it settles
+                    if (int rc = timed(march_waves, &ms)) return rc;
+                    for (int settle = 0; settle < 6; ++settle)
+                    {
+                        if (int rc = timed(march_waves, &best_ms)) return rc;
+                        const bool steady = std::fabs(best_ms - ms) < 0.015f * best_ms;
+                        ms = best_ms;
+                        if (steady) break;
+                    }
+                    for (int dir = -1; dir <= 1; dir += 2)
+                    {
+                        bool moved = false;
+                        for (int mw = march_waves + dir; mw >= 2 && mw <= 12; mw += dir)
+                        {
+                            if (int rc = timed(mw, &ms)) return rc;
+                            if (ms >= best_ms) break;
+                            best_ms = ms, march_waves = mw, moved = true;
+                        }
+                        if (moved) break;  // downhill in this direction: the other one was uphill
+                    }
+                }
+                e->aq_key = key;
+                e->aq_march = march_waves;
+                if (std::getenv("DDGI_VERBOSE")) std::fprintf(stderr, "[ddgi] queue kernel: %d march waves / %d event waves for this configuration\n", march_waves, 16 - march_waves);
+            }
         }
+        HIP_TRY(hipEventRecord(ev[0], e->stream));
+        if (use_async)
+            HIP_TRY(launch_probe_trace_aq(a, pool, static_cast<int>(grid), march_waves, e->d_work, e->d_work + 1, e->stream));
         else
             HIP_TRY(launch_probe_trace_wf(a, wf_threads, pool, static_cast<int>(grid), e->d_work, e->stream));
     }
@@ -1082,6 +1157,7 @@ static uint32_t noise_id()
 
 static int fill_user_scene(ddgi_engine* e, const int lo[3], const int dim[3], const uint8_t* types)
 {
+    e->aq_march = 0;  // the trace kernel's wave split is measured again for the new scene
     for (int a = 0; a < 3; ++a)
         if (dim[a] < 1 || dim[a] > 4096 || lo[a] < -(1 << 20) || lo[a] > (1 << 20)) return fail(DDGI_ERR_INVALID_ARGUMENT, "bad scene box");
     const size_t n = static_cast<size_t>(dim[0]) * dim[1] * dim[2];

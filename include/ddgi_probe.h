@@ -166,7 +166,11 @@ int ddgi_get_probe_rays(ddgi_handle h, ddgi_probe_ray* rays, size_t n);
 /* Replaces, per frame: RVPT::update()'s uploads (rvpt.cpp:281-287) + the probe half of
  * record_compute_command_buffer (barrier + vkCmdDispatch, rvpt.cpp:1105-1129) + Queue::submit
  * (rvpt.cpp:378-380).  Asynchronous on the handle's stream.  `settings` may be NULL to reuse the
- * last one; the function does NOT add +2 to time (the caller's RVPT::update does, rvpt.cpp:281). */
+ * last one; the function does NOT add +2 to time (the caller's RVPT::update does, rvpt.cpp:281).
+ * The first update of a configuration (grid, rays, scene, bounces, lights, mode) also measures how the
+ * trace kernel should split its waves between marching and shading: a few extra launches of the same
+ * trace (idempotent) and one synchronisation, some tens of milliseconds once; DDGI_AUTOTUNE=0 or
+ * DDGI_AQ_MARCH=<n> skips it. */
 int ddgi_probe_update(ddgi_handle h, const ddgi_render_settings* settings);
 
 /* Waits for the stream (≙ Fence::wait, vk_util.cpp:94-97; here without the 1 s timeout). */

@@ -5,14 +5,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ddgi_amd
 
-CASES = {"cave": ((32, 16, 32), 4, 16, (-3.0, -1.0, -3.0), 0), "cornell": ((16, 16, 16), 1, 16, (0.0, 0.0, 15.0), 1), "house": ((32, 8, 24), 1, 16, (0.0, 0.0, 0.0), 2)}
+CASES = {"c3": ((32, 16, 32), 2, 16, (1.4, 0.0, 1.0), 0), "cave": ((32, 16, 32), 4, 16, (-3.0, -1.0, -3.0), 0), "cornell": ((16, 16, 16), 1, 16, (0.0, 0.0, 15.0), 1), "house": ((32, 8, 24), 1, 16, (0.0, 0.0, 0.0), 2)}
 for name, (counts, side, s, origin, scene) in CASES.items():
     row = []
-    for split in ("wf", 5, 6, 7, 8, 9, 10, 11, 12):
-        if split == "wf":
-            os.environ.pop("DDGI_TRACE_KERNEL", None)
+    for split in ("rounds", "auto", 3, 4, 5, 6, 7, 8):
+        os.environ.pop("DDGI_AQ_MARCH", None)
+        if split == "rounds":
+            os.environ["DDGI_TRACE_KERNEL"] = "rounds"
+        elif split == "auto":
+            os.environ["DDGI_TRACE_KERNEL"] = "queues"
         else:
-            os.environ["DDGI_TRACE_KERNEL"] = "async"
+            os.environ["DDGI_TRACE_KERNEL"] = "queues"
             os.environ["DDGI_AQ_MARCH"] = str(split)
         eng = ddgi_amd.ProbeEngine(ddgi_amd.make_field(counts, side, s, origin), ddgi_amd.make_settings(scene, 8))
         eng.generate_probe_rays(seed=1)
