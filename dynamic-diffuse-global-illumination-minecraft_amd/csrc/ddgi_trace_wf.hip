@@ -823,7 +823,9 @@ DDGI_D void aq_push(uint16_t* ring, uint32_t* tail, bool pred, uint32_t value, i
     if (pred) ring[at & kAqMask] = static_cast<uint16_t>(value);
 }
 
-template <bool kStats>
+// kPool > 0: the pool size is a compile-time constant, so every pool array is the LDS base plus a constant
+// offset (folded into the ds instructions: no address arithmetic, one SGPR instead of eleven).
+template <bool kStats, int kPool>
 __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, const int pool_size, const int march_waves, uint32_t* __restrict__ work_counter,
                                                             uint32_t* __restrict__ status)
 {
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const uint32_t PS = static_cast<uint32_t>(pool_size);
+    const uint32_t PS = kPool > 0 ? static_cast<uint32_t>(kPool) : static_cast<uint32_t>(pool_size);
     const int fetch_lanes = A.wf_fetch > 0 ? A.wf_fetch : kWfFetchLanes;
 
     // ---- carve LDS: control block | occupancy bitmap | pool arrays | rings ----
@@ -1097,27 +1099,30 @@ int aq_pool_size(int nwords, size_t lds_limit)
     return pool >= 1024 ? pool : 0;
 }
 
-template <bool kStats>
+template <bool kStats, int kPool>
 static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
 {
     const size_t lds = aq_lds_bytes(args.scene.nwords, pool);
     static bool attr_set = false;
     if (!attr_set)
     {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_aq<kStats>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_aq<kStats, kPool>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_probe_trace_aq<kStats>, dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter, status);
+    hipLaunchKernelGGL((k_probe_trace_aq<kStats, kPool>), dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter, status);
     return hipGetLastError();
 }
 
+constexpr int kAqPool = 1536;  // the usual pool (ddgi_engine.cpp); other sizes take the generic instantiation
+
 hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
 {
-    return args.stats ? launch_aq<true>(args, pool, grid_blocks, march_waves, work_counter, status, stream)
-                      : launch_aq<false>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+    if (args.stats) return launch_aq<true, 0>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+    if (pool == kAqPool) return launch_aq<false, kAqPool>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+    return launch_aq<false, 0>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
 }
 
 // LDS bytes of k_probe_trace_wf for a pool of `pool` rays
