@@ -54,11 +54,14 @@ DDGI_D float axis_inv(float d) { return d == 0.0f ? __builtin_inff() : 1.0f / d;
 // The light-sphere half of intersect_scene (intersection.glsl:1264-1279): nearest hit of the ray
 // (o, d) with the radius-0.1 spheres around the lights; +inf / -1 if none.
 // Unit-sphere quadratic in a space scaled by 10 (x/0.1 := x*10, P5).
+// kNl > 0: the number of lights is known at compile time (the queue kernel's one-light instantiation)
+template <int kNl = 0>
 DDGI_D void light_spheres(f3 o, f3 d, const TraceArgs& A, float& tl_out, int& lid_out)
 {
     float closest = __builtin_inff();
     int lid = -1;
-    for (int i = 0; i < A.nl; ++i)
+    const int nl = kNl > 0 ? kNl : A.nl;
+    for (int i = 0; i < nl; ++i)
     {
         const f3 lp{A.lights[i].pos[0], A.lights[i].pos[1], A.lights[i].pos[2]};
         const f3 so = (o - lp) * 10.0f;

@@ -148,6 +148,25 @@ constexpr uint32_t kBucketRefill = 6;  // an empty slot that can take a new ray
 
 // A new voxel march for pool slot `slot` (intersect_scene's set-up, intersection.glsl:1253-1279 +
 // grid_march's, 1053-1058): origin, normalised direction and its reciprocal, light spheres.
+// What the shared event code may know at compile time.  CfgRuntime reads everything from the arguments;
+// CfgPlain<kMode> is the common case — one light, no profiling switches, REF (0) or DDGI (1) output —
+// whose light loops and mode branches fold away (fewer instructions, far fewer scalar registers to spill).
+struct CfgRuntime
+{
+    static constexpr int kNl = 0;
+    static DDGI_D int nl(const TraceArgs& A) { return A.nl; }
+    static DDGI_D int ablate(const TraceArgs& A) { return A.ablate; }
+    static DDGI_D bool ddgi(const TraceArgs& A) { return A.ddgi != 0; }
+};
+template <int kMode>
+struct CfgPlain
+{
+    static constexpr int kNl = 1;
+    static DDGI_D int nl(const TraceArgs&) { return 1; }
+    static DDGI_D int ablate(const TraceArgs&) { return 0; }
+    static DDGI_D bool ddgi(const TraceArgs&) { return kMode != 0; }
+};
+
 // The first kInlineSteps voxel steps are taken right here, by the event lane that sets the march up: 59 % of
 // the cave workload's marches end within 3 steps (probes inside rock, rays that start in a corner), and for
 // those a trip through the march queue and a 16-step burst is almost all overhead.  Returns -1 when the march
@@ -158,11 +177,12 @@ constexpr uint32_t kBucketRefill = 6;  // an empty slot that can take a new ray
 #endif
 constexpr int kInlineSteps = DDGI_INLINE_STEPS;
 
+template <class Cfg>
 DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, bool feeler, const TraceArgs& A, const uint32_t* s_bits)
 {
     float tl;
     int lid;
-    light_spheres(o, d, A, tl, lid);
+    light_spheres<Cfg::kNl>(o, d, A, tl, lid);
     const f3 dn = normalize3(d);
     st3(P.ro, slot, o);
     st3(P.dn, slot, dn);
@@ -210,10 +230,11 @@ DDGI_D void wf_store_distance(const TraceArgs& A, uint32_t dst, float t)
     rec[0] = d, rec[8] = d * d;
 }
 
+template <class Cfg>
 DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst, const TraceArgs& A)
 {
     const f3 c = div3(color, static_cast<float>(A.max_bounces));  // Q14: always /max_bounces
-    if (A.ddgi)
+    if (Cfg::ddgi(A))
     {
         float* rec = A.rad_rgb + static_cast<size_t>(dst >> 3) * 24 + (dst & 7u);  // (the distance was written at bounce 0)
         rec[0] = c.x, rec[8] = c.y, rec[16] = c.z;
@@ -229,6 +250,7 @@ DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst
 // End of get_direct_lighting for one hit: accumulate, then bounce or finish (probe_pass.comp:286-292).
 // Returns true when the ray bounces; the caller then posts the march (o, d) — every path of an event
 // group shares ONE wf_post_march call site, so divergent lanes do not run its code twice.
+template <class Cfg>
 DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A, f3& o, f3& d)
 {
     const f3 color = v3of(c.col) + contribution;
@@ -238,10 +260,10 @@ DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contr
         set3(c.col, color);
         c.cnt = bounce;
         o = hpos + hnrm * 0.0001f;
-        d = (A.ablate & 2) ? normalize3(hnrm + mk3(0.3f, 0.2f, 0.1f)) : hemisphere_dir(hnrm, c.rng);
+        d = (Cfg::ablate(A) & 2) ? normalize3(hnrm + mk3(0.3f, 0.2f, 0.1f)) : hemisphere_dir(hnrm, c.rng);
         return true;
     }
-    wf_finish_ray(P, slot, color, c.dst, A);
+    wf_finish_ray<Cfg>(P, slot, color, c.dst, A);
     return false;
 }
 
@@ -250,12 +272,13 @@ DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contr
 // posted that goes on (return 1: its state is in the pool arrays, its shading record stored), when the new
 // march already ended within its first steps (return 2 + the event bucket it now waits in), or 0 when the ray
 // is finished (it has written its output and left the slot empty).
+template <class Cfg>
 DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits, uint32_t b, uint32_t slot, uint32_t r, bool r_valid)
 {
     const GridK& G = A.grid;
     const int rays_per_probe = G.s * G.s;
     const float inf = __builtin_inff();
-    const bool multi_light = A.nl > 1;
+    const bool multi_light = Cfg::nl(A) > 1;
     bool posted = false;
     if (b == kBucketRefill)
     {
@@ -271,7 +294,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             const uint32_t global_ray = static_cast<uint32_t>(p) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i);
             f3 ray_o, ray_d;
             WfCold c;
-            if (A.ddgi)
+            if (Cfg::ddgi(A))
             {
                 // in-kernel ray generation: probe position + rotated spherical Fibonacci direction
                 const int pxz = p - y * G.cx * G.cz;
@@ -293,7 +316,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             c.cnt = 0u;
             set3(c.col, mk3(0, 0, 0));
             set3(c.hn, mk3(0, 0, 0));
-            const int pb = wf_post_march(P, slot, c, ray_o, ray_d, false, A, s_bits);
+            const int pb = wf_post_march<Cfg>(P, slot, c, ray_o, ray_d, false, A, s_bits);
             store_cold(P.cold + slot, c);
             return pb < 0 ? 1 : 2 + pb;
         }
@@ -310,11 +333,11 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
         const bool any_hit = block_wins || (tl < inf);       // closest_t < INF
         if (b != kBucketFeeler)
         {
-            const bool first_bounce = A.ddgi && (c.cnt & 255u) == 0u;
+            const bool first_bounce = Cfg::ddgi(A) && (c.cnt & 255u) == 0u;
             if (!any_hit)
             {
                 if (first_bounce) wf_store_distance(A, c.dst, kMissDistance);
-                wf_finish_ray(P, slot, v3of(c.col), c.dst, A);  // probe_pass.comp:288-290 break
+                wf_finish_ray<Cfg>(P, slot, v3of(c.col), c.dst, A);  // probe_pass.comp:288-290 break
             }
             else
             {
@@ -350,7 +373,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     // n stays (0,0,0) only if diff is NaN, where the reference yields NaN as well
                     const f3 nn = best > 0.0f ? n : normalize3(n);
                     const int type = static_cast<int>((fl >> 16) & 15u);
-                    hcol = (A.ablate & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
+                    hcol = (Cfg::ablate(A) & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
                     nraw = nn;
                     axis_normal = best > 0.0f;
                 }
@@ -367,7 +390,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 const f3 hpos = ray_at(ro, rd, th) + hnrm * 0.001f;
                 set3(c.hn, hnrm);
                 const uint32_t cnt = c.cnt & 255u;  // light index 0, no visible light yet
-                if (A.nl > 0)
+                if (Cfg::nl(A) > 0)
                 {
                     const LightK& L = A.lights[0];
                     const f3 to_light = normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos);
@@ -378,8 +401,8 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     const f3 nh = axis_normal ? hnrm : normalize3(hnrm);
                     const bool finite_albedo = fabsf(hcol.x) < inf && fabsf(hcol.y) < inf && fabsf(hcol.z) < inf;
                     set3(c.hc, hcol);
-                    if (A.nl == 1 && finite_albedo && dot3(nh, to_light) <= 0.0f && !(A.ablate & 4))
-                        posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
+                    if (Cfg::nl(A) == 1 && finite_albedo && dot3(nh, to_light) <= 0.0f && !(Cfg::ablate(A) & 4))
+                        posted = wf_lighting_done<Cfg>(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
                     else
                     {
                         c.cnt = cnt;
@@ -391,7 +414,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 else
                 {
                     set3(c.hc, hcol);
-                    posted = wf_lighting_done(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
+                    posted = wf_lighting_done<Cfg>(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
                 }
             }
         }
@@ -432,7 +455,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 }
             }
             li += 1;
-            if (!early && li < A.nl)
+            if (!early && li < Cfg::nl(A))
             {
                 c.cnt = (cnt & 255u) | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
                 if (multi_light) P.dirbuf[slot] = float4{direct.x, direct.y, direct.z, 0.0f};
@@ -443,12 +466,12 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             else
             {
                 if (!early && nvis != 0) contribution = nvis == 1 ? hcol * direct : div3(hcol * direct, static_cast<float>(nvis));  // x / 1.0f == x
-                posted = wf_lighting_done(P, slot, c, contribution, hpos, hnrm, cnt, A, mo, md);
+                posted = wf_lighting_done<Cfg>(P, slot, c, contribution, hpos, hnrm, cnt, A, mo, md);
             }
         }
         if (posted)
         {
-            const int pb = wf_post_march(P, slot, c, mo, md, as_feeler, A, s_bits);
+            const int pb = wf_post_march<Cfg>(P, slot, c, mo, md, as_feeler, A, s_bits);
             store_cold(P.cold + slot, c);  // the slot lives on: write its shading state back
             return pb < 0 ? 1 : 2 + pb;
         }
@@ -594,7 +617,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
             if (valid)
             {
                 slot = P.event_list[sh->bucket_base[b] + e];
-                posted = wf_event(A, P, s_bits, b, slot, ray_cur + e, ray_cur + e < ray_end) == 1;  // (a march that ended at once waits in its event state for the next round)
+                posted = wf_event<CfgRuntime>(A, P, s_bits, b, slot, ray_cur + e, ray_cur + e < ray_end) == 1;  // (a march that ended at once waits in its event state for the next round)
             }
             const uint32_t at = wave_append(posted, &sh->n_march[cur_list], lane);
             if (posted) (P.march_list[0] + cur_list * PS)[at] = static_cast<uint16_t>(slot);
@@ -825,7 +848,7 @@ DDGI_D void aq_push(uint16_t* ring, uint32_t* tail, bool pred, uint32_t value, i
 
 // kPool > 0: the pool size is a compile-time constant, so every pool array is the LDS base plus a constant
 // offset (folded into the ds instructions: no address arithmetic, one SGPR instead of eleven).
-template <bool kStats, int kPool>
+template <bool kStats, int kPool, class Cfg>
 __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, const int pool_size, const int march_waves, uint32_t* __restrict__ work_counter,
                                                             uint32_t* __restrict__ status)
 {
@@ -850,7 +873,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     P.tl = takef();
     P.flags = takeu();
     P.cold = static_cast<WfCold*>(A.wf_cold) + static_cast<size_t>(blockIdx.x) * PS;
-    P.dirbuf = A.nl > 1 ? A.wf_dir + static_cast<size_t>(blockIdx.x) * PS : nullptr;
+    P.dirbuf = Cfg::nl(A) > 1 ? A.wf_dir + static_cast<size_t>(blockIdx.x) * PS : nullptr;
     P.march_list[0] = P.march_list[1] = P.event_list = nullptr;
     uint16_t* ring_mq = reinterpret_cast<uint16_t*>(cursor);
     uint16_t* ring_fq = ring_mq + kAqCap;
@@ -1042,7 +1065,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if (r_valid)
                 {
-                    const int rc = wf_event(A, P, s_bits, kBucketRefill, slot, r, true);
+                    const int rc = wf_event<Cfg>(A, P, s_bits, kBucketRefill, slot, r, true);
                     posted = rc == 1;
                     if (rc >= 2) ev_bucket = rc - 2;
                 }
@@ -1060,14 +1083,14 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 {
                     slot = aq_take(ring_eq + b * kAqCap, base + lane, &sh->abort);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const int rc = wf_event(A, P, s_bits, b, slot, 0u, false);
+                    const int rc = wf_event<Cfg>(A, P, s_bits, b, slot, 0u, false);
                     posted = rc == 1;
                     if (rc >= 2) ev_bucket = rc - 2;  // the new march ended within its first steps: straight to its event queue
                     freed = rc == 0;                  // the ray is finished: its output is written, the slot is empty
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            aq_push(ring_mq, &sh->mq_tail, posted && !(A.ablate & 8), slot, lane);  // DDGI_ABLATE=8: fault injection for the safety-net test
+            aq_push(ring_mq, &sh->mq_tail, posted && !(Cfg::ablate(A) & 8), slot, lane);  // DDGI_ABLATE=8: fault injection for the safety-net test
             aq_push(ring_fq, &sh->fq_tail, freed, slot, lane);
             if (ev_bucket >= 0)
             {
@@ -1099,20 +1122,20 @@ int aq_pool_size(int nwords, size_t lds_limit)
     return pool >= 1024 ? pool : 0;
 }
 
-template <bool kStats, int kPool>
+template <bool kStats, int kPool, class Cfg>
 static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
 {
     const size_t lds = aq_lds_bytes(args.scene.nwords, pool);
     static bool attr_set = false;
     if (!attr_set)
     {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_aq<kStats, kPool>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_aq<kStats, kPool, Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_probe_trace_aq<kStats, kPool>), dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter, status);
+    hipLaunchKernelGGL((k_probe_trace_aq<kStats, kPool, Cfg>), dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter, status);
     return hipGetLastError();
 }
 
@@ -1120,9 +1143,11 @@ constexpr int kAqPool = 1536;  // the usual pool (ddgi_engine.cpp); other sizes 
 
 hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
 {
-    if (args.stats) return launch_aq<true, 0>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
-    if (pool == kAqPool) return launch_aq<false, kAqPool>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
-    return launch_aq<false, 0>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+    if (args.stats) return launch_aq<true, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+    if (pool == kAqPool && args.nl == 1 && args.ablate == 0)
+        return args.ddgi ? launch_aq<false, kAqPool, CfgPlain<1>>(args, pool, grid_blocks, march_waves, work_counter, status, stream)
+                         : launch_aq<false, kAqPool, CfgPlain<0>>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+    return launch_aq<false, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
 }
 
 // LDS bytes of k_probe_trace_wf for a pool of `pool` rays
