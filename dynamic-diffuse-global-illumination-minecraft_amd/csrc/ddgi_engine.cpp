@@ -244,19 +244,15 @@ static int ensure_noise(ddgi_engine* e)
         HIP_TRY(hipMemcpy(e->d_noise[i], src[i]->data(), src[i]->size() * sizeof(float), hipMemcpyHostToDevice));
     }
     e->noise.n2 = e->d_noise[0];
-    e->noise.n2_x0 = h.n2_x0, e->noise.n2_nx = h.n2_nx, e->noise.n2_y0 = h.n2_y0, e->noise.n2_ny = h.n2_ny;
     e->noise.n1 = e->d_noise[1];
-    e->noise.n1_i0 = h.n1_i0, e->noise.n1_n = h.n1_n;
     e->noise.wp = e->d_noise[2];
     e->noise.wall = e->d_noise[3];
     e->noise.r1 = e->d_noise[4];
-    for (int a = 0; a < 3; ++a) e->noise.r1_lo[a] = h.r1_lo[a], e->noise.r1_n[a] = h.r1_n[a];
     if (const char* v = std::getenv("DDGI_LUT_OFF"))  // profiling: 1 = no wall table, 2 = no random1 table
     {
         if (std::atoi(v) & 1) e->noise.wall = nullptr;
         if (std::atoi(v) & 2) e->noise.r1 = nullptr;
     }
-    e->noise.wp_c0 = h.wp_c0, e->noise.wp_n = h.wp_n;
     return DDGI_OK;
 }
 

@@ -113,9 +113,9 @@ const SceneBake& baked_scene(int scene)
 static NoiseLutHost build_noise_lut()
 {
     NoiseLutHost t;
-    t.n2_x0 = -2, t.n2_nx = 520, t.n2_y0 = -2048, t.n2_ny = 4096;
-    t.n1_i0 = -8192, t.n1_n = 16384;
-    t.wp_c0 = -16, t.wp_n = 32;
+    t.n2_x0 = lut::kN2X0, t.n2_nx = lut::kN2NX, t.n2_y0 = lut::kN2Y0, t.n2_ny = lut::kN2NY;
+    t.n1_i0 = lut::kN1I0, t.n1_n = lut::kN1N;
+    t.wp_c0 = lut::kWpC0, t.wp_n = lut::kWpN;
     t.n2.resize(static_cast<size_t>(t.n2_nx) * t.n2_ny);
     for (int ix = 0; ix < t.n2_nx; ++ix)
         for (int iy = 0; iy < t.n2_ny; ++iy)
@@ -135,7 +135,8 @@ static NoiseLutHost build_noise_lut()
     }
     // random1 over the cave's bake box (cave wall and ground colours hash the voxel id)
     {
-        const int lo[3] = {-42, -21, -38}, hi[3] = {32, 18, 31};
+        const int lo[3] = {lut::kR1Lo0, lut::kR1Lo1, lut::kR1Lo2};
+        const int hi[3] = {lo[0] + lut::kR1N0 - 1, lo[1] + lut::kR1N1 - 1, lo[2] + lut::kR1N2 - 1};  // the cave's bake box
         for (int a = 0; a < 3; ++a) t.r1_lo[a] = lo[a], t.r1_n[a] = hi[a] - lo[a] + 1;
         t.r1.resize(static_cast<size_t>(t.r1_n[0]) * t.r1_n[1] * t.r1_n[2]);
         size_t k = 0;

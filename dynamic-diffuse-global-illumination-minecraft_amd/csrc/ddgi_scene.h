@@ -99,32 +99,34 @@ DDGI_HD float noise2D(float px, float py)  // :402
 // (ddgi_host.cpp: build_noise_lut) and the kernels load the stored binary32 value instead of
 // re-evaluating a binary64 sine; outside the rectangle (or with null tables) the hash is computed.
 // A stored value IS the function's value, so results are unchanged bit for bit.
+// The tables' extents are compile-time constants (ddgi_host.cpp: build_noise_lut fills exactly these): the
+// kernels compare against immediates instead of carrying two dozen scalars per launch.
+namespace lut {
+constexpr int kN2X0 = -2, kN2NX = 520, kN2Y0 = -2048, kN2NY = 4096;  // noise2D(ix, iy): ix in [x0, x0+nx), iy in [y0, y0+ny)
+constexpr int kN1I0 = -8192, kN1N = 16384;                           // noise1(i)
+constexpr int kWpC0 = -16, kWpN = 32;                                // worley_point(cx, cy)
+constexpr int kR1Lo0 = -42, kR1Lo1 = -21, kR1Lo2 = -38;              // random1(cell) over the cave's bake box
+constexpr int kR1N0 = 75, kR1N1 = 40, kR1N2 = 70;
+}  // namespace lut
+
 struct NoiseLut
 {
-    // noise2D(ix, iy) for ix in [x0, x0+nx), iy in [y0, y0+ny); index (ix-x0)*ny + (iy-y0)
-    const float* n2 = nullptr;
-    int n2_x0 = 0, n2_nx = 0, n2_y0 = 0, n2_ny = 0;
-    // noise1(i) for i in [n1_i0, n1_i0+n1_n)
-    const float* n1 = nullptr;
-    int n1_i0 = 0, n1_n = 0;
-    // worley_point(cx, cy) for cx, cy in [wp_c0, wp_c0+wp_n): 2 floats each, index ((cx-c0)*n + (cy-c0))*2
-    const float* wp = nullptr;
-    int wp_c0 = 0, wp_n = 0;
+    const float* n2 = nullptr;    // noise2D, index (ix-x0)*ny + (iy-y0)
+    const float* n1 = nullptr;    // noise1, index i - i0
+    const float* wp = nullptr;    // worley_point, 2 floats each, index ((cx-c0)*n + (cy-c0))*2
     // cave wall: fbm2(kWallFbmX, y) has a constant x, so each octave's two x-interpolations
     // mix(noise2D(ix,iy), noise2D(ix+1,iy), fract(x*freq)) depend on iy alone:
-    // wall[o*n2_ny + (iy-n2_y0)] for octave o = 0..7 (freq 2..256) holds that value
+    // wall[o*ny + (iy-y0)] for octave o = 0..7 (freq 2..256) holds that value
     const float* wall = nullptr;
-    // random1(cell) for cell ids in [r1_lo, r1_lo + r1_n) per axis (the cave's bake box); x fastest
-    const float* r1 = nullptr;
-    int r1_lo[3] = {0, 0, 0}, r1_n[3] = {0, 0, 0};
+    const float* r1 = nullptr;    // random1(cell), x fastest
 };
 constexpr float kWallFbmX = 0.05f;
 DDGI_HD float random1_at(f3 cell, const NoiseLut& L)  // random1 of a voxel id (integer-valued floats)
 {
-    const unsigned ux = static_cast<unsigned>(gl_int(cell.x) - L.r1_lo[0]), uy = static_cast<unsigned>(gl_int(cell.y) - L.r1_lo[1]),
-                   uz = static_cast<unsigned>(gl_int(cell.z) - L.r1_lo[2]);
-    if (L.r1 && ux < static_cast<unsigned>(L.r1_n[0]) && uy < static_cast<unsigned>(L.r1_n[1]) && uz < static_cast<unsigned>(L.r1_n[2]))
-        return L.r1[(uz * static_cast<unsigned>(L.r1_n[1]) + uy) * static_cast<unsigned>(L.r1_n[0]) + ux];
+    const unsigned ux = static_cast<unsigned>(gl_int(cell.x) - lut::kR1Lo0), uy = static_cast<unsigned>(gl_int(cell.y) - lut::kR1Lo1),
+                   uz = static_cast<unsigned>(gl_int(cell.z) - lut::kR1Lo2);
+    if (L.r1 && ux < static_cast<unsigned>(lut::kR1N0) && uy < static_cast<unsigned>(lut::kR1N1) && uz < static_cast<unsigned>(lut::kR1N2))
+        return L.r1[(uz * static_cast<unsigned>(lut::kR1N1) + uy) * static_cast<unsigned>(lut::kR1N0) + ux];
     return random1(cell);
 }
 
@@ -134,11 +136,11 @@ DDGI_HD float interp_noise2D(float x, float y, const NoiseLut& L = NoiseLut())  
     const int ix = gl_int(fx0), iy = gl_int(fy0);
     const float tx = gl_fract(x), ty = gl_fract(y);
     float a, b, c, d;
-    const unsigned ux = static_cast<unsigned>(ix - L.n2_x0), uy = static_cast<unsigned>(iy - L.n2_y0);
-    if (L.n2 && ux < static_cast<unsigned>(L.n2_nx - 1) && uy < static_cast<unsigned>(L.n2_ny - 1))
+    const unsigned ux = static_cast<unsigned>(ix - lut::kN2X0), uy = static_cast<unsigned>(iy - lut::kN2Y0);
+    if (L.n2 && ux < static_cast<unsigned>(lut::kN2NX - 1) && uy < static_cast<unsigned>(lut::kN2NY - 1))
     {
-        const float* q = L.n2 + static_cast<size_t>(ux) * L.n2_ny + uy;
-        a = q[0], c = q[1], b = q[L.n2_ny], d = q[L.n2_ny + 1];
+        const float* q = L.n2 + static_cast<size_t>(ux) * lut::kN2NY + uy;
+        a = q[0], c = q[1], b = q[lut::kN2NY], d = q[lut::kN2NY + 1];
     }
     else
     {
@@ -169,7 +171,7 @@ DDGI_HD float fbm2_wall(float y, const NoiseLut& L = NoiseLut())
     {
         float total = 0.0f;
         float freq = 1.0f, amp = 1.0f;
-        const float* row = L.wall - L.n2_y0;
+        const float* row = L.wall - lut::kN2Y0;
         for (int i = 1; i <= 8; ++i)
         {
             freq *= 2.0f;
@@ -177,7 +179,7 @@ DDGI_HD float fbm2_wall(float y, const NoiseLut& L = NoiseLut())
             const float yo = y * freq;
             const float* q = row + gl_int(floorf(yo));
             total += gl_mix(q[0], q[1], gl_fract(yo)) * amp;
-            row += L.n2_ny;
+            row += lut::kN2NY;
         }
         return total;
     }
@@ -186,8 +188,8 @@ DDGI_HD float fbm2_wall(float y, const NoiseLut& L = NoiseLut())
 DDGI_HD float noise1(float i) { return gl_fract(hash_sin(203.311f * i)); }  // :437-439 (.x only)
 DDGI_HD float noise1_at(float i, const NoiseLut& L)
 {
-    const unsigned u = static_cast<unsigned>(gl_int(i) - L.n1_i0);
-    if (L.n1 && u < static_cast<unsigned>(L.n1_n)) return L.n1[u];
+    const unsigned u = static_cast<unsigned>(gl_int(i) - lut::kN1I0);
+    if (L.n1 && u < static_cast<unsigned>(lut::kN1N)) return L.n1[u];
     return noise1(i);
 }
 DDGI_HD float interp_noise1D(float x, const NoiseLut& L = NoiseLut())  // :441-448
@@ -215,10 +217,10 @@ DDGI_HD f2 worley_point_eval(f2 cell)  // generate_point :467-471 (cell_size 5)
 }
 DDGI_HD f2 worley_point(f2 cell, const NoiseLut& L)
 {
-    const unsigned ux = static_cast<unsigned>(gl_int(cell.x) - L.wp_c0), uy = static_cast<unsigned>(gl_int(cell.y) - L.wp_c0);
-    if (L.wp && ux < static_cast<unsigned>(L.wp_n) && uy < static_cast<unsigned>(L.wp_n))
+    const unsigned ux = static_cast<unsigned>(gl_int(cell.x) - lut::kWpC0), uy = static_cast<unsigned>(gl_int(cell.y) - lut::kWpC0);
+    if (L.wp && ux < static_cast<unsigned>(lut::kWpN) && uy < static_cast<unsigned>(lut::kWpN))
     {
-        const float* q = L.wp + (static_cast<size_t>(ux) * L.wp_n + uy) * 2;
+        const float* q = L.wp + (static_cast<size_t>(ux) * lut::kWpN + uy) * 2;
         return f2{q[0], q[1]};
     }
     return worley_point_eval(cell);
