@@ -185,10 +185,14 @@ DDGI_D bool march_step_burst(March& m, const SceneK& S, const uint32_t* __restri
 // fbm of (x, z) BEFORE it looks at the hollow (intersection.glsl:726-742), so it continues under the
 // solid rock outside the box.  No ray can reach those voxels from the hollow, but a probe placed in
 // the rock there starts inside one — evaluate the rule itself for them.
+// (kept out of line: it is reached by almost no ray, and inlined into the march loops its fbm — sines in
+// binary64 — costs every ray registers and instruction-cache space)
+__device__ __attribute__((noinline, cold)) inline int cave_floor_band_type(f3 cell) { return block_at(cell, 0); }
+
 DDGI_D int hit_block_type(const SceneK& S, int scene_id, f3 cell, int raw)
 {
     if (scene_id == 0 && cell.y < -15.0f && (cell.x < S.lo_f[0] || cell.x > S.hi_f[0] || cell.z < S.lo_f[2] || cell.z > S.hi_f[2]))
-        return block_at(cell, 0);
+        return cave_floor_band_type(cell);
     return S.types[raw - S.bias];
 }
 
