@@ -8,7 +8,7 @@ The product is libddgi_probe.so (hand-written HIP kernels behind include/ddgi_pr
 package only binds it (ctypes) and adds the torch.distributed plumbing for the z-slab sharded
 multi-GPU path.  It never imports anything from oracle/.
 """
-from .build import build_library, library_path  # noqa: F401
+from .build import build_library, build_profiling_library, library_path, profiling_library_path  # noqa: F401
 from .probe_engine import (  # noqa: F401
     Camera,
     DDGIError,
@@ -20,6 +20,9 @@ from .probe_engine import (  # noqa: F401
     LIGHT_DTYPE,
     MODE_REF,
     MODE_DDGI,
+    comm_create,
+    comm_destroy,
+    comm_unique_id,
     generate_probe_rays_host,
     load_library,
     make_camera,

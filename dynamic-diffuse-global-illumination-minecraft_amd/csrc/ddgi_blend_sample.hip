@@ -75,7 +75,7 @@ DDGI_D void blend_column_texel(int c, bool& is_dep, int& tx, int& ty)
 __global__ __launch_bounds__(kBlendCols) void k_blend_weights(const BlendArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float blend_lds[];
-    const int n = A.grid.s * A.grid.s;
+    const int n = A.grid.n;
     const int c = threadIdx.x;
     for (int i = c; i < n; i += kBlendCols)
     {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(128) void k_probe_blend_s(const BlendArgs A, const 
     // the read-only inputs come as separate noalias kernel arguments (not through BlendArgs) so that the
     // compiler can prove the tile stores do not clobber them and selects scalar loads for the ray records
     const GridK& G = A.grid;
-    const int n = G.s * G.s;
+    const int n = G.n;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool is_dep = wave == 0;  // wave-uniform
     const float hyst = G.hysteresis;
@@ -226,14 +226,16 @@ __global__ __launch_bounds__(128) void k_probe_blend_s(const BlendArgs A, const 
                 const uint32_t pl = g0 * kRecGroup + q;
                 if (pl < A.n_local_probes && valid)
                 {
-                    float* tile = A.depth + blend_tile_slot(G, pl) * (kDepTile * kDepTile * 2);
+                    const size_t tile_off = blend_tile_slot(G, pl) * (kDepTile * kDepTile * 2);
+                    float* tile = A.depth + tile_off;
+                    const float* tile_old = A.depth_old + tile_off;
 #pragma unroll
                     for (int t = 0; t < kDepT; ++t)
                     {
                         const float s1 = a1[q / kRecGroup][(q % kRecGroup) / 2][t][q & 1], s2 = a2[q / kRecGroup][(q % kRecGroup) / 2][t][q & 1];
                         float r1 = 0.0f, r2 = 0.0f;
                         if (sw[t] > 1e-6f) r1 = s1 / sw[t], r2 = s2 / sw[t];
-                        const float2 old = *reinterpret_cast<const float2*>(tile + dst[t][0] * 2);
+                        const float2 old = *reinterpret_cast<const float2*>(tile_old + dst[t][0] * 2);
                         const float2 out{gl_mix(old.x, r1, hyst), gl_mix(old.y, r2, hyst)};
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
@@ -300,10 +302,11 @@ __global__ __launch_bounds__(128) void k_probe_blend_s(const BlendArgs A, const 
                     const uint32_t pl = grp * kRecGroup + j;
                     if (pl < A.n_local_probes && valid)
                     {
-                        float* tile = A.irradiance + blend_tile_slot(G, pl) * (kIrrTile * kIrrTile * 4);
+                        const size_t tile_off = blend_tile_slot(G, pl) * (kIrrTile * kIrrTile * 4);
+                        float* tile = A.irradiance + tile_off;
                         float res[3] = {0.0f, 0.0f, 0.0f};
                         if (sw > 1e-6f) res[0] = ac[0][j / 2][j & 1] / sw, res[1] = ac[1][j / 2][j & 1] / sw, res[2] = ac[2][j / 2][j & 1] / sw;
-                        const float4 old = *reinterpret_cast<const float4*>(tile + dst[0] * 4);
+                        const float4 old = *reinterpret_cast<const float4*>(A.irradiance_old + tile_off + dst[0] * 4);
                         const float4 out{gl_mix(old.x, res[0], hyst), gl_mix(old.y, res[1], hyst), gl_mix(old.z, res[2], hyst), 1.0f};
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(kBlendBlock) void k_probe_blend(const BlendArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float blend_lds[];
     const GridK& G = A.grid;
-    const int n = G.s * G.s;
+    const int n = G.n;
     float4* s_rad = reinterpret_cast<float4*>(blend_lds);  // n: r, g, b, clamped distance
     float* s_dir = blend_lds + 4 * n;                      // 3 n
     float* s_irr = s_dir + 3 * n;                          // 8*8*4
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(kBlendBlock) void k_probe_blend(const BlendArgs A)
             float res[3] = {0.0f, 0.0f, 0.0f};
             if (sw > 1e-6f) res[0] = sr / sw, res[1] = sg / sw, res[2] = sb / sw;
             const int o = (ty * kIrrTile + tx) * 4;
-            const float4 old = *reinterpret_cast<const float4*>(g_irr + o);
+            const float4 old = *reinterpret_cast<const float4*>(A.irradiance_old + slot * (kIrrTile * kIrrTile * 4) + o);
             s_irr[o + 0] = gl_mix(old.x, res[0], hyst);
             s_irr[o + 1] = gl_mix(old.y, res[1], hyst);
             s_irr[o + 2] = gl_mix(old.z, res[2], hyst);
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(kBlendBlock) void k_probe_blend(const BlendArgs A)
             float r1 = 0.0f, r2 = 0.0f;
             if (sw > 1e-6f) r1 = s1 / sw, r2 = s2 / sw;
             const int o = (ty * kDepTile + tx) * 2;
-            const float2 old = *reinterpret_cast<const float2*>(g_dep + o);
+            const float2 old = *reinterpret_cast<const float2*>(A.depth_old + slot * (kDepTile * kDepTile * 2) + o);
             s_dep[o + 0] = gl_mix(old.x, r1, hyst);
             s_dep[o + 1] = gl_mix(old.y, r2, hyst);
         }
@@ -442,7 +445,7 @@ size_t blend_record_groups(uint32_t n_local_probes)
 
 hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t stream)
 {
-    const int n = args.grid.s * args.grid.s;
+    const int n = args.grid.n;
     if (args.n_local_probes == 0) return hipSuccess;
     const size_t dir_lds = static_cast<size_t>(3) * n * sizeof(float);
     if (args.w && args.w_sum && dir_lds <= 64 * 1024)

@@ -8,10 +8,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
+#include "ddgi_engine.h"
 #include "ddgi_host.h"
 #include "ddgi_pinned_math.h"
 #include "ddgi_scene.h"
@@ -21,7 +26,7 @@ namespace ddgi {
 hipError_t launch_probe_trace_ref(const TraceArgs& args, int grid_blocks, hipStream_t stream);
 hipError_t launch_probe_sample_ref(const SampleArgs& args, hipStream_t stream);
 hipError_t trace_kernel_occupancy(int* blocks_per_cu, size_t lds_bytes);
-int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads);
+int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads, int max_pool);
 hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream);
 hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t stream);
 int aq_pool_size(int nwords, size_t lds_limit);
@@ -31,9 +36,67 @@ size_t blend_record_groups(uint32_t n_local_probes);
 hipError_t launch_carry_tiles(void* dst, const void* src, const int32_t* map, uint32_t n_probes, uint32_t words_per_tile, hipStream_t stream);
 hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream);
 hipError_t launch_render_primary(const RenderArgs& args, hipStream_t stream);
+
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;  // (device ordinal, kernel)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({dev, kernel});
+    return e;
+}
 }  // namespace ddgi
 
 using namespace ddgi;
+#define make_grid ddgi_make_grid
+#define texture_bytes ddgi_texture_bytes
+#define alloc_texture_pair ddgi_alloc_texture_pair
+
+struct TuningKey
+{
+    const char* name;
+    int Tuning::*field;
+    const char* env;
+};
+static const TuningKey kTuningKeys[] = {
+    {"trace_kernel", &Tuning::trace_kernel, nullptr},  // env DDGI_TRACE_KERNEL takes names, see read_env_tuning
+    {"march_waves", &Tuning::march_waves, "DDGI_AQ_MARCH"},
+    {"autotune", &Tuning::autotune, "DDGI_AUTOTUNE"},
+    {"blend_kernel", &Tuning::blend_kernel, nullptr},
+    {"aq_pool", &Tuning::aq_pool, "DDGI_AQ_POOL"},
+    {"wf_pool", &Tuning::wf_pool, "DDGI_WF_POOL"},
+    {"wf_maxpool", &Tuning::wf_maxpool, "DDGI_WF_MAXPOOL"},
+    {"wf_threads", &Tuning::wf_threads, "DDGI_WF_THREADS"},
+    {"wf_fetch", &Tuning::wf_fetch, "DDGI_WF_FETCH"},
+    {"wf_tail", &Tuning::wf_tail, "DDGI_WF_TAIL"},
+    {"wf_chunk", &Tuning::wf_chunk, "DDGI_WF_CHUNK"},
+    {"wf_drain", &Tuning::wf_drain, "DDGI_WF_DRAIN"},
+    {"wait_threshold", &Tuning::wait_threshold, "DDGI_WAIT_THRESHOLD"},
+    {"noise_lut", &Tuning::noise_lut, nullptr},
+    {"lut_off", &Tuning::lut_off, "DDGI_LUT_OFF"},
+    {"verbose", &Tuning::verbose, "DDGI_VERBOSE"},
+#ifdef DDGI_PROFILING
+    {"ablate", &Tuning::ablate, "DDGI_ABLATE"},
+#endif
+};
+
+static Tuning read_env_tuning()
+{
+    Tuning t;
+    for (const TuningKey& k : kTuningKeys)
+        if (k.env)
+            if (const char* v = std::getenv(k.env)) t.*(k.field) = std::atoi(v);
+    if (const char* v = std::getenv("DDGI_TRACE_KERNEL"))
+        t.trace_kernel = !std::strcmp(v, "rounds") ? 1 : !std::strcmp(v, "lane") ? 2 : !std::strcmp(v, "queues") ? 3 : 0;
+    if (std::getenv("DDGI_BLEND_KERNEL")) t.blend_kernel = 1;
+    if (std::getenv("DDGI_NO_NOISE_LUT")) t.noise_lut = 0;
+    return t;
+}
 
 static_assert(sizeof(ddgi_irradiance_field) == 48, "IrradianceField must be 48 bytes (rvpt.h:82-90)");
 static_assert(sizeof(ddgi_render_settings) == 32, "RenderSettings must be 32 bytes (rvpt.h:70-80)");
@@ -44,7 +107,7 @@ static_assert(offsetof(ddgi_irradiance_field, field_origin) == 32, "std140 layou
 
 static thread_local std::string g_last_error;
 
-static int fail(int code, const char* fmt, ...)
+int ddgi_fail(int code, const char* fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -55,86 +118,15 @@ static int fail(int code, const char* fmt, ...)
     return code;
 }
 
-#define HIP_TRY(expr)                                                                                   \
-    do                                                                                                  \
-    {                                                                                                   \
-        hipError_t e_ = (expr);                                                                         \
-        if (e_ != hipSuccess)                                                                           \
-            return fail(e_ == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY                              \
-                        : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? DDGI_ERR_NO_DEVICE  \
-                                                                                   : DDGI_ERR_HIP,      \
-                        "%s failed: %s", #expr, hipGetErrorString(e_));                                 \
-    } while (0)
-
-// ---- the handle ----------------------------------------------------------------------------------------
-
-struct ddgi_engine
-{
-    int device = 0;
-    int rank = 0, world = 1;
-    int mode = DDGI_MODE_REF;
-    ddgi_irradiance_field field{};
-    ddgi_render_settings settings{};
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int num_cus = 256;
-
-    // lights per scene
-    LightK lights[4][kMaxLights];  // [3] = the user scene (DDGI_SCENE_USER)
-    int n_lights[4] = {0, 0, 0, 0};
-    SceneBake user_scene;          // host copy of the loaded user scene (scene id 3); empty until loaded
-
-    // baked scene on device (per scene id, uploaded lazily)
-    struct DevScene
-    {
-        uint32_t* bits = nullptr;
-        uint8_t* types = nullptr;
-        SceneK k{};
-        bool ready = false;
-    } dev_scene[4];
-
-    // memoised lattice hashes on device
-    float* d_noise[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    NoiseLut noise{};
-
-    // rays
-    GlibcRand rand;
-    bool rand_seeded = false;
-    std::vector<ddgi_probe_ray> host_rays;  // full grid (what RVPT::probe_rays holds)
-    float4* d_rays = nullptr;               // local slab
-    size_t d_rays_capacity = 0;             // in rays
-    uint32_t n_local_rays = 0;
-
-    // textures (REF: rgba8 texels, slab-major)
-    void* own_tex[2] = {nullptr, nullptr};
-    void* tex[2] = {nullptr, nullptr};
-    size_t tex_bytes[2] = {0, 0};
-
-    static constexpr int kRing = 64;  // timing history: one event triple per recent update
-    hipEvent_t ev[kRing][3] = {};
-    unsigned long long updates = 0;
-    int wait_threshold = 64;
-    uint32_t* d_work = nullptr;             // chunk counter of the wavefront trace kernel
-    void* d_wf_cold = nullptr;              // wavefront kernel scratch: per-slot shading state
-    float4* d_wf_dir = nullptr;
-    size_t wf_cold_slots = 0, wf_dir_slots = 0;
-    float* d_radiance = nullptr;            // DDGI mode ray records: rgb part then (d, d*d) part (ddgi_types.h: kRecGroup)
-    size_t d_radiance_capacity = 0;         // in (record group, ray) pairs
-    uint32_t frame = 0;                     // DDGI mode: updates done so far (seeds the ray rotation)
-    unsigned long long aq_key = 0;  // configuration the march/event wave split was measured for
-    int aq_march = 0;               // that split (0: not measured yet)
-    float* d_blend_w = nullptr;  // k_blend_weights output: [256 sums][n][256]
-    size_t d_blend_w_floats = 0;
-    unsigned long long* d_stats = nullptr;  // profiling aid, allocated on first ddgi_trace_stats(enable)
-};
-
-static GridK make_grid(const ddgi_engine* e)
+GridK ddgi_make_grid(const ddgi_engine* e)
 {
     GridK g;
     g.cx = e->field.probe_count[0];
     g.cy = e->field.probe_count[1];
     g.cz = e->field.probe_count[2];
-    g.s = e->field.sqrt_rays_per_probe;
+    g.sx = e->tile[0] > 0 ? e->tile[0] : e->field.sqrt_rays_per_probe;
+    g.sy = e->tile[1] > 0 ? e->tile[1] : e->field.sqrt_rays_per_probe;
+    g.n = g.sx * g.sy;
     g.side = e->field.side_length;
     for (int a = 0; a < 3; ++a) g.origin[a] = e->field.field_origin[a];
     g.hysteresis = e->field.hysteresis;
@@ -161,33 +153,67 @@ static int validate_config(const ddgi_irradiance_field* f, const ddgi_render_set
     return DDGI_OK;
 }
 
+static int validate_tile(const ddgi_irradiance_field* f, int tx, int ty)
+{
+    if (tx < 1 || ty < 1 || tx > 4096 || ty > 4096) return fail(DDGI_ERR_INVALID_ARGUMENT, "ray tile %d x %d not in [1,4096]^2", tx, ty);
+    const unsigned long long rays = 1ull * f->probe_count[0] * f->probe_count[1] * f->probe_count[2] * tx * ty;
+    if (rays >= (1ull << 32)) return fail(DDGI_ERR_UNSUPPORTED, "more than 2^32 probe rays: the reference's uint RNG seed wraps");
+    return DDGI_OK;
+}
+
+constexpr int kMaxDdgiRays = 4096;  // k_blend_weights keeps the frame's ray directions in LDS (12 B each, 64 KB without opt-in)
+
 static int check_kernel_status(ddgi_engine* e);
 
+// Byte sizes of the two probe textures of a configuration.
+void ddgi_texture_bytes(int mode, const ddgi_irradiance_field& f, int rays_per_probe, size_t bytes[2])
+{
+    const size_t probes = static_cast<size_t>(f.probe_count[0]) * f.probe_count[1] * f.probe_count[2];
+    if (mode == DDGI_MODE_DDGI)
+    {
+        bytes[0] = probes * 8 * 8 * 4 * sizeof(float);    // irradiance tiles
+        bytes[1] = probes * 16 * 16 * 2 * sizeof(float);  // depth-moment tiles
+    }
+    else
+        bytes[0] = bytes[1] = probes * static_cast<size_t>(rays_per_probe) * 4;
+}
+
+// Allocates and zero-fills a texture pair; on failure nothing is left allocated.
+// (the reference leaves the images undefined until the first probe pass, rvpt.cpp:873-890; here they start zeroed)
+int ddgi_alloc_texture_pair(ddgi_engine* e, const size_t bytes[2], void* out[2])
+{
+    out[0] = out[1] = nullptr;
+    for (int i = 0; i < 2; ++i)
+    {
+        hipError_t he = hipMalloc(&out[i], bytes[i]);
+        if (he == hipSuccess) he = hipMemsetAsync(out[i], 0, bytes[i], e->stream);
+        if (he != hipSuccess)
+        {
+            for (int k = 0; k < 2; ++k)
+                if (out[k]) (void)hipFree(out[k]);
+            out[0] = out[1] = nullptr;
+            return fail(he == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY : DDGI_ERR_HIP, "probe texture allocation (%zu B) failed: %s", bytes[i], hipGetErrorString(he));
+        }
+    }
+    return DDGI_OK;
+}
+
+// (Re)creates the handle's own textures for its current field / tile / mode, zeroed, and makes them current.
+// On failure the previous textures stay in place.
 static int alloc_textures(ddgi_engine* e)
 {
+    ddgi_exchange_release(e);  // a new configuration: the exchange is set up again by ddgi_exchange_init
+    size_t bytes[2];
+    texture_bytes(e->mode, e->field, make_grid(e).n, bytes);
+    void* fresh[2];
+    if (int rc = alloc_texture_pair(e, bytes, fresh)) return rc;
     for (int i = 0; i < 2; ++i)
     {
         if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
-        e->own_tex[i] = nullptr;
+        e->own_tex[i] = e->tex[i] = fresh[i];
+        e->tex_bytes[i] = bytes[i];
     }
-    const size_t probes = static_cast<size_t>(e->field.probe_count[0]) * e->field.probe_count[1] * e->field.probe_count[2];
-    const size_t s2 = static_cast<size_t>(e->field.sqrt_rays_per_probe) * e->field.sqrt_rays_per_probe;
-    if (e->mode == DDGI_MODE_DDGI)
-    {
-        e->tex_bytes[0] = probes * 8 * 8 * 4 * sizeof(float);    // irradiance tiles
-        e->tex_bytes[1] = probes * 16 * 16 * 2 * sizeof(float);  // depth-moment tiles
-    }
-    else
-        e->tex_bytes[0] = e->tex_bytes[1] = probes * s2 * 4;
     e->frame = 0;
-    for (int i = 0; i < 2; ++i)
-    {
-        HIP_TRY(hipMalloc(&e->own_tex[i], e->tex_bytes[i]));
-        // the reference leaves the images undefined until the first probe pass (rvpt.cpp:873-890);
-        // here they start zeroed
-        HIP_TRY(hipMemsetAsync(e->own_tex[i], 0, e->tex_bytes[i], e->stream));
-        e->tex[i] = e->own_tex[i];
-    }
     return DDGI_OK;
 }
 
@@ -235,7 +261,7 @@ static int ensure_scene(ddgi_engine* e, int scene)
 
 static int ensure_noise(ddgi_engine* e)
 {
-    if (e->noise.n2 || std::getenv("DDGI_NO_NOISE_LUT")) return DDGI_OK;
+    if (e->noise.n2 || !e->tuning.noise_lut) return DDGI_OK;
     const NoiseLutHost& h = noise_lut_host();
     const std::vector<float>* src[5] = {&h.n2, &h.n1, &h.wp, &h.wall, &h.r1};
     for (int i = 0; i < 5; ++i)
@@ -248,18 +274,15 @@ static int ensure_noise(ddgi_engine* e)
     e->noise.wp = e->d_noise[2];
     e->noise.wall = e->d_noise[3];
     e->noise.r1 = e->d_noise[4];
-    if (const char* v = std::getenv("DDGI_LUT_OFF"))  // profiling: 1 = no wall table, 2 = no random1 table
-    {
-        if (std::atoi(v) & 1) e->noise.wall = nullptr;
-        if (std::atoi(v) & 2) e->noise.r1 = nullptr;
-    }
+    if (e->tuning.lut_off & 1) e->noise.wall = nullptr;  // profiling
+    if (e->tuning.lut_off & 2) e->noise.r1 = nullptr;
     return DDGI_OK;
 }
 
 static int upload_local_rays(ddgi_engine* e)
 {
     const GridK g = make_grid(e);
-    const size_t n = static_cast<size_t>(g.s) * g.s;
+    const size_t n = static_cast<size_t>(g.n);
     const size_t local_probes = static_cast<size_t>(g.cx) * g.cy * g.czl;
     const size_t local_rays = local_probes * n;
     if (local_rays > e->d_rays_capacity)
@@ -318,6 +341,7 @@ int ddgi_create_sharded(const ddgi_irradiance_field* field, const ddgi_render_se
     e->world = world;
     e->field = *field;
     e->settings = *settings;
+    e->tuning = read_env_tuning();
     e->num_cus = prop.multiProcessorCount;
     for (int s = 0; s < 3; ++s) shipped_lights(s, e->lights[s], &e->n_lights[s]);
     int rc = DDGI_OK;
@@ -354,6 +378,7 @@ int ddgi_destroy(ddgi_handle e)
     if (!e) return DDGI_OK;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    ddgi_exchange_release(e);
     for (int i = 0; i < 2; ++i)
         if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
     if (e->d_rays) (void)hipFree(e->d_rays);
@@ -385,6 +410,7 @@ int ddgi_configure(ddgi_handle e, const ddgi_irradiance_field* field, const ddgi
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->field = *field;
+    e->tile[0] = e->tile[1] = 0;  // the new field's square tile; ddgi_set_ray_tile changes it
     e->settings = *settings;
     e->host_rays.clear();
     e->n_local_rays = 0;
@@ -408,7 +434,8 @@ int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const dd
     const ddgi_irradiance_field old = e->field;
     // a tile can be carried over only if it has the same size: always in DDGI mode (8x8 / 16x16
     // octahedral tiles), in REF mode when the rays per probe did not change
-    const bool same_tiles = e->mode == DDGI_MODE_DDGI || old.sqrt_rays_per_probe == field->sqrt_rays_per_probe;
+    const GridK old_grid = make_grid(e);
+    const bool same_tiles = e->mode == DDGI_MODE_DDGI || (old_grid.sx == field->sqrt_rays_per_probe && old_grid.sy == field->sqrt_rays_per_probe);
     // per axis: which old probe index has exactly the new probe's coordinate (-1: none)
     std::vector<int> axis_map[3];
     for (int a = 0; a < 3; ++a)
@@ -434,33 +461,45 @@ int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const dd
                     map[(static_cast<size_t>(z) * cy + y) * cx + x] = (oz * old.probe_count[1] + oy) * old.probe_count[0] + ox;
                     carried += 1;
                 }
-    // keep the old textures alive across the re-allocation
-    void* old_own[2] = {e->own_tex[0], e->own_tex[1]};
-    const void* old_tex[2] = {e->tex[0], e->tex[1]};
-    const size_t old_words[2] = {e->tex_bytes[0] / 4 / (static_cast<size_t>(old.probe_count[0]) * old.probe_count[1] * old.probe_count[2]),
-                                 e->tex_bytes[1] / 4 / (static_cast<size_t>(old.probe_count[0]) * old.probe_count[1] * old.probe_count[2])};
-    e->own_tex[0] = e->own_tex[1] = nullptr;
-    const uint32_t frame = e->frame;
+    // New textures first, into temporaries: the handle's state is committed only when everything worked.
+    const size_t old_probes = static_cast<size_t>(old.probe_count[0]) * old.probe_count[1] * old.probe_count[2];
+    const size_t old_words[2] = {e->tex_bytes[0] / 4 / old_probes, e->tex_bytes[1] / 4 / old_probes};
+    size_t bytes[2];
+    texture_bytes(e->mode, *field, field->sqrt_rays_per_probe * field->sqrt_rays_per_probe, bytes);
+    void* fresh[2];
+    if (int rc = alloc_texture_pair(e, bytes, fresh)) return rc;
+    if (carried > 0)
+    {
+        int32_t* d_map = nullptr;
+        hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_map), map.size() * sizeof(int32_t));
+        if (he == hipSuccess) he = hipMemcpyAsync(d_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+        for (int i = 0; i < 2 && he == hipSuccess; ++i)
+            he = launch_carry_tiles(fresh[i], e->tex[i], d_map, static_cast<uint32_t>(map.size()), static_cast<uint32_t>(old_words[i]), e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        if (d_map) (void)hipFree(d_map);
+        if (he != hipSuccess)
+        {
+            (void)hipFree(fresh[0]);
+            (void)hipFree(fresh[1]);
+            return fail(he == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY : DDGI_ERR_HIP, "carrying the probe tiles over failed: %s (the handle keeps its previous configuration)",
+                        hipGetErrorString(he));
+        }
+    }
+    // commit.  Caller-bound textures (ddgi_bind_textures) are unbound: the handle uses its own from here on.
+    ddgi_exchange_release(e);
+    for (int i = 0; i < 2; ++i)
+    {
+        if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
+        e->own_tex[i] = e->tex[i] = fresh[i];
+        e->tex_bytes[i] = bytes[i];
+    }
     e->field = *field;
+    e->tile[0] = e->tile[1] = 0;
     e->settings = *settings;
     e->host_rays.clear();
     e->n_local_rays = 0;
-    e->updates = 0;
-    int rc = alloc_textures(e);
-    e->frame = frame;  // the temporal sequence (ray rotation, RNG keys) goes on
-    if (rc == DDGI_OK && carried > 0)
-    {
-        int32_t* d_map = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_map), map.size() * sizeof(int32_t)));
-        HIP_TRY(hipMemcpyAsync(d_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream));
-        for (int i = 0; i < 2; ++i)
-            HIP_TRY(launch_carry_tiles(e->tex[i], old_tex[i], d_map, static_cast<uint32_t>(map.size()), static_cast<uint32_t>(old_words[i]), e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        (void)hipFree(d_map);
-    }
-    for (void* p : old_own)
-        if (p) (void)hipFree(p);
-    return rc;
+    e->updates = 0;  // (the DDGI frame sequence — ray rotation, RNG keys — goes on: e->frame is kept)
+    return DDGI_OK;
 }
 
 int ddgi_set_mode(ddgi_handle e, int mode)
@@ -474,6 +513,42 @@ int ddgi_set_mode(ddgi_handle e, int mode)
     e->mode = mode;
     e->updates = 0;
     return alloc_textures(e);  // the two modes keep differently shaped textures; both start zeroed
+}
+
+int ddgi_set_ray_tile(ddgi_handle e, int tile_x, int tile_y)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    const int s = e->field.sqrt_rays_per_probe;
+    if (tile_x == 0 && tile_y == 0) tile_x = tile_y = s;
+    if (int rc = validate_tile(&e->field, tile_x, tile_y)) return rc;
+    const GridK g = make_grid(e);
+    if (g.sx == tile_x && g.sy == tile_y) return DDGI_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->tex[0] != e->own_tex[0]) return fail(DDGI_ERR_INVALID_ARGUMENT, "unbind caller textures before changing the ray tile");
+    e->tile[0] = tile_x, e->tile[1] = tile_y;
+    e->host_rays.clear();
+    e->n_local_rays = 0;
+    e->updates = 0;
+    return alloc_textures(e);  // REF: the texel tile follows the ray tile; both modes restart from zeroed textures
+}
+
+int ddgi_get_ray_tile(ddgi_handle e, int* tile_x, int* tile_y)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    const GridK g = make_grid(e);
+    if (tile_x) *tile_x = g.sx;
+    if (tile_y) *tile_y = g.sy;
+    return DDGI_OK;
+}
+
+int ddgi_get_texture_size(ddgi_handle e, int* width, int* height)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    const GridK g = make_grid(e);
+    if (width) *width = g.cx * g.cz * g.sx;
+    if (height) *height = g.cy * g.sy;
+    return DDGI_OK;
 }
 
 int ddgi_set_lights(ddgi_handle e, int scene, const ddgi_light* lights, int n)
@@ -503,7 +578,8 @@ int ddgi_generate_probe_rays(ddgi_handle e, uint32_t seed, int reseed)
         e->rand.seed(seed);
         e->rand_seeded = true;
     }
-    generate_probe_rays(e->field, e->rand, e->host_rays);
+    const GridK g = make_grid(e);
+    generate_probe_rays(e->field, g.sx, g.sy, e->rand, e->host_rays);
     return upload_local_rays(e);
 }
 
@@ -513,15 +589,15 @@ int ddgi_upload_probe_rays(ddgi_handle e, const ddgi_probe_ray* rays, size_t n)
     HIP_TRY(hipSetDevice(e->device));
     const GridK g = make_grid(e);
     const size_t probes = static_cast<size_t>(g.cx) * g.cy * g.cz;
-    const size_t expect = probes * g.s * g.s;
+    const size_t expect = probes * g.n;
     if (n != expect) return fail(DDGI_ERR_INVALID_ARGUMENT, "expected %zu rays (full grid), got %zu", expect, n);
     // the reference's shader trusts probe_info blindly (Q13); an out-of-range tile would write
     // outside the texture, so reject it here
     for (size_t i = 0; i < n; ++i)
     {
         const float p = rays[i].probe_info[0], tx = rays[i].probe_info[1], ty = rays[i].probe_info[2];
-        if (!(p >= 0.0f && p < static_cast<float>(probes) && tx >= 0.0f && tx < static_cast<float>(g.s) && ty >= 0.0f &&
-              ty < static_cast<float>(g.s)))
+        if (!(p >= 0.0f && p < static_cast<float>(probes) && tx >= 0.0f && tx < static_cast<float>(g.sx) && ty >= 0.0f &&
+              ty < static_cast<float>(g.sy)))
             return fail(DDGI_ERR_INVALID_ARGUMENT, "ray %zu: probe_info (%g,%g,%g) outside the grid", i, p, tx, ty);
     }
     e->host_rays.assign(rays, rays + n);
@@ -544,7 +620,7 @@ static unsigned long long aq_config_key(const ddgi_engine* e, const TraceArgs& a
     auto mix = [&](unsigned long long v) { h = (h ^ v) * 1099511628211ull; };
     for (int i = 0; i < 3; ++i) mix(static_cast<unsigned>(e->field.probe_count[i]));
     mix(static_cast<unsigned>(e->field.side_length));
-    mix(static_cast<unsigned>(e->field.sqrt_rays_per_probe));
+    mix(static_cast<unsigned>(a.grid.sx)), mix(static_cast<unsigned>(a.grid.sy));
     for (int i = 0; i < 3; ++i)
     {
         unsigned u;
@@ -553,25 +629,35 @@ static unsigned long long aq_config_key(const ddgi_engine* e, const TraceArgs& a
     }
     mix(static_cast<unsigned>(a.scene_id)), mix(static_cast<unsigned>(a.max_bounces)), mix(static_cast<unsigned>(a.nl));
     mix(ddgi_mode ? 1u : 0u), mix(static_cast<unsigned>(e->rank)), mix(static_cast<unsigned>(e->world)), mix(a.n_rays);
+    mix(e->scene_epoch);
     return h | 1ull;
 }
 
-int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
+// One probe update's trace launch, fully decided: arguments, kernel, pool, grid.  Built by plan_trace (which
+// also makes sure every buffer the launch needs exists), used by ddgi_probe_update and ddgi_tune.
+struct TracePlan
 {
-    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
-    if (settings)
-    {
-        if (settings->scene < 0 || settings->scene > 3) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2,3}", settings->scene);
-        e->settings = *settings;
-    }
-    const bool ddgi_mode = e->mode == DDGI_MODE_DDGI;
-    if (!ddgi_mode && e->n_local_rays == 0) return fail(DDGI_ERR_NOT_READY, "ddgi_probe_update before any probe rays were generated/uploaded");
-    HIP_TRY(hipSetDevice(e->device));
+    TraceArgs a{};
+    bool ddgi_mode = false;
+    int pool = 0;            // ray pool of the wavefront kernels; 0: the ray-per-lane kernel
+    bool use_async = false;  // k_probe_trace_aq (queues) rather than k_probe_trace_wf (rounds)
+    int wf_threads = 1024;
+    uint32_t grid = 0;
+    size_t rec_pairs = 0;    // DDGI mode: (record group, ray) pairs of the ray-record buffer
+    unsigned long long key = 0;
+};
+
+static int plan_trace(ddgi_engine* e, TracePlan& p)
+{
+    const Tuning& tn = e->tuning;
+    p.ddgi_mode = e->mode == DDGI_MODE_DDGI;
+    if (!p.ddgi_mode && e->n_local_rays == 0) return fail(DDGI_ERR_NOT_READY, "ddgi_probe_update before any probe rays were generated/uploaded");
     const int scene = e->settings.scene;
     if (int rc = ensure_scene(e, scene)) return rc;
     if (int rc = ensure_noise(e)) return rc;
 
-    TraceArgs a{};
+    TraceArgs& a = p.a;
+    a = TraceArgs{};
     a.grid = make_grid(e);
     a.scene = e->dev_scene[scene].k;
     a.scene_id = scene;
@@ -580,65 +666,59 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     for (int i = 0; i < a.nl; ++i) a.lights[i] = e->lights[scene][i];
     a.rays = e->d_rays;
     a.n_rays = e->n_local_rays;
-    if (ddgi_mode)
+    if (p.ddgi_mode && a.grid.n > kMaxDdgiRays)
+        return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode: %d rays per probe; the blend's direction table holds at most %d", a.grid.n, kMaxDdgiRays);
+    if (p.ddgi_mode)
     {
         // rays are generated in the kernel; lights follow update_lights(time) (probe_pass.comp:217-251)
-        const size_t local_rays = static_cast<size_t>(a.grid.cx) * a.grid.cy * a.grid.czl * a.grid.s * a.grid.s;
-        const size_t rec_pairs = blend_record_groups(static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.czl) * a.grid.s * a.grid.s;
-        if (rec_pairs > e->d_radiance_capacity)
+        const size_t local_rays = static_cast<size_t>(a.grid.cx) * a.grid.cy * a.grid.czl * a.grid.n;
+        p.rec_pairs = blend_record_groups(static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.czl) * a.grid.n;
+        if (p.rec_pairs > e->d_radiance_capacity)
         {
             if (e->d_radiance) (void)hipFree(e->d_radiance);
             e->d_radiance = nullptr;
             e->d_radiance_capacity = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_radiance), rec_pairs * 40 * sizeof(float)));
-            HIP_TRY(hipMemsetAsync(e->d_radiance, 0, rec_pairs * 40 * sizeof(float), e->stream));
-            e->d_radiance_capacity = rec_pairs;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_radiance), p.rec_pairs * 40 * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(e->d_radiance, 0, p.rec_pairs * 40 * sizeof(float), e->stream));
+            e->d_radiance_capacity = p.rec_pairs;
         }
         animate_lights(scene, e->settings.time, e->lights[scene], a.nl, a.lights);
         a.ddgi = 1;
         a.frame_key = frame_key(e->frame);
         frame_rotation(e->frame, a.rot);
         a.rad_rgb = e->d_radiance;
-        a.rad_dd = e->d_radiance + rec_pairs * 24;
+        a.rad_dd = e->d_radiance + p.rec_pairs * 24;
         a.rays = nullptr;
         a.n_rays = static_cast<uint32_t>(local_rays);
     }
     a.albedo = static_cast<uint32_t*>(e->tex[0]);
     a.distance = static_cast<uint32_t*>(e->tex[1]);
-    a.wait_threshold = e->wait_threshold;
+    a.wait_threshold = tn.wait_threshold;
     a.stats = e->d_stats;
     a.noise = e->noise;
-    if (const char* v = std::getenv("DDGI_WAIT_THRESHOLD")) a.wait_threshold = std::atoi(v);
-    if (const char* v = std::getenv("DDGI_ABLATE")) a.ablate = std::atoi(v);
-    if (const char* v = std::getenv("DDGI_WF_TAIL")) a.wf_tail = std::atoi(v);
-    if (const char* v = std::getenv("DDGI_WF_FETCH")) a.wf_fetch = std::atoi(v);
-    if (const char* v = std::getenv("DDGI_WF_CHUNK")) a.wf_chunk = std::atoi(v);
-    if (const char* v = std::getenv("DDGI_WF_DRAIN")) a.wf_drain = std::atoi(v);
+    a.ablate = tn.ablate;  // always 0 in the release library (Tuning)
+    a.wf_tail = tn.wf_tail, a.wf_fetch = tn.wf_fetch, a.wf_chunk = tn.wf_chunk, a.wf_drain = tn.wf_drain;
 
     // Kernel choice: the wavefront kernel (one persistent 1024-lane workgroup per CU, ray pool in
     // LDS) whenever its pool fits next to the scene bitmap; the ray-per-lane kernel otherwise
-    // (or when DDGI_TRACE_KERNEL=lane asks for it, e.g. to cross-check the two).
-    const char* kernel_env = std::getenv("DDGI_TRACE_KERNEL");
-    const bool force_lane = kernel_env && std::strcmp(kernel_env, "lane") == 0;
-    if (ddgi_mode && (force_lane || a.max_bounces < 1)) return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode needs the wavefront trace kernel and max_bounces >= 1");
-    int wf_threads = 1024;
-    if (const char* v = std::getenv("DDGI_WF_THREADS")) wf_threads = std::atoi(v) == 512 ? 512 : 1024;
-    const int wf_blocks_per_cu = 1024 / wf_threads;
-    int pool = (force_lane || a.max_bounces < 1) ? 0 : wf_pool_size(a.scene.nwords, a.nl > 1, 160 * 1024 / wf_blocks_per_cu, wf_threads);
-    if (const char* v = std::getenv("DDGI_WF_POOL")) pool = pool ? std::min(pool, std::max(wf_threads, std::atoi(v) / 64 * 64)) : 0;
-    // the barrier-free queue kernel (k_probe_trace_aq) whenever its pool fits; DDGI_TRACE_KERNEL=rounds asks
-    // for the round-based k_probe_trace_wf (cross-check), which also serves the utilisation counters
-    const bool ask_queues = kernel_env && std::strcmp(kernel_env, "queues") == 0;
-    const bool force_rounds = (kernel_env && std::strcmp(kernel_env, "rounds") == 0) || (a.stats != nullptr && !ask_queues) || wf_threads != 1024;
-    const bool use_async = pool > 0 && !force_rounds && aq_pool_size(a.scene.nwords, 160 * 1024) > 0;
-    if (use_async)
+    // (or when tuning "trace_kernel" = 2 asks for it, e.g. to cross-check the two).
+    const bool force_lane = tn.trace_kernel == 2;
+    if (p.ddgi_mode && (force_lane || a.max_bounces < 1)) return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode needs the wavefront trace kernel and max_bounces >= 1");
+    p.wf_threads = tn.wf_threads == 512 ? 512 : 1024;
+    const int wf_blocks_per_cu = 1024 / p.wf_threads;
+    p.pool = (force_lane || a.max_bounces < 1) ? 0 : wf_pool_size(a.scene.nwords, a.nl > 1, 160 * 1024 / wf_blocks_per_cu, p.wf_threads, tn.wf_maxpool);
+    if (tn.wf_pool > 0) p.pool = p.pool ? std::min(p.pool, std::max(p.wf_threads, tn.wf_pool / 64 * 64)) : 0;
+    // the barrier-free queue kernel (k_probe_trace_aq) whenever its pool fits; "trace_kernel" = 1 asks for the
+    // round-based k_probe_trace_wf (cross-check), which also serves the utilisation counters
+    const bool force_rounds = tn.trace_kernel == 1 || (a.stats != nullptr && tn.trace_kernel != 3) || p.wf_threads != 1024;
+    p.use_async = p.pool > 0 && !force_rounds && aq_pool_size(a.scene.nwords, 160 * 1024) > 0;
+    if (p.use_async)
     {
-        pool = std::min(1536, aq_pool_size(a.scene.nwords, 160 * 1024));  // more slots than ~1300 buy nothing (C3: 1024: 3.64 ms, 1280: 3.36, 1536: 3.35, 2048: 3.39)
-        if (const char* v = std::getenv("DDGI_AQ_POOL")) pool = std::min(aq_pool_size(a.scene.nwords, 160 * 1024), std::max(1024, std::atoi(v) / 64 * 64));
+        p.pool = std::min(1536, aq_pool_size(a.scene.nwords, 160 * 1024));  // more slots than ~1300 buy nothing (C3: 1024: 3.64 ms, 1280: 3.36, 1536: 3.35, 2048: 3.39)
+        if (tn.aq_pool > 0) p.pool = std::min(aq_pool_size(a.scene.nwords, 160 * 1024), std::max(1024, tn.aq_pool / 64 * 64));
     }
-
-    hipEvent_t* ev = e->ev[e->updates % ddgi_engine::kRing];
-    if (pool > 0)
+    if (p.ddgi_mode && p.pool <= 0) return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode: the ray pool does not fit in LDS next to the scene bitmap");
+    if (p.pool > 0)
     {
         if (!e->d_work)
         {
@@ -648,9 +728,9 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         // one persistent workgroup per CU unless the launch is tiny (the launcher sizes the ray claims
         // so that every workgroup gets several: launch_probe_trace_wf)
         const uint32_t chunks = (a.n_rays + 255u) / 256u;
-        uint32_t grid = static_cast<uint32_t>(e->num_cus * wf_blocks_per_cu);
-        if (grid > chunks) grid = chunks;
-        const size_t slots = static_cast<size_t>(grid) * pool;
+        p.grid = static_cast<uint32_t>(e->num_cus * wf_blocks_per_cu);
+        if (p.grid > chunks) p.grid = chunks;
+        const size_t slots = static_cast<size_t>(p.grid) * p.pool;
         if (slots > e->wf_cold_slots)
         {
             if (e->d_wf_cold) (void)hipFree(e->d_wf_cold);
@@ -669,68 +749,6 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         }
         a.wf_cold = e->d_wf_cold;
         a.wf_dir = e->d_wf_dir;
-        int march_waves = 5;
-        if (use_async)
-        {
-            // How many of the 16 waves march (the rest run events) is the one knob the balance of a scene
-            // moves: C3 is fastest at 5 (4: 3.44 ms, 5: 2.96, 6: 3.14, 8: 3.7), Cornell and the house at 6,
-            // a sparser cave grid at 3.  The first update of a configuration measures it: a few extra
-            // launches of the same (idempotent) trace, hill-climbing from the last value.
-            const unsigned long long key = aq_config_key(e, a, ddgi_mode);
-            if (const char* v = std::getenv("DDGI_AQ_MARCH")) march_waves = std::min(15, std::max(1, std::atoi(v)));
-            else if (e->aq_key == key && e->aq_march > 0) march_waves = e->aq_march;
-            else
-            {
-                const char* tune = std::getenv("DDGI_AUTOTUNE");
-                march_waves = e->aq_march > 0 ? e->aq_march : 5;
-                if (!(tune && std::atoi(tune) == 0) && a.ablate == 0)  // (not under the profiling / fault-injection switches)
-                {
-                    auto timed = [&](int mw, float* ms) -> int {  // the faster of two launches
-                        *ms = 0.0f;
-                        for (int rep = 0; rep < 2; ++rep)
-                        {
-                            float t = 0.0f;
-                            HIP_TRY(hipEventRecord(ev[0], e->stream));
-                            HIP_TRY(launch_probe_trace_aq(a, pool, static_cast<int>(grid), mw, e->d_work, e->d_work + 1, e->stream));
-                            HIP_TRY(hipEventRecord(ev[1], e->stream));
-                            HIP_TRY(hipEventSynchronize(ev[1]));
-                            HIP_TRY(hipEventElapsedTime(&t, ev[0], ev[1]));
-                            if (rep == 0 || t < *ms) *ms = t;
-                        }
-                        return DDGI_OK;
-                    };
-                    float best_ms = 0.0f, ms = 0.0f;
-                    // first touches, cold caches, clocks still low: repeat the starting point until it settles
-                    if (int rc = timed(march_waves, &ms)) return rc;
-                    for (int settle = 0; settle < 6; ++settle)
-                    {
-                        if (int rc = timed(march_waves, &best_ms)) return rc;
-                        const bool steady = std::fabs(best_ms - ms) < 0.015f * best_ms;
-                        ms = best_ms;
-                        if (steady) break;
-                    }
-                    for (int dir = -1; dir <= 1; dir += 2)
-                    {
-                        bool moved = false;
-                        for (int mw = march_waves + dir; mw >= 2 && mw <= 12; mw += dir)
-                        {
-                            if (int rc = timed(mw, &ms)) return rc;
-                            if (ms >= best_ms) break;
-                            best_ms = ms, march_waves = mw, moved = true;
-                        }
-                        if (moved) break;  // downhill in this direction: the other one was uphill
-                    }
-                }
-                e->aq_key = key;
-                e->aq_march = march_waves;
-                if (std::getenv("DDGI_VERBOSE")) std::fprintf(stderr, "[ddgi] queue kernel: %d march waves / %d event waves for this configuration\n", march_waves, 16 - march_waves);
-            }
-        }
-        HIP_TRY(hipEventRecord(ev[0], e->stream));
-        if (use_async)
-            HIP_TRY(launch_probe_trace_aq(a, pool, static_cast<int>(grid), march_waves, e->d_work, e->d_work + 1, e->stream));
-        else
-            HIP_TRY(launch_probe_trace_wf(a, wf_threads, pool, static_cast<int>(grid), e->d_work, e->stream));
     }
     else
     {
@@ -739,15 +757,134 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         HIP_TRY(trace_kernel_occupancy(&per_cu, lds));
         if (per_cu < 1) return fail(DDGI_ERR_UNSUPPORTED, "scene bitmap (%zu B) does not fit in LDS", lds);
         const uint32_t chunks = (a.n_rays + kTraceBlock - 1) / kTraceBlock;
-        uint32_t grid = static_cast<uint32_t>(e->num_cus) * static_cast<uint32_t>(per_cu);
-        if (grid > chunks) grid = chunks;
+        p.grid = static_cast<uint32_t>(e->num_cus) * static_cast<uint32_t>(per_cu);
+        if (p.grid > chunks) p.grid = chunks;
+    }
+    p.key = aq_config_key(e, a, p.ddgi_mode);
+    return DDGI_OK;
+}
+
+// How many of the queue kernel's 16 waves march (the rest run events) is the one knob the balance of a scene
+// moves: C3 is fastest at 5 (4: 3.44 ms, 5: 2.96, 6: 3.14, 8: 3.7), Cornell and the house at 6, a sparser cave
+// grid at 3.  Measured per configuration: a few extra launches of the same (idempotent) trace, hill-climbing
+// from `start`.  BLOCKS the host (hipEventSynchronize); some tens of milliseconds.
+static int measure_march_waves(ddgi_engine* e, const TracePlan& p, int start, int* out)
+{
+    hipEvent_t* ev = e->ev[e->updates % ddgi_engine::kRing];
+    int march_waves = start;
+    auto timed = [&](int mw, float* ms) -> int {  // the faster of two launches
+        *ms = 0.0f;
+        for (int rep = 0; rep < 2; ++rep)
+        {
+            float t = 0.0f;
+            HIP_TRY(hipEventRecord(ev[0], e->stream));
+            HIP_TRY(launch_probe_trace_aq(p.a, p.pool, static_cast<int>(p.grid), mw, e->d_work, e->d_work + 1, e->stream));
+            HIP_TRY(hipEventRecord(ev[1], e->stream));
+            HIP_TRY(hipEventSynchronize(ev[1]));
+            HIP_TRY(hipEventElapsedTime(&t, ev[0], ev[1]));
+            if (rep == 0 || t < *ms) *ms = t;
+        }
+        return DDGI_OK;
+    };
+    float best_ms = 0.0f, ms = 0.0f;
+    // first touches, cold caches, clocks still low: repeat the starting point until it settles
+    if (int rc = timed(march_waves, &ms)) return rc;
+    for (int settle = 0; settle < 6; ++settle)
+    {
+        if (int rc = timed(march_waves, &best_ms)) return rc;
+        const bool steady = std::fabs(best_ms - ms) < 0.015f * best_ms;
+        ms = best_ms;
+        if (steady) break;
+    }
+    for (int dir = -1; dir <= 1; dir += 2)
+    {
+        bool moved = false;
+        for (int mw = march_waves + dir; mw >= 2 && mw <= 12; mw += dir)
+        {
+            if (int rc = timed(mw, &ms)) return rc;
+            if (ms >= best_ms) break;
+            best_ms = ms, march_waves = mw, moved = true;
+        }
+        if (moved) break;  // downhill in this direction: the other one was uphill
+    }
+    if (e->tuning.verbose) std::fprintf(stderr, "[ddgi] queue kernel: %d march waves / %d event waves for this configuration\n", march_waves, 16 - march_waves);
+    *out = march_waves;
+    return DDGI_OK;
+}
+
+// The split for plan p: pinned ("march_waves" tuning) > measured earlier for this configuration > measured now
+// (when `may_block` and "autotune" allow it) > the last measured value / 5.
+static int choose_march_waves(ddgi_engine* e, const TracePlan& p, bool may_block, bool force_measure, int* out)
+{
+    const Tuning& tn = e->tuning;
+    if (tn.march_waves > 0 && !force_measure)
+    {
+        *out = std::min(15, std::max(1, tn.march_waves));
+        return DDGI_OK;
+    }
+    auto it = e->aq_split.find(p.key);
+    if (it != e->aq_split.end() && !force_measure)
+    {
+        *out = it->second;
+        return DDGI_OK;
+    }
+    int mw = e->aq_last > 0 ? e->aq_last : 5;
+    if (force_measure || (may_block && tn.autotune && tn.ablate == 0))
+    {
+        if (int rc = measure_march_waves(e, p, mw, &mw)) return rc;
+        if (e->aq_split.size() >= 64) e->aq_split.erase(e->aq_split.begin());  // bounded: an app cycling through more configurations re-measures
+        e->aq_split[p.key] = mw;
+        e->aq_last = mw;
+    }
+    *out = mw;
+    return DDGI_OK;
+}
+
+int ddgi_tune(ddgi_handle e)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    HIP_TRY(hipSetDevice(e->device));
+    TracePlan p;
+    if (int rc = plan_trace(e, p)) return rc;
+    if (!p.use_async) return DDGI_OK;  // nothing to tune for the other trace kernels
+    int mw = 0;
+    return choose_march_waves(e, p, true, true, &mw);
+}
+
+int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (settings)
+    {
+        if (settings->scene < 0 || settings->scene > 3) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2,3}", settings->scene);
+        e->settings = *settings;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    if (int rc = ddgi_exchange_before_update(e)) return rc;  // pipelined exchange: which texture pair this update writes
+    TracePlan p;
+    if (int rc = plan_trace(e, p)) return rc;
+    const TraceArgs& a = p.a;
+
+    hipEvent_t* ev = e->ev[e->updates % ddgi_engine::kRing];
+    if (p.pool > 0)
+    {
+        int march_waves = 5;
+        if (p.use_async)
+            if (int rc = choose_march_waves(e, p, true, false, &march_waves)) return rc;
         HIP_TRY(hipEventRecord(ev[0], e->stream));
-        HIP_TRY(launch_probe_trace_ref(a, static_cast<int>(grid), e->stream));
+        if (p.use_async)
+            HIP_TRY(launch_probe_trace_aq(a, p.pool, static_cast<int>(p.grid), march_waves, e->d_work, e->d_work + 1, e->stream));
+        else
+            HIP_TRY(launch_probe_trace_wf(a, p.wf_threads, p.pool, static_cast<int>(p.grid), e->d_work, e->stream));
+    }
+    else
+    {
+        HIP_TRY(hipEventRecord(ev[0], e->stream));
+        HIP_TRY(launch_probe_trace_ref(a, static_cast<int>(p.grid), e->stream));
     }
     HIP_TRY(hipEventRecord(ev[1], e->stream));
-    if (ddgi_mode)
+    if (p.ddgi_mode)
     {
-        if (pool <= 0) return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode: the ray pool does not fit in LDS next to the scene bitmap");
         BlendArgs b{};
         b.grid = a.grid;
         for (int i = 0; i < 9; ++i) b.rot[i] = a.rot[i];
@@ -755,9 +892,11 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         b.rad_dd = a.rad_dd;
         b.irradiance = static_cast<float*>(e->tex[0]);
         b.depth = static_cast<float*>(e->tex[1]);
+        b.irradiance_old = static_cast<const float*>(e->tex_prev[0] ? e->tex_prev[0] : e->tex[0]);
+        b.depth_old = static_cast<const float*>(e->tex_prev[1] ? e->tex_prev[1] : e->tex[1]);
         b.n_local_probes = static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.czl;
         {
-            const size_t need = blend_weights_floats(a.grid.s * a.grid.s) + 256;
+            const size_t need = blend_weights_floats(a.grid.n) + 256;
             if (need > e->d_blend_w_floats)
             {
                 if (e->d_blend_w) (void)hipFree(e->d_blend_w);
@@ -767,7 +906,7 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
             }
             b.w_sum = e->d_blend_w;
             b.w = e->d_blend_w + 256;
-            if (std::getenv("DDGI_BLEND_KERNEL")) b.w = b.w_sum = nullptr;  // "probe": one probe per workgroup, weights in place
+            if (e->tuning.blend_kernel == 1) b.w = b.w_sum = nullptr;  // one probe per workgroup, weights in place
         }
         HIP_TRY(launch_probe_blend(b, e->num_cus, e->stream));
         e->frame += 1;
@@ -784,7 +923,12 @@ static int check_kernel_status(ddgi_engine* e)
     if (!e->d_work) return DDGI_OK;
     uint32_t status = 0;
     HIP_TRY(hipMemcpy(&status, e->d_work + 1, sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (status != 0) return fail(DDGI_ERR_HIP, "the trace kernel aborted (status %u): the probe textures are not valid", status);
+    if (status != 0)
+    {
+        // reported once: the flag is cleared so that later (clean) updates on this handle are usable again
+        (void)hipMemset(e->d_work + 1, 0, sizeof(uint32_t));
+        return fail(DDGI_ERR_HIP, "the trace kernel aborted (status %u): the probe textures are not valid", status);
+    }
     return DDGI_OK;
 }
 
@@ -859,8 +1003,9 @@ int ddgi_read_textures(ddgi_handle e, uint8_t* albedo, uint8_t* distance)
     if (e->mode != DDGI_MODE_REF) return fail(DDGI_ERR_UNSUPPORTED, "ddgi_read_textures is REF-mode only; use ddgi_read_tiles");
     HIP_TRY(hipSetDevice(e->device));
     const GridK g = make_grid(e);
-    const size_t s = g.s, s2 = s * s;
+    const size_t s = g.sx, sh = g.sy, s2 = g.n;
     const size_t W = static_cast<size_t>(g.cx) * g.cz * s;
+    if (int rc = ddgi_exchange_wait_latest(e)) return rc;
     std::vector<uint32_t> slab(e->tex_bytes[0] / 4);
     uint8_t* outs[2] = {albedo, distance};
     for (int t = 0; t < 2; ++t)
@@ -877,8 +1022,8 @@ int ddgi_read_textures(ddgi_handle e, uint8_t* albedo, uint8_t* distance)
                 {
                     const uint32_t* tile = slab.data() + ((static_cast<size_t>(z) * g.cy + y) * g.cx + x) * s2;
                     const size_t col0 = (static_cast<size_t>(z) * g.cx + x) * s;
-                    const size_t row0 = static_cast<size_t>(y) * s;
-                    for (size_t ty = 0; ty < s; ++ty)
+                    const size_t row0 = static_cast<size_t>(y) * sh;
+                    for (size_t ty = 0; ty < sh; ++ty)
                         std::memcpy(raster + (row0 + ty) * W + col0, tile + ty * s, s * 4);
                 }
     }
@@ -891,6 +1036,7 @@ int ddgi_read_tiles(ddgi_handle e, float* irradiance, float* depth)
     if (e->mode != DDGI_MODE_DDGI) return fail(DDGI_ERR_UNSUPPORTED, "ddgi_read_tiles is DDGI-mode only; use ddgi_read_textures");
     HIP_TRY(hipSetDevice(e->device));
     const GridK g = make_grid(e);
+    if (int rc = ddgi_exchange_wait_latest(e)) return rc;
     float* outs[2] = {irradiance, depth};
     const size_t per_probe[2] = {8 * 8 * 4, 16 * 16 * 2};
     for (int t = 0; t < 2; ++t)
@@ -913,6 +1059,35 @@ int ddgi_read_tiles(ddgi_handle e, float* irradiance, float* depth)
     return DDGI_OK;
 }
 
+int ddgi_set_tuning(ddgi_handle e, const char* name, int value)
+{
+    if (!e || !name) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/name");
+    for (const TuningKey& k : kTuningKeys)
+        if (!std::strcmp(k.name, name))
+        {
+            e->tuning.*(k.field) = value;
+            return DDGI_OK;
+        }
+    return fail(DDGI_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", name);
+}
+
+int ddgi_get_tuning(ddgi_handle e, const char* name, int* value)
+{
+    if (!e || !name || !value) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/name/value");
+    if (!std::strcmp(name, "march_waves_measured"))  // the split in use for the last planned configuration (0: none yet)
+    {
+        *value = e->aq_last;
+        return DDGI_OK;
+    }
+    for (const TuningKey& k : kTuningKeys)
+        if (!std::strcmp(k.name, name))
+        {
+            *value = e->tuning.*(k.field);
+            return DDGI_OK;
+        }
+    return fail(DDGI_ERR_INVALID_ARGUMENT, "unknown tuning key '%s'", name);
+}
+
 int ddgi_set_frame(ddgi_handle e, uint32_t frame)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
@@ -927,6 +1102,7 @@ int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, si
     if (!d_pos || !d_nrm || !d_rgb) return fail(DDGI_ERR_INVALID_ARGUMENT, "null device pointer");
     if (n > 0xffffffffull) return fail(DDGI_ERR_INVALID_ARGUMENT, "too many points");
     HIP_TRY(hipSetDevice(e->device));
+    if (int rc = ddgi_exchange_wait_latest(e)) return rc;
     SampleArgs a{};
     a.grid = make_grid(e);
     a.albedo = static_cast<const uint32_t*>(e->tex[0]);
@@ -1004,6 +1180,9 @@ int ddgi_render_device(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_
     const int scene = st->scene;
     if (int rc = ensure_scene(e, scene)) return rc;
     if (int rc = ensure_noise(e)) return rc;
+    if ((256 + static_cast<size_t>(e->dev_scene[scene].k.nwords)) * sizeof(uint32_t) > 160 * 1024)
+        return fail(DDGI_ERR_UNSUPPORTED, "ddgi_render: the scene's occupancy bitmap (%d words) does not fit in the 160 KB of LDS", e->dev_scene[scene].k.nwords);
+    if (int rc = ddgi_exchange_wait_latest(e)) return rc;
     RenderArgs r{};
     r.trace.grid = make_grid(e);
     r.trace.scene = e->dev_scene[scene].k;
@@ -1092,6 +1271,7 @@ int ddgi_bind_textures(ddgi_handle e, void* tex0, void* tex1)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     if ((tex0 == nullptr) != (tex1 == nullptr)) return fail(DDGI_ERR_INVALID_ARGUMENT, "bind both textures or neither");
+    if (e->xch.pipelined) return fail(DDGI_ERR_INVALID_ARGUMENT, "the pipelined exchange owns the texture pairs: ddgi_exchange_init(h, NULL, 0) first");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->tex[0] = tex0 ? tex0 : e->own_tex[0];
@@ -1119,22 +1299,28 @@ int ddgi_probe_tile_origin(const ddgi_irradiance_field* f, int probe_index, int*
     return DDGI_OK;
 }
 
-int ddgi_generate_probe_rays_host(const ddgi_irradiance_field* f, uint32_t seed, int skip_calls, ddgi_probe_ray* rays, size_t n)
+int ddgi_generate_probe_rays_host_tile(const ddgi_irradiance_field* f, int tx, int ty, uint32_t seed, int skip_calls, ddgi_probe_ray* rays, size_t n)
 {
     if (!f || !rays) return fail(DDGI_ERR_INVALID_ARGUMENT, "null field/rays");
     ddgi_render_settings st{};
     if (int rc = validate_config(f, &st, 1)) return rc;
-    const size_t expect = static_cast<size_t>(f->probe_count[0]) * f->probe_count[1] * f->probe_count[2] *
-                          f->sqrt_rays_per_probe * f->sqrt_rays_per_probe;
+    if (int rc = validate_tile(f, tx, ty)) return rc;
+    const size_t expect = static_cast<size_t>(f->probe_count[0]) * f->probe_count[1] * f->probe_count[2] * tx * ty;
     if (n != expect) return fail(DDGI_ERR_INVALID_ARGUMENT, "expected room for %zu rays, got %zu", expect, n);
     GlibcRand rng;
     rng.seed(seed);
     // each generate_probe_rays() call draws 2*s*s values (rvpt.cpp:1161-1162)
-    for (long long i = 0; i < 2ll * skip_calls * f->sqrt_rays_per_probe * f->sqrt_rays_per_probe; ++i) (void)rng.next();
+    for (long long i = 0; i < 2ll * skip_calls * tx * ty; ++i) (void)rng.next();
     std::vector<ddgi_probe_ray> tmp;
-    generate_probe_rays(*f, rng, tmp);
+    generate_probe_rays(*f, tx, ty, rng, tmp);
     std::memcpy(rays, tmp.data(), tmp.size() * sizeof(ddgi_probe_ray));
     return DDGI_OK;
+}
+
+int ddgi_generate_probe_rays_host(const ddgi_irradiance_field* f, uint32_t seed, int skip_calls, ddgi_probe_ray* rays, size_t n)
+{
+    if (!f) return fail(DDGI_ERR_INVALID_ARGUMENT, "null field/rays");
+    return ddgi_generate_probe_rays_host_tile(f, f->sqrt_rays_per_probe, f->sqrt_rays_per_probe, seed, skip_calls, rays, n);
 }
 
 // ---- baked scenes on disk, user scenes -------------------------------------------
@@ -1153,7 +1339,7 @@ static uint32_t noise_id()
 
 static int fill_user_scene(ddgi_engine* e, const int lo[3], const int dim[3], const uint8_t* types)
 {
-    e->aq_march = 0;  // the trace kernel's wave split is measured again for the new scene
+    e->scene_epoch += 1;  // the trace kernel's wave split is measured again for the new scene
     for (int a = 0; a < 3; ++a)
         if (dim[a] < 1 || dim[a] > 4096 || lo[a] < -(1 << 20) || lo[a] > (1 << 20)) return fail(DDGI_ERR_INVALID_ARGUMENT, "bad scene box");
     const size_t n = static_cast<size_t>(dim[0]) * dim[1] * dim[2];

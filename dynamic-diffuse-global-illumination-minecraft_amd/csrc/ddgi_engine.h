@@ -1,0 +1,136 @@
+// ddgi_engine.h — the handle behind include/ddgi_probe.h (private to the library's host side:
+// ddgi_engine.cpp = configuration, launches, outputs; ddgi_exchange.cpp = the multi-GPU exchange).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ddgi_host.h"
+#include "ddgi_scene.h"
+#include "ddgi_types.h"
+
+using namespace ddgi;  // (private header of the library's own translation units)
+
+// Tuning / diagnostic switches of a handle (ddgi_set_tuning / ddgi_get_tuning).  The environment variables of
+// the same meaning are read ONCE, when the handle is created — never on the per-frame path.
+struct Tuning
+{
+    int trace_kernel = 0;   // 0 auto (queues when the pool fits), 1 rounds, 2 ray per lane, 3 queues even with counters on
+    int march_waves = 0;    // queue kernel: waves that march; 0 = per configuration (measured, see "autotune")
+    int autotune = 1;       // measure the march/event split on the first update of a configuration (blocks once)
+    int blend_kernel = 0;   // DDGI blend: 0 auto, 1 one probe per workgroup (cross-check)
+    int aq_pool = 0, wf_pool = 0, wf_maxpool = 0, wf_threads = 1024;
+    int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
+    int noise_lut = 1;      // memoised lattice hashes (0: compute every hash)
+    int lut_off = 0;        // profiling: 1 = no wall table, 2 = no random1 table
+    int verbose = 0;
+    int ablate = 0;         // profiling build only (-DDDGI_PROFILING): ablations / fault injection
+};
+
+// ---- error reporting ---------------------------------------------------------------------------------
+
+// Records the calling thread's last error message (ddgi_last_error) and returns `code`.
+int ddgi_fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+#define fail ddgi_fail
+
+#define HIP_TRY(expr)                                                                                   \
+    do                                                                                                  \
+    {                                                                                                   \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY                              \
+                        : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? DDGI_ERR_NO_DEVICE  \
+                                                                                   : DDGI_ERR_HIP,      \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                                 \
+    } while (0)
+
+// ---- the handle ----------------------------------------------------------------------------------------
+
+struct ddgi_engine
+{
+    int device = 0;
+    int rank = 0, world = 1;
+    int mode = DDGI_MODE_REF;
+    ddgi_irradiance_field field{};
+    int tile[2] = {0, 0};  // ddgi_set_ray_tile: non-square ray tile (0 = the field's sqrt_rays_per_probe)
+    ddgi_render_settings settings{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+
+    // lights per scene
+    LightK lights[4][kMaxLights];  // [3] = the user scene (DDGI_SCENE_USER)
+    int n_lights[4] = {0, 0, 0, 0};
+    SceneBake user_scene;          // host copy of the loaded user scene (scene id 3); empty until loaded
+
+    // baked scene on device (per scene id, uploaded lazily)
+    struct DevScene
+    {
+        uint32_t* bits = nullptr;
+        uint8_t* types = nullptr;
+        SceneK k{};
+        bool ready = false;
+    } dev_scene[4];
+
+    // memoised lattice hashes on device
+    float* d_noise[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    NoiseLut noise{};
+
+    // rays
+    GlibcRand rand;
+    bool rand_seeded = false;
+    std::vector<ddgi_probe_ray> host_rays;  // full grid (what RVPT::probe_rays holds)
+    float4* d_rays = nullptr;               // local slab
+    size_t d_rays_capacity = 0;             // in rays
+    uint32_t n_local_rays = 0;
+
+    // textures (REF: rgba8 texels, slab-major)
+    void* own_tex[2] = {nullptr, nullptr};
+    void* tex[2] = {nullptr, nullptr};       // the textures the next update writes and consumers read
+    void* tex_prev[2] = {nullptr, nullptr};  // DDGI blend: where the previous update's tiles are, when not in tex (pipelined exchange)
+    size_t tex_bytes[2] = {0, 0};
+
+    static constexpr int kRing = 64;  // timing history: one event triple per recent update
+    hipEvent_t ev[kRing][3] = {};
+    unsigned long long updates = 0;
+    int wait_threshold = 64;
+    uint32_t* d_work = nullptr;             // chunk counter of the wavefront trace kernel
+    void* d_wf_cold = nullptr;              // wavefront kernel scratch: per-slot shading state
+    float4* d_wf_dir = nullptr;
+    size_t wf_cold_slots = 0, wf_dir_slots = 0;
+    float* d_radiance = nullptr;            // DDGI mode ray records: rgb part then (d, d*d) part (ddgi_types.h: kRecGroup)
+    size_t d_radiance_capacity = 0;         // in (record group, ray) pairs
+    uint32_t frame = 0;                     // DDGI mode: updates done so far (seeds the ray rotation)
+    Tuning tuning;
+    std::map<unsigned long long, int> aq_split;  // configuration key -> measured march/event wave split of the queue kernel
+    int aq_last = 0;                             // the most recently measured split (starting point of the next measurement)
+    unsigned scene_epoch = 0;                    // bumped when the user scene changes (part of the configuration key)
+    float* d_blend_w = nullptr;  // k_blend_weights output: [256 sums][n][256]
+    size_t d_blend_w_floats = 0;
+    // multi-GPU exchange of the blended textures through RCCL (ddgi_exchange.cpp)
+    struct Exchange
+    {
+        void* comm = nullptr;   // ncclComm_t; caller-owned unless made by ddgi_comm_create
+        bool pipelined = false;
+        void* pair[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // pipelined: two engine-owned texture pairs, used alternately
+        hipStream_t comm_stream = nullptr;
+        hipEvent_t written = nullptr;           // handle's stream: the update's kernels have finished
+        hipEvent_t sent[2] = {nullptr, nullptr};  // comm stream: pair i's last exchange is over
+        bool sent_valid[2] = {false, false};
+        int cur = 0;               // pair written by the most recent update
+        unsigned long long k = 0;  // updates issued since ddgi_exchange_init
+    } xch;
+    unsigned long long* d_stats = nullptr;  // profiling aid, allocated on first ddgi_trace_stats(enable)
+};
+
+// shared by ddgi_engine.cpp and ddgi_exchange.cpp
+GridK ddgi_make_grid(const ddgi_engine* e);
+void ddgi_texture_bytes(int mode, const ddgi_irradiance_field& f, int rays_per_probe, size_t bytes[2]);
+int ddgi_alloc_texture_pair(ddgi_engine* e, const size_t bytes[2], void* out[2]);
+// exchange hooks called by the engine (no-ops without an initialised exchange)
+int ddgi_exchange_before_update(ddgi_engine* e);   // pipelined: pick + bind the pair the update writes, wait for its last exchange
+int ddgi_exchange_wait_latest(ddgi_engine* e);     // consumers: the handle's stream waits until the latest pair is complete
+void ddgi_exchange_release(ddgi_engine* e);        // configuration changed / handle destroyed: drop pairs, stream, events

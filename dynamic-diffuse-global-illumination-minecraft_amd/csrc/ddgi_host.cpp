@@ -198,26 +198,26 @@ int32_t GlibcRand::next()
 
 // ---- probe rays -------------------------------------------------------------------------------------
 
-void generate_probe_rays(const ddgi_irradiance_field& f, GlibcRand& rng, std::vector<ddgi_probe_ray>& out)
+void generate_probe_rays(const ddgi_irradiance_field& f, int tile_x, int tile_y, GlibcRand& rng, std::vector<ddgi_probe_ray>& out)
 {
     const int cx = f.probe_count[0], cy = f.probe_count[1], cz = f.probe_count[2];
-    const int s = f.sqrt_rays_per_probe;
-    const int n = s * s;
+    const int s = tile_x, sh = tile_y;  // the reference: s == sh == sqrt_rays_per_probe
+    const int n = s * sh;
     const size_t probes = static_cast<size_t>(cx) * cy * cz;
 
     // generate_samples (rvpt.cpp:1147-1173): stratified jitter on [0,1)^2 warped to the unit sphere.
     // The reference's host PI is 3.1415926 (rvpt.cpp:1145) and the angle product is formed in
     // double before cosf/sinf narrow it.  Jitter draw order is g++'s: y first, then x (Q1).
     std::vector<f3> dirs(static_cast<size_t>(n));
-    const float inv_s = 1.f / static_cast<float>(s);
+    const float inv_s = 1.f / static_cast<float>(s), inv_sh = 1.f / static_cast<float>(sh);
     const float rand_max = static_cast<float>(2147483647);
-    for (int y = 0, i = 0; y < s; ++y)
+    for (int y = 0, i = 0; y < sh; ++y)
         for (int x = 0; x < s; ++x, ++i)
         {
             const float jy = static_cast<float>(rng.next()) / rand_max;
             const float jx = static_cast<float>(rng.next()) / rand_max;
             const float u = (static_cast<float>(x) + jx) * inv_s;
-            const float v = (static_cast<float>(y) + jy) * inv_s;
+            const float v = (static_cast<float>(y) + jy) * inv_sh;
             const float z = 1 - (2 * u);
             const float phi = static_cast<float>(2.0 * 3.1415926 * static_cast<double>(v));
             const float rxy = sqrtf(1 - (z * z));

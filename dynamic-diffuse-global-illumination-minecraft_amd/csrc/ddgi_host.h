@@ -35,7 +35,8 @@ struct GlibcRand
 
 // generate_samples + RVPT::generate_probe_rays (src/rvpt/rvpt.cpp:1147-1224): full-grid array in
 // the reference's order (probe-major p = py*cx*cz + pz*cx + px, ray i = y*s + x).
-void generate_probe_rays(const ddgi_irradiance_field& f, GlibcRand& rng, std::vector<ddgi_probe_ray>& out);
+// tile_x x tile_y: the ray tile (the reference: both = sqrt_rays_per_probe; see ddgi_set_ray_tile)
+void generate_probe_rays(const ddgi_irradiance_field& f, int tile_x, int tile_y, GlibcRand& rng, std::vector<ddgi_probe_ray>& out);
 
 // Host copy of the memoised lattice hashes (ddgi_scene.h: NoiseLut).  Scene independent.
 struct NoiseLutHost

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
     __syncthreads();
 
     const GridK& G = A.grid;
-    const int rays_per_probe = G.s * G.s;
+    const int rays_per_probe = G.n;
     const uint32_t n_chunks = (A.n_rays + kTraceBlock - 1) / kTraceBlock;
     const float inf = __builtin_inff();
 
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
                             const f3 nn = normalize3(n);
                             const int idx = cell_index(A.scene, static_cast<int>(cell.x), static_cast<int>(cell.y), static_cast<int>(cell.z));
                             const int type = hit_block_type(A.scene, A.scene_id, cell, idx);
-                            hcol = (A.ablate & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(m.p, type, nn, A.noise);
+                            hcol = block_albedo(m.p, type, nn, A.noise);
                             nraw = nn;
                         }
                         else
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
                     {
                         phase = kPrimary;
                         const f3 no = hpos + hnrm * 0.0001f;
-                        const f3 nd = (A.ablate & 2) ? normalize3(hnrm + mk3(0.3f, 0.2f, 0.1f)) : hemisphere_dir(hnrm, rng);
+                        const f3 nd = hemisphere_dir(hnrm, rng);
                         start_march(m, no, nd, A);
                         marching = true;
                     }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_probe_trace_ref(const TraceArgs
         {
             const f3 c = div3(color, static_cast<float>(A.max_bounces));  // Q14: always /max_bounces
             const uint32_t texel = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
-            const size_t dst = static_cast<size_t>(slab_slot(G, dst_probe)) * rays_per_probe + tile_y * G.s + tile_x;
+            const size_t dst = static_cast<size_t>(slab_slot(G, dst_probe)) * rays_per_probe + tile_y * G.sx + tile_x;
             A.albedo[dst] = texel;
             A.distance[dst] = 0u;  // `distances` is never assigned (probe_pass.comp:276,302)
         }

@@ -185,6 +185,11 @@ hipError_t launch_render_primary(const RenderArgs& args, hipStream_t stream)
     const unsigned n = static_cast<unsigned>(args.width) * static_cast<unsigned>(args.height);
     if (n == 0) return hipSuccess;
     const size_t lds = (256 + static_cast<size_t>(args.trace.scene.nwords)) * sizeof(uint32_t);
+    if (lds > 64 * 1024)  // a large user scene: opt in to more dynamic LDS (ddgi_render_device has checked the 160 KB bound)
+    {
+        hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_render_primary), 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(k_render_primary, dim3((n + 255u) / 256u), dim3(256), lds, stream, args);
     return hipGetLastError();
 }

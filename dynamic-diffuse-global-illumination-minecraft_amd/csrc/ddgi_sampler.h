@@ -23,14 +23,14 @@ DDGI_D f3 sample_probe_ref(const GridK& G, const uint32_t* albedo, const uint32_
     const int cxz = G.cx * G.cz;
     // get_text_coord_from_probe_number (:1152-1174): out of range -> magenta
     if (probe >= cxz * G.cy || probe < 0) return mk3(1, 0, 1);
-    const int s = G.s;
+    const int s = G.sx, sh = G.sy;
     const f3 id = normalize3(dir);
     int rx = gl_int(((-1.0f * (id.z - 1.0f)) / 2.0f) * static_cast<float>(s));
     if (rx == s) rx = 0;
     const float sqrt_z = sqrtf(1.0f - (id.z * id.z));
     const float kPi = 3.1415926535897932384626433832795f;
-    const int ry = gl_int((pm::acosf_pinned(id.x / sqrt_z) / (2.0f * kPi)) * static_cast<float>(s));
-    const size_t base = static_cast<size_t>(slab_slot(G, probe)) * s * s;
+    const int ry = gl_int((pm::acosf_pinned(id.x / sqrt_z) / (2.0f * kPi)) * static_cast<float>(sh));
+    const size_t base = static_cast<size_t>(slab_slot(G, probe)) * G.n;
     f3 result = load_rgb(albedo, base + ry * s + rx, s_unorm);
     int count = 0;
     for (int dx = -2; dx <= 2; ++dx)
@@ -40,7 +40,7 @@ DDGI_D f3 sample_probe_ref(const GridK& G, const uint32_t* albedo, const uint32_
         for (int dy = -2; dy <= 2; ++dy)
         {
             const int y = ry + dy;
-            if (y < 0 || y >= s) continue;
+            if (y < 0 || y >= sh) continue;
             count += 1;
             result = result + load_rgb(tex, base + y * s + x, s_unorm);
         }

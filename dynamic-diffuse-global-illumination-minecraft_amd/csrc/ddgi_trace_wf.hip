@@ -155,7 +155,11 @@ struct CfgRuntime
 {
     static constexpr int kNl = 0;
     static DDGI_D int nl(const TraceArgs& A) { return A.nl; }
+#ifdef DDGI_PROFILING  // the ablation / fault-injection switches exist only in the profiling build (make prof)
     static DDGI_D int ablate(const TraceArgs& A) { return A.ablate; }
+#else
+    static DDGI_D int ablate(const TraceArgs&) { return 0; }
+#endif
     static DDGI_D bool ddgi(const TraceArgs& A) { return A.ddgi != 0; }
 };
 template <int kMode>
@@ -276,7 +280,7 @@ template <class Cfg>
 DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits, uint32_t b, uint32_t slot, uint32_t r, bool r_valid)
 {
     const GridK& G = A.grid;
-    const int rays_per_probe = G.s * G.s;
+    const int rays_per_probe = G.n;
     const float inf = __builtin_inff();
     const bool multi_light = Cfg::nl(A) > 1;
     bool posted = false;
@@ -310,7 +314,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 ray_o = mk3(ra.x, ra.y, ra.z);
                 ray_d = mk3(rb.x, rb.y, rb.z);
                 const int dst_probe = static_cast<int>(rc.x);  // int(probe_info.x), probe_pass.comp:269
-                c.dst = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.s + static_cast<int>(rc.y);
+                c.dst = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.sx + static_cast<int>(rc.y);
                 c.rng = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
             }
             c.cnt = 0u;
@@ -1126,14 +1130,9 @@ template <bool kStats, int kPool, class Cfg>
 static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
 {
     const size_t lds = aq_lds_bytes(args.scene.nwords, pool);
-    static bool attr_set = false;
-    if (!attr_set)
-    {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_aq<kStats, kPool, Cfg>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_probe_trace_aq<kStats, kPool, Cfg>), 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_probe_trace_aq<kStats, kPool, Cfg>), dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter, status);
     return hipGetLastError();
@@ -1159,10 +1158,10 @@ static size_t wf_lds_bytes(int nwords, int pool, bool multi_light)
 
 // Largest pool (multiple of 64, at most 2 per lane) that fits in `lds_limit` bytes; 0 if not even
 // one ray per lane fits (then the caller uses k_probe_trace_ref).
-int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads)
+int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads, int max_pool)
 {
     int pool = 3 * threads;  // at most 3 slots per lane (the bucket pass keeps that many ranks in registers)
-    if (const char* v = std::getenv("DDGI_WF_MAXPOOL")) pool = std::min(pool, std::max(threads, std::atoi(v) / 64 * 64));
+    if (max_pool > 0) pool = std::min(pool, std::max(threads, max_pool / 64 * 64));
     while (pool >= threads && wf_lds_bytes(nwords, pool, multi_light) > lds_limit) pool -= 64;
     return pool >= threads ? pool : 0;
 }
@@ -1171,14 +1170,9 @@ template <int T, int B, bool kStats>
 static hipError_t launch_wf(const TraceArgs& args, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream)
 {
     const size_t lds = wf_lds_bytes(args.scene.nwords, pool, args.nl > 1);
-    static bool attr_set = false;
-    if (!attr_set)
-    {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_trace_wf<T, B, kStats>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 / B);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipError_t e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_probe_trace_wf<T, B, kStats>), 160 * 1024 / B);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_probe_trace_wf<T, B, kStats>), dim3(grid_blocks), dim3(T), lds, stream, args, pool, work_counter);
     return hipGetLastError();

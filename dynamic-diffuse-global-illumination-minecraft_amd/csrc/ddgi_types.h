@@ -44,12 +44,18 @@ struct SceneK
 struct GridK
 {
     int cx, cy, cz;  // probe counts
-    int s;           // sqrt rays per probe
+    int sx, sy;      // ray tile: sx strata along z (texel columns) x sy strata along phi (texel rows); the reference's
+                     // tile is square (sx == sy == sqrt_rays_per_probe), ddgi_set_ray_tile makes it sx x sy
+    int n;           // rays per probe = sx * sy
     int side;        // integer probe spacing
     float origin[3];
     float hysteresis;
     int z0, czl;  // this rank's z-slab: probes with z in [z0, z0+czl)
 };
+
+// Opts a kernel in to `bytes` of dynamic LDS (more than the 64 KB default) on the CURRENT device, once per
+// (device, kernel): a process may hold handles on several devices (ddgi_engine.cpp).
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
 
 struct TraceArgs
 {
@@ -97,8 +103,10 @@ struct BlendArgs
     float rot[9];
     const float* rad_rgb;  // ray records of the local slab (probes in (y, zl, x) order), see kRecGroup
     const float* rad_dd;
-    float* irradiance;       // full-grid slab-major [cz][cy][cx][8][8][4]
+    float* irradiance;       // full-grid slab-major [cz][cy][cx][8][8][4]: the tiles this update writes
     float* depth;            // full-grid slab-major [cz][cy][cx][16][16][2]
+    const float* irradiance_old;  // the previous update's tiles the hysteresis mixes with: the same buffers, or — when the
+    const float* depth_old;       // multi-GPU exchange is pipelined (ddgi_exchange.cpp) — the other buffer pair
     uint32_t n_local_probes;
     float* w;      // per-update texel weights [ray][256 texel columns] (k_blend_weights), or null
     float* w_sum;  // [256] weight sum per texel column

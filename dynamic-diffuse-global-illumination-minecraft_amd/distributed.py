@@ -51,15 +51,17 @@ def slab_major_to_raster(slab, counts, s, texel_shape=()):
     """[cz][cy][cx][s][s]+texel -> the reference raster [cy*s][cx*cz*s]+texel
     (tile of probe p at ((p mod cx*cz)*s, (p div cx*cz)*s), probe_pass.comp:139-145)."""
     cx, cy, cz = counts
-    a = np.asarray(slab).reshape((cz, cy, cx, s, s) + tuple(texel_shape))
-    # raster[y*s + ty][(z*cx + x)*s + tx]
+    sx, sy = (s, s) if np.isscalar(s) else s  # ray tile (tile_x, tile_y), ddgi_set_ray_tile
+    a = np.asarray(slab).reshape((cz, cy, cx, sy, sx) + tuple(texel_shape))
+    # raster[y*sy + ty][(z*cx + x)*sx + tx]
     a = np.moveaxis(a, (0, 1, 2, 3, 4), (2, 0, 3, 1, 4))  # -> [cy][ty][cz][cx][tx]
-    return a.reshape((cy * s, cz * cx * s) + tuple(texel_shape))
+    return a.reshape((cy * sy, cz * cx * sx) + tuple(texel_shape))
 
 
 def raster_to_slab_major(raster, counts, s, texel_shape=()):
     cx, cy, cz = counts
-    a = np.asarray(raster).reshape((cy, s, cz, cx, s) + tuple(texel_shape))
+    sx, sy = (s, s) if np.isscalar(s) else s
+    a = np.asarray(raster).reshape((cy, sy, cz, cx, sx) + tuple(texel_shape))
     a = np.moveaxis(a, (0, 1, 2, 3, 4), (1, 3, 0, 2, 4))  # -> [cz][cy][cx][ty][tx]
     return np.ascontiguousarray(a)
 
@@ -69,6 +71,8 @@ class ShardedTextures:
 
     Usage per update:   tex.begin_step(); engine.probe_update(); tex.all_gather()
     and once before the textures are consumed / timed:   tex.finish()
+    Construct it (and call its methods) under the torch stream the updates should run on: the
+    constructor points the engine at torch's current stream (ddgi_set_stream).
 
     pipelined=False: one buffer pair; the collectives run in order with the kernels on the current
     stream (update k+1 starts after update k's exchange).
@@ -104,6 +108,11 @@ class ShardedTextures:
         self.k = 0                  # updates exchanged so far
         self.cur = 0
         self.tex0, self.tex1 = self.bufs[0]
+        if self.cuda:
+            # the collectives, the `written` event and the waits below all live on torch's current stream:
+            # the engine must launch on that stream too (its own stream is a private non-blocking one),
+            # or an exchange could start before the kernels that fill the slab have finished
+            engine.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         engine.bind_textures(self.tex0.data_ptr(), self.tex1.data_ptr())
 
     def begin_step(self):

@@ -121,11 +121,26 @@ _SIGNATURES = {
     "ddgi_reconfigure": (C.c_int, [_VP, _VP, _VP, C.c_int]),
     "ddgi_set_mode": (C.c_int, [_VP, C.c_int]),
     "ddgi_set_lights": (C.c_int, [_VP, C.c_int, _VP, C.c_int]),
+    "ddgi_set_ray_tile": (C.c_int, [_VP, C.c_int, C.c_int]),
+    "ddgi_get_ray_tile": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ddgi_get_texture_size": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ddgi_generate_probe_rays": (C.c_int, [_VP, C.c_uint32, C.c_int]),
     "ddgi_upload_probe_rays": (C.c_int, [_VP, _VP, C.c_size_t]),
     "ddgi_get_probe_rays": (C.c_int, [_VP, _VP, C.c_size_t]),
     "ddgi_probe_update": (C.c_int, [_VP, _VP]),
     "ddgi_synchronize": (C.c_int, [_VP]),
+    "ddgi_tune": (C.c_int, [_VP]),
+    "ddgi_set_tuning": (C.c_int, [_VP, C.c_char_p, C.c_int]),
+    "ddgi_get_tuning": (C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int)]),
+    "ddgi_exchange_init": (C.c_int, [_VP, _VP, C.c_int]),
+    "ddgi_exchange": (C.c_int, [_VP]),
+    "ddgi_exchange_finish": (C.c_int, [_VP]),
+    "ddgi_exchange_group_begin": (C.c_int, []),
+    "ddgi_exchange_group_end": (C.c_int, []),
+    "ddgi_comm_unique_id": (C.c_int, [_VP]),
+    "ddgi_comm_create": (C.c_int, [_VP, C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "ddgi_comm_create_all": (C.c_int, [C.c_int, _VP, _VP]),
+    "ddgi_comm_destroy": (C.c_int, [_VP]),
     "ddgi_last_update_ms": (C.c_int, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "ddgi_update_history_ms": (C.c_int, [_VP, _VP, _VP, C.c_int, C.POINTER(C.c_int)]),
     "ddgi_trace_stats": (C.c_int, [_VP, C.c_int, _VP]),
@@ -144,6 +159,7 @@ _SIGNATURES = {
     "ddgi_texture_size": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ddgi_probe_tile_origin": (C.c_int, [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ddgi_generate_probe_rays_host": (C.c_int, [_VP, C.c_uint32, C.c_int, _VP, C.c_size_t]),
+    "ddgi_generate_probe_rays_host_tile": (C.c_int, [_VP, C.c_int, C.c_int, C.c_uint32, C.c_int, _VP, C.c_size_t]),
     "ddgi_scene_save": (C.c_int, [C.c_int, C.c_char_p]),
     "ddgi_scene_load": (C.c_int, [_VP, C.c_char_p]),
     "ddgi_scene_set_grid": (C.c_int, [_VP, _VP, _VP, _VP]),
@@ -210,14 +226,35 @@ def probe_tile_origin(field, probe_index):
     return x.value, y.value
 
 
-def generate_probe_rays_host(field, seed=1, skip_calls=0):
-    """Host-only RVPT::generate_probe_rays (rvpt.cpp:1147-1224); no GPU needed."""
+def generate_probe_rays_host(field, seed=1, skip_calls=0, tile=None):
+    """Host-only RVPT::generate_probe_rays (rvpt.cpp:1147-1224); no GPU needed.  tile = (tile_x, tile_y)
+    for a non-square ray tile (ddgi_set_ray_tile)."""
     c = field.probe_count
-    n = c[0] * c[1] * c[2] * field.sqrt_rays_per_probe ** 2
-    rays = np.zeros(n, dtype=PROBE_RAY_DTYPE)
-    _check(load_library().ddgi_generate_probe_rays_host(C.byref(field), seed, skip_calls,
-                                                        rays.ctypes.data_as(C.c_void_p), n))
+    tx, ty = tile if tile else (field.sqrt_rays_per_probe, field.sqrt_rays_per_probe)
+    n = max(c[0] * c[1] * c[2] * tx * ty, 0)
+    rays = np.zeros(min(n, 1 << 33), dtype=PROBE_RAY_DTYPE)
+    _check(load_library().ddgi_generate_probe_rays_host_tile(C.byref(field), tx, ty, seed, skip_calls,
+                                                             rays.ctypes.data_as(C.c_void_p), n))
     return rays
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 makes it and hands it to the other ranks)."""
+    buf = (C.c_uint8 * 128)()
+    _check(load_library().ddgi_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_create(unique_id, world, rank, device):
+    """ncclCommInitRank through the library's RCCL instance -> communicator address (int)."""
+    buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+    comm = C.c_void_p()
+    _check(load_library().ddgi_comm_create(buf, world, rank, device, C.byref(comm)))
+    return comm.value
+
+
+def comm_destroy(comm):
+    _check(load_library().ddgi_comm_destroy(C.c_void_p(comm)))
 
 
 def scene_save(scene, path):
@@ -299,6 +336,26 @@ class ProbeEngine:
     def set_mode(self, mode):
         _check(self._lib.ddgi_set_mode(self._h, mode))
 
+    def set_ray_tile(self, tile_x=0, tile_y=0):
+        """Non-square ray tile: rays per probe = tile_x * tile_y (include/ddgi_probe.h: ddgi_set_ray_tile)."""
+        _check(self._lib.ddgi_set_ray_tile(self._h, int(tile_x), int(tile_y)))
+
+    @property
+    def ray_tile(self):
+        tx, ty = C.c_int(), C.c_int()
+        _check(self._lib.ddgi_get_ray_tile(self._h, C.byref(tx), C.byref(ty)))
+        return tx.value, ty.value
+
+    @property
+    def rays_per_probe(self):
+        tx, ty = self.ray_tile
+        return tx * ty
+
+    def texture_size(self):
+        w, h = C.c_int(), C.c_int()
+        _check(self._lib.ddgi_get_texture_size(self._h, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
     def load_scene(self, path):
         """User scene (scene id 3) from a DDGIVOX1 file."""
         _check(self._lib.ddgi_scene_load(self._h, os.fsencode(path)))
@@ -322,7 +379,7 @@ class ProbeEngine:
 
     @property
     def num_rays(self):
-        return self.num_probes * self.ir.sqrt_rays_per_probe ** 2
+        return self.num_probes * self.rays_per_probe
 
     def generate_probe_rays(self, seed=1, reseed=False):
         """RVPT::generate_probe_rays (rvpt.cpp:1177-1224) + upload (rvpt.cpp:285)."""
@@ -346,6 +403,29 @@ class ProbeEngine:
 
     def synchronize(self):
         _check(self._lib.ddgi_synchronize(self._h))
+
+    def tune(self):
+        """Measure the trace kernel's wave split for the current configuration now (blocking)."""
+        _check(self._lib.ddgi_tune(self._h))
+
+    def set_tuning(self, name, value):
+        _check(self._lib.ddgi_set_tuning(self._h, name.encode(), int(value)))
+
+    def get_tuning(self, name):
+        v = C.c_int()
+        _check(self._lib.ddgi_get_tuning(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    # -- multi-GPU exchange (include/ddgi_probe.h: ddgi_exchange_*) ------------------------------
+    def exchange_init(self, nccl_comm, pipelined=False):
+        """nccl_comm: an ncclComm_t as an integer address (comm_create below), or None to detach."""
+        _check(self._lib.ddgi_exchange_init(self._h, C.c_void_p(nccl_comm), 1 if pipelined else 0))
+
+    def exchange(self):
+        _check(self._lib.ddgi_exchange(self._h))
+
+    def exchange_finish(self):
+        _check(self._lib.ddgi_exchange_finish(self._h))
 
     def last_update_ms(self):
         t, b, tot = C.c_float(), C.c_float(), C.c_float()
@@ -374,7 +454,7 @@ class ProbeEngine:
     # -- outputs -------------------------------------------------------------------------------
     def read_textures(self):
         """(albedo, distance) as uint8 [H, W, 4] in the reference's raster layout."""
-        w, h = texture_size(self.ir)
+        w, h = self.texture_size()
         albedo = np.empty((h, w, 4), dtype=np.uint8)
         distance = np.empty((h, w, 4), dtype=np.uint8)
         _check(self._lib.ddgi_read_textures(self._h, _ptr(albedo), _ptr(distance)))

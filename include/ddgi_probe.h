@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DDGI_ABI_VERSION 1
+#define DDGI_ABI_VERSION 2
 
 /* ---- wire formats: byte-identical to the reference's UBO/SSBO records ------------------------ */
 
@@ -39,7 +39,7 @@ typedef struct ddgi_irradiance_field
     int32_t probe_count[3];      /* @0  probes along x, y, z (default 9,7,9)                    */
     int32_t side_length;         /* @12 integer probe spacing (rvpt.h:85)                       */
     float hysteresis;            /* @16 blend coefficient (dormant in the reference)            */
-    int32_t sqrt_rays_per_probe; /* @20 s; rays per probe = s*s                                 */
+    int32_t sqrt_rays_per_probe; /* @20 s; rays per probe = s*s (ddgi_set_ray_tile: tile_x*tile_y) */
     int32_t _pad0[2];            /* @24                                                         */
     float field_origin[3];       /* @32 world position of the field centre (default 1.4,0,1)    */
     uint8_t visualize;           /* @44 host-only flag                                          */
@@ -137,6 +137,22 @@ int ddgi_reconfigure(ddgi_handle h, const ddgi_irradiance_field* field,
 
 int ddgi_set_mode(ddgi_handle h, int mode /* ddgi_mode */);
 
+/* Non-square ray counts.  The reference only knows rays per probe = sqrt_rays_per_probe^2 (rvpt.h:87, UI
+ * rvpt.cpp:342; generate_samples' s x s strata, rvpt.cpp:1147-1173); BASELINE's 8-GPU configuration asks for
+ * 512.  The 48-byte field record keeps its layout; this setter makes the ray tile tile_x x tile_y:
+ *   REF  tile_x strata along z (= texel columns of a probe's tile), tile_y strata along phi (= rows):
+ *        u = (x + jitter)/tile_x, v = (y + jitter)/tile_y, ray i = y*tile_x + x; textures become
+ *        W = cx*cz*tile_x by H = cy*tile_y; sample_probe inverts with tile_x / tile_y.  With
+ *        tile_x == tile_y == sqrt_rays_per_probe every formula is the reference's.
+ *   DDGI rays per probe n = tile_x*tile_y (the spherical Fibonacci set is defined for every n).
+ * (0, 0) restores the field's square tile; ddgi_configure / ddgi_reconfigure also do.  Textures restart
+ * zeroed and probe rays must be regenerated or re-uploaded. */
+int ddgi_set_ray_tile(ddgi_handle h, int tile_x, int tile_y);
+int ddgi_get_ray_tile(ddgi_handle h, int* tile_x, int* tile_y);
+/* Reference raster size of the handle's REF-mode textures for its current ray tile
+ * (ddgi_texture_size for the square tile). */
+int ddgi_get_texture_size(ddgi_handle h, int* width, int* height);
+
 /* Overrides the light table of one scene (the reference compiles them into the shader,
  * structs.glsl:61-89; defaults here are the shipped tables).  n <= DDGI_MAX_LIGHTS. */
 int ddgi_set_lights(ddgi_handle h, int scene, const ddgi_light* lights, int n);
@@ -167,11 +183,28 @@ int ddgi_get_probe_rays(ddgi_handle h, ddgi_probe_ray* rays, size_t n);
  * record_compute_command_buffer (barrier + vkCmdDispatch, rvpt.cpp:1105-1129) + Queue::submit
  * (rvpt.cpp:378-380).  Asynchronous on the handle's stream.  `settings` may be NULL to reuse the
  * last one; the function does NOT add +2 to time (the caller's RVPT::update does, rvpt.cpp:281).
- * The first update of a configuration (grid, rays, scene, bounces, lights, mode) also measures how the
- * trace kernel should split its waves between marching and shading: a few extra launches of the same
- * trace (idempotent) and one synchronisation, some tens of milliseconds once; DDGI_AUTOTUNE=0 or
- * DDGI_AQ_MARCH=<n> skips it. */
+ * By default the first update of a configuration (grid, rays, scene, bounces, lights, mode) also measures
+ * how the trace kernel should split its waves between marching and shading: a few extra launches of the
+ * same trace (idempotent) and one host synchronisation, some tens of milliseconds, once per configuration
+ * (the handle remembers up to 64 configurations).  A host that must never block in its frame loop calls
+ * ddgi_tune() at load time, or turns it off: ddgi_set_tuning(h, "autotune", 0) [+ "march_waves", n]. */
 int ddgi_probe_update(ddgi_handle h, const ddgi_render_settings* settings);
+
+/* Measures, now and blocking, the trace kernel's march/event wave split for the handle's CURRENT
+ * configuration (what the first ddgi_probe_update of a configuration would do) and remembers it. */
+int ddgi_tune(ddgi_handle h);
+
+/* Tuning switches of a handle, by name.  The environment variables in brackets are read ONCE, when the handle
+ * is created, as initial values — never on the per-frame path.
+ *   "autotune"      1 = measure the wave split on a configuration's first update (default), 0 = never block [DDGI_AUTOTUNE]
+ *   "march_waves"   n > 0 pins the split (waves that march, of 16); 0 = per configuration            [DDGI_AQ_MARCH]
+ *   "trace_kernel"  0 auto, 1 round-based, 2 ray per lane, 3 queues (cross-checks)   [DDGI_TRACE_KERNEL=rounds|lane|queues]
+ *   "blend_kernel"  0 auto, 1 one probe per workgroup (cross-check)                                  [DDGI_BLEND_KERNEL]
+ *   "verbose", "noise_lut", "aq_pool", "wf_pool", ... (profiling; see ddgi_engine.cpp: kTuningKeys)
+ * ddgi_get_tuning also answers "march_waves_measured": the split most recently measured (0 = none yet), so a
+ * host can persist it and pin it next time. */
+int ddgi_set_tuning(ddgi_handle h, const char* name, int value);
+int ddgi_get_tuning(ddgi_handle h, const char* name, int* value);
 
 /* Waits for the stream (≙ Fence::wait, vk_util.cpp:94-97; here without the 1 s timeout). */
 int ddgi_synchronize(ddgi_handle h);
@@ -269,6 +302,41 @@ int ddgi_bind_textures(ddgi_handle h, void* tex0, void* tex1);
 int ddgi_sample_device(ddgi_handle h, const float* d_pos_xyz, const float* d_nrm_xyz, size_t n,
                        float* d_rgb_out, int32_t* d_cage_idx8_out);
 
+/* ---- multi-GPU: the exchange of the blended textures ---------------------------------
+ * New design — the reference is single-GPU (one vkQueueSubmit, rvpt.cpp:372-380) and has no collective.
+ * Handles made by ddgi_create_sharded(rank, world) trace + blend their z-slab; ONE in-place all-gather
+ * per texture (RCCL over xGMI; the slab-major layout makes a rank's contribution one contiguous chunk)
+ * then gives every rank the whole field before the cage sample.  Per frame, on every rank:
+ *       ddgi_probe_update(h, settings);  ddgi_exchange(h);          ... ddgi_sample_device / ddgi_render_device
+ * RCCL is loaded at run time (the librccl.so.1 already in the process, else the system's); a host that never
+ * shards needs none.  One process per GPU, or one process driving several handles (then bracket the
+ * ddgi_exchange calls of one frame with ddgi_exchange_group_begin/end, ≙ ncclGroupStart/End). */
+
+/* Attaches a communicator (an ncclComm_t whose size/rank equal the handle's world/rank; the caller keeps
+ * ownership) and sets the exchange up; nccl_comm == NULL detaches.
+ *   pipelined == 0  the all-gather runs on the handle's stream, in order after the update.
+ *   pipelined != 0  two texture pairs are used alternately and the all-gather of update k runs on a
+ *                   communication stream while update k+1 already traces into the other pair (the DDGI
+ *                   blend reads its own slab's previous tiles from the pair it wrote last).  Every
+ *                   consumer call on the handle (sample / render / read) waits for the latest exchange.
+ * ddgi_configure / ddgi_reconfigure / ddgi_set_mode / ddgi_set_ray_tile detach: call this again after them. */
+int ddgi_exchange_init(ddgi_handle h, void* nccl_comm, int pipelined);
+/* Issues the all-gather of the most recent ddgi_probe_update (asynchronous). */
+int ddgi_exchange(ddgi_handle h);
+/* Makes the handle's stream wait for every exchange issued so far (needed only before work the caller
+ * enqueues itself on that stream, e.g. a timing fence; the handle's own consumers wait by themselves). */
+int ddgi_exchange_finish(ddgi_handle h);
+int ddgi_exchange_group_begin(void);
+int ddgi_exchange_group_end(void);
+
+/* Communicator bootstrap through the same RCCL instance (thin wrappers of ncclGetUniqueId /
+ * ncclCommInitRank / ncclCommInitAll / ncclCommDestroy), for hosts that do not link RCCL themselves:
+ * rank 0 makes the 128-byte id and hands it to the other ranks by whatever channel the host has. */
+int ddgi_comm_unique_id(uint8_t id128[128]);
+int ddgi_comm_create(const uint8_t id128[128], int world, int rank, int device, void** nccl_comm_out);
+int ddgi_comm_create_all(int ndev, const int* devices, void** nccl_comms_out);
+int ddgi_comm_destroy(void* nccl_comm);
+
 /* ---- introspection ------------------------------------------------------------------------------ */
 
 int ddgi_abi_version(void);
@@ -286,6 +354,10 @@ int ddgi_probe_tile_origin(const ddgi_irradiance_field* field, int probe_index, 
  * n must be probe_count.x*y*z * s*s. */
 int ddgi_generate_probe_rays_host(const ddgi_irradiance_field* field, uint32_t seed, int skip_calls,
                                   ddgi_probe_ray* rays, size_t n);
+
+/* Same for a tile_x x tile_y ray tile (ddgi_set_ray_tile); n = probes * tile_x * tile_y. */
+int ddgi_generate_probe_rays_host_tile(const ddgi_irradiance_field* field, int tile_x, int tile_y, uint32_t seed,
+                                       int skip_calls, ddgi_probe_ray* rays, size_t n);
 
 /* ---- baked scenes on disk, user scenes ------------------------------------ */
 

@@ -11,7 +11,7 @@
  * FetchContent and glm/GLFW, so oracle/_ref is "unbuildable" by the rules of this project).
  * What pins this restatement instead: the hand-derived known-answer values of SURVEY.md
  * Appendix D (re-derived by tests/test_oracle_kat.py), glibc's real rand() for the host jitter,
- * and structural invariants of the reference code (tests/test_oracle_invariants.py).
+ * and structural invariants of the reference code (tests/test_oracle_kat.py, tests/test_independent_restatement.py).
  *
  * What it is: a plain-C (C11, binary32 arithmetic, -ffp-contract=off) restatement of the LIVE
  * probe path of the reference, function by function, each citing the reference file:line
@@ -95,6 +95,16 @@ static int g_pinned = 1;
 
 void oracle_set_arith(int pinned) { g_pinned = pinned ? 1 : 0; }
 int oracle_get_arith(void) { return g_pinned; }
+
+/* Ray tile.  The reference only knows square tiles (rays per probe = sqrt_rays_per_probe^2, rvpt.h:87,
+ * rvpt.cpp:342); BASELINE config C4 asks for 512 rays per probe, which SURVEY.md H5 resolves as a
+ * 32 x 16 tile: tile_x strata along z (texel column), tile_y strata along phi (texel row).  The 48-byte
+ * field record keeps its layout; a non-square tile is set here (0, 0 = square, from the field).
+ * Every formula below reduces to the reference's when tile_x == tile_y == sqrt_rays_per_probe. */
+static int g_tile[2] = {0, 0};
+void oracle_set_ray_tile(int tile_x, int tile_y) { g_tile[0] = tile_x, g_tile[1] = tile_y; }
+static inline int tile_w(const o_field* f) { return g_tile[0] > 0 ? g_tile[0] : f->sqrt_rays_per_probe; }
+static inline int tile_h(const o_field* f) { return g_tile[1] > 0 ? g_tile[1] : f->sqrt_rays_per_probe; }
 
 /* GLSL min/max (spec: max(x,y) = x < y ? y : x ; min(x,y) = y < x ? y : x) */
 static inline float gmax(float x, float y) { return x < y ? y : x; }
@@ -287,20 +297,20 @@ int32_t oracle_glibc_rand(o_rand_state* st)
 /* Argument evaluation order pinned to g++'s (right to left): the y jitter takes the first       */
 /* rand() draw, the x jitter the second.                                          */
 
-static void generate_samples(v3* out, int s, o_rand_state* rs)
+static void generate_samples(v3* out, int sw, int sh, o_rand_state* rs)
 {
     const double PI_HOST = 3.1415926;
-    float inv_sqrt = 1.f / (float)s;
+    float inv_sqrt_x = 1.f / (float)sw, inv_sqrt_y = 1.f / (float)sh; /* both 1/sqrt_samples for a square tile */
     const float rand_max_f = (float)2147483647; /* float(RAND_MAX) = 2147483648.0f */
     int i = 0;
-    for (int y = 0; y < s; y++)
+    for (int y = 0; y < sh; y++)
     {
-        for (int x = 0; x < s; x++)
+        for (int x = 0; x < sw; x++)
         {
             float jy = (float)oracle_glibc_rand(rs) / rand_max_f; /* 2nd ctor argument, drawn 1st */
             float jx = (float)oracle_glibc_rand(rs) / rand_max_f;
-            float sx = ((float)x + jx) * inv_sqrt;
-            float sy = ((float)y + jy) * inv_sqrt;
+            float sx = ((float)x + jx) * inv_sqrt_x;
+            float sy = ((float)y + jy) * inv_sqrt_y;
             float z = 1 - (2 * sx);
             /* cosf(2.0f * PI * sample.y): the product is formed in double, cosf takes a float */
             float ang = (float)(2.0 * PI_HOST * (double)sy);
@@ -326,11 +336,11 @@ static inline v3 glm_normalize(v3 a)
 void oracle_generate_probe_rays(const o_field* f, o_rand_state* rs, o_probe_ray* out)
 {
     int cx = f->probe_count[0], cy = f->probe_count[1], cz = f->probe_count[2];
-    int s = f->sqrt_rays_per_probe;
-    int n = s * s;
+    int s = tile_w(f);
+    int n = s * tile_h(f);
     int num_probes = cx * cy * cz;
     v3* samples = (v3*)malloc(sizeof(v3) * (size_t)n);
-    generate_samples(samples, s, rs);
+    generate_samples(samples, s, tile_h(f), rs);
     for (int p = 0; p < num_probes; p++)
     {
         int py = p / (cx * cz);
@@ -1206,7 +1216,7 @@ void oracle_probe_update(const o_field* f, const o_settings* st, const o_probe_r
     TraceCtx cx;
     make_ctx(&cx, st, lights, nl);
     int cxz = f->probe_count[0] * f->probe_count[2];
-    int s = f->sqrt_rays_per_probe;
+    int s = tile_w(f), sh = tile_h(f);
     int W = cxz * s;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -1227,7 +1237,7 @@ void oracle_probe_update(const o_field* f, const o_settings* st, const o_probe_r
         int y_probe = probe / cxz;
         int x_probe = probe - y_probe * cxz;
         int tx = x_probe * s + gint(pr->probe_info[1]);
-        int ty = y_probe * s + gint(pr->probe_info[2]);
+        int ty = y_probe * sh + gint(pr->probe_info[2]);
         size_t o = ((size_t)ty * (size_t)W + (size_t)tx) * 4;
         if (albedo)
         {
@@ -1248,8 +1258,8 @@ void oracle_probe_update_probes(const o_field* f, const o_settings* st, const o_
     TraceCtx cx;
     make_ctx(&cx, st, NULL, 0);
     int cxz = f->probe_count[0] * f->probe_count[2];
-    int s = f->sqrt_rays_per_probe;
-    int n = s * s;
+    int s = tile_w(f), sh = tile_h(f);
+    int n = s * sh;
     int W = cxz * s;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -1264,7 +1274,7 @@ void oracle_probe_update_probes(const o_field* f, const o_settings* st, const o_
         int y_probe = probe / cxz;
         int x_probe = probe - y_probe * cxz;
         int tx = x_probe * s + gint(pr->probe_info[1]);
-        int ty = y_probe * s + gint(pr->probe_info[2]);
+        int ty = y_probe * sh + gint(pr->probe_info[2]);
         size_t o = ((size_t)ty * (size_t)W + (size_t)tx) * 4;
         albedo[o + 0] = unorm8(c.x);
         albedo[o + 1] = unorm8(c.y);
@@ -1359,8 +1369,8 @@ static int text_coord_from_probe_number(const o_field* f, int probe_number, int*
     int rx = gint(gmod((float)probe_number, (float)x_dim));
     int ry = probe_number / x_dim;
     if (ry >= f->probe_count[1]) return 0;
-    *ox = rx * f->sqrt_rays_per_probe;
-    *oy = ry * f->sqrt_rays_per_probe;
+    *ox = rx * tile_w(f);
+    *oy = ry * tile_h(f);
     return 1;
 }
 
@@ -1369,13 +1379,13 @@ static v3 sample_probe(const SampleCtx* sc, int probe_number, v3 dir, int textur
 {
     int cx0, cy0;
     if (!text_coord_from_probe_number(sc->f, probe_number, &cx0, &cy0)) return V3(1, 0, 1);
-    int s = sc->f->sqrt_rays_per_probe;
+    int s = tile_w(sc->f), sh = tile_h(sc->f);
     v3 id = normalize3(dir);
     int rx = gint(((-1.0f * (id.z - 1.0f)) / 2.0f) * (float)s);
     if (rx == s) rx = 0;
     float sqrt_z = sqrtf(1.0f - (id.z * id.z));
     const float PI_F = 3.1415926535897932384626433832795f;
-    int ry = gint((o_acos(id.x / sqrt_z) / (2.0f * PI_F)) * (float)s);
+    int ry = gint((o_acos(id.x / sqrt_z) / (2.0f * PI_F)) * (float)sh);
     int sx = cx0 + rx, sy = cy0 + ry;
     v3 result = image_load(sc->albedo, sc->W, sx, sy);
     int count = 0;
@@ -1386,7 +1396,7 @@ static v3 sample_probe(const SampleCtx* sc, int probe_number, v3 dir, int textur
         for (int y = -2; y <= 2; y++)
         {
             int yy = sy + y;
-            if (yy < cy0 || yy >= cy0 + s) continue;
+            if (yy < cy0 || yy >= cy0 + sh) continue;
             count++;
             if (texture_to_sample == 0)
                 result = vadd(result, image_load(sc->albedo, sc->W, temp, yy));
@@ -1460,8 +1470,8 @@ void oracle_sample(const o_field* f, const uint8_t* albedo, const uint8_t* dista
     sc.f = f;
     sc.albedo = albedo;
     sc.distance = distance;
-    sc.W = f->probe_count[0] * f->probe_count[2] * f->sqrt_rays_per_probe;
-    sc.H = f->probe_count[1] * f->sqrt_rays_per_probe;
+    sc.W = f->probe_count[0] * f->probe_count[2] * tile_w(f);
+    sc.H = f->probe_count[1] * tile_h(f);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; i++)
     {
@@ -1476,14 +1486,14 @@ void oracle_sample(const o_field* f, const uint8_t* albedo, const uint8_t* dista
 /* KAT helper: sample_probe's texel inversion only; returns (rx, ry) */
 void oracle_sample_texel(const o_field* f, const float* dir, int* rx_out, int* ry_out)
 {
-    int s = f->sqrt_rays_per_probe;
+    int s = tile_w(f);
     v3 id = normalize3(V3(dir[0], dir[1], dir[2]));
     int rx = gint(((-1.0f * (id.z - 1.0f)) / 2.0f) * (float)s);
     if (rx == s) rx = 0;
     float sqrt_z = sqrtf(1.0f - (id.z * id.z));
     const float PI_F = 3.1415926535897932384626433832795f;
     *rx_out = rx;
-    *ry_out = gint((o_acos(id.x / sqrt_z) / (2.0f * PI_F)) * (float)s);
+    *ry_out = gint((o_acos(id.x / sqrt_z) / (2.0f * PI_F)) * (float)tile_h(f));
 }
 
 /* =========================================================================================== */
@@ -1685,7 +1695,7 @@ void oracle_ddgi_update(const o_field* f, const o_settings* st, const o_light* b
     float rot[9];
     oracle_frame_rotation(frame, rot);
     int cxn = f->probe_count[0], cyn = f->probe_count[1], czn = f->probe_count[2];
-    int s = f->sqrt_rays_per_probe, n = s * s;
+    int n = tile_w(f) * tile_h(f); /* DDGI mode: any ray count (the Fibonacci set is defined for every n) */
     float hyst = f->hysteresis;
     float max_dist = (float)f->side_length * 1.5f;
     uint32_t frame_key = oracle_wang_hash(frame);
@@ -1947,8 +1957,8 @@ static v3 probe_field_gi(const RenderProbes* rp, v3 pos, v3 nrm)
     sc.f = rp->f;
     sc.albedo = rp->albedo;
     sc.distance = rp->distance;
-    sc.W = rp->f->probe_count[0] * rp->f->probe_count[2] * rp->f->sqrt_rays_per_probe;
-    sc.H = rp->f->probe_count[1] * rp->f->sqrt_rays_per_probe;
+    sc.W = rp->f->probe_count[0] * rp->f->probe_count[2] * tile_w(rp->f);
+    sc.H = rp->f->probe_count[1] * tile_h(rp->f);
     int32_t cage[8];
     return get_diffuse_gi(&sc, pos, nrm, cage);
 }

@@ -125,17 +125,36 @@ def glibc_rand(st):
     return lib().oracle_glibc_rand(C.byref(st))
 
 
+_tile = [0, 0]
+
+
+def set_ray_tile(tile_x=0, tile_y=0):
+    """Non-square ray tile (tile_x strata along z x tile_y strata along phi); (0, 0) = square, from the field."""
+    _tile[0], _tile[1] = int(tile_x), int(tile_y)
+    lib().oracle_set_ray_tile(int(tile_x), int(tile_y))
+
+
+def ray_tile(field):
+    s = field.sqrt_rays_per_probe
+    return (_tile[0] or s, _tile[1] or s)
+
+
+def rays_per_probe(field):
+    tx, ty = ray_tile(field)
+    return tx * ty
+
+
 def generate_probe_rays(field, rand_state):
     P = field.probe_count[0] * field.probe_count[1] * field.probe_count[2]
-    n = P * field.sqrt_rays_per_probe ** 2
+    n = P * rays_per_probe(field)
     rays = np.zeros(n, dtype=RAY_DTYPE)
     lib().oracle_generate_probe_rays(C.byref(field), C.byref(rand_state), rays.ctypes.data_as(C.c_void_p))
     return rays
 
 
 def texture_size(field):
-    s = field.sqrt_rays_per_probe
-    return field.probe_count[0] * field.probe_count[2] * s, field.probe_count[1] * s
+    tx, ty = ray_tile(field)
+    return field.probe_count[0] * field.probe_count[2] * tx, field.probe_count[1] * ty
 
 
 def probe_update(field, settings, rays, first=0, count=None, lights=None, nthreads=0, want_float=False):
@@ -238,7 +257,7 @@ def new_tiles(field):
 def ddgi_update(field, settings, frame, irradiance, depth, lights=None, probes=None, nthreads=0, want_radiance=False):
     """One DDGI-mode probe update in place on (irradiance, depth) -> optional radiance [P*n, 4]."""
     P = field.probe_count[0] * field.probe_count[1] * field.probe_count[2]
-    n = field.sqrt_rays_per_probe ** 2
+    n = rays_per_probe(field)
     rad = np.zeros((P * n, 4), dtype=np.float32) if want_radiance else None
     lp, nl = None, 0
     if lights is not None:

@@ -40,5 +40,6 @@ def _pinned_arith_by_default():
 
         if oracle_py._lib is not None:
             oracle_py.set_arith(True)
+            oracle_py.set_ray_tile(0, 0)
     except Exception:
         pass

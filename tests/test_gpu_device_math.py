@@ -15,3 +15,12 @@ def test_host_and_device_evaluate_pinned_arithmetic_identically(tmp_path):
                     "-fno-fast-math", os.path.join(HERE, "device_math_check.hip"), "-o", str(exe)], check=True)
     res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
+
+
+def test_f32_mfma_accumulates_in_k_order_like_an_fmaf_chain(tmp_path):
+    """The premise of the MFMA blend kernel: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 == a k-ordered binary32 fma chain."""
+    exe = tmp_path / "mfma_order_check"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                    "-fno-fast-math", os.path.join(HERE, "mfma_order_check.hip"), "-o", str(exe)], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr

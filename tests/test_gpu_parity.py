@@ -147,9 +147,10 @@ def test_sharded_slabs_equal_the_full_grid(ddgi, oracle):
     assert np.array_equal(parts[1][:, ~colmask], want_a[:, ~colmask]) and not parts[1][:, colmask].any()
 
 
-def test_full_size_c3_properties_and_sampled_oracle_check(ddgi, oracle):
-    """BASELINE config C3 (32x16x32 probes x 256 rays, cave): size-independent properties plus an
-    oracle check of a sample of probes (the oracle cannot finish 4.2 M rays in seconds)."""
+def test_full_size_c3_full_grid_vs_oracle(ddgi, oracle):
+    """BASELINE config C3 (32x16x32 probes x 256 rays, cave): size-independent properties and a byte
+    comparison of EVERY texel of the grid with the oracle (4 194 304 rays; seconds on the GPU box's host
+    cores, see BENCH_r01.json's cpu_baseline)."""
     counts, side, s, origin, scene = CONFIGS["c3_cave"]
     with _engine(ddgi, "c3_cave") as eng:
         eng.generate_probe_rays(seed=1)
@@ -168,13 +169,10 @@ def test_full_size_c3_properties_and_sampled_oracle_check(ddgi, oracle):
     assert tiles.mean() > 0.9
     f = oracle.make_field(counts, side, s, origin)
     rays = oracle.generate_probe_rays(f, oracle.new_rand_state(1))
-    st = oracle.make_settings(scene, 8)
-    rng = np.random.default_rng(5)
-    probes = rng.choice(32 * 16 * 32, size=64, replace=False)
-    want = oracle.probe_update_probes(f, st, rays, probes)
-    for p in probes:
-        x0, y0 = ddgi.probe_tile_origin(ddgi.make_field(counts, side, s, origin), int(p))
-        assert np.array_equal(a1[y0:y0 + 16, x0:x0 + 16], want[y0:y0 + 16, x0:x0 + 16]), f"probe {p}"
+    want, want_d = oracle.probe_update(f, oracle.make_settings(scene, 8), rays)
+    nbad = int((a1 != want).any(axis=-1).sum())
+    assert nbad == 0, f"{nbad} of {a1.shape[0] * a1.shape[1]} texels of the full C3 grid differ from the oracle"
+    assert not want_d.any()
 
 
 def test_torch_owned_textures_and_stream(ddgi, oracle):
