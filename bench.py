@@ -11,8 +11,10 @@ shipped light table, REF mode (the reference's live behaviour), ray jitter seed 
          --master-port P bench.py --gpus N --steps K --warmup W
 
 N > 1: the probe grid is sharded by z-slab (cz/N layers per rank); every step each rank traces its
-slab and the blended textures are exchanged with one RCCL all-gather per texture over xGMI
-(torch.distributed, backend nccl).  Total work is fixed, so `scaling` is "strong".
+slab and the blended textures are exchanged with one RCCL all-gather per texture over xGMI, issued by the
+engine itself (ddgi_exchange: double-buffered pairs + a communication stream inside libddgi_probe.so;
+torch.distributed only hands the 128-byte RCCL id around and provides the barrier / max-over-ranks).
+Total work is fixed, so `scaling` is "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
 dominant kernel (k_probe_trace_ref) and, at N = 1, `cpu_baseline` (the CPU oracle timed on the
@@ -82,10 +84,11 @@ def _traffic_from_profiles():
     return best
 
 
-def cpu_baseline(n_probes=96):
+def cpu_baseline(n_probes=96, gpu_albedo=None):
     """The oracle (a CPU restatement of the reference's algorithm: procedural getBlockAt per march
     step, exactly what the reference's shader does) over a bounded, evenly spread sample of the
-    workload's probes, all host threads."""
+    workload's probes, all host threads.  The texels it computes are also compared, byte for byte, with
+    the ones the GPU produced in the timed run (`parity_checked`)."""
     from oracle import oracle_py as O
 
     O.set_arith(True)
@@ -103,16 +106,43 @@ def cpu_baseline(n_probes=96):
     n = int(min(total, max(len(calib), rate * 12.0)))
     probes = np.linspace(0, total - 1, n).astype(np.int32)
     t0 = time.perf_counter()
-    O.probe_update_probes(f, st, rays, probes)
+    want = O.probe_update_probes(f, st, rays, probes)
     dt = time.perf_counter() - t0
     nrays = len(probes) * w["s"] ** 2
-    return {
+    out = {
         "value": nrays / dt,
         "unit": "rays/s",
         "cores": O.num_threads(),
         "kind": "port",
         "sample": f"{len(probes)} of {total} probes evenly spread over the grid ({nrays} rays), {dt:.1f} s",
     }
+    if gpu_albedo is not None:
+        # the probes of the sample as tile masks of the reference raster (tile of probe p at ((p mod cx*cz)*s, (p div cx*cz)*s))
+        s, cxz = w["s"], w["counts"][0] * w["counts"][2]
+        mask = np.zeros((w["counts"][1], cxz), dtype=bool)
+        mask[np.unique(probes) // cxz, np.unique(probes) % cxz] = True
+        tiles_gpu = gpu_albedo.reshape(w["counts"][1], s, cxz, s, 4).transpose(0, 2, 1, 3, 4)[mask]
+        tiles_cpu = want.reshape(w["counts"][1], s, cxz, s, 4).transpose(0, 2, 1, 3, 4)[mask]
+        differ = int((tiles_gpu != tiles_cpu).any(axis=-1).sum())
+        n_tex = int(mask.sum()) * s * s
+        scope = "c3 full grid" if int(mask.sum()) == total else f"{int(mask.sum())} of {total} probes of c3"
+        out["parity_checked"] = f"{scope}, {n_tex - differ} of {n_tex} texels equal (HIP vs oracle, rgba8 bytes)"
+        out["parity_texels_differing"] = differ
+    return out
+
+
+class _c_stdout_to_stderr:
+    """RCCL prints its version banner to the C-level stdout when a communicator is created; bench.py's stdout
+    must carry exactly one JSON line, so file descriptor 1 points at stderr while communicators are made."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
 
 
 def main():
@@ -146,7 +176,8 @@ def main():
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        with _c_stdout_to_stderr():
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     w = WORKLOAD
     field = ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"])
@@ -160,30 +191,32 @@ def main():
     else:
         eng.generate_probe_rays(seed=w["seed"])  # ray buffer resident in HBM from here on
 
-    tex = None
+    comm = None
     if sharded:
-        from ddgi_amd import distributed as ddist
-
-        # REF mode: the exchange of update k overlaps the kernel of update k+1 (two buffer pairs)
-        tex = ddist.ShardedTextures(eng, torch.device("cuda", local_rank), pipelined=not ddgi_mode, ddgi_mode=ddgi_mode)
+        # the engine issues the RCCL all-gather itself (include/ddgi_probe.h: ddgi_exchange_*): rank 0 makes the
+        # 128-byte RCCL id, torch.distributed carries it to the other ranks, every rank joins the communicator
+        with _c_stdout_to_stderr():
+            ids = [ddgi_amd.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = ddgi_amd.comm_create(ids[0], world, rank, local_rank)
+        # pipelined: the exchange of update k overlaps the kernels of update k+1 (two texture pairs inside the engine)
+        eng.exchange_init(comm, pipelined=True)
 
     frame_time = [0.0]
 
     def step():
-        if tex is not None:
-            tex.begin_step()
         if ddgi_mode:
             frame_time[0] += 2.0                # RVPT::update: render_settings.time += 2 (rvpt.cpp:281)
             settings.time = frame_time[0]
             eng.probe_update(settings)
         else:
             eng.probe_update()
-        if tex is not None:
-            tex.all_gather()
+        if comm is not None:
+            eng.exchange()
 
     def fence():
-        if tex is not None:
-            tex.finish()                        # every exchange issued so far has completed on this stream
+        if comm is not None:
+            eng.exchange_finish()               # the stream waits for every exchange issued so far
         if sharded:
             dist.barrier()
         torch.cuda.synchronize()
@@ -208,9 +241,17 @@ def main():
     total_rays = eng.num_rays
     local_rays = total_rays // world
     ms_per_step = elapsed / args.steps * 1e3
-    # REF: 48 B ProbeRay in + two 4 B texels out; DDGI: rays are generated in the kernel, 16 B (rgb, distance) record out
-    algo_bytes_per_ray = 20 if ddgi_mode else ALGO_BYTES_PER_RAY  # DDGI: the (r, g, b, d, d*d) ray record out, no ray buffer in
-    achieved = algo_bytes_per_ray * local_rays / (kernel_ms * 1e-3) / 1e9
+    # REF: 48 B ProbeRay in + two 4 B texels out per ray.  DDGI: rays are generated in the kernel and the
+    # ray records between trace and blend are an intermediate that does not count: 3072 B of tiles per probe (old tiles in +
+    # new tiles out of the 8x8 rgba16f-equivalent irradiance and 16x16 rg16f-equivalent depth tiles), over trace + blend.
+    probes_local = eng.num_probes // world
+    bms = float(np.mean(blend_ms)) if len(blend_ms) else 0.0
+    if ddgi_mode:
+        algo_bytes = 3072 * probes_local
+        kernel_ms = kernel_ms + bms
+    else:
+        algo_bytes = ALGO_BYTES_PER_RAY * local_rays
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
     out = {
         "metric": "probe_rays_per_sec",
         "value": total_rays / (elapsed / args.steps),
@@ -242,26 +283,27 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None if ddgi_mode else _traffic_from_profiles(),
-            "algorithmic_bytes_per_launch": algo_bytes_per_ray * local_rays,
+            "algorithmic_bytes_per_launch": algo_bytes,
             "kernel_ms": kernel_ms,
             "issue": None if ddgi_mode else _issue_from_profiles(),
             "note": "the trace kernel is VALU-issue bound (dependent voxel steps + hit shading), not HBM bound: `issue` = the VALU's occupancy from profiles/ (rocprofv3 --pmc), see DESIGN.md section 4",
         },
     }
     if ddgi_mode:
-        # the blend kernels (k_blend_weights + k_probe_blend_s): 20 B ray record per ray in (rgb, d, d*d),
-        # 3 KB old tiles in + 3 KB new tiles out per probe
-        bms = float(np.mean(blend_ms)) if len(blend_ms) else float("nan")
-        probes_local = eng.num_probes // world
+        # the blend kernels on their own: what THEY must move is the ray records the trace left (20 B per ray: r, g, b, d, d*d;
+        # an intermediate of the pass, so not part of `roofline`) + the f32 tiles in and out (6144 B per probe)
         bbytes = 20 * local_rays + 6144 * probes_local
         out["config"]["workload"] = w["name"].replace("_ref", "_ddgi")
-        out["blend"] = {"kernel": "k_blend_weights+k_probe_blend_s", "kernel_ms": bms, "algorithmic_bytes_per_launch": bbytes,
+        out["roofline"]["kernel"] += "+k_blend_weights+k_probe_blend"
+        out["blend"] = {"kernel": "k_blend_weights+k_probe_blend", "kernel_ms": bms, "kernel_io_bytes_per_launch": bbytes,
                         "achieved_GBps": bbytes / (bms * 1e-3) / 1e9, "frac_of_hbm_peak": bbytes / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not ddgi_mode:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_probes)
-    if tex is not None:
-        tex.close()
+        out["cpu_baseline"] = cpu_baseline(args.cpu_probes, gpu_albedo=eng.read_textures()[0])
+    if comm is not None:
+        eng.exchange_init(None)
     eng.close()
+    if comm is not None:
+        ddgi_amd.comm_destroy(comm)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -26,6 +26,11 @@ public:
     ddgi_irradiance_field ir{{9, 7, 9}, 11, 0.9f, 20, {0, 0}, {1.4f, 0.f, 1.f}, 1, {0, 0, 0}};
 
     explicit RVPTProbePath(int device = 0) : device_(device) {}
+    // One z-slab of a probe grid sharded over `world` GPUs (the reference is single-GPU): this object
+    // traces + blends the probes with z in [rank*cz/world, (rank+1)*cz/world) on `device`.  `nccl_comm` is an
+    // ncclComm_t of that size/rank (ddgi_comm_create / ddgi_comm_create_all, or the host's own RCCL); draw() then
+    // also issues the in-place all-gather of the probe textures, pipelined behind the next frame's update.
+    RVPTProbePath(int device, int rank, int world, void* nccl_comm) : device_(device), rank_(rank), world_(world), comm_(nccl_comm) {}
     ~RVPTProbePath() { shutdown(); }
     RVPTProbePath(const RVPTProbePath&) = delete;
     RVPTProbePath& operator=(const RVPTProbePath&) = delete;
@@ -42,7 +47,8 @@ public:
     bool initialize()
     {
         if (handle_) return true;
-        if (!ok(ddgi_create(&ir, &render_settings, device_, &handle_), "ddgi_create")) return false;
+        if (!ok(ddgi_create_sharded(&ir, &render_settings, device_, rank_, world_, &handle_), "ddgi_create_sharded")) return false;
+        if (comm_ && !ok(ddgi_exchange_init(handle_, comm_, 1), "ddgi_exchange_init")) return false;
         return flush_rays();
     }
 
@@ -55,7 +61,13 @@ public:
     }
 
     // probe half of rvpt.cpp:372-431 (record_compute_command_buffer 1096-1129 + submit)
-    bool draw() { return handle_ && ok(ddgi_probe_update(handle_, &render_settings), "ddgi_probe_update"); }
+    // Sharded: + the all-gather of this frame's textures (asynchronous; the sample / read calls below wait for it).
+    // A process that drives several slabs brackets the draw() calls of one frame with ddgi_exchange_group_begin/end.
+    bool draw()
+    {
+        if (!handle_ || !ok(ddgi_probe_update(handle_, &render_settings), "ddgi_probe_update")) return false;
+        return !comm_ || ok(ddgi_exchange(handle_), "ddgi_exchange");
+    }
 
     // rvpt.cpp:661-755; keep_surviving_probes: probes that stand where an old probe stood keep their tiles
     // (ddgi_reconfigure) — the reference itself drops every texture
@@ -64,6 +76,7 @@ public:
         need_change_probe_texture_ = false;
         if (!handle_) return initialize();
         if (!ok(ddgi_reconfigure(handle_, &ir, &render_settings, keep_surviving_probes ? 1 : 0), "ddgi_reconfigure")) return false;
+        if (comm_ && !ok(ddgi_exchange_init(handle_, comm_, 1), "ddgi_exchange_init")) return false;  // reconfiguring detaches the exchange
         need_generate_probe_rays_ = true;
         return flush_rays();
     }
@@ -108,7 +121,8 @@ private:
         return rc == DDGI_OK;
     }
 
-    int device_ = 0;
+    int device_ = 0, rank_ = 0, world_ = 1;
+    void* comm_ = nullptr;  // ncclComm_t, caller-owned
     ddgi_handle handle_ = nullptr;
     bool need_generate_probe_rays_ = true;    // rvpt.h:96
     bool need_change_probe_texture_ = false;  // rvpt.h:95
