@@ -12,6 +12,13 @@ namespace ddgi {
 
 #define DDGI_D __device__ __forceinline__
 
+// Timing experiments only (make alt ALTFLAGS=-DDDGI_EXP=<bits>): each bit swaps one piece of the trace kernels for a
+// cheap stand-in to measure what that piece costs.  Results are NOT exact with any bit set; the release build has 0.
+//   1 hemisphere sine/cosine  2 no light-sphere test  8 constant albedo  16 light feelers are not marched
+#ifndef DDGI_EXP
+#define DDGI_EXP 0
+#endif
+
 // ---- per-ray RNG: wang_hash seed + xorshift32 (probe_pass.comp:45-71) -------------------------
 
 DDGI_D uint32_t wang_hash(uint32_t seed)
@@ -60,7 +67,7 @@ DDGI_D void light_spheres(f3 o, f3 d, const TraceArgs& A, float& tl_out, int& li
 {
     float closest = __builtin_inff();
     int lid = -1;
-    const int nl = kNl > 0 ? kNl : A.nl;
+    const int nl = (DDGI_EXP & 2) ? 0 : (kNl > 0 ? kNl : A.nl);
     for (int i = 0; i < nl; ++i)
     {
         const f3 lp{A.lights[i].pos[0], A.lights[i].pos[1], A.lights[i].pos[2]};
@@ -232,9 +239,13 @@ DDGI_D f3 hemisphere_dir(f3 n, uint32_t& rng)
     if (!axis) p1 = normalize3(p1);
     f3 p2 = cross3(n, p1);
     if (!axis) p2 = normalize3(p2);
+#if DDGI_EXP & 1
+    const float ca = __cosf(around) * over, sa = __sinf(around) * over;
+#else
     const pm::SinCos sc = pm::sincos_core(around);
     const float ca = static_cast<float>(sc.c) * over;
     const float sa = static_cast<float>(sc.s) * over;
+#endif
     return (n * up + p1 * ca) + p2 * sa;
 }
 

@@ -32,14 +32,14 @@ namespace ddgi {
 
 constexpr int kWfStepsPerTrip = 16;  // voxel steps per march-loop trip (burst)
 #ifndef DDGI_AQ_STEPS
-#define DDGI_AQ_STEPS 16
+#define DDGI_AQ_STEPS 24
 #endif
 constexpr int kAqStepsPerTrip = DDGI_AQ_STEPS;  // the same for k_probe_trace_aq
 constexpr int kWfTailSteps = 1;          // straggler trips (bursts) after the march list is drained
 constexpr int kWfDrainTail = 8;      // straggler trips once no new ray can be claimed (8 x 16 steps >= kMarchIters)
 constexpr int kWfFetchLanes = 8;     // pull new march tasks once this many lanes are idle
 constexpr uint32_t kWfChunk = 4096;  // rays a workgroup claims at a time from the global counter (upper bound, see wf_chunk)
-constexpr int kWfBuckets = 7;
+constexpr int kWfBuckets = 8;
 
 enum : uint32_t
 {
@@ -48,9 +48,10 @@ enum : uint32_t
     kSlotEvPrimary = 2,
     kSlotEvFeeler = 3,
     // flags word: [1:0] state, [2] feeler march, [3] voxel hit, [11:4] march iterations,
-    //             [15:12] light id + 1, [19:16] block type of the voxel hit
+    //             [15:12] light id + 1, [19:16] block type of the voxel hit, [20] routing hint: dead feeler expected
     kFlagFeeler = 4,
     kFlagHit = 8,
+    kFlagDeadHint = 1u << 20,
 };
 
 struct WfShared  // control block at the start of dynamic LDS (32 dwords)
@@ -144,7 +145,36 @@ DDGI_D uint32_t shade_bucket(int type)
 }
 constexpr uint32_t kBucketNoBlock = 4;  // primary march that ended on a light sphere or missed
 constexpr uint32_t kBucketFeeler = 5;
-constexpr uint32_t kBucketRefill = 6;  // an empty slot that can take a new ray
+constexpr uint32_t kBucketDead = 6;    // block hit whose light feeler is expected to be dead (see dead_feeler_hint): no albedo, no feeler
+constexpr uint32_t kBucketRefill = 7;  // an empty slot that can take a new ray
+
+// ROUTING HINT, never a result: will the single light's feeler of this block hit be dead, i.e. is the Lambert term
+// clamp(dot(n, to_light), 0, 1) == 0 (then wf_event skips albedo, feeler march and feeler event — every outcome
+// adds exactly +0)?  For an axis normal n = +-e_k the sign of dot(n, normalize(light - hit)) is the sign of
+// +-(light_k - hit_k).  Hits expected dead are shaded in groups of their own (kBucketDead), so that a group
+// runs EITHER the albedo + feeler set-up OR the bounce set-up, not both at half occupancy.  wf_event decides
+// exactly, whatever the bucket; a wrong hint costs time only.  p: the march position at the hit.
+DDGI_D bool dead_feeler_hint(f3 p, const LightK& L)
+{
+    const f3 cell = cell_id(p);
+    const float dx = p.x - (cell.x - 0.5f), dy = p.y - (cell.y - 0.5f), dz = p.z - (cell.z - 0.5f);
+    const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+    float d = dz, pk = p.z, lk = L.pos[2];
+    if (ax >= ay && ax >= az) d = dx, pk = p.x, lk = L.pos[0];
+    else if (ay >= az) d = dy, pk = p.y, lk = L.pos[1];
+    const float to_light = lk - pk;  // (the hit position is p + 0.001 n: irrelevant at this resolution)
+    return d > 0.0f ? to_light <= 0.001f : to_light >= -0.001f;
+}
+
+// flags bits [20:16] + [3] of a march that ended in an occupied voxel of block type `type` at position p
+template <class Cfg>
+DDGI_D uint32_t hit_flags(const TraceArgs& A, uint32_t type, f3 p, bool feeler)
+{
+    uint32_t f = kFlagHit | (type << 16);
+    if (Cfg::nl(A) == 1 && !feeler && type != 12u && type != 13u && dead_feeler_hint(p, A.lights[0])) f |= kFlagDeadHint;  // (12, 13: albedo may be NaN, see wf_event)
+    return f;
+}
+DDGI_D uint32_t primary_bucket(uint32_t fl) { return (fl & kFlagDeadHint) ? kBucketDead : shade_bucket(static_cast<int>((fl >> 16) & 15u)); }
 
 // A new voxel march for pool slot `slot` (intersect_scene's set-up, intersection.glsl:1253-1279 +
 // grid_march's, 1053-1058): origin, normalised direction and its reciprocal, light spheres.
@@ -193,6 +223,12 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
     if (!feeler) set3(c.hc, d);  // the hit albedo is dead until this march is shaded
     P.tl[slot] = tl;
     const uint32_t base_flags = (feeler ? kFlagFeeler : 0u) | (static_cast<uint32_t>(lid + 1) << 12);
+    if ((DDGI_EXP & 16) && feeler)  // timing experiment: a feeler "reaches the light" without being marched
+    {
+        P.t[slot] = tl;
+        P.flags[slot] = base_flags | kSlotEvFeeler;
+        return static_cast<int>(kBucketFeeler);
+    }
     if (kInlineSteps > 0)
     {
         March m;
@@ -213,10 +249,10 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
         P.t[slot] = m.t;
         if (fin)
         {
-            const uint32_t type = occ ? static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)) : 0u;
-            P.flags[slot] = base_flags | (feeler ? kSlotEvFeeler : kSlotEvPrimary) | (occ ? kFlagHit : 0u) | (type << 16);
+            const uint32_t hf = occ ? hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, feeler) : 0u;
+            P.flags[slot] = base_flags | (feeler ? kSlotEvFeeler : kSlotEvPrimary) | hf;
             const bool block_wins = occ && (m.t < tl);
-            return static_cast<int>(feeler ? kBucketFeeler : (block_wins ? shade_bucket(static_cast<int>(type)) : kBucketNoBlock));
+            return static_cast<int>(feeler ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock));
         }
         P.flags[slot] = kSlotMarch | base_flags | (static_cast<uint32_t>(kInlineSteps) << 4);
         return -1;
@@ -346,13 +382,15 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             else
             {
                 const f3 rd = v3of(c.hc);  // the ray direction as given (see WfCold::hc)
-                f3 nraw, hcol;
+                f3 nraw, hcol = mk3(0, 0, 0);  // (light-sphere hit: Q12, unassigned Material pinned to zero)
+                f3 p = mk3(0, 0, 0), nn = mk3(0, 0, 0);  // block hit: march position and block normal, for the albedo
+                const int type = static_cast<int>((fl >> 16) & 15u);
                 float th;
                 bool axis_normal = false;
                 if (block_wins)
                 {
                     th = t;
-                    const f3 p = ray_at(ro, ld3(P.dn, slot), t);  // the march position at the hit
+                    p = ray_at(ro, ld3(P.dn, slot), t);  // the march position at the hit
                     const f3 cell = cell_id(p);
                     const f3 centre = f3{cell.x - 0.5f, cell.y - 0.5f, cell.z - 0.5f};
                     // The reference picks the axis of the largest |component| of normalize(p - centre).  The
@@ -375,9 +413,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     if (fabsf(diff.z) > best) { best = fabsf(diff.z); n = mk3(0, 0, gl_sign(diff.z)); }
                     // normalize(n) of a unit axis vector is n itself (1*(1/sqrt(1)) = 1, 0*1 = 0);
                     // n stays (0,0,0) only if diff is NaN, where the reference yields NaN as well
-                    const f3 nn = best > 0.0f ? n : normalize3(n);
-                    const int type = static_cast<int>((fl >> 16) & 15u);
-                    hcol = (Cfg::ablate(A) & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
+                    nn = best > 0.0f ? n : normalize3(n);
                     nraw = nn;
                     axis_normal = best > 0.0f;
                 }
@@ -387,7 +423,6 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     const LightK& L = A.lights[static_cast<int>((fl >> 12) & 15u) - 1];
                     const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
                     nraw = ray_at((ro - lp) * 10.0f, rd * 10.0f, th);  // sphere-space position
-                    hcol = mk3(0, 0, 0);  // Q12: unassigned Material, pinned to zero
                 }
                 if (first_bounce) wf_store_distance(A, c.dst, th);  // Isect.t of the probe ray
                 const f3 hnrm = axis_normal ? nraw : normalize3(nraw);
@@ -401,11 +436,19 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     // Dead-feeler elimination (single light): whatever the feeler finds, the hit's
                     // direct light is scaled by lambert = clamp(dot(n, to_light), 0, 1)
                     // (probe_pass.comp:194-204), so for lambert == 0 and a finite albedo every
-                    // outcome adds exactly +0 to the colour: skip the march and its event.
+                    // outcome adds exactly +0 to the colour: skip the march and its event — and the albedo itself:
+                    // for a hit position of ordinary magnitude (|p| < 2^20: no product in the noise functions overflows)
+                    // every block type's albedo is finite, except the moss / mold pattern (types 12, 13), whose
+                    // normalize() of a texel-centre offset can be 0/0; those are evaluated and checked.  (Hits expected to be dead come in groups of their own, kBucketDead,
+                    // so a group normally runs either this branch or the albedo + feeler set-up.)
                     const f3 nh = axis_normal ? hnrm : normalize3(hnrm);
+                    const bool lambert_zero = Cfg::nl(A) == 1 && dot3(nh, to_light) <= 0.0f && !(Cfg::ablate(A) & 4);
+                    const bool ordinary = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))) < 0x1.0p20f;
+                    if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary))
+                        hcol = ((Cfg::ablate(A) & 1) || (DDGI_EXP & 8)) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
                     const bool finite_albedo = fabsf(hcol.x) < inf && fabsf(hcol.y) < inf && fabsf(hcol.z) < inf;
                     set3(c.hc, hcol);
-                    if (Cfg::nl(A) == 1 && finite_albedo && dot3(nh, to_light) <= 0.0f && !(Cfg::ablate(A) & 4))
+                    if (lambert_zero && finite_albedo)
                         posted = wf_lighting_done<Cfg>(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
                     else
                     {
@@ -417,7 +460,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 }
                 else
                 {
-                    set3(c.hc, hcol);
+                    set3(c.hc, hcol);  // no light: the albedo is never used
                     posted = wf_lighting_done<Cfg>(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
                 }
             }
@@ -557,7 +600,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                 else if (st == kSlotEvPrimary)
                 {
                     const bool block_wins = (fl & kFlagHit) && (P.t[slot] < P.tl[slot]);
-                    b = block_wins ? shade_bucket(static_cast<int>((fl >> 16) & 15u)) : kBucketNoBlock;
+                    b = block_wins ? primary_bucket(fl) : kBucketNoBlock;
                 }
                 else if (st == kSlotEmpty && have_rays) b = kBucketRefill;
                 my_bucket[k] = b;
@@ -718,10 +761,9 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                     if (!fin && ((trips & 3) == 3)) fin = march_escaped(m, A.scene);
                     if (fin)
                     {
-                        const uint32_t type = occ ? static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)) : 0u;
+                        const uint32_t hf = occ ? hit_flags<CfgRuntime>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, (fl & kFlagFeeler) != 0u) : 0u;
                         P.t[slot] = m.t;
-                        P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) |
-                                        (occ ? kFlagHit : 0u) | (type << 16);
+                        P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | hf;
                         have = false;
                     }
                 }
@@ -794,7 +836,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
 // =================================================================================================
 constexpr uint32_t kAqCap = 2048, kAqMask = kAqCap - 1;
 constexpr int kAqThinTrip = 32;     // a march wave with fewer lanes in flight (and nothing queued) yields for a moment
-constexpr int kAqEventQueues = 6;  // buckets 0..5 (kBucketRefill is served from FQ)
+constexpr int kAqEventQueues = 7;  // buckets 0..6 (kBucketRefill is served from FQ)
 
 struct AqShared  // control block at the start of dynamic LDS (32 dwords)
 {
@@ -970,11 +1012,11 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 if (!fin && ((trips & 3) == 3)) fin = march_escaped(m, A.scene);
                 if (fin)
                 {
-                    const uint32_t type = occ ? static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)) : 0u;
+                    const uint32_t hf = occ ? hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, (fl & kFlagFeeler) != 0u) : 0u;
                     P.t[slot] = m.t;
-                    P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | (occ ? kFlagHit : 0u) | (type << 16);
+                    P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | hf;
                     const bool block_wins = occ && (m.t < m.tl);
-                    bucket = (fl & kFlagFeeler) ? kBucketFeeler : (block_wins ? shade_bucket(static_cast<int>(type)) : kBucketNoBlock);
+                    bucket = (fl & kFlagFeeler) ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock);
                     have = false;
                     finished = true;
                 }
@@ -1195,3 +1237,66 @@ hipError_t launch_probe_trace_wf(const TraceArgs& args_in, int threads, int pool
 }
 
 }  // namespace ddgi
+
+#ifdef DDGI_ISA_PROBE
+// instruction-count probes (hipcc -S -DDDGI_ISA_PROBE): the building blocks of an event as kernels of their own
+namespace ddgi {
+__global__ void k_isa_post_march(const TraceArgs A, float* io, uint32_t* lds_src)
+{
+    extern __shared__ uint32_t pl[];
+    WfPool P;
+    float* f = reinterpret_cast<float*>(pl);
+    for (int a = 0; a < 3; ++a) P.ro[a] = f + 1536 * a, P.dn[a] = f + 1536 * (3 + a);
+    P.t = f + 1536 * 6, P.tl = f + 1536 * 7, P.flags = pl + 1536 * 8;
+    WfCold c = load_cold(reinterpret_cast<const WfCold*>(io) + threadIdx.x);
+    const f3 o = v3of(c.hn), d = v3of(c.hc);
+    const int r = wf_post_march<CfgPlain<0>>(P, threadIdx.x, c, o, d, c.cnt != 0, A, pl + 1536 * 9);
+    store_cold(reinterpret_cast<WfCold*>(io) + threadIdx.x, c);
+    io[threadIdx.x] = static_cast<float>(r);
+}
+__global__ void k_isa_hemisphere(float* io)
+{
+    uint32_t rng = __float_as_uint(io[threadIdx.x + 512]);
+    const f3 d = hemisphere_dir(f3{io[threadIdx.x], io[threadIdx.x + 64], io[threadIdx.x + 128]}, rng);
+    io[threadIdx.x] = d.x, io[threadIdx.x + 64] = d.y, io[threadIdx.x + 128] = d.z, io[threadIdx.x + 512] = __uint_as_float(rng);
+}
+__global__ void k_isa_light_spheres(const TraceArgs A, float* io)
+{
+    float tl;
+    int lid;
+    light_spheres<1>(f3{io[threadIdx.x], io[threadIdx.x + 64], io[threadIdx.x + 128]}, f3{io[threadIdx.x + 192], io[threadIdx.x + 256], io[threadIdx.x + 320]}, A, tl, lid);
+    io[threadIdx.x] = tl, io[threadIdx.x + 64] = static_cast<float>(lid);
+}
+__global__ void k_isa_normalize(float* io)
+{
+    const f3 d = normalize3(f3{io[threadIdx.x], io[threadIdx.x + 64], io[threadIdx.x + 128]});
+    io[threadIdx.x] = d.x, io[threadIdx.x + 64] = d.y, io[threadIdx.x + 128] = d.z;
+}
+__global__ void k_isa_albedo_wall(const TraceArgs A, float* io)
+{
+    const f3 d = block_albedo(f3{io[threadIdx.x], io[threadIdx.x + 64], io[threadIdx.x + 128]}, 10, f3{1.0f, 0.0f, 0.0f}, A.noise);
+    io[threadIdx.x] = d.x, io[threadIdx.x + 64] = d.y, io[threadIdx.x + 128] = d.z;
+}
+__global__ void k_isa_step(const TraceArgs A, float* io, int n)
+{
+    extern __shared__ uint32_t pl[];
+    March m;
+    m.ro = f3{io[threadIdx.x], io[threadIdx.x + 64], io[threadIdx.x + 128]};
+    m.dn = f3{io[threadIdx.x + 192], io[threadIdx.x + 256], io[threadIdx.x + 320]};
+    m.inv = f3{io[threadIdx.x + 384], io[threadIdx.x + 448], io[threadIdx.x + 512]};
+    m.cc = f3{io[threadIdx.x + 576], io[threadIdx.x + 640], io[threadIdx.x + 704]};
+    m.t = 0, m.tl = io[threadIdx.x + 768], m.p = m.ro, m.it = 0, m.cell = 0, m.lid = 0, m.rd = m.dn;
+    f3 hi = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
+    asm volatile("" : "+v"(hi.x), "+v"(hi.y), "+v"(hi.z));
+    bool occ = false;
+    for (int i = 0; i < n; ++i)
+    {
+        asm volatile("; STEP BEGIN");
+        occ = march_step_burst(m, A.scene, pl, hi);
+        asm volatile("; STEP END");
+        if (occ | (m.t >= m.tl)) break;
+    }
+    io[threadIdx.x] = m.t + (occ ? 1.0f : 0.0f);
+}
+}  // namespace ddgi
+#endif

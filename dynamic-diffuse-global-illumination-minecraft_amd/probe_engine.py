@@ -447,8 +447,8 @@ class ProbeEngine:
         keys = ("trips", "lane_steps", "event_rounds", "lane_events", "waves", "rounds", "fetches", "_7",
                 "cyc_scan", "cyc_march", "cyc_march_wait", "cyc_list", "cyc_events", "cyc_events_wait")
         st = dict(zip(keys, (int(v) for v in out[:14])))
-        st["bucket_cycles"] = [int(v) for v in out[16:23]]   # event groups by bucket (ddgi_trace_wf.hip: shade_bucket)
-        st["bucket_groups"] = [int(v) for v in out[24:31]]
+        st["bucket_cycles"] = [int(v) for v in out[16:24]]   # event groups by bucket (ddgi_trace_wf.hip: shade_bucket)
+        st["bucket_groups"] = [int(v) for v in out[24:32]]
         return st
 
     # -- outputs -------------------------------------------------------------------------------

@@ -26,7 +26,7 @@ if sum(cyc):
 print("steps/ray %.1f  march-lane-utilisation %.3f  events/ray %.2f  lanes/event-round %.1f  trips/wave %.0f rounds/wave %.0f" % (
     st["lane_steps"] / rays, st["lane_steps"] / (64.0 * st["trips"]), st["lane_events"] / rays,
     st["lane_events"] / st["event_rounds"], st["trips"] / st["waves"], st["event_rounds"] / st["waves"]))
-names = ("stem", "wall", "ground/moss/mold", "caps+flat", "light-or-miss", "feeler", "refill")
+names = ("stem", "wall", "ground/moss/mold", "caps+flat", "light-or-miss", "feeler", "dead-primary", "refill")
 tot = sum(st["bucket_cycles"]) or 1
 for nm, cyc, n in zip(names, st["bucket_cycles"], st["bucket_groups"]):
     print("  bucket %-18s groups %8d  cycles/group %8.0f  share of event time %.3f" % (nm, n, cyc / max(n, 1), cyc / tot))
