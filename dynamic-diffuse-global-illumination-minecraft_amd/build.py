@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 _SO = os.path.join(_HERE, "libddgi_probe.so")
 _SOURCES = ["ddgi_kernels.hip", "ddgi_trace_wf.hip", "ddgi_blend_sample.hip", "ddgi_device.h", "ddgi_oct.h", "ddgi_sampler.h", "ddgi_render.hip", "ddgi_host.cpp", "ddgi_engine.cpp", "ddgi_engine.h",
-            "ddgi_exchange.cpp", "ddgi_pinned_math.h", "ddgi_scene.h", "ddgi_types.h", "ddgi_host.h", "Makefile"]
+            "ddgi_exchange.cpp", "ddgi_visibility.hip", "ddgi_pinned_math.h", "ddgi_scene.h", "ddgi_types.h", "ddgi_host.h", "Makefile"]
 _PROF_SO = os.path.join(_HERE, "libddgi_probe_prof.so")
 
 

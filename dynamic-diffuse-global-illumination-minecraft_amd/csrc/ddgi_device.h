@@ -77,15 +77,21 @@ DDGI_D void light_spheres(f3 o, f3 d, const TraceArgs& A, float& tl_out, int& li
         const float qb = -dot3(sd, so);
         const float qc = dot3(so, so) - 1.0f;
         float disc = qb * qb - qa * qc;
-        disc = disc > 0.0f ? sqrtf(disc) : __builtin_inff();
-        const float inv_a = 1.0f / qa;
-        float t1 = (qb - disc) * inv_a;
-        float t2 = (qb + disc) * inv_a;
-        t1 = (0.0f < t1 && t1 < closest) ? t1 : __builtin_inff();
-        t2 = (0.0f < t2 && t2 < closest) ? t2 : __builtin_inff();
-        const float ts = gl_min(t1, t2);
-        if (ts < closest) lid = i;
-        closest = gl_min(ts, closest);
+        // A ray that misses the sphere (disc <= 0, or NaN): the reference sets the root term to INF and both
+        // candidate roots (qb -+ INF) / qa then fail 0 < t < closest whatever qa is (-inf, NaN, or inf * 0 = NaN),
+        // so nothing changes — skipped as a whole (bounce rays almost never point at a radius-0.1 sphere)
+        if (disc > 0.0f)
+        {
+            disc = sqrtf(disc);
+            const float inv_a = 1.0f / qa;
+            float t1 = (qb - disc) * inv_a;
+            float t2 = (qb + disc) * inv_a;
+            t1 = (0.0f < t1 && t1 < closest) ? t1 : __builtin_inff();
+            t2 = (0.0f < t2 && t2 < closest) ? t2 : __builtin_inff();
+            const float ts = gl_min(t1, t2);
+            if (ts < closest) lid = i;
+            closest = gl_min(ts, closest);
+        }
     }
     tl_out = closest;
     lid_out = lid;
@@ -101,30 +107,7 @@ DDGI_D void start_march(March& m, f3 o, f3 d, const TraceArgs& A)
     m.p = o;
     m.t = 0.0f;
     m.it = 0;
-    // light spheres of radius 0.1: unit-sphere quadratic in a space scaled by 10 (x/0.1 := x*10)
-    float closest = __builtin_inff();
-    int lid = -1;
-    for (int i = 0; i < A.nl; ++i)
-    {
-        const f3 lp{A.lights[i].pos[0], A.lights[i].pos[1], A.lights[i].pos[2]};
-        const f3 so = (o - lp) * 10.0f;
-        const f3 sd = d * 10.0f;
-        const float qa = dot3(sd, sd);
-        const float qb = -dot3(sd, so);
-        const float qc = dot3(so, so) - 1.0f;
-        float disc = qb * qb - qa * qc;
-        disc = disc > 0.0f ? sqrtf(disc) : __builtin_inff();
-        const float inv_a = 1.0f / qa;
-        float t1 = (qb - disc) * inv_a;
-        float t2 = (qb + disc) * inv_a;
-        t1 = (0.0f < t1 && t1 < closest) ? t1 : __builtin_inff();
-        t2 = (0.0f < t2 && t2 < closest) ? t2 : __builtin_inff();
-        const float ts = gl_min(t1, t2);
-        if (ts < closest) lid = i;
-        closest = gl_min(ts, closest);
-    }
-    m.tl = closest;
-    m.lid = lid;
+    light_spheres<0>(o, d, A, m.tl, m.lid);
 }
 
 // Raw linear cell index of voxel id (x,y,z) clamped into the baked box.  Outside the box the world is

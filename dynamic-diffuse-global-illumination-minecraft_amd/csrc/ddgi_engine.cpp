@@ -36,6 +36,7 @@ size_t blend_record_groups(uint32_t n_local_probes);
 hipError_t launch_carry_tiles(void* dst, const void* src, const int32_t* map, uint32_t n_probes, uint32_t words_per_tile, hipStream_t stream);
 hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream);
 hipError_t launch_render_primary(const RenderArgs& args, hipStream_t stream);
+hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], uint8_t* out, int n_vox, hipStream_t stream);
 
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes)
 {
@@ -77,6 +78,7 @@ static const TuningKey kTuningKeys[] = {
     {"wf_chunk", &Tuning::wf_chunk, "DDGI_WF_CHUNK"},
     {"wf_drain", &Tuning::wf_drain, "DDGI_WF_DRAIN"},
     {"wait_threshold", &Tuning::wait_threshold, "DDGI_WAIT_THRESHOLD"},
+    {"light_vis", &Tuning::light_vis, "DDGI_LIGHT_VIS"},
     {"noise_lut", &Tuning::noise_lut, nullptr},
     {"lut_off", &Tuning::lut_off, "DDGI_LUT_OFF"},
     {"verbose", &Tuning::verbose, "DDGI_VERBOSE"},
@@ -394,6 +396,7 @@ int ddgi_destroy(ddgi_handle e)
     {
         if (d.bits) (void)hipFree(d.bits);
         if (d.types) (void)hipFree(d.types);
+        if (d.vis) (void)hipFree(d.vis);
     }
     for (auto& triple : e->ev)
         for (auto& ev : triple)
@@ -690,6 +693,20 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
         a.rad_dd = e->d_radiance + p.rec_pairs * 24;
         a.rays = nullptr;
         a.n_rays = static_cast<uint32_t>(local_rays);
+    }
+    // single light: which feelers need no march (ddgi_visibility.hip); recomputed when the light has moved
+    if (a.nl == 1 && tn.light_vis && tn.trace_kernel != 2)
+    {
+        ddgi_engine::DevScene& d = e->dev_scene[scene];
+        const int n_vox = (a.scene.hi[0] - a.scene.lo[0] + 1) * (a.scene.hi[1] - a.scene.lo[1] + 1) * (a.scene.hi[2] - a.scene.lo[2] + 1);
+        if (!d.vis) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis), static_cast<size_t>(n_vox)));
+        if (!d.vis_valid || std::memcmp(d.vis_light, a.lights[0].pos, sizeof(d.vis_light)) != 0)
+        {
+            HIP_TRY(launch_light_visibility(a.scene, a.lights[0].pos, d.vis, n_vox, e->stream));
+            std::memcpy(d.vis_light, a.lights[0].pos, sizeof(d.vis_light));
+            d.vis_valid = true;
+        }
+        a.vis = d.vis;
     }
     a.albedo = static_cast<uint32_t*>(e->tex[0]);
     a.distance = static_cast<uint32_t*>(e->tex[1]);
@@ -1385,6 +1402,7 @@ static int fill_user_scene(ddgi_engine* e, const int lo[3], const int dim[3], co
     ddgi_engine::DevScene& d = e->dev_scene[3];
     if (d.bits) (void)hipFree(d.bits);
     if (d.types) (void)hipFree(d.types);
+    if (d.vis) (void)hipFree(d.vis);
     d = ddgi_engine::DevScene{};
     e->user_scene = std::move(b);
     return DDGI_OK;

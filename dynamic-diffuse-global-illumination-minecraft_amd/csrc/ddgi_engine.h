@@ -24,6 +24,7 @@ struct Tuning
     int blend_kernel = 0;   // DDGI blend: 0 auto, 1 one probe per workgroup (cross-check)
     int aq_pool = 0, wf_pool = 0, wf_maxpool = 0, wf_threads = 1024;
     int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
+    int light_vis = 1;      // per-voxel light-feeler classes (k_light_visibility): 0 = march every feeler
     int noise_lut = 1;      // memoised lattice hashes (0: compute every hash)
     int lut_off = 0;        // profiling: 1 = no wall table, 2 = no random1 table
     int verbose = 0;
@@ -73,6 +74,9 @@ struct ddgi_engine
         uint8_t* types = nullptr;
         SceneK k{};
         bool ready = false;
+        uint8_t* vis = nullptr;             // k_light_visibility table for the scene's single light
+        float vis_light[3] = {0, 0, 0};     // ... computed for this light position
+        bool vis_valid = false;
     } dev_scene[4];
 
     // memoised lattice hashes on device

@@ -211,8 +211,14 @@ struct CfgPlain
 #endif
 constexpr int kInlineSteps = DDGI_INLINE_STEPS;
 
+struct InlineEnd  // how a march that ended within its first (inline) steps ended
+{
+    float t, tl;
+    bool occ;
+};
+
 template <class Cfg>
-DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, bool feeler, const TraceArgs& A, const uint32_t* s_bits)
+DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, bool feeler, const TraceArgs& A, const uint32_t* s_bits, InlineEnd* end = nullptr)
 {
     float tl;
     int lid;
@@ -249,8 +255,10 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
         P.t[slot] = m.t;
         if (fin)
         {
-            const uint32_t hf = occ ? hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, feeler) : 0u;
+            // (a feeler only asks whether a block was hit, not which)
+            const uint32_t hf = !occ ? 0u : (feeler ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
             P.flags[slot] = base_flags | (feeler ? kSlotEvFeeler : kSlotEvPrimary) | hf;
+            if (end) end->t = m.t, end->tl = tl, end->occ = occ;
             const bool block_wins = occ && (m.t < tl);
             return static_cast<int>(feeler ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock));
         }
@@ -305,6 +313,46 @@ DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contr
     }
     wf_finish_ray<Cfg>(P, slot, color, c.dst, A);
     return false;
+}
+
+// The feeler class of the voxel a feeler would start in (k_light_visibility; ddgi_visibility.hip), or kVisUnknown
+// when there is no table, the origin is outside the baked box, or it is not at least 5e-4 inside its voxel on
+// every axis (the table's guarantee is for the voxel's interior; the origin is 1e-3 off the face that was hit).
+DDGI_D uint32_t light_vis_class(const TraceArgs& A, f3 o)
+{
+    if (!A.vis) return kVisUnknown;
+    const SceneK& S = A.scene;
+    const f3 cell = cell_id(o);
+    const float ux = cell.x - o.x, uy = cell.y - o.y, uz = cell.z - o.z;  // in [0, 1): distance to the voxel's upper faces
+    const float lo = fminf(ux, fminf(uy, uz)), hi = fmaxf(ux, fmaxf(uy, uz));
+    const bool inside = lo >= 5.0e-4f && hi <= 1.0f - 5.0e-4f && cell.x >= S.lo_f[0] && cell.x <= S.hi_f[0] && cell.y >= S.lo_f[1] && cell.y <= S.hi_f[1] &&
+                        cell.z >= S.lo_f[2] && cell.z <= S.hi_f[2];  // (false for NaN)
+    if (!inside) return kVisUnknown;
+    const int idx = static_cast<int>(fmaf(cell.z, S.nxy_f, fmaf(cell.y, S.nx_f, cell.x))) - S.bias;
+    return A.vis[idx];
+}
+
+// get_direct_lighting's loop body for the light L once its feeler's outcome is known (probe_pass.comp:194-207):
+// the feeler reached the light (any_hit, !block_wins): direct += lambert * col * I / dist, one more visible light;
+// it hit a block: early return 0.2 * base * lambert (Q10).  hpos: the feeler's origin; nh: the hit normal as
+// get_direct_lighting normalises it.  Shared by the feeler event and the table-decided feelers of a primary event.
+DDGI_D void feeler_outcome(const LightK& L, f3 hpos, f3 nh, f3 hcol, bool any_hit, bool block_wins, f3& direct, int& nvis, f3& contribution, bool& early)
+{
+    if (!any_hit) return;
+    const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
+    const float lambert = gl_clamp(dot3(nh, normalize3(lp - hpos)), 0.0f, 1.0f);
+    if (!block_wins)
+    {
+        const float dist = length3(lp - hpos);
+        const f3 lc{L.col[0], L.col[1], L.col[2]};
+        direct = direct + div3((lc * lambert) * L.intensity, dist);
+        nvis += 1;
+    }
+    else
+    {
+        contribution = (hcol * 0.2f) * lambert;  // Q10 early return
+        early = true;
+    }
 }
 
 // One event of pool slot `slot` in bucket b (ddgi_trace_wf.hip: shade_bucket): shades a finished march /
@@ -448,8 +496,51 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                         hcol = ((Cfg::ablate(A) & 1) || (DDGI_EXP & 8)) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
                     const bool finite_albedo = fabsf(hcol.x) < inf && fabsf(hcol.y) < inf && fabsf(hcol.z) < inf;
                     set3(c.hc, hcol);
+                    // Is the feeler's outcome certain (k_light_visibility)?  Then its march, queue trip and event are
+                    // skipped: the light-sphere test it would start with (does the ray reach the sphere at all) and
+                    // get_direct_lighting's arithmetic are evaluated right here, on the same values.
+                    const uint32_t vis = (Cfg::nl(A) == 1 && block_wins && axis_normal && !(lambert_zero && finite_albedo)) ? light_vis_class(A, hpos) : kVisUnknown;
+                    if (A.stats && block_wins) atomicAdd(&A.stats[(lambert_zero && finite_albedo) ? 43 : 40 + vis], 1ull);  // profiling: feeler classes
                     if (lambert_zero && finite_albedo)
                         posted = wf_lighting_done<Cfg>(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
+                    else if (vis != kVisUnknown)
+                    {
+                        bool feeler_any = true, feeler_block = true;  // kVisShadow: a block before the light (t_block < t_light, or no sphere hit at all)
+                        if (vis == kVisLit)
+                        {
+                            float ftl;
+                            int flid;
+                            light_spheres<Cfg::kNl>(hpos, to_light, A, ftl, flid);  // intersect_scene's sphere half for the feeler ray
+                            feeler_block = false, feeler_any = ftl < inf;
+                        }
+                        f3 direct = mk3(0, 0, 0), contribution = mk3(0, 0, 0);
+                        int nvis = 0;
+                        bool early = false;
+                        feeler_outcome(L, hpos, nh, hcol, feeler_any, feeler_block, direct, nvis, contribution, early);
+                        if (!early && nvis != 0) contribution = hcol * direct;  // one visible light: x / 1.0f == x
+                        posted = wf_lighting_done<Cfg>(P, slot, c, contribution, hpos, hnrm, cnt, A, mo, md);
+                    }
+                    else if (Cfg::nl(A) == 1 && kInlineSteps > 0)
+                    {
+                        // The feeler is set up right here.  Most shadowed feelers end within their first steps (on the
+                        // surface's own relief); then get_direct_lighting goes on in this event as well — no record round
+                        // trip, no second event.  A feeler that has to be marched takes the slot to the march queue.
+                        c.cnt = cnt;
+                        InlineEnd fe;
+                        if (wf_post_march<Cfg>(P, slot, c, hpos, to_light, true, A, s_bits, &fe) < 0)
+                        {
+                            store_cold(P.cold + slot, c);
+                            return 1;
+                        }
+                        const bool feeler_block = fe.occ && (fe.t < fe.tl);
+                        const bool feeler_any = feeler_block || (fe.tl < inf);
+                        f3 direct = mk3(0, 0, 0), contribution = mk3(0, 0, 0);
+                        int nvis = 0;
+                        bool early = false;
+                        feeler_outcome(L, hpos, nh, hcol, feeler_any, feeler_block, direct, nvis, contribution, early);
+                        if (!early && nvis != 0) contribution = hcol * direct;  // one visible light: x / 1.0f == x
+                        posted = wf_lighting_done<Cfg>(P, slot, c, contribution, hpos, hnrm, cnt, A, mo, md);
+                    }
                     else
                     {
                         c.cnt = cnt;
@@ -478,28 +569,14 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 const float4 dv = P.dirbuf[slot];
                 direct = mk3(dv.x, dv.y, dv.z);
             }
-            const LightK& L = A.lights[li];
-            const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
             f3 contribution = mk3(0, 0, 0);
             bool early = false;
-            if (any_hit)
+            if (A.stats) atomicAdd(&A.stats[block_wins ? 45 : (any_hit ? 44 : 46)], 1ull);  // profiling: outcomes of marched feelers
             {
                 const bool is_axis = (fabsf(hnrm.x) + fabsf(hnrm.y) + fabsf(hnrm.z) == 1.0f) &&
                                      (fabsf(hnrm.x) == 1.0f || fabsf(hnrm.y) == 1.0f || fabsf(hnrm.z) == 1.0f);
                 const f3 nh = is_axis ? hnrm : normalize3(hnrm);  // identity for a unit axis vector
-                const float lambert = gl_clamp(dot3(nh, normalize3(lp - hpos)), 0.0f, 1.0f);
-                if (!block_wins)
-                {
-                    const float dist = length3(lp - hpos);
-                    const f3 lc{L.col[0], L.col[1], L.col[2]};
-                    direct = direct + div3((lc * lambert) * L.intensity, dist);
-                    nvis += 1;
-                }
-                else
-                {
-                    contribution = (hcol * 0.2f) * lambert;  // Q10 early return
-                    early = true;
-                }
+                feeler_outcome(A.lights[li], hpos, nh, hcol, any_hit, block_wins, direct, nvis, contribution, early);
             }
             li += 1;
             if (!early && li < Cfg::nl(A))
@@ -761,7 +838,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                     if (!fin && ((trips & 3) == 3)) fin = march_escaped(m, A.scene);
                     if (fin)
                     {
-                        const uint32_t hf = occ ? hit_flags<CfgRuntime>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, (fl & kFlagFeeler) != 0u) : 0u;
+                        const uint32_t hf = !occ ? 0u : ((fl & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<CfgRuntime>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
                         P.t[slot] = m.t;
                         P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | hf;
                         have = false;
@@ -1012,7 +1089,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 if (!fin && ((trips & 3) == 3)) fin = march_escaped(m, A.scene);
                 if (fin)
                 {
-                    const uint32_t hf = occ ? hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, (fl & kFlagFeeler) != 0u) : 0u;
+                    const uint32_t hf = !occ ? 0u : ((fl & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
                     P.t[slot] = m.t;
                     P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | hf;
                     const bool block_wins = occ && (m.t < m.tl);

@@ -57,6 +57,14 @@ struct GridK
 // (device, kernel): a process may hold handles on several devices (ddgi_engine.cpp).
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
 
+// k_light_visibility's classes (ddgi_visibility.hip): what a light feeler that starts in a voxel is certain to find
+enum : uint8_t
+{
+    kVisUnknown = 0,  // march it
+    kVisLit = 1,      // reaches the light
+    kVisShadow = 2,   // lands in an occupied voxel before the light
+};
+
 struct TraceArgs
 {
     GridK grid;
@@ -87,6 +95,7 @@ struct TraceArgs
     float rot[9];
     float* rad_rgb;  // ray records, see RayRecords
     float* rad_dd;
+    const uint8_t* vis;  // single light: per-voxel feeler classes over the baked box (k_light_visibility), or null
 };
 
 // DDGI-mode ray records, laid out for the blend kernel: local probes in groups of 8; for group g and

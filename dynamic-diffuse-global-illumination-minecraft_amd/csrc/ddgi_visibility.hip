@@ -1,0 +1,134 @@
+// ddgi_visibility.hip — k_light_visibility: per voxel and light, is a light feeler that starts in this voxel
+// CERTAIN to reach the light, CERTAIN to be blocked, or neither?
+//
+// A light feeler (get_direct_lighting, probe_pass.comp:186-207 -> intersect_scene -> grid_march) only decides a
+// boolean: does the march land in an occupied voxel before it reaches the light sphere.  For most surface
+// points that is decided by the geometry with room to spare, and the trace kernel (wf_event) then skips the
+// feeler's march, its queue trip and its event.  The table is CONSERVATIVE — a class is only given when the
+// reference's float march provably comes to that outcome for EVERY start point in the voxel's interior — so
+// results are bit-identical with and without it (tests: trace with/without table agree; both equal the oracle).
+//
+// Voxel id n covers (n-1, n] per axis (voxel id = ceil(p)).  Start points o: the voxel shrunk by
+// kShrink on every face (wf_event only uses the table for a hit position at least kInside = 5e-4 from every
+// face; the feeler origin is 1e-3 off the face that was hit).  Rays run from o to the light centre L; the march
+// positions p_k = fma(dn, t_k, o) stay within ~3e-5 of that segment for t_k <= t_light (binary32 rounding at
+// |p| < 2^10 and a unit direction good to 1e-7), so every voxel the march looks up intersects the kEps-tube
+// around the bundle B = hull(shrunk voxel, L).  Cross-sections of B are axis-aligned boxes
+//     X(s) = (1-s) * voxel + s * L,   s in [0, 1],
+// so along the dominant axis a of (L - centre) the part of B inside voxel layer i is covered by the bounding box
+// of X(s_in) and X(s_out), the cross-sections where the bundle enters and leaves the layer (+- kEps).
+//   LIT     every voxel (other than the start voxel) in every layer's bounding box, from the start layer to
+//           the light's, is empty: no march position can be in an occupied voxel.
+//   SHADOW  some layer strictly between (>= 3 layers before the light's: t_hit < t_light with a margin far above
+//           the error of the sphere quadratic) has its bounding box fully occupied, and is reached within
+//           grid_march's 125 iterations: an iteration ends 1e-4 past the NEXT voxel boundary on its way, so it
+//           crosses at least one boundary, and a ray of the bundle crosses at most (layers + lateral voxel offsets
+//           of the bounding box) boundaries before it is inside the layer; kVisMaxCrossings leaves 15 iterations
+//           for the rare step that starts exactly on a boundary.  A march cannot step over a layer, so it lands
+//           in an occupied voxel there or earlier — and the outcome "blocked" does not depend on where.
+//   UNKNOWN otherwise: the feeler is marched.
+#include "ddgi_device.h"
+
+namespace ddgi {
+
+constexpr double kVisShrink = 4.0e-4;  // start points: the voxel shrunk by this much (wf_event requires 5e-4)
+constexpr double kVisEps = 1.0e-4;     // tube around the exact bundle that contains every march position
+constexpr int kVisMaxCrossings = 110;  // boundary crossings to a blocking layer (grid_march: 125 iterations)
+constexpr double kVisMinRange = 4.0;   // lights closer than this along the dominant axis: not classified
+constexpr double kVisMaxRange = 400.0;
+
+DDGI_D bool vis_occupied(const SceneK& S, int x, int y, int z)
+{
+    const int idx = cell_index(S, x, y, z);  // clamped: outside the box the world is the extrusion of the border layer
+    return ((S.bits[(idx >> 5) - (S.bias32 >> 5)] >> (idx & 31)) & 1u) != 0u;
+}
+
+__global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const double lx, const double ly, const double lz, uint8_t* __restrict__ out, const int n_vox)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_vox) return;
+    const int ny = S.nxy / S.nx;
+    int v[3] = {S.lo[0] + r % S.nx, S.lo[1] + (r / S.nx) % ny, S.lo[2] + r / S.nxy};
+    uint8_t cls = kVisUnknown;
+    // only empty voxels with an occupied face neighbour can hold a feeler origin (1e-3 off the face that was hit)
+    bool relevant = !vis_occupied(S, v[0], v[1], v[2]);
+    if (relevant)
+        relevant = vis_occupied(S, v[0] - 1, v[1], v[2]) || vis_occupied(S, v[0] + 1, v[1], v[2]) || vis_occupied(S, v[0], v[1] - 1, v[2]) ||
+                   vis_occupied(S, v[0], v[1] + 1, v[2]) || vis_occupied(S, v[0], v[1], v[2] - 1) || vis_occupied(S, v[0], v[1], v[2] + 1);
+    const double L[3] = {lx, ly, lz};
+    double lo0[3], hi0[3];
+    int a = 0;
+    double best = -1.0;
+    for (int k = 0; k < 3; ++k)
+    {
+        lo0[k] = static_cast<double>(v[k] - 1) + kVisShrink;
+        hi0[k] = static_cast<double>(v[k]) - kVisShrink;
+        const double d = fabs(L[k] - (static_cast<double>(v[k]) - 0.5));
+        if (d > best) best = d, a = k;
+    }
+    if (relevant && best >= kVisMinRange && best <= kVisMaxRange)
+    {
+        const int b = (a + 1) % 3, c = (a + 2) % 3;
+        const int sgn = L[a] > hi0[a] ? 1 : -1;
+        const int n_a = v[a], m_a = static_cast<int>(ceil(L[a]));
+        bool all_empty = true, blocked = false;
+        for (int i = n_a; sgn > 0 ? i <= m_a : i >= m_a; i += sgn)
+        {
+            // s-range over which the cross-section X(s) reaches into layer i = (i-1, i] (widened by kVisEps)
+            double s_in, s_out;
+            if (sgn > 0)
+            {
+                s_in = (static_cast<double>(i - 1) - kVisEps - hi0[a]) / (L[a] - hi0[a]);
+                s_out = (static_cast<double>(i) + kVisEps - lo0[a]) / (L[a] - lo0[a]);
+            }
+            else
+            {
+                s_in = (lo0[a] - (static_cast<double>(i) + kVisEps)) / (lo0[a] - L[a]);
+                s_out = (hi0[a] - (static_cast<double>(i - 1) - kVisEps)) / (hi0[a] - L[a]);
+            }
+            s_in = fmin(fmax(s_in, 0.0), 1.0), s_out = fmin(fmax(s_out, 0.0), 1.0);
+            int w0[2], w1[2];  // voxel-id range of the bounding box along b and c
+            const int ax2[2] = {b, c};
+            for (int q = 0; q < 2; ++q)
+            {
+                const int k = ax2[q];
+                const double lo_in = (1.0 - s_in) * lo0[k] + s_in * L[k], lo_out = (1.0 - s_out) * lo0[k] + s_out * L[k];
+                const double hi_in = (1.0 - s_in) * hi0[k] + s_in * L[k], hi_out = (1.0 - s_out) * hi0[k] + s_out * L[k];
+                w0[q] = static_cast<int>(ceil(fmin(lo_in, lo_out) - kVisEps));
+                w1[q] = static_cast<int>(ceil(fmax(hi_in, hi_out) + kVisEps));
+            }
+            bool layer_full = true;
+            for (int wb = w0[0]; wb <= w1[0]; ++wb)
+                for (int wc = w0[1]; wc <= w1[1]; ++wc)
+                {
+                    int w[3];
+                    w[a] = i, w[b] = wb, w[c] = wc;
+                    if (w[0] == v[0] && w[1] == v[1] && w[2] == v[2])
+                    {
+                        layer_full = false;  // the start voxel itself: empty, and never looked up by the march
+                        continue;
+                    }
+                    const bool occ = vis_occupied(S, w[0], w[1], w[2]);
+                    all_empty = all_empty && !occ;
+                    layer_full = layer_full && occ;
+                }
+            const int from_start = sgn * (i - n_a), to_light = sgn * (m_a - i);
+            const int lat_b = max(abs(w0[0] - v[b]), abs(w1[0] - v[b])), lat_c = max(abs(w0[1] - v[c]), abs(w1[1] - v[c]));
+            const int crossings = from_start + lat_b + lat_c + 2;
+            if (layer_full && from_start >= 1 && crossings <= kVisMaxCrossings && to_light >= 3) blocked = true;
+            if (blocked || (!all_empty && crossings > kVisMaxCrossings)) break;  // decided, or can no longer be decided
+        }
+        cls = blocked ? kVisShadow : (all_empty ? kVisLit : kVisUnknown);
+    }
+    out[r] = cls;
+}
+
+hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], uint8_t* out, int n_vox, hipStream_t stream)
+{
+    if (n_vox <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_light_visibility, dim3((n_vox + 255) / 256), dim3(256), 0, stream, scene, static_cast<double>(light_pos[0]), static_cast<double>(light_pos[1]),
+                       static_cast<double>(light_pos[2]), out, n_vox);
+    return hipGetLastError();
+}
+
+}  // namespace ddgi

@@ -449,6 +449,9 @@ class ProbeEngine:
         st = dict(zip(keys, (int(v) for v in out[:14])))
         st["bucket_cycles"] = [int(v) for v in out[16:24]]   # event groups by bucket (ddgi_trace_wf.hip: shade_bucket)
         st["bucket_groups"] = [int(v) for v in out[24:32]]
+        # light feelers of block hits: decided by the visibility table (unknown = marched / lit / shadow), dead (Lambert 0), and
+        # what the marched ones found (reached the light / hit a block / neither)
+        st["feeler_classes"] = dict(zip(("unknown", "table_lit", "table_shadow", "dead", "marched_lit", "marched_shadow", "marched_none"), (int(v) for v in out[40:47])))
         return st
 
     # -- outputs -------------------------------------------------------------------------------
