@@ -414,6 +414,12 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
         WfCold c = load_cold(P.cold + slot);
         f3 mo = mk3(0, 0, 0), md = mk3(0, 0, 0);  // the march this event posts, if any
         bool as_feeler = false;
+        // Every path on which get_direct_lighting has come to its end for this hit sets these and meets at ONE
+        // wf_lighting_done below (the bounce set-up — hemisphere sample, new march — is the longest stretch of an event:
+        // run once per group by all lanes that need it, not once per path by a few lanes each)
+        bool lit_done = false;
+        f3 ld_contribution = mk3(0, 0, 0), ld_hpos = mk3(0, 0, 0), ld_hnrm = mk3(0, 0, 0);
+        uint32_t ld_cnt = 0u;
         const uint32_t fl = P.flags[slot];
         const float t = P.t[slot], tl = P.tl[slot];
         const f3 ro = ld3(P.ro, slot);
@@ -501,8 +507,9 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     // get_direct_lighting's arithmetic are evaluated right here, on the same values.
                     const uint32_t vis = (Cfg::nl(A) == 1 && block_wins && axis_normal && !(lambert_zero && finite_albedo)) ? light_vis_class(A, hpos) : kVisUnknown;
                     if (A.stats && block_wins) atomicAdd(&A.stats[(lambert_zero && finite_albedo) ? 43 : 40 + vis], 1ull);  // profiling: feeler classes
+                    ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt;
                     if (lambert_zero && finite_albedo)
-                        posted = wf_lighting_done<Cfg>(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
+                        lit_done = true;  // contributes +0
                     else if (vis != kVisUnknown)
                     {
                         bool feeler_any = true, feeler_block = true;  // kVisShadow: a block before the light (t_block < t_light, or no sphere hit at all)
@@ -518,7 +525,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                         bool early = false;
                         feeler_outcome(L, hpos, nh, hcol, feeler_any, feeler_block, direct, nvis, contribution, early);
                         if (!early && nvis != 0) contribution = hcol * direct;  // one visible light: x / 1.0f == x
-                        posted = wf_lighting_done<Cfg>(P, slot, c, contribution, hpos, hnrm, cnt, A, mo, md);
+                        ld_contribution = contribution, lit_done = true;
                     }
                     else if (Cfg::nl(A) == 1 && kInlineSteps > 0)
                     {
@@ -539,7 +546,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                         bool early = false;
                         feeler_outcome(L, hpos, nh, hcol, feeler_any, feeler_block, direct, nvis, contribution, early);
                         if (!early && nvis != 0) contribution = hcol * direct;  // one visible light: x / 1.0f == x
-                        posted = wf_lighting_done<Cfg>(P, slot, c, contribution, hpos, hnrm, cnt, A, mo, md);
+                        ld_contribution = contribution, lit_done = true;
                     }
                     else
                     {
@@ -552,7 +559,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 else
                 {
                     set3(c.hc, hcol);  // no light: the albedo is never used
-                    posted = wf_lighting_done<Cfg>(P, slot, c, mk3(0, 0, 0), hpos, hnrm, cnt, A, mo, md);
+                    ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt, lit_done = true;
                 }
             }
         }
@@ -590,9 +597,10 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             else
             {
                 if (!early && nvis != 0) contribution = nvis == 1 ? hcol * direct : div3(hcol * direct, static_cast<float>(nvis));  // x / 1.0f == x
-                posted = wf_lighting_done<Cfg>(P, slot, c, contribution, hpos, hnrm, cnt, A, mo, md);
+                ld_contribution = contribution, ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt, lit_done = true;
             }
         }
+        if (lit_done) posted = wf_lighting_done<Cfg>(P, slot, c, ld_contribution, ld_hpos, ld_hnrm, ld_cnt, A, mo, md);
         if (posted)
         {
             const int pb = wf_post_march<Cfg>(P, slot, c, mo, md, as_feeler, A, s_bits);

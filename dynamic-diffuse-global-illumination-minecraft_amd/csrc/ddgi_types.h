@@ -86,7 +86,7 @@ struct TraceArgs
     int wf_fetch;         // wavefront kernel: idle lanes that trigger a task fetch (0 = default)
     int wf_drain;         // wavefront kernel: straggler trips while the pool drains (0 = default)
     int wf_chunk;         // wavefront kernel: rays a workgroup claims at a time (set by the launcher)
-    int ablate;           // profiling ablations (DDGI_ABLATE env, default 0 = exact): 1 constant albedo, 2 constant bounce direction, 4 no dead-feeler elimination, 8 queue kernel: posted marches are dropped (tests the safety net)
+    int ablate;           // profiling build only (tuning "ablate"; 0 = exact): 1 constant albedo, 2 constant bounce direction, 4 no dead-feeler elimination, 8 queue kernel: posted marches are dropped (tests the safety net), 16 count feeler classes into stats (slow)
     // DDGI mode (ddgi != 0): rays are generated in the kernel (spherical Fibonacci set rotated by
     // rot, origin = probe position), the RNG seed is ray index ^ frame_key, and each ray writes
     // its radiance and clamped first-hit distance to the ray records (below) instead of an rgba8 texel

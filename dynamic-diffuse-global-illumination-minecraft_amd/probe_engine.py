@@ -451,6 +451,7 @@ class ProbeEngine:
         st["bucket_groups"] = [int(v) for v in out[24:32]]
         # light feelers of block hits: decided by the visibility table (unknown = marched / lit / shadow), dead (Lambert 0), and
         # what the marched ones found (reached the light / hit a block / neither)
+        st["idle_polls"] = {"march_waves": int(out[48]), "event_waves": int(out[49]), "thin_trip_waits": int(out[50])}
         st["feeler_classes"] = dict(zip(("unknown", "table_lit", "table_shadow", "dead", "marched_lit", "marched_shadow", "marched_none"), (int(v) for v in out[40:47])))
         return st
 

@@ -17,3 +17,4 @@ trips, lanes, groups, glanes = st["trips"], st["lane_steps"], st["event_rounds"]
 print("march: %.1f lane-trips/ray, %.1f of 64 lanes busy per trip;  events: %.2f per ray, %.1f of 64 lanes per group;  kernel %.3f ms" % (
     lanes / rays, lanes / max(trips, 1), glanes / rays, glanes / max(groups, 1), eng.last_update_ms()["trace_ms"]))
 print("feelers per ray:", {k: round(v / rays, 3) for k, v in st["feeler_classes"].items()})
+print("idle polls:", st["idle_polls"], " march trips", trips, " event groups", groups)
