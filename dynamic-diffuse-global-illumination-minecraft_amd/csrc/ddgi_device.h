@@ -225,9 +225,9 @@ DDGI_D f3 hemisphere_dir(f3 n, uint32_t& rng)
 #if DDGI_EXP & 1
     const float ca = __cosf(around) * over, sa = __sinf(around) * over;
 #else
-    const pm::SinCos sc = pm::sincos_core(around);
-    const float ca = static_cast<float>(sc.c) * over;
-    const float sa = static_cast<float>(sc.s) * over;
+    float sn, cs;
+    pm::sincos_small(around, sn, cs);  // P6b
+    const float ca = cs * over, sa = sn * over;
 #endif
     return (n * up + p1 * ca) + p2 * sa;
 }

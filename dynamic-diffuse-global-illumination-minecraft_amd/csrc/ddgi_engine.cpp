@@ -1466,5 +1466,13 @@ int ddgi_scene_block_at(int scene, int x, int y, int z)
 float ddgi_pinned_sinf(float x) { return pm::sinf_pinned(x); }
 float ddgi_pinned_cosf(float x) { return pm::cosf_pinned(x); }
 float ddgi_pinned_acosf(float x) { return pm::acosf_pinned(x); }
+int ddgi_pinned_sincos_small(float x, float* s, float* c)
+{
+    float sn, cs;
+    pm::sincos_small(x, sn, cs);
+    if (s) *s = sn;
+    if (c) *c = cs;
+    return DDGI_OK;
+}
 
 }  // extern "C"

@@ -69,6 +69,30 @@ __host__ __device__ __attribute__((noinline)) inline SinCos sincos_core(float xf
     return out;
 }
 
+// P6b — sine and cosine of a SMALL angle (the hemisphere sample's `around` in [0, 2 pi), probe_pass.comp:153,176):
+// binary32 throughout, every operation written out (fmaf = one rounding), so host, device and the oracle's copy
+// (oracle/pinned_math.h: opm_sincos_small) agree bit for bit.  Cody-Waite reduction by k = rint(x * 2/pi) against
+// pi/2 split in two binary32 parts, then the degree-7 / degree-8 minimax polynomials of Cephes' sinf/cosf
+// (S. Moshier, 1992) on [-pi/4, pi/4].  |error| < 2e-7 for |x| < 64 — the Vulkan spec lets a driver's sin/cos be
+// off by 2^-11.  A third of the instructions of sincos_core (binary64, for the hashes' huge arguments).
+DDGI_HD void sincos_small(float x, float& s_out, float& c_out)
+{
+    const float k = rintf(x * 0.636619747f);           // fl(2/pi)
+    float r = fmaf(-k, 1.57079637f, x);               // fl(pi/2)
+    r = fmaf(-k, -4.37113883e-08f, r);                // fl(pi/2 - fl(pi/2))
+    const float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    const float sr = fmaf(r * z, ps, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    const float cr = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+    const int q = static_cast<int>(k) & 3;
+    const float s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    s_out = (q & 2) ? -s0 : s0;
+    c_out = ((q + 1) & 2) ? -c0 : c0;
+}
+
 DDGI_HD float sinf_pinned(float x) { return static_cast<float>(sincos_core(x).s); }
 DDGI_HD float cosf_pinned(float x) { return static_cast<float>(sincos_core(x).c); }
 

@@ -218,11 +218,13 @@ struct InlineEnd  // how a march that ended within its first (inline) steps ende
 };
 
 template <class Cfg>
-DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, bool feeler, const TraceArgs& A, const uint32_t* s_bits, InlineEnd* end = nullptr)
+DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, bool feeler, const TraceArgs& A, const uint32_t* s_bits, InlineEnd* end = nullptr,
+                         bool have_spheres = false, float tl_in = 0.0f, int lid_in = -1)
 {
-    float tl;
-    int lid;
-    light_spheres<Cfg::kNl>(o, d, A, tl, lid);
+    // have_spheres: the caller has already evaluated light_spheres(o, d) -> (tl_in, lid_in)
+    float tl = tl_in;
+    int lid = lid_in;
+    if (!have_spheres) light_spheres<Cfg::kNl>(o, d, A, tl, lid);
     const f3 dn = normalize3(d);
     st3(P.ro, slot, o);
     st3(P.dn, slot, dn);
@@ -506,41 +508,34 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     // skipped: the light-sphere test it would start with (does the ray reach the sphere at all) and
                     // get_direct_lighting's arithmetic are evaluated right here, on the same values.
                     const uint32_t vis = (Cfg::nl(A) == 1 && block_wins && axis_normal && !(lambert_zero && finite_albedo)) ? light_vis_class(A, hpos) : kVisUnknown;
-                    if (A.stats && block_wins) atomicAdd(&A.stats[(lambert_zero && finite_albedo) ? 43 : 40 + vis], 1ull);  // profiling: feeler classes
+                    if ((Cfg::ablate(A) & 16) && A.stats && block_wins) atomicAdd(&A.stats[(lambert_zero && finite_albedo) ? 43 : 40 + vis], 1ull);  // profiling build: feeler classes
                     ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt;
                     if (lambert_zero && finite_albedo)
                         lit_done = true;  // contributes +0
-                    else if (vis != kVisUnknown)
-                    {
-                        bool feeler_any = true, feeler_block = true;  // kVisShadow: a block before the light (t_block < t_light, or no sphere hit at all)
-                        if (vis == kVisLit)
-                        {
-                            float ftl;
-                            int flid;
-                            light_spheres<Cfg::kNl>(hpos, to_light, A, ftl, flid);  // intersect_scene's sphere half for the feeler ray
-                            feeler_block = false, feeler_any = ftl < inf;
-                        }
-                        f3 direct = mk3(0, 0, 0), contribution = mk3(0, 0, 0);
-                        int nvis = 0;
-                        bool early = false;
-                        feeler_outcome(L, hpos, nh, hcol, feeler_any, feeler_block, direct, nvis, contribution, early);
-                        if (!early && nvis != 0) contribution = hcol * direct;  // one visible light: x / 1.0f == x
-                        ld_contribution = contribution, lit_done = true;
-                    }
                     else if (Cfg::nl(A) == 1 && kInlineSteps > 0)
                     {
-                        // The feeler is set up right here.  Most shadowed feelers end within their first steps (on the
-                        // surface's own relief); then get_direct_lighting goes on in this event as well — no record round
-                        // trip, no second event.  A feeler that has to be marched takes the slot to the march queue.
-                        c.cnt = cnt;
-                        InlineEnd fe;
-                        if (wf_post_march<Cfg>(P, slot, c, hpos, to_light, true, A, s_bits, &fe) < 0)
+                        // The single light's feeler.  intersect_scene's sphere half for it (does the ray reach the light's
+                        // sphere at all, and where) is evaluated once, for the table's "lit" class and for the feeler's march.
+                        float ftl = inf;
+                        int flid = -1;
+                        if (vis != kVisShadow) light_spheres<Cfg::kNl>(hpos, to_light, A, ftl, flid);
+                        bool feeler_any = true, feeler_block = true;  // kVisShadow: a block before the light (t_block < t_light, or no sphere hit at all)
+                        if (vis == kVisLit) feeler_block = false, feeler_any = ftl < inf;
+                        else if (vis == kVisUnknown)
                         {
-                            store_cold(P.cold + slot, c);
-                            return 1;
+                            // The feeler is set up right here.  Most shadowed feelers end within their first steps (on the
+                            // surface's own relief); then get_direct_lighting goes on in this event as well — no record round
+                            // trip, no second event.  A feeler that has to be marched takes the slot to the march queue.
+                            c.cnt = cnt;
+                            InlineEnd fe;
+                            if (wf_post_march<Cfg>(P, slot, c, hpos, to_light, true, A, s_bits, &fe, true, ftl, flid) < 0)
+                            {
+                                store_cold(P.cold + slot, c);
+                                return 1;
+                            }
+                            feeler_block = fe.occ && (fe.t < fe.tl);
+                            feeler_any = feeler_block || (fe.tl < inf);
                         }
-                        const bool feeler_block = fe.occ && (fe.t < fe.tl);
-                        const bool feeler_any = feeler_block || (fe.tl < inf);
                         f3 direct = mk3(0, 0, 0), contribution = mk3(0, 0, 0);
                         int nvis = 0;
                         bool early = false;
@@ -578,7 +573,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             }
             f3 contribution = mk3(0, 0, 0);
             bool early = false;
-            if (A.stats) atomicAdd(&A.stats[block_wins ? 45 : (any_hit ? 44 : 46)], 1ull);  // profiling: outcomes of marched feelers
+            if ((Cfg::ablate(A) & 16) && A.stats) atomicAdd(&A.stats[block_wins ? 45 : (any_hit ? 44 : 46)], 1ull);  // profiling build: outcomes of marched feelers
             {
                 const bool is_axis = (fabsf(hnrm.x) + fabsf(hnrm.y) + fabsf(hnrm.z) == 1.0f) &&
                                      (fabsf(hnrm.x) == 1.0f || fabsf(hnrm.y) == 1.0f || fabsf(hnrm.z) == 1.0f);

@@ -167,6 +167,7 @@ _SIGNATURES = {
     "ddgi_pinned_sinf": (C.c_float, [C.c_float]),
     "ddgi_pinned_cosf": (C.c_float, [C.c_float]),
     "ddgi_pinned_acosf": (C.c_float, [C.c_float]),
+    "ddgi_pinned_sincos_small": (C.c_int, [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

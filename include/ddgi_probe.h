@@ -386,6 +386,8 @@ int ddgi_scene_block_at(int scene, int x, int y, int z);
 float ddgi_pinned_sinf(float x);
 float ddgi_pinned_cosf(float x);
 float ddgi_pinned_acosf(float x);
+/* P6b: sine and cosine of a small angle in binary32 (the hemisphere sample, probe_pass.comp:153,176) */
+int ddgi_pinned_sincos_small(float x, float* sin_out, float* cos_out);
 
 #ifdef __cplusplus
 }

@@ -1152,7 +1152,12 @@ static v3 random_dir_hemisphere(v3 normal, uint32_t* rng)
         dnn = V3(0, 0, 1);
     v3 p1 = normalize3(cross3(normal, dnn));
     v3 p2 = normalize3(cross3(normal, p1));
-    float ca = o_cos(around) * over, sa = o_sin(around) * over;
+    float cs, sn; /* P6b: PINNED evaluates this small angle in binary32 (opm_sincos_small); LITERAL uses libm */
+    if (g_pinned)
+        opm_sincos_small(around, &sn, &cs);
+    else
+        cs = cosf(around), sn = sinf(around);
+    float ca = cs * over, sa = sn * over;
     return vadd(vadd(vscale(normal, up), vscale(p1, ca)), vscale(p2, sa));
 }
 
@@ -1338,6 +1343,7 @@ int oracle_intersect_scene(const o_settings* st, const float* o, const float* d,
 }
 
 float oracle_sinf(float x) { return o_sin(x); }
+void oracle_sincos_small(float x, float* s, float* c) { opm_sincos_small(x, s, c); }
 float oracle_cosf(float x) { return o_cos(x); }
 float oracle_acosf(float x) { return o_acos(x); }
 

@@ -65,6 +65,27 @@ static inline void opm_sincos_core(float xf, double* s_out, double* c_out)
     }
 }
 
+/* P6b — sine and cosine of a small angle (the hemisphere sample's `around` in [0, 2 pi)): binary32 Cody-Waite
+ * reduction + Cephes' sinf/cosf minimax polynomials, every operation one binary32 rounding (fmaf exact-then-round).
+ * The product's copy: csrc/ddgi_pinned_math.h sincos_small. */
+static inline void opm_sincos_small(float x, float* s_out, float* c_out)
+{
+    const float k = rintf(x * 0.636619747f);
+    float r = fmaf(-k, 1.57079637f, x);
+    r = fmaf(-k, -4.37113883e-08f, r);
+    const float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    const float sr = fmaf(r * z, ps, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    const float cr = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)k & 3;
+    const float s0 = (q & 1) ? cr : sr, c0 = (q & 1) ? sr : cr;
+    *s_out = (q & 2) ? -s0 : s0;
+    *c_out = ((q + 1) & 2) ? -c0 : c0;
+}
+
 static inline float opm_sinf(float x)
 {
     double s, c;

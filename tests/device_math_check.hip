@@ -32,7 +32,11 @@ __host__ __device__ inline void eval(float a, float b, float c, float* o)
     o[11] = fbm2(a * 0.3f, b * 0.3f);
     o[12] = worley(f2{a, b});
     o[13] = static_cast<float>(static_cast<int>(ceilf(a)));
-    o[14] = fbm1(c);
+    {
+        float sn, cs;
+        pm::sincos_small(fabsf(c) * 0.07f, sn, cs);  // P6b, angles in [0, ~7)
+        o[14] = fbm1(c) + sn * 3.0f + cs;
+    }
     const f3 col = block_albedo(f3{a, b, c}, 6 + (static_cast<int>(fabsf(c)) % 8), f3{0.0f, 1.0f, 0.0f});
     o[15] = col.x + col.y * 2.0f + col.z * 4.0f;
 }

@@ -46,6 +46,29 @@ def test_pinned_sincos_product_equals_oracle_bitwise_and_tracks_libm(ddgi, oracl
     assert np.isnan(lib.ddgi_pinned_sinf(float("inf"))) and np.isnan(lib.ddgi_pinned_cosf(float("nan")))
 
 
+def test_pinned_small_angle_sincos_product_equals_oracle_bitwise(ddgi, oracle):
+    """P6b: the binary32 sine/cosine of the hemisphere sample's angle (around = rand * 2 pi): product and oracle copies
+    agree bit for bit, and stay within 2e-7 of the true value — the Vulkan spec allows a driver 2^-11."""
+    lib = ddgi.load_library()
+    olib = oracle.lib()
+    olib.oracle_sincos_small.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    rng = np.random.default_rng(9)
+    two_pi = np.float32(6.2831853071795864769)
+    xs = np.concatenate([(rng.random(60000, dtype=np.float32) * two_pi), rng.uniform(-40, 40, 5000).astype(np.float32),
+                         np.float32([0.0, -0.0, 1e-30, 0.78539816, 0.7853982, 1.5707964, 3.1415927, 4.712389, 6.2831850, 6.2831855])]).astype(np.float32)
+    got = np.zeros((len(xs), 2), dtype=np.float32)
+    want = np.zeros((len(xs), 2), dtype=np.float32)
+    s, c = C.c_float(), C.c_float()
+    for i, x in enumerate(xs):
+        lib.ddgi_pinned_sincos_small(float(x), C.byref(s), C.byref(c))
+        got[i] = (s.value, c.value)
+        olib.oracle_sincos_small(float(x), C.byref(s), C.byref(c))
+        want[i] = (s.value, c.value)
+    assert np.array_equal(_bits(got), _bits(want))
+    x64 = xs.astype(np.float64)
+    assert np.max(np.abs(got[:, 0] - np.sin(x64))) < 2e-7 and np.max(np.abs(got[:, 1] - np.cos(x64))) < 2e-7
+
+
 def test_pinned_acos_product_equals_oracle_bitwise_and_tracks_libm(ddgi, oracle):
     lib = ddgi.load_library()
     rng = np.random.default_rng(8)
