@@ -64,10 +64,13 @@ struct WfShared  // control block at the start of dynamic LDS (32 dwords)
 };
 static_assert(sizeof(WfShared) == 32 * 4, "control block is 32 dwords");
 
-// Shading state of a pool slot: touched only by event groups (phase D), never by the march loop, so
-// it lives in global memory (one 48-byte record per slot, 3 x dwordx4; 256 workgroups x 2048 slots
-// = 25 MB, L2 / Infinity-Cache resident) and LDS holds only what the march needs.  That buys a
-// pool of 2 rays per lane instead of 1.3.
+// Shading state of a pool slot — what an event needs besides the march state: touched only by event groups, never
+// by the march loop.  During an event it is this struct (registers); between events it is split:
+//   LDS     col, rng, cnt, dst, and hc while a PRIMARY march is in flight (then it is the ray direction as given):
+//           9 dwords per slot next to the 9 of the march state (WfPool)
+//   global  hc (the albedo) and hn while a MARCHED light feeler is in flight: a 32-byte record per slot
+//           (WfColdGlobal) — about one feeler per ray still is marched (ddgi_visibility.hip, wf_event)
+// (All 48 bytes used to be a global record: 96 B of scratch traffic per event, 25 x the pass's algorithmic bytes.)
 struct WfCold
 {
     float hn[3];   // hit normal (live while the feelers of a hit are in flight)
@@ -77,22 +80,13 @@ struct WfCold
     uint32_t cnt;  // [7:0] bounce, [11:8] light index, [15:12] visible lights
     uint32_t dst;  // REF: texel index; DDGI: ray record id (ddgi_types.h: kRecGroup)
 };
-static_assert(sizeof(WfCold) == 48, "3 x 16 bytes");
+struct WfColdGlobal
+{
+    float hc[3], pad0;
+    float hn[3], pad1;
+};
+static_assert(sizeof(WfColdGlobal) == kWfColdBytes, "2 x 16 bytes (ddgi_types.h: kWfColdBytes)");
 
-DDGI_D WfCold load_cold(const WfCold* p)
-{
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    union { uint4 v[3]; WfCold c; } u;
-    u.v[0] = q[0], u.v[1] = q[1], u.v[2] = q[2];
-    return u.c;
-}
-DDGI_D void store_cold(WfCold* p, const WfCold& c)
-{
-    union { uint4 v[3]; WfCold c; } u;
-    u.c = c;
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = u.v[0], q[1] = u.v[1], q[2] = u.v[2];
-}
 DDGI_D f3 v3of(const float* a) { return f3{a[0], a[1], a[2]}; }
 DDGI_D void set3(float* a, f3 v) { a[0] = v.x, a[1] = v.y, a[2] = v.z; }
 
@@ -103,13 +97,19 @@ struct WfPool
     float* t;
     float* tl;
     uint32_t* flags;
-    struct WfCold* cold;  // per-slot shading state, in global memory (see WfCold)
+    float* col[3];  // shading state kept in LDS (see WfCold)
+    float* rd[3];   // WfCold::hc while a primary march is in flight
+    uint32_t* rng;
+    uint32_t* cnt;
+    uint32_t* dst;
+    struct WfColdGlobal* cold;  // the rest of the shading state, in global memory
     float4* dirbuf;       // accumulated direct light per slot; only when there is more than one light
     uint16_t* march_list[2];  // double buffered: stragglers and new marches are appended for the next round
     uint16_t* event_list;
 };
 
-constexpr int wf_dwords_per_ray(bool) { return 9; }  // LDS part: ro, dn, t, tl, flags
+constexpr int kPoolDwords = 18;  // LDS per slot: ro, dn, t, tl, flags + col, rd, rng, cnt, dst
+constexpr int wf_dwords_per_ray(bool) { return kPoolDwords; }
 
 DDGI_D f3 ld3(float* const* a, uint32_t i) { return f3{a[0][i], a[1][i], a[2][i]}; }
 DDGI_D void st3(float* const* a, uint32_t i, f3 v)
@@ -117,6 +117,38 @@ DDGI_D void st3(float* const* a, uint32_t i, f3 v)
     a[0][i] = v.x;
     a[1][i] = v.y;
     a[2][i] = v.z;
+}
+
+// A slot's shading state in and out of an event.  with_hn: the hit normal travels too (a marched feeler is in flight).
+DDGI_D WfCold load_cold(const WfPool& P, uint32_t slot, bool with_hn)
+{
+    WfCold c;
+    c.hn[0] = c.hn[1] = c.hn[2] = 0.0f;
+    if (with_hn)
+    {
+        const uint4* q = reinterpret_cast<const uint4*>(P.cold + slot);
+        const uint4 a = q[0], b = q[1];
+        c.hc[0] = __uint_as_float(a.x), c.hc[1] = __uint_as_float(a.y), c.hc[2] = __uint_as_float(a.z);
+        c.hn[0] = __uint_as_float(b.x), c.hn[1] = __uint_as_float(b.y), c.hn[2] = __uint_as_float(b.z);
+    }
+    else
+        c.hc[0] = P.rd[0][slot], c.hc[1] = P.rd[1][slot], c.hc[2] = P.rd[2][slot];
+    c.col[0] = P.col[0][slot], c.col[1] = P.col[1][slot], c.col[2] = P.col[2][slot];
+    c.rng = P.rng[slot], c.cnt = P.cnt[slot], c.dst = P.dst[slot];
+    return c;
+}
+DDGI_D void store_cold(const WfPool& P, uint32_t slot, const WfCold& c, bool with_hn)
+{
+    if (with_hn)
+    {
+        uint4* q = reinterpret_cast<uint4*>(P.cold + slot);
+        q[0] = uint4{__float_as_uint(c.hc[0]), __float_as_uint(c.hc[1]), __float_as_uint(c.hc[2]), 0u};
+        q[1] = uint4{__float_as_uint(c.hn[0]), __float_as_uint(c.hn[1]), __float_as_uint(c.hn[2]), 0u};
+    }
+    else
+        P.rd[0][slot] = c.hc[0], P.rd[1][slot] = c.hc[1], P.rd[2][slot] = c.hc[2];
+    P.col[0][slot] = c.col[0], P.col[1][slot] = c.col[1], P.col[2][slot] = c.col[2];
+    P.rng[slot] = c.rng, P.cnt[slot] = c.cnt, P.dst[slot] = c.dst;
 }
 
 // Appends one entry per lane with pred to a list whose fill count is *counter; returns the lane's
@@ -407,13 +439,13 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             set3(c.col, mk3(0, 0, 0));
             set3(c.hn, mk3(0, 0, 0));
             const int pb = wf_post_march<Cfg>(P, slot, c, ray_o, ray_d, false, A, s_bits);
-            store_cold(P.cold + slot, c);
+            store_cold(P, slot, c, false);
             return pb < 0 ? 1 : 2 + pb;
         }
     }
     else
     {
-        WfCold c = load_cold(P.cold + slot);
+        WfCold c = load_cold(P, slot, b == kBucketFeeler);
         f3 mo = mk3(0, 0, 0), md = mk3(0, 0, 0);  // the march this event posts, if any
         bool as_feeler = false;
         // Every path on which get_direct_lighting has come to its end for this hit sets these and meets at ONE
@@ -530,7 +562,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                             InlineEnd fe;
                             if (wf_post_march<Cfg>(P, slot, c, hpos, to_light, true, A, s_bits, &fe, true, ftl, flid) < 0)
                             {
-                                store_cold(P.cold + slot, c);
+                                store_cold(P, slot, c, true);  // (hn and the albedo travel with the marched feeler)
                                 return 1;
                             }
                             feeler_block = fe.occ && (fe.t < fe.tl);
@@ -599,7 +631,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
         if (posted)
         {
             const int pb = wf_post_march<Cfg>(P, slot, c, mo, md, as_feeler, A, s_bits);
-            store_cold(P.cold + slot, c);  // the slot lives on: write its shading state back
+            store_cold(P, slot, c, as_feeler);  // the slot lives on: write its shading state back
             return pb < 0 ? 1 : 2 + pb;
         }
     }
@@ -632,7 +664,10 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
     P.t = takef();
     P.tl = takef();
     P.flags = takeu();
-    P.cold = static_cast<WfCold*>(A.wf_cold) + static_cast<size_t>(blockIdx.x) * PS;
+    for (int a = 0; a < 3; ++a) P.col[a] = takef();
+    for (int a = 0; a < 3; ++a) P.rd[a] = takef();
+    P.rng = takeu(), P.cnt = takeu(), P.dst = takeu();
+    P.cold = static_cast<WfColdGlobal*>(A.wf_cold) + static_cast<size_t>(blockIdx.x) * PS;
     P.dirbuf = multi_light ? A.wf_dir + static_cast<size_t>(blockIdx.x) * PS : nullptr;
     P.march_list[0] = reinterpret_cast<uint16_t*>(cursor);
     P.march_list[1] = P.march_list[0] + PS;
@@ -998,7 +1033,10 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     P.t = takef();
     P.tl = takef();
     P.flags = takeu();
-    P.cold = static_cast<WfCold*>(A.wf_cold) + static_cast<size_t>(blockIdx.x) * PS;
+    for (int a = 0; a < 3; ++a) P.col[a] = takef();
+    for (int a = 0; a < 3; ++a) P.rd[a] = takef();
+    P.rng = takeu(), P.cnt = takeu(), P.dst = takeu();
+    P.cold = static_cast<WfColdGlobal*>(A.wf_cold) + static_cast<size_t>(blockIdx.x) * PS;
     P.dirbuf = Cfg::nl(A) > 1 ? A.wf_dir + static_cast<size_t>(blockIdx.x) * PS : nullptr;
     P.march_list[0] = P.march_list[1] = P.event_list = nullptr;
     uint16_t* ring_mq = reinterpret_cast<uint16_t*>(cursor);
@@ -1239,7 +1277,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     if (status && lane == 0 && aq_load(&sh->abort) != 0u) atomicOr(status, 1u);  // the safety net tripped: the output is not valid
 }
 
-static size_t aq_lds_bytes(int nwords, int pool) { return (32 + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * 9 * 4 + kAqCap * 2 * (2 + kAqEventQueues) + 16; }
+static size_t aq_lds_bytes(int nwords, int pool) { return (32 + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * kPoolDwords * 4 + kAqCap * 2 * (2 + kAqEventQueues) + 16; }
 
 int aq_pool_size(int nwords, size_t lds_limit)
 {
@@ -1260,7 +1298,7 @@ static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, in
     return hipGetLastError();
 }
 
-constexpr int kAqPool = 1536;  // the usual pool (ddgi_engine.cpp); other sizes take the generic instantiation
+constexpr int kAqPool = 1344;  // the usual pool (ddgi_engine.cpp); other sizes take the generic instantiation
 
 hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
 {
@@ -1328,10 +1366,13 @@ __global__ void k_isa_post_march(const TraceArgs A, float* io, uint32_t* lds_src
     float* f = reinterpret_cast<float*>(pl);
     for (int a = 0; a < 3; ++a) P.ro[a] = f + 1536 * a, P.dn[a] = f + 1536 * (3 + a);
     P.t = f + 1536 * 6, P.tl = f + 1536 * 7, P.flags = pl + 1536 * 8;
-    WfCold c = load_cold(reinterpret_cast<const WfCold*>(io) + threadIdx.x);
+    for (int a = 0; a < 3; ++a) P.col[a] = f + 1536 * (10 + a), P.rd[a] = f + 1536 * (17 + a);
+    P.rng = pl + 1536 * 13, P.cnt = pl + 1536 * 14, P.dst = pl + 1536 * 15;
+    P.cold = reinterpret_cast<WfColdGlobal*>(io);
+    WfCold c = load_cold(P, threadIdx.x, true);
     const f3 o = v3of(c.hn), d = v3of(c.hc);
-    const int r = wf_post_march<CfgPlain<0>>(P, threadIdx.x, c, o, d, c.cnt != 0, A, pl + 1536 * 9);
-    store_cold(reinterpret_cast<WfCold*>(io) + threadIdx.x, c);
+    const int r = wf_post_march<CfgPlain<0>>(P, threadIdx.x, c, o, d, c.cnt != 0, A, pl + 1536 * 16);
+    store_cold(P, threadIdx.x, c, true);
     io[threadIdx.x] = static_cast<float>(r);
 }
 __global__ void k_isa_hemisphere(float* io)

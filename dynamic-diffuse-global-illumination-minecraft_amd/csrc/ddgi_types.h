@@ -14,6 +14,7 @@ namespace ddgi {
 constexpr int kMaxLights = DDGI_MAX_LIGHTS;
 constexpr int kMarchIters = 125;  // grid_march's loop bound, intersection.glsl:1059
 constexpr int kTraceBlock = 256;  // threads per workgroup = 4 wave64
+constexpr int kWfColdBytes = 32;  // wavefront trace kernels: global scratch per pool slot (ddgi_trace_wf.hip: WfColdGlobal)
 
 struct LightK
 {
@@ -80,7 +81,7 @@ struct TraceArgs
     int wait_threshold;   // event batching: handle finished marches once this many lanes wait
     NoiseLut noise;       // memoised lattice hashes (device pointers)
     unsigned long long* stats;  // profiling aid (null = off): [0] march-loop trips, [1] lane-steps, [2] event rounds, [3] lane-events, [4] waves
-    void* wf_cold;        // wavefront kernel: per-slot shading state, grid x pool x 48 B (device scratch)
+    void* wf_cold;        // wavefront kernel: per-slot shading state, grid x pool x kWfColdBytes (device scratch)
     float4* wf_dir;       // wavefront kernel: per-slot accumulated direct light (only with > 1 light)
     int wf_tail;          // wavefront kernel: straggler steps after the march list is drained (0 = default)
     int wf_fetch;         // wavefront kernel: idle lanes that trigger a task fetch (0 = default)
