@@ -14,55 +14,58 @@
 namespace ddgi {
 
 // ------------------------------------------------------------------------------------------------
-// The octahedral blend (DDGI paper; hysteresis: dormant probe_pass.comp:298-299).
+// The octahedral blend (DDGI paper; hysteresis: dormant probe_pass.comp:298-299) as a dense contraction.
 //
-// For every probe and interior texel:  sum_i w(texel, ray i) * value(probe, ray i)  over the frame's
-// rays IN ORDER i = 0..n-1 as one fma chain per channel (the oracle's order), divided by the weight
-// sum, mixed with the old texel, border texels copied from their octahedral-wrap source.
+// For every probe and interior texel:  sum_i w(texel, ray i) * value(probe, ray i)  over the frame's rays IN ORDER
+// i = 0..n-1 as one fma chain per channel (the oracle's order), divided by the weight sum, mixed with the old
+// texel, border texels copied from their octahedral-wrap source.
 //
-//  * A texel's weights depend on the frame's ray directions and the texel direction only — not on
-//    the probe.  k_blend_weights evaluates them once per update: w[i][c] for ray i and texel column c
-//    (256 columns: [0,196) depth texels, [196,232) irradiance texels, the rest zero) plus every
-//    column's weight sum.
-//  * A ray's values are the same for every texel lane, so the trace kernel stores them as
-//    records of 8 probes (ddgi_types.h: kRecGroup) and k_probe_blend_s reads them with SCALAR
-//    loads: the inner loop is one coalesced w load per ray and one fma (SGPR x VGPR + VGPR) per
-//    (texel, ray, probe, channel).  No LDS, no barrier: a wave owns a set of texel columns (one
-//    depth wave of 49 lanes x 4 texels, one irradiance wave of 36 lanes) for kNG record groups at a
-//    time, finishes its texels (division, hysteresis) and writes them and their border copies itself.
-//  HBM traffic per probe: 20 n B of ray records in, 3 KB old tiles in, 3 KB new tiles out.
-//  Measured on C3 (16 384 probes x 256 rays): 0.157 ms + 0.017 ms for the weights (one-probe-per-
-//  workgroup kernel: 0.52 ms); of it ~70 us is the fma stream at the VALU's rate (2.1 G lane-fma,
-//  49/64 and 36/64 lanes used) and ~50 us the tile read-modify-write at ~4 TB/s, executed by the same
-//  waves one after the other.
+// A texel's weights depend on the frame's ray directions and the texel direction only — not on the probe.  So
+// the sums are a matrix product  D[texel][column] = sum_i W[texel][i] * V[i][column]  with the columns running over
+// (probe, channel): W is 196 x n (depth texels: weights max(0, cos)^50) and 36 x n (irradiance texels: max(0, cos)),
+// V are the ray records the trace kernel left (ddgi_types.h: rec_dd_index / rec_rgb_index).  On gfx950
+// v_mfma_f32_32x32x2_f32 IS a k-ordered binary32 fma chain (D = fma(a1, b1, fma(a0, b0, C)), one rounding per
+// term, nothing wider inside; tests/mfma_order_check.hip), so consecutive MFMAs over ascending ray pairs give
+// bit for bit the oracle's per-texel loop — at the matrix pipe's rate with all 64 lanes busy, where the VALU
+// version ran its fma stream at 49/64 and 36/64 lanes.
+//
+//   k_blend_weights      W as MFMA A tiles: tile mt (0..6 depth rows 32 mt .. 32 mt + 31, 7..8 irradiance), ray pair
+//                        q, lane l holds W[row = l & 31][ray 2q + (l >> 5)]  ->  one coalesced 256-byte load per MFMA.
+//                        Rows past the last texel and rays past n are zero (fma(0, x, acc) == acc: a chain that
+//                        starts at +0 never holds -0).
+//   k_blend_weight_sums  every texel's weight sum, added in ray order (one lane per texel, 16 loads in flight)
+//   k_probe_blend_depth  workgroup = 7 waves, one depth tile each, for the 16 probes of a group: B = the group's (d, d^2)
+//                        records, 32 columns = 2 moments x 16 probes.  One accumulator tile (16 VGPRs) per wave: a
+//                        32x32x2 MFMA's issue interval equals its dependent latency, so one chain per wave keeps the
+//                        pipe busy; operands are prefetched 8 ray pairs ahead.
+//   k_probe_blend_irr    workgroup = 2 waves, one irradiance tile each, the three colour channels one after the other, for
+//                        the 32 probes of a group; the epilogue joins a texel's channels: rgba texels leave as 16-byte stores.
+//                        Epilogue of both: the accumulators are transposed through LDS so that lanes = texels: divide by
+//                        the weight sum, hysteresis with the old texel (read from the previous tiles: the same buffers, or
+//                        the other pair of a pipelined exchange), store the texel and its octahedral-wrap border copies —
+//                        runs of consecutive addresses per probe, per-texel set-up done once per task.
+// Both weight kernels depend on the frame's rotation only and are launched BEFORE the trace kernel.
+// HBM traffic per probe: 20 n B of ray records in, 3 KB old tiles in, 3 KB new tiles out.
 // ------------------------------------------------------------------------------------------------
 constexpr int kIrrInterior = (kIrrTile - 2) * (kIrrTile - 2);  // 36
 constexpr int kDepInterior = (kDepTile - 2) * (kDepTile - 2);  // 196
 constexpr int kBlendCols = 256;
-// tuning knob of k_probe_blend_s: record groups (of 8 probes) per pass
-#ifndef DDGI_BLEND_NG
-#define DDGI_BLEND_NG 1
-#endif
+constexpr int kDepMTiles = (kDepInterior + 31) / 32;  // 7
+constexpr int kIrrMTiles = (kIrrInterior + 31) / 32;  // 2
+constexpr int kBlendMTiles = kDepMTiles + kIrrMTiles;
+constexpr int kBlendWaves = kDepMTiles;               // waves per workgroup of k_probe_blend_mfma
 
-typedef float f2v __attribute__((ext_vector_type(2)));
-typedef float f8v __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
-// Scalar-memory requests whose position in the instruction stream is fixed (volatile asm), and the wait
-// that makes their results readable; the "+s" operands tie the wait to every later use of the registers.
-DDGI_D void sload16(f16v& dst, const float* p)
+
+// texel column c in [0, 232) -> (M tile, row)
+DDGI_D void blend_column_tile(int c, int& mt, int& row)
 {
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(dst) : "s"(p));
+    const int k = c < kDepInterior ? c : c - kDepInterior;
+    mt = (c < kDepInterior ? 0 : kDepMTiles) + (k >> 5);
+    row = k & 31;
 }
-DDGI_D void sload8(f8v& dst, const float* p) { asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(dst) : "s"(p)); }
-template <int N>
-DDGI_D void swait(f16v (&r)[N])
-{
-    if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r[0]));
-    if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r[0]), "+s"(r[1]));
-    if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r[0]), "+s"(r[1]), "+s"(r[2]), "+s"(r[3]));
-    static_assert(N == 1 || N == 2 || N == 4, "record groups per pass");
-}
-DDGI_D void swait2(f16v& a, f8v& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
+// index of W[tile mt][row][ray i] in the A-operand layout (ddgi_types.h: mfma_operand_offset)
+DDGI_D size_t weight_index(int mt, int row, int i, int n_pad) { return static_cast<size_t>(mt) * n_pad * 32 + mfma_operand_offset(static_cast<uint32_t>(i), static_cast<uint32_t>(row)); }
 
 DDGI_D void blend_column_texel(int c, bool& is_dep, int& tx, int& ty)
 {
@@ -72,35 +75,50 @@ DDGI_D void blend_column_texel(int c, bool& is_dep, int& tx, int& ty)
     tx = 1 + k % inner, ty = 1 + k / inner;
 }
 
-__global__ __launch_bounds__(kBlendCols) void k_blend_weights(const BlendArgs A)
+// grid: (ray chunks of 64, kBlendMTiles); block 64 x 4: thread (l, u) -> row l & 31, ray 2 (4 blockIdx.x + u) + (l >> 5)
+__global__ __launch_bounds__(256) void k_blend_weights(const BlendArgs A)
 {
-    extern __shared__ __attribute__((aligned(16))) float blend_lds[];
-    const int n = A.grid.n;
-    const int c = threadIdx.x;
-    for (int i = c; i < n; i += kBlendCols)
+    const int n = A.grid.n, n_pad = static_cast<int>(rec_ray_pad(static_cast<uint32_t>(n))), q_pairs = n_pad / 2;
+    const int l = threadIdx.x & 63, q = static_cast<int>(blockIdx.x) * 4 + (threadIdx.x >> 6), mt = blockIdx.y;
+    if (q >= q_pairs) return;
+    const int row = l & 31, i = 2 * q + (l >> 5);
+    const bool is_dep = mt < kDepMTiles;
+    const int k = (is_dep ? mt : mt - kDepMTiles) * 32 + row;  // interior texel number within its tile kind
+    float w = 0.0f;
+    if (i < n && k < (is_dep ? kDepInterior : kIrrInterior))
     {
-        const f3 d = fibonacci_dir(i, n, A.rot);
-        blend_lds[3 * i] = d.x, blend_lds[3 * i + 1] = d.y, blend_lds[3 * i + 2] = d.z;
+        const int inner = is_dep ? (kDepTile - 2) : (kIrrTile - 2);
+        const f3 td = texel_dir(1 + k % inner, 1 + k / inner, is_dep ? kDepTile : kIrrTile);
+        w = gl_max(0.0f, dot3(td, fibonacci_dir(i, n, A.rot)));
+        if (is_dep) w = pow50(w);
     }
-    __syncthreads();
+    A.w[weight_index(mt, row, i, n_pad)] = w;
+}
+
+// one lane per texel column: the weight sum in ray order (sw += w, i = 0..n-1: the oracle's order)
+__global__ __launch_bounds__(kBlendCols) void k_blend_weight_sums(const BlendArgs A)
+{
+    const int n = A.grid.n, q_pairs = static_cast<int>(rec_ray_pad(static_cast<uint32_t>(n))) / 2;
+    const int c = threadIdx.x;
     if (c >= kDepInterior + kIrrInterior)
     {
-        for (int i = 0; i < n; ++i) A.w[static_cast<size_t>(i) * kBlendCols + c] = 0.0f;
         A.w_sum[c] = 0.0f;
         return;
     }
-    bool is_dep;
-    int tx, ty;
-    blend_column_texel(c, is_dep, tx, ty);
-    const f3 td = texel_dir(tx, ty, is_dep ? kDepTile : kIrrTile);
+    int mt, row;
+    blend_column_tile(c, mt, row);
+    const int n_pad = 2 * q_pairs;
     float sw = 0.0f;
-    for (int i = 0; i < n; ++i)
+    int i = 0;
+    for (; i + 16 <= n; i += 16)
     {
-        float w = gl_max(0.0f, dot3(td, f3{blend_lds[3 * i], blend_lds[3 * i + 1], blend_lds[3 * i + 2]}));
-        if (is_dep) w = pow50(w);
-        A.w[static_cast<size_t>(i) * kBlendCols + c] = w;
-        sw += w;
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = A.w[weight_index(mt, row, i + u, n_pad)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sw += v[u];
     }
+    for (; i < n; ++i) sw += A.w[weight_index(mt, row, i, n_pad)];
     A.w_sum[c] = sw;
 }
 
@@ -132,189 +150,194 @@ DDGI_D void blend_destinations(int tx, int ty, int S, int (&dst)[4])
     if (tx == last - 1 && ty == 1) dst[nd++] = last * S;  // (0, last)
 }
 
-// Workgroup = 2 waves working on the same kNG record groups: wave 0 the 196 depth texels (49 lanes x
-// kDepT = 4 consecutive texel columns each, so that every scalar record value feeds 4 fma's per lane —
-// the scalar data path returns only a few bytes per clock), wave 1 the 36 irradiance texels.
-constexpr int kDepT = 4, kDepLanes = kDepInterior / kDepT;  // 49
-static_assert(kDepLanes * kDepT == kDepInterior && kDepLanes <= 64 && kIrrInterior <= 64, "texel columns per lane");
-
-template <int kNG>
-__global__ __launch_bounds__(128) void k_probe_blend_s(const BlendArgs A, const float* __restrict__ rad_rgb, const float* __restrict__ rad_dd,
-                                                       const float* __restrict__ w_table, const float* __restrict__ w_sum)
+// acc += A-operand stream x B-operand stream over all ray pairs, in order.  wa / vb: this lane's operand streams
+// (ddgi_types.h: mfma_operand_offset), i.e. base + lane * 4: element u of float4 number k is ray pair 4k + u.
+// Operands are fetched 16 ray pairs (4 float4 per stream) ahead of the MFMAs that consume them.
+DDGI_D f16v blend_contract(const float* __restrict__ wa, const float* __restrict__ vb, int q_pairs)
 {
-    // the read-only inputs come as separate noalias kernel arguments (not through BlendArgs) so that the
-    // compiler can prove the tile stores do not clobber them and selects scalar loads for the ray records
-    const GridK& G = A.grid;
-    const int n = G.n;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool is_dep = wave == 0;  // wave-uniform
-    const float hyst = G.hysteresis;
-    const uint32_t n_groups = (A.n_local_probes + kRecGroup - 1) / kRecGroup;
-    const uint32_t n_super = (n_groups + kNG - 1) / kNG;
-    const int n_even = n & ~1, last = n - 1;
-
-    if (is_dep)
+    f16v acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const float4* __restrict__ pa = reinterpret_cast<const float4*>(wa);
+    const float4* __restrict__ pb = reinterpret_cast<const float4*>(vb);
+    const int n4 = q_pairs / 4;  // float4 per stream; a multiple of 2 (kRecRayPad = 16)
+    float4 a0[4], b0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a0[u] = pa[static_cast<size_t>(min(u, n4 - 1)) * 64], b0[u] = pb[static_cast<size_t>(min(u, n4 - 1)) * 64];
+    for (int k = 0; k < n4; k += 4)
     {
-        const bool valid = lane < kDepLanes;
-        const int c0 = valid ? lane * kDepT : kBlendCols - kDepT;  // columns 252..255: zero weights
-        int dst[kDepT][4];
+        float4 a1[4], b1[4];
 #pragma unroll
-        for (int t = 0; t < kDepT; ++t)
+        for (int u = 0; u < 4; ++u)
         {
-            const int k = (valid ? c0 : 0) + t;
-            blend_destinations(1 + k % (kDepTile - 2), 1 + k / (kDepTile - 2), kDepTile, dst[t]);
+            const int kn = min(k + 4 + u, n4 - 1);  // past the end: re-read the last one (dropped)
+            a1[u] = pa[static_cast<size_t>(kn) * 64], b1[u] = pb[static_cast<size_t>(kn) * 64];
         }
-        const float4 sw4 = *reinterpret_cast<const float4*>(w_sum + c0);
-        const float sw[kDepT] = {sw4.x, sw4.y, sw4.z, sw4.w};
-        const float4* __restrict__ wcol = reinterpret_cast<const float4*>(w_table + c0);  // row stride kBlendCols / 4
-        constexpr int kRow = kBlendCols / 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k + u < n4)  // wave-uniform
+            {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].x, b0[u].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].y, b0[u].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].z, b0[u].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].w, b0[u].w, acc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a0[u] = a1[u], b0[u] = b1[u];
+    }
+    return acc;
+}
 
-        for (uint32_t sg = blockIdx.x; sg < n_super; sg += gridDim.x)
+// Epilogue staging: a wave parks its accumulator tile in LDS as [texel row][column] (row stride 33 words: conflict-free
+// for a fixed column) and then walks it with lanes = texels, so that a probe's texels are written as runs of
+// consecutive addresses and everything that depends on the texel only (wrap destinations, weight sum) is set up once.
+constexpr int kStageStride = 33;
+DDGI_D void stage_tile(float* stage, const f16v& acc, int col, int half)
+{
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * half) * kStageStride + col] = acc[r];  // C/D map of the 32x32 MFMA
+}
+
+// depth: workgroup = 7 waves, wave m = depth tile m of the 16 probes of a group; B columns = moment * 16 + probe
+__global__ __launch_bounds__(kBlendWaves * 64) void k_probe_blend_depth(const BlendArgs A, const float* __restrict__ rad_dd, const float* __restrict__ w_tiles,
+                                                                        const float* __restrict__ w_sum)
+{
+    static_assert(kRecRayPad % 32 == 0, "the contraction consumes 16 ray pairs per chunk");
+    __shared__ float stage_all[kBlendWaves][32 * kStageStride];
+    __shared__ uint32_t slot_sh[16];  // tile slots of the group's probes (through LDS, not readlane: the epilogue runs under a partial exec mask)
+    __shared__ float4 b_stage[2][256];  // the group's records, 16 ray pairs (256 float4) at a time, double buffered: all seven waves
+                                        // consume the same B operand — fetched from L2 once per workgroup, not once per wave
+    const GridK& G = A.grid;
+    const int n_pad = static_cast<int>(rec_ray_pad(static_cast<uint32_t>(G.n))), q_pairs = n_pad / 2;
+    const int mt = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* stage = stage_all[mt];
+    const float hyst = G.hysteresis;
+    const uint32_t n_tasks = (A.n_local_probes + 15u) / 16u;
+    // epilogue role of this lane: texel c = 32 mt + (lane >> 1), moment lane & 1
+    const int trow = lane >> 1, ch = lane & 1, c = mt * 32 + trow;
+    const bool texel_valid = c < kDepInterior;
+    int dst[4] = {0, -1, -1, -1};
+    float sw = 0.0f;
+    if (texel_valid)
+    {
+        blend_destinations(1 + c % (kDepTile - 2), 1 + c / (kDepTile - 2), kDepTile, dst);
+        sw = w_sum[c];
+    }
+    for (uint32_t task = blockIdx.x; task < n_tasks; task += gridDim.x)
+    {
+        // ---- contraction: acc = W tile x records, ray pairs in order ----
+        f16v acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         {
-            const uint32_t g0 = sg * kNG;
-            // accumulators as (probe 2k, probe 2k+1) pairs: [group][pair][texel]
-            f2v a1[kNG][4][kDepT], a2[kNG][4][kDepT];
+            const float4* __restrict__ pa = reinterpret_cast<const float4*>(w_tiles + static_cast<size_t>(mt) * n_pad * 32) + lane;
+            const float4* __restrict__ gb = reinterpret_cast<const float4*>(rad_dd + static_cast<size_t>(task) * n_pad * 32);
+            const int n_chunks = q_pairs / 16, n4 = q_pairs / 4;  // 16 ray pairs = 4 float4 per lane per chunk
+            const bool loader = threadIdx.x < 256;
+            float4 b_next = loader ? gb[threadIdx.x] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            float4 a_cur[4];
 #pragma unroll
-            for (int g = 0; g < kNG; ++g)
+            for (int u = 0; u < 4; ++u) a_cur[u] = pa[static_cast<size_t>(min(u, n4 - 1)) * 64];
+            for (int ck = 0; ck < n_chunks; ++ck)
+            {
+                if (loader) b_stage[ck & 1][threadIdx.x] = b_next;
+                if (loader && ck + 1 < n_chunks) b_next = gb[static_cast<size_t>(ck + 1) * 256 + threadIdx.x];
+                float4 a_next[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int u = 0; u < 4; ++u) a_next[u] = pa[static_cast<size_t>(min(4 * (ck + 1) + u, n4 - 1)) * 64];
+                __syncthreads();  // chunk ck is staged; (buffer (ck+1)&1 is free: every wave has passed this barrier since it read it)
 #pragma unroll
-                    for (int t = 0; t < kDepT; ++t) a1[g][k][t] = a2[g][k][t] = f2v{0.0f, 0.0f};
-            const float* __restrict__ rec = rad_dd + static_cast<size_t>(g0) * n * 16;
-            // Software pipeline over ray pairs with two scalar register sets X, Y: the records of ray
-            // i+1 are requested (s_load_dwordx16, written as asm so that the request stays where it is)
-            // right after ray i's have arrived and before ray i's fma's are issued.
-            f16v X[kNG], Y[kNG];
+                for (int u = 0; u < 4; ++u)
+                {
+                    const float4 bv = b_stage[ck & 1][u * 64 + lane];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u].x, bv.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u].y, bv.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u].z, bv.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u].w, bv.w, acc, 0, 0, 0);
+                }
 #pragma unroll
-            for (int g = 0; g < kNG; ++g) sload16(X[g], rec + (static_cast<size_t>(g) * n) * 16);
-            // weights run two ray pairs ahead (their L2 latency is longer than one pair's arithmetic)
-            float4 wx = wcol[0], wy = wcol[static_cast<size_t>(min(1, last)) * kRow];
-            float4 wx_n = wcol[static_cast<size_t>(min(2, last)) * kRow], wy_n = wcol[static_cast<size_t>(min(3, last)) * kRow];
-            auto accumulate = [&](const f16v(&R)[kNG], const float4& w4) {
-                const float w[kDepT] = {w4.x, w4.y, w4.z, w4.w};
+                for (int u = 0; u < 4; ++u) a_cur[u] = a_next[u];
+            }
+        }
+        __syncthreads();  // (the previous task's staging has been read; the last chunk's too)
+        stage_tile(stage, acc, lane & 31, lane >> 5);
+        // tile slot of every probe of the group, once per task (two integer divisions each)
+        if (threadIdx.x < 16) slot_sh[threadIdx.x] = static_cast<uint32_t>(blend_tile_slot(G, min(task * 16u + threadIdx.x, A.n_local_probes - 1u)));
+        __syncthreads();
+        const uint32_t np = min(16u, A.n_local_probes - task * 16u);
+        if (texel_valid)
+        {
+            float old[16];  // all 16 probes' old texels in flight at once
 #pragma unroll
-                for (int g = 0; g < kNG; ++g)
+            for (uint32_t p = 0; p < 16u; ++p)
+                old[p] = p < np ? A.depth_old[static_cast<size_t>(slot_sh[p]) * (kDepTile * kDepTile * 2) + dst[0] * 2 + ch] : 0.0f;
+#pragma unroll
+            for (uint32_t p = 0; p < 16u; ++p)
+                if (p < np)
+                {
+                    float* tile = A.depth + static_cast<size_t>(slot_sh[p]) * (kDepTile * kDepTile * 2);
+                    const float s = stage[trow * kStageStride + ch * 16 + static_cast<int>(p)];
+                    float res = 0.0f;
+                    if (sw > 1e-6f) res = s / sw;
+                    const float out = gl_mix(old[p], res, hyst);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int t = 0; t < kDepT; ++t)
-                        {
-                            a1[g][k][t] = __builtin_elementwise_fma(f2v{R[g][2 * k], R[g][2 * k + 1]}, f2v{w[t], w[t]}, a1[g][k][t]);
-                            a2[g][k][t] = __builtin_elementwise_fma(f2v{R[g][8 + 2 * k], R[g][9 + 2 * k]}, f2v{w[t], w[t]}, a2[g][k][t]);
-                        }
-            };
-            for (int i = 0; i < n_even; i += 2)
-            {
-                const int i2 = min(i + 2, last);  // requests past the end repeat the last ray and are dropped
-                const float4 wx_nn = wcol[static_cast<size_t>(min(i + 4, last)) * kRow], wy_nn = wcol[static_cast<size_t>(min(i + 5, last)) * kRow];
-                swait(X);
-#pragma unroll
-                for (int g = 0; g < kNG; ++g) sload16(Y[g], rec + (static_cast<size_t>(g) * n + i + 1) * 16);
-                accumulate(X, wx);
-                swait(Y);
-#pragma unroll
-                for (int g = 0; g < kNG; ++g) sload16(X[g], rec + (static_cast<size_t>(g) * n + i2) * 16);
-                accumulate(Y, wy);
-                wx = wx_n, wy = wy_n;
-                wx_n = wx_nn, wy_n = wy_nn;
-            }
-            swait(X);  // X holds ray n_even (the last ray when n is odd; else a repeat that is dropped)
-            if (n & 1) accumulate(X, wx);
-#pragma unroll
-            for (int q = 0; q < kNG * kRecGroup; ++q)
-            {
-                const uint32_t pl = g0 * kRecGroup + q;
-                if (pl < A.n_local_probes && valid)
-                {
-                    const size_t tile_off = blend_tile_slot(G, pl) * (kDepTile * kDepTile * 2);
-                    float* tile = A.depth + tile_off;
-                    const float* tile_old = A.depth_old + tile_off;
-#pragma unroll
-                    for (int t = 0; t < kDepT; ++t)
-                    {
-                        const float s1 = a1[q / kRecGroup][(q % kRecGroup) / 2][t][q & 1], s2 = a2[q / kRecGroup][(q % kRecGroup) / 2][t][q & 1];
-                        float r1 = 0.0f, r2 = 0.0f;
-                        if (sw[t] > 1e-6f) r1 = s1 / sw[t], r2 = s2 / sw[t];
-                        const float2 old = *reinterpret_cast<const float2*>(tile_old + dst[t][0] * 2);
-                        const float2 out{gl_mix(old.x, r1, hyst), gl_mix(old.y, r2, hyst)};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (dst[t][k] >= 0) *reinterpret_cast<float2*>(tile + dst[t][k] * 2) = out;
-                    }
+                        if (dst[k] >= 0) tile[dst[k] * 2 + ch] = out;
                 }
-            }
         }
     }
-    else
-    {
-        const bool valid = lane < kIrrInterior;
-        const int c = valid ? kDepInterior + lane : kBlendCols - 1;  // column 255: zero weights
-        int dst[4];
-        blend_destinations(1 + (valid ? lane : 0) % (kIrrTile - 2), 1 + (valid ? lane : 0) / (kIrrTile - 2), kIrrTile, dst);
-        const float sw = w_sum[c];
-        const float* __restrict__ wcol = w_table + c;
+}
 
-        for (uint32_t sg = blockIdx.x; sg < n_super; sg += gridDim.x)
-        {
-            // the irradiance wave takes its record groups one after the other (24 scalars per ray and group)
-            for (int g = 0; g < kNG; ++g)
+// irradiance: workgroup = 2 waves, wave m = irradiance tile m, the three colour channels one after the other, for the
+// 32 probes of a group; B columns = probe.  The epilogue joins a texel's three channels: rgba texels leave as 16-byte
+// stores.  (Six waves per group — one per (channel, tile) — were slower: 55 us against 38 us on 16 384 probes; the
+// contraction is bound by requests in flight to L2 / HBM, not by the matrix pipe.)
+constexpr int kIrrWaves = kIrrMTiles;
+__global__ __launch_bounds__(kIrrWaves * 64) void k_probe_blend_irr(const BlendArgs A, const float* __restrict__ rad_rgb, const float* __restrict__ w_tiles,
+                                                                    const float* __restrict__ w_sum)
+{
+    __shared__ float stage_all[kIrrMTiles][3][32 * kStageStride];
+    __shared__ uint32_t slot_sh[32];
+    const GridK& G = A.grid;
+    const int n_pad = static_cast<int>(rec_ray_pad(static_cast<uint32_t>(G.n))), q_pairs = n_pad / 2;
+    const int mi = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float hyst = G.hysteresis;
+    const uint32_t n_tasks = (A.n_local_probes + 31u) / 32u;
+    // epilogue role: texel c = 32 mi + (lane & 31), probes of parity lane >> 5
+    const int trow = lane & 31, c = mi * 32 + trow;
+    const uint32_t p_first = static_cast<uint32_t>(lane >> 5);
+    const bool texel_valid = c < kIrrInterior;
+    int dst[4] = {0, -1, -1, -1};
+    float sw = 0.0f;
+    if (texel_valid)
+    {
+        blend_destinations(1 + c % (kIrrTile - 2), 1 + c / (kIrrTile - 2), kIrrTile, dst);
+        sw = w_sum[kDepInterior + c];
+    }
+    for (uint32_t task = blockIdx.x; task < n_tasks; task += gridDim.x)
+    {
+        const float* wa = w_tiles + static_cast<size_t>(kDepMTiles + mi) * n_pad * 32 + lane * 4;
+        const float* vb = rad_rgb + static_cast<size_t>(task) * 3 * n_pad * 32 + lane * 4;
+        f16v acc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] = blend_contract(wa, vb + static_cast<size_t>(k) * n_pad * 32, q_pairs);
+        __syncthreads();  // (the previous task's staging has been read)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) stage_tile(stage_all[mi][k], acc[k], lane & 31, lane >> 5);
+        if (threadIdx.x < 32) slot_sh[threadIdx.x] = static_cast<uint32_t>(blend_tile_slot(G, min(task * 32u + threadIdx.x, A.n_local_probes - 1u)));
+        __syncthreads();
+        const uint32_t np = min(32u, A.n_local_probes - task * 32u);
+        if (texel_valid)
+            for (uint32_t p = p_first; p < np; p += 2u)
             {
-                const uint32_t grp = sg * kNG + g;
-                f2v ac[3][4];  // [channel][probe pair]
+                const size_t tile_off = static_cast<size_t>(slot_sh[p]) * (kIrrTile * kIrrTile * 4);
+                float* tile = A.irradiance + tile_off;
+                float res[3] = {0.0f, 0.0f, 0.0f};
+                if (sw > 1e-6f)
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch)
+                    for (int k = 0; k < 3; ++k) res[k] = stage_all[mi][k][trow * kStageStride + static_cast<int>(p)] / sw;
+                const float4 old = *reinterpret_cast<const float4*>(A.irradiance_old + tile_off + dst[0] * 4);
+                const float4 out{gl_mix(old.x, res[0], hyst), gl_mix(old.y, res[1], hyst), gl_mix(old.z, res[2], hyst), 1.0f};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) ac[ch][k] = f2v{0.0f, 0.0f};
-                const float* __restrict__ rec = rad_rgb + static_cast<size_t>(grp) * n * 24;
-                f16v X16, Y16;
-                f8v X8, Y8;
-                sload16(X16, rec);
-                sload8(X8, rec + 16);
-                float wx = wcol[0], wy = wcol[static_cast<size_t>(min(1, last)) * kBlendCols];
-                auto accumulate = [&](const f16v& R16, const f8v& R8, float w) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                    {
-                        ac[0][k] = __builtin_elementwise_fma(f2v{R16[2 * k], R16[2 * k + 1]}, f2v{w, w}, ac[0][k]);
-                        ac[1][k] = __builtin_elementwise_fma(f2v{R16[8 + 2 * k], R16[9 + 2 * k]}, f2v{w, w}, ac[1][k]);
-                        ac[2][k] = __builtin_elementwise_fma(f2v{R8[2 * k], R8[2 * k + 1]}, f2v{w, w}, ac[2][k]);
-                    }
-                };
-                for (int i = 0; i < n_even; i += 2)
-                {
-                    const int i2 = min(i + 2, last), i3 = min(i + 3, last);
-                    const float wx_n = wcol[static_cast<size_t>(i2) * kBlendCols], wy_n = wcol[static_cast<size_t>(i3) * kBlendCols];
-                    swait2(X16, X8);
-                    sload16(Y16, rec + static_cast<size_t>(i + 1) * 24);
-                    sload8(Y8, rec + static_cast<size_t>(i + 1) * 24 + 16);
-                    accumulate(X16, X8, wx);
-                    swait2(Y16, Y8);
-                    sload16(X16, rec + static_cast<size_t>(i2) * 24);
-                    sload8(X8, rec + static_cast<size_t>(i2) * 24 + 16);
-                    accumulate(Y16, Y8, wy);
-                    wx = wx_n, wy = wy_n;
-                }
-                swait2(X16, X8);
-                if (n & 1) accumulate(X16, X8, wx);
-#pragma unroll
-                for (int j = 0; j < kRecGroup; ++j)
-                {
-                    const uint32_t pl = grp * kRecGroup + j;
-                    if (pl < A.n_local_probes && valid)
-                    {
-                        const size_t tile_off = blend_tile_slot(G, pl) * (kIrrTile * kIrrTile * 4);
-                        float* tile = A.irradiance + tile_off;
-                        float res[3] = {0.0f, 0.0f, 0.0f};
-                        if (sw > 1e-6f) res[0] = ac[0][j / 2][j & 1] / sw, res[1] = ac[1][j / 2][j & 1] / sw, res[2] = ac[2][j / 2][j & 1] / sw;
-                        const float4 old = *reinterpret_cast<const float4*>(A.irradiance_old + tile_off + dst[0] * 4);
-                        const float4 out{gl_mix(old.x, res[0], hyst), gl_mix(old.y, res[1], hyst), gl_mix(old.z, res[2], hyst), 1.0f};
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (dst[k] >= 0) *reinterpret_cast<float4*>(tile + dst[k] * 4) = out;
-                    }
-                }
+                for (int k = 0; k < 4; ++k)
+                    if (dst[k] >= 0) *reinterpret_cast<float4*>(tile + dst[k] * 4) = out;
             }
-        }
     }
 }
 
@@ -342,13 +365,13 @@ __global__ __launch_bounds__(kBlendBlock) void k_probe_blend(const BlendArgs A)
         const size_t slot = blend_tile_slot(G, pl);
         float* g_irr = A.irradiance + slot * (kIrrTile * kIrrTile * 4);
         float* g_dep = A.depth + slot * (kDepTile * kDepTile * 2);
-        const float* rgb = A.rad_rgb + static_cast<size_t>(pl / kRecGroup) * n * 24 + (pl % kRecGroup);
-        const float* dd = A.rad_dd + static_cast<size_t>(pl / kRecGroup) * n * 16 + (pl % kRecGroup);
+        const uint32_t n_pad = rec_ray_pad(static_cast<uint32_t>(n));
 
         __syncthreads();  // previous probe's LDS fully consumed
         for (int i = tid; i < n; i += kBlendBlock)
         {
-            s_rad[i] = float4{rgb[i * 24], rgb[i * 24 + 8], rgb[i * 24 + 16], dd[i * 16]};
+            s_rad[i] = float4{A.rad_rgb[rec_rgb_index(pl, i, n_pad, 0)], A.rad_rgb[rec_rgb_index(pl, i, n_pad, 1)], A.rad_rgb[rec_rgb_index(pl, i, n_pad, 2)],
+                              A.rad_dd[rec_dd_index(pl, i, n_pad, 0)]};
             const f3 d = fibonacci_dir(i, n, A.rot);
             s_dir[3 * i] = d.x, s_dir[3 * i + 1] = d.y, s_dir[3 * i + 2] = d.z;
         }
@@ -433,29 +456,29 @@ __global__ __launch_bounds__(256) void k_probe_sample_ddgi(const SampleArgs A)
 
 // ---- launchers -----------------------------------------------------------------------------------
 
-// sizes of the per-update weight table (BlendArgs::w; w_sum holds kBlendCols floats) and of the ray
-// records for n_local_probes probes of n rays (rounded up to whole passes of the blend kernel)
-constexpr int kBlendNG = DDGI_BLEND_NG;
-size_t blend_weights_floats(int n) { return static_cast<size_t>(n) * kBlendCols; }
-size_t blend_record_groups(uint32_t n_local_probes)
+// size of the per-update weight tiles (BlendArgs::w; w_sum holds kBlendCols floats)
+size_t blend_weights_floats(int n) { return static_cast<size_t>(kBlendMTiles) * rec_ray_pad(static_cast<uint32_t>(n)) * 32; }
+
+// k_blend_weights + k_blend_weight_sums: depend on the frame's rotation only — the engine launches them BEFORE the trace
+hipError_t launch_blend_weights(const BlendArgs& args, hipStream_t stream)
 {
-    const size_t groups = (static_cast<size_t>(n_local_probes) + kRecGroup - 1) / kRecGroup;
-    return (groups + kBlendNG - 1) / kBlendNG * kBlendNG;
+    if (!args.w || !args.w_sum) return hipSuccess;
+    const int q_pairs = static_cast<int>(rec_ray_pad(static_cast<uint32_t>(args.grid.n))) / 2;
+    hipLaunchKernelGGL(k_blend_weights, dim3((q_pairs + 3) / 4, kBlendMTiles), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(k_blend_weight_sums, dim3(1), dim3(kBlendCols), 0, stream, args);
+    return hipGetLastError();
 }
 
 hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t stream)
 {
     const int n = args.grid.n;
     if (args.n_local_probes == 0) return hipSuccess;
-    const size_t dir_lds = static_cast<size_t>(3) * n * sizeof(float);
-    if (args.w && args.w_sum && dir_lds <= 64 * 1024)
+    if (args.w && args.w_sum)
     {
-        hipLaunchKernelGGL(k_blend_weights, dim3(1), dim3(kBlendCols), dir_lds, stream, args);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        const uint32_t n_super = static_cast<uint32_t>(blend_record_groups(args.n_local_probes) / kBlendNG);
-        const uint32_t blocks = std::min<uint32_t>(n_super, static_cast<uint32_t>(num_cus) * 16u);
-        hipLaunchKernelGGL(k_probe_blend_s<kBlendNG>, dim3(blocks), dim3(128), 0, stream, args, args.rad_rgb, args.rad_dd,
+        const uint32_t dep_tasks = (args.n_local_probes + 15u) / 16u, irr_tasks = (args.n_local_probes + 31u) / 32u;
+        hipLaunchKernelGGL(k_probe_blend_depth, dim3(std::min<uint32_t>(dep_tasks, static_cast<uint32_t>(num_cus) * 8u)), dim3(kBlendWaves * 64), 0, stream, args, args.rad_dd,
+                           static_cast<const float*>(args.w), static_cast<const float*>(args.w_sum));
+        hipLaunchKernelGGL(k_probe_blend_irr, dim3(std::min<uint32_t>(irr_tasks, static_cast<uint32_t>(num_cus) * 16u)), dim3(kIrrWaves * 64), 0, stream, args, args.rad_rgb,
                            static_cast<const float*>(args.w), static_cast<const float*>(args.w_sum));
         return hipGetLastError();
     }

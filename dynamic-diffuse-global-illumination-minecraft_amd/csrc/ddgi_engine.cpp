@@ -32,11 +32,11 @@ hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t st
 int aq_pool_size(int nwords, size_t lds_limit);
 hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream);
 size_t blend_weights_floats(int n);
-size_t blend_record_groups(uint32_t n_local_probes);
+hipError_t launch_blend_weights(const BlendArgs& args, hipStream_t stream);
 hipError_t launch_carry_tiles(void* dst, const void* src, const int32_t* map, uint32_t n_probes, uint32_t words_per_tile, hipStream_t stream);
 hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream);
 hipError_t launch_render_primary(const RenderArgs& args, hipStream_t stream);
-hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], uint8_t* out, int n_vox, hipStream_t stream);
+hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], const int32_t* list, int n_list, uint8_t* out, hipStream_t stream);
 
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes)
 {
@@ -163,7 +163,7 @@ static int validate_tile(const ddgi_irradiance_field* f, int tx, int ty)
     return DDGI_OK;
 }
 
-constexpr int kMaxDdgiRays = 4096;  // k_blend_weights keeps the frame's ray directions in LDS (12 B each, 64 KB without opt-in)
+constexpr int kMaxDdgiRays = 4096;  // DDGI mode: rays per probe (the cross-check blend kernel keeps 28 B per ray in LDS)
 
 static int check_kernel_status(ddgi_engine* e);
 
@@ -397,6 +397,7 @@ int ddgi_destroy(ddgi_handle e)
         if (d.bits) (void)hipFree(d.bits);
         if (d.types) (void)hipFree(d.types);
         if (d.vis) (void)hipFree(d.vis);
+        if (d.vis_list) (void)hipFree(d.vis_list);
     }
     for (auto& triple : e->ev)
         for (auto& ev : triple)
@@ -646,7 +647,7 @@ struct TracePlan
     bool use_async = false;  // k_probe_trace_aq (queues) rather than k_probe_trace_wf (rounds)
     int wf_threads = 1024;
     uint32_t grid = 0;
-    size_t rec_pairs = 0;    // DDGI mode: (record group, ray) pairs of the ray-record buffer
+    size_t rec_rgb = 0;      // DDGI mode: floats in the rgb part of the ray-record buffer (the (d, d*d) part follows)
     unsigned long long key = 0;
 };
 
@@ -670,27 +671,31 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     a.rays = e->d_rays;
     a.n_rays = e->n_local_rays;
     if (p.ddgi_mode && a.grid.n > kMaxDdgiRays)
-        return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode: %d rays per probe; the blend's direction table holds at most %d", a.grid.n, kMaxDdgiRays);
+        return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode: %d rays per probe; at most %d are supported", a.grid.n, kMaxDdgiRays);
     if (p.ddgi_mode)
     {
         // rays are generated in the kernel; lights follow update_lights(time) (probe_pass.comp:217-251)
         const size_t local_rays = static_cast<size_t>(a.grid.cx) * a.grid.cy * a.grid.czl * a.grid.n;
-        p.rec_pairs = blend_record_groups(static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.czl) * a.grid.n;
-        if (p.rec_pairs > e->d_radiance_capacity)
+        const uint32_t local_probes = static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.czl;
+        p.rec_rgb = rec_rgb_floats(local_probes, static_cast<uint32_t>(a.grid.n));
+        const size_t rec_floats = p.rec_rgb + rec_dd_floats(local_probes, static_cast<uint32_t>(a.grid.n));
+        if (rec_floats > e->d_radiance_capacity || e->d_radiance_rays != a.grid.n)
         {
+            // (re)allocated zeroed: the records of padding rays / padding probes are never written and must read as 0
             if (e->d_radiance) (void)hipFree(e->d_radiance);
             e->d_radiance = nullptr;
             e->d_radiance_capacity = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_radiance), p.rec_pairs * 40 * sizeof(float)));
-            HIP_TRY(hipMemsetAsync(e->d_radiance, 0, p.rec_pairs * 40 * sizeof(float), e->stream));
-            e->d_radiance_capacity = p.rec_pairs;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_radiance), rec_floats * sizeof(float)));
+            HIP_TRY(hipMemsetAsync(e->d_radiance, 0, rec_floats * sizeof(float), e->stream));
+            e->d_radiance_capacity = rec_floats;
+            e->d_radiance_rays = a.grid.n;
         }
         animate_lights(scene, e->settings.time, e->lights[scene], a.nl, a.lights);
         a.ddgi = 1;
         a.frame_key = frame_key(e->frame);
         frame_rotation(e->frame, a.rot);
         a.rad_rgb = e->d_radiance;
-        a.rad_dd = e->d_radiance + p.rec_pairs * 24;
+        a.rad_dd = e->d_radiance + p.rec_rgb;
         a.rays = nullptr;
         a.n_rays = static_cast<uint32_t>(local_rays);
     }
@@ -699,10 +704,33 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     {
         ddgi_engine::DevScene& d = e->dev_scene[scene];
         const int n_vox = (a.scene.hi[0] - a.scene.lo[0] + 1) * (a.scene.hi[1] - a.scene.lo[1] + 1) * (a.scene.hi[2] - a.scene.lo[2] + 1);
-        if (!d.vis) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis), static_cast<size_t>(n_vox)));
+        if (!d.vis)
+        {
+            // the voxels a feeler can start in, once per scene: empty with an occupied face neighbour (clamped lookups: outside
+            // the box the world is the extrusion of the border layer)
+            const SceneBake& bk = scene == 3 ? e->user_scene : baked_scene(scene);
+            std::vector<int32_t> list;
+            for (int z = bk.lo[2]; z <= bk.hi[2]; ++z)
+                for (int y = bk.lo[1]; y <= bk.hi[1]; ++y)
+                    for (int x = bk.lo[0]; x <= bk.hi[0]; ++x)
+                    {
+                        if (bk.block_at(x, y, z) > 0) continue;
+                        if (bk.block_at(x - 1, y, z) > 0 || bk.block_at(x + 1, y, z) > 0 || bk.block_at(x, y - 1, z) > 0 || bk.block_at(x, y + 1, z) > 0 ||
+                            bk.block_at(x, y, z - 1) > 0 || bk.block_at(x, y, z + 1) > 0)
+                            list.push_back(((z - bk.lo[2]) * bk.dim[1] + (y - bk.lo[1])) * bk.dim[0] + (x - bk.lo[0]));
+                    }
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis), static_cast<size_t>(n_vox)));
+            HIP_TRY(hipMemsetAsync(d.vis, 0, static_cast<size_t>(n_vox), e->stream));
+            d.n_vis_list = static_cast<int>(list.size());
+            if (d.n_vis_list > 0)
+            {
+                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis_list), list.size() * sizeof(int32_t)));
+                HIP_TRY(hipMemcpy(d.vis_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            }
+        }
         if (!d.vis_valid || std::memcmp(d.vis_light, a.lights[0].pos, sizeof(d.vis_light)) != 0)
         {
-            HIP_TRY(launch_light_visibility(a.scene, a.lights[0].pos, d.vis, n_vox, e->stream));
+            HIP_TRY(launch_light_visibility(a.scene, a.lights[0].pos, d.vis_list, d.n_vis_list, d.vis, e->stream));
             std::memcpy(d.vis_light, a.lights[0].pos, sizeof(d.vis_light));
             d.vis_valid = true;
         }
@@ -883,26 +911,13 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     const TraceArgs& a = p.a;
 
     hipEvent_t* ev = e->ev[e->updates % ddgi_engine::kRing];
-    if (p.pool > 0)
-    {
-        int march_waves = 5;
-        if (p.use_async)
-            if (int rc = choose_march_waves(e, p, true, false, &march_waves)) return rc;
-        HIP_TRY(hipEventRecord(ev[0], e->stream));
-        if (p.use_async)
-            HIP_TRY(launch_probe_trace_aq(a, p.pool, static_cast<int>(p.grid), march_waves, e->d_work, e->d_work + 1, e->stream));
-        else
-            HIP_TRY(launch_probe_trace_wf(a, p.wf_threads, p.pool, static_cast<int>(p.grid), e->d_work, e->stream));
-    }
-    else
-    {
-        HIP_TRY(hipEventRecord(ev[0], e->stream));
-        HIP_TRY(launch_probe_trace_ref(a, static_cast<int>(p.grid), e->stream));
-    }
-    HIP_TRY(hipEventRecord(ev[1], e->stream));
+    int march_waves = 5;
+    if (p.pool > 0 && p.use_async)
+        if (int rc = choose_march_waves(e, p, true, false, &march_waves)) return rc;
+    HIP_TRY(hipEventRecord(ev[0], e->stream));  // (DDGI mode: the trace time includes the blend's two small weight kernels)
+    BlendArgs b{};
     if (p.ddgi_mode)
     {
-        BlendArgs b{};
         b.grid = a.grid;
         for (int i = 0; i < 9; ++i) b.rot[i] = a.rot[i];
         b.rad_rgb = a.rad_rgb;
@@ -912,19 +927,33 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         b.irradiance_old = static_cast<const float*>(e->tex_prev[0] ? e->tex_prev[0] : e->tex[0]);
         b.depth_old = static_cast<const float*>(e->tex_prev[1] ? e->tex_prev[1] : e->tex[1]);
         b.n_local_probes = static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.czl;
+        const size_t need = blend_weights_floats(a.grid.n) + 256;
+        if (need > e->d_blend_w_floats)
         {
-            const size_t need = blend_weights_floats(a.grid.n) + 256;
-            if (need > e->d_blend_w_floats)
-            {
-                if (e->d_blend_w) (void)hipFree(e->d_blend_w);
-                e->d_blend_w = nullptr, e->d_blend_w_floats = 0;
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_blend_w), need * sizeof(float)));
-                e->d_blend_w_floats = need;
-            }
-            b.w_sum = e->d_blend_w;
-            b.w = e->d_blend_w + 256;
-            if (e->tuning.blend_kernel == 1) b.w = b.w_sum = nullptr;  // one probe per workgroup, weights in place
+            if (e->d_blend_w) (void)hipFree(e->d_blend_w);
+            e->d_blend_w = nullptr, e->d_blend_w_floats = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_blend_w), need * sizeof(float)));
+            e->d_blend_w_floats = need;
         }
+        b.w_sum = e->d_blend_w;
+        b.w = e->d_blend_w + 256;
+        if (e->tuning.blend_kernel == 1) b.w = b.w_sum = nullptr;  // one probe per workgroup, weights in place
+        // the blend's weight tiles depend on the frame's ray directions only: made before the trace, off the critical path
+        // between the last ray and the first tile
+        HIP_TRY(launch_blend_weights(b, e->stream));
+    }
+    if (p.pool > 0)
+    {
+        if (p.use_async)
+            HIP_TRY(launch_probe_trace_aq(a, p.pool, static_cast<int>(p.grid), march_waves, e->d_work, e->d_work + 1, e->stream));
+        else
+            HIP_TRY(launch_probe_trace_wf(a, p.wf_threads, p.pool, static_cast<int>(p.grid), e->d_work, e->stream));
+    }
+    else
+        HIP_TRY(launch_probe_trace_ref(a, static_cast<int>(p.grid), e->stream));
+    HIP_TRY(hipEventRecord(ev[1], e->stream));
+    if (p.ddgi_mode)
+    {
         HIP_TRY(launch_probe_blend(b, e->num_cus, e->stream));
         e->frame += 1;
     }
@@ -1403,6 +1432,7 @@ static int fill_user_scene(ddgi_engine* e, const int lo[3], const int dim[3], co
     if (d.bits) (void)hipFree(d.bits);
     if (d.types) (void)hipFree(d.types);
     if (d.vis) (void)hipFree(d.vis);
+    if (d.vis_list) (void)hipFree(d.vis_list);
     d = ddgi_engine::DevScene{};
     e->user_scene = std::move(b);
     return DDGI_OK;

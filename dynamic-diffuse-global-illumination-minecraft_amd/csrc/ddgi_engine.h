@@ -75,6 +75,8 @@ struct ddgi_engine
         SceneK k{};
         bool ready = false;
         uint8_t* vis = nullptr;             // k_light_visibility table for the scene's single light
+        int32_t* vis_list = nullptr;        // the voxels it classifies: empty, with an occupied face neighbour
+        int n_vis_list = 0;
         float vis_light[3] = {0, 0, 0};     // ... computed for this light position
         bool vis_valid = false;
     } dev_scene[4];
@@ -105,8 +107,9 @@ struct ddgi_engine
     void* d_wf_cold = nullptr;              // wavefront kernel scratch: per-slot shading state
     float4* d_wf_dir = nullptr;
     size_t wf_cold_slots = 0, wf_dir_slots = 0;
-    float* d_radiance = nullptr;            // DDGI mode ray records: rgb part then (d, d*d) part (ddgi_types.h: kRecGroup)
-    size_t d_radiance_capacity = 0;         // in (record group, ray) pairs
+    float* d_radiance = nullptr;            // DDGI mode ray records: rgb part then (d, d*d) part (ddgi_types.h: rec_rgb_index)
+    size_t d_radiance_capacity = 0;         // in floats
+    int d_radiance_rays = 0;                // rays per probe the buffer was zeroed for (its padding layout)
     uint32_t frame = 0;                     // DDGI mode: updates done so far (seeds the ray rotation)
     Tuning tuning;
     std::map<unsigned long long, int> aq_split;  // configuration key -> measured march/event wave split of the queue kernel

@@ -78,7 +78,7 @@ struct WfCold
     float col[3];  // accumulated radiance
     uint32_t rng;
     uint32_t cnt;  // [7:0] bounce, [11:8] light index, [15:12] visible lights
-    uint32_t dst;  // REF: texel index; DDGI: ray record id (ddgi_types.h: kRecGroup)
+    uint32_t dst;  // REF: texel index; DDGI: the local ray index pl * n + i (-> ddgi_types.h: rec_dd_index, rec_rgb_index)
 };
 struct WfColdGlobal
 {
@@ -308,8 +308,9 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
 DDGI_D void wf_store_distance(const TraceArgs& A, uint32_t dst, float t)
 {
     const float d = gl_min(t, static_cast<float>(A.grid.side) * 1.5f);
-    float* rec = A.rad_dd + static_cast<size_t>(dst >> 3) * 16 + (dst & 7u);
-    rec[0] = d, rec[8] = d * d;
+    const uint32_t n = static_cast<uint32_t>(A.grid.n), pl = dst / n, i = dst - pl * n;
+    const uint32_t n_pad = rec_ray_pad(n);
+    A.rad_dd[rec_dd_index(pl, i, n_pad, 0)] = d, A.rad_dd[rec_dd_index(pl, i, n_pad, 1)] = d * d;
 }
 
 template <class Cfg>
@@ -318,8 +319,9 @@ DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst
     const f3 c = div3(color, static_cast<float>(A.max_bounces));  // Q14: always /max_bounces
     if (Cfg::ddgi(A))
     {
-        float* rec = A.rad_rgb + static_cast<size_t>(dst >> 3) * 24 + (dst & 7u);  // (the distance was written at bounce 0)
-        rec[0] = c.x, rec[8] = c.y, rec[16] = c.z;
+        const uint32_t n = static_cast<uint32_t>(A.grid.n), n_pad = rec_ray_pad(n), pl = dst / n, i = dst - pl * n;  // (the distance was written at bounce 0)
+        float* rec = A.rad_rgb + rec_rgb_index(pl, i, n_pad, 0);
+        rec[0] = c.x, rec[static_cast<size_t>(n_pad) * 32] = c.y, rec[static_cast<size_t>(n_pad) * 64] = c.z;  // channel stride: n_pad * 32
     }
     else
     {
@@ -422,7 +424,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 const int pxz = p - y * G.cx * G.cz;
                 ray_o = probe_position(G, pxz % G.cx, y, pxz / G.cx);
                 ray_d = fibonacci_dir(i, rays_per_probe, A.rot);
-                c.dst = ((static_cast<uint32_t>(pl) >> 3) * static_cast<uint32_t>(rays_per_probe) + static_cast<uint32_t>(i)) * 8u + (static_cast<uint32_t>(pl) & 7u);  // record id (kRecGroup)
+                c.dst = r;  // pl * n + i
                 c.rng = wang_hash(global_ray ^ A.frame_key);
             }
             else

@@ -99,27 +99,45 @@ struct TraceArgs
     const uint8_t* vis;  // single light: per-voxel feeler classes over the baked box (k_light_visibility), or null
 };
 
-// DDGI-mode ray records, laid out for the blend kernel: local probes in groups of 8; for group g and
-// ray i   rad_rgb[(g*n + i)*24 + {0,8,16} + j] = r, g, b   and   rad_dd[(g*n + i)*16 + {0,8} + j] = d, d*d
-// of probe 8g + j, with d = min(first-hit distance, 1.5 * spacing).  One ray's values for 8 probes
-// are contiguous, so the blend reads them with scalar loads (they are uniform across its texel lanes).
-// A ray's record id is  (g*n + i)*8 + j.
-constexpr int kRecGroup = 8;
+// DDGI-mode ray records, laid out as the B operand of the blend's MFMA contraction (ddgi_blend_sample.hip): for local
+// probe pl (the slab's (y, zl, x) enumeration) and ray i of n_pad (n rounded up to kRecRayPad; the padding stays zero)
+//     rad_dd [(pl >> 4) * n_pad * 32 + mfma_operand_offset(i, ch * 16 + (pl & 15))]   ch: 0 = d, 1 = d * d,  d = min(first-hit distance, 1.5 * spacing)
+//     rad_rgb[((pl >> 5) * 3 + ch) * n_pad * 32 + mfma_operand_offset(i, pl & 31)]    ch: r, g, b
+// One v_mfma_f32_32x32x2_f32 consumes, per lane l, the operand element (k = ray 2q + (l >> 5), column l & 31) of ray
+// pair q.  mfma_operand_offset stores, for every lane, the elements of FOUR consecutive ray pairs next to each other:
+// a lane fetches 4 MFMAs' worth of operand with one 16-byte load and a wave reads 1 KB contiguous.
+constexpr uint32_t kRecRayPad = 32;  // 16 ray pairs: the chunk the blend kernels stage and prefetch
+inline __host__ __device__ uint32_t rec_ray_pad(uint32_t n) { return (n + kRecRayPad - 1) / kRecRayPad * kRecRayPad; }
+// element (k index i, row-or-column j in [0, 32)) of a 32-wide MFMA operand stream: [i / 8][lane = (i & 1) * 32 + j][(i / 2) & 3]
+inline __host__ __device__ size_t mfma_operand_offset(uint32_t i, uint32_t j)
+{
+    return ((static_cast<size_t>(i >> 3) * 64 + (i & 1u) * 32 + j) * 4) + ((i >> 1) & 3u);
+}
+inline __host__ __device__ size_t rec_dd_index(uint32_t pl, uint32_t i, uint32_t n_pad, uint32_t ch)
+{
+    return static_cast<size_t>(pl >> 4) * n_pad * 32 + mfma_operand_offset(i, ch * 16 + (pl & 15u));
+}
+inline __host__ __device__ size_t rec_rgb_index(uint32_t pl, uint32_t i, uint32_t n_pad, uint32_t ch)
+{
+    return (static_cast<size_t>(pl >> 5) * 3 + ch) * n_pad * 32 + mfma_operand_offset(i, pl & 31u);
+}
+inline size_t rec_dd_floats(uint32_t n_local_probes, uint32_t n) { return static_cast<size_t>((n_local_probes + 15u) / 16u) * rec_ray_pad(n) * 32; }
+inline size_t rec_rgb_floats(uint32_t n_local_probes, uint32_t n) { return static_cast<size_t>((n_local_probes + 31u) / 32u) * 3 * rec_ray_pad(n) * 32; }
 
 // k_probe_blend: per-probe update of the octahedral irradiance / depth-moment tiles
 struct BlendArgs
 {
     GridK grid;
     float rot[9];
-    const float* rad_rgb;  // ray records of the local slab (probes in (y, zl, x) order), see kRecGroup
+    const float* rad_rgb;  // ray records of the local slab (probes in (y, zl, x) order), see rec_rgb_index / rec_dd_index
     const float* rad_dd;
     float* irradiance;       // full-grid slab-major [cz][cy][cx][8][8][4]: the tiles this update writes
     float* depth;            // full-grid slab-major [cz][cy][cx][16][16][2]
     const float* irradiance_old;  // the previous update's tiles the hysteresis mixes with: the same buffers, or — when the
     const float* depth_old;       // multi-GPU exchange is pipelined (ddgi_exchange.cpp) — the other buffer pair
     uint32_t n_local_probes;
-    float* w;      // per-update texel weights [ray][256 texel columns] (k_blend_weights), or null
-    float* w_sum;  // [256] weight sum per texel column
+    float* w;      // per-update texel weights as MFMA A tiles (k_blend_weights; ddgi_blend_sample.hip: weight_index), or null
+    float* w_sum;  // [256] weight sum per texel column: [0,196) depth texels, [196,232) irradiance texels
 };
 
 struct SampleArgs

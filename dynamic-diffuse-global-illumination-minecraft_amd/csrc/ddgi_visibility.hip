@@ -36,25 +36,38 @@ constexpr double kVisEps = 1.0e-4;     // tube around the exact bundle that cont
 constexpr int kVisMaxCrossings = 110;  // boundary crossings to a blocking layer (grid_march: 125 iterations)
 constexpr double kVisMinRange = 4.0;   // lights closer than this along the dominant axis: not classified
 constexpr double kVisMaxRange = 400.0;
+constexpr int kVisLanes = 16;          // lanes that share one voxel's layers
 
-DDGI_D bool vis_occupied(const SceneK& S, int x, int y, int z)
+DDGI_D bool vis_occupied(const SceneK& S, const uint32_t* __restrict__ bits, int x, int y, int z)
 {
     const int idx = cell_index(S, x, y, z);  // clamped: outside the box the world is the extrusion of the border layer
-    return ((S.bits[(idx >> 5) - (S.bias32 >> 5)] >> (idx & 31)) & 1u) != 0u;
+    return ((bits[(idx >> 5) - (S.bias32 >> 5)] >> (idx & 31)) & 1u) != 0u;
 }
 
-__global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const double lx, const double ly, const double lz, uint8_t* __restrict__ out, const int n_vox)
+// list: the voxels that can hold a feeler origin — empty, with an occupied face neighbour (the origin is 1e-3 off the face
+// that was hit); built once per scene on the host (ddgi_engine.cpp: ensure_scene).  Every other voxel keeps class 0.
+// kLds: the occupancy bitmap is copied to LDS first (a thread makes several hundred dependent lookups)
+template <bool kLds>
+__global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const double lx, const double ly, const double lz, const int32_t* __restrict__ list,
+                                                          const int n_list, uint8_t* __restrict__ out)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_vox) return;
+    extern __shared__ uint32_t vis_lds[];
+    const uint32_t* __restrict__ bits = S.bits;
+    if (kLds)
+    {
+        for (int i = threadIdx.x; i < S.nwords; i += blockDim.x) vis_lds[i] = S.bits[i];
+        __syncthreads();
+        bits = vis_lds;
+    }
+    // kVisLanes lanes per voxel: the layers between the voxel and the light are independent tests, dealt round robin to the
+    // lanes of a group and joined with an OR / AND across the group (a single lane walking ~60 layers was 150 us per update)
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) / kVisLanes, sub = threadIdx.x % kVisLanes;
+    const bool live = t < n_list;  // (no early return: the group shuffles below need every lane)
+    const int r = list[live ? t : n_list - 1];
     const int ny = S.nxy / S.nx;
     int v[3] = {S.lo[0] + r % S.nx, S.lo[1] + (r / S.nx) % ny, S.lo[2] + r / S.nxy};
     uint8_t cls = kVisUnknown;
-    // only empty voxels with an occupied face neighbour can hold a feeler origin (1e-3 off the face that was hit)
-    bool relevant = !vis_occupied(S, v[0], v[1], v[2]);
-    if (relevant)
-        relevant = vis_occupied(S, v[0] - 1, v[1], v[2]) || vis_occupied(S, v[0] + 1, v[1], v[2]) || vis_occupied(S, v[0], v[1] - 1, v[2]) ||
-                   vis_occupied(S, v[0], v[1] + 1, v[2]) || vis_occupied(S, v[0], v[1], v[2] - 1) || vis_occupied(S, v[0], v[1], v[2] + 1);
+    const bool relevant = true;
     const double L[3] = {lx, ly, lz};
     double lo0[3], hi0[3];
     int a = 0;
@@ -72,7 +85,7 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
         const int sgn = L[a] > hi0[a] ? 1 : -1;
         const int n_a = v[a], m_a = static_cast<int>(ceil(L[a]));
         bool all_empty = true, blocked = false;
-        for (int i = n_a; sgn > 0 ? i <= m_a : i >= m_a; i += sgn)
+        for (int i = n_a + sgn * sub; sgn > 0 ? i <= m_a : i >= m_a; i += sgn * kVisLanes)
         {
             // s-range over which the cross-section X(s) reaches into layer i = (i-1, i] (widened by kVisEps)
             double s_in, s_out;
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
                         layer_full = false;  // the start voxel itself: empty, and never looked up by the march
                         continue;
                     }
-                    const bool occ = vis_occupied(S, w[0], w[1], w[2]);
+                    const bool occ = vis_occupied(S, bits, w[0], w[1], w[2]);
                     all_empty = all_empty && !occ;
                     layer_full = layer_full && occ;
                 }
@@ -116,18 +129,33 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
             const int lat_b = max(abs(w0[0] - v[b]), abs(w1[0] - v[b])), lat_c = max(abs(w0[1] - v[c]), abs(w1[1] - v[c]));
             const int crossings = from_start + lat_b + lat_c + 2;
             if (layer_full && from_start >= 1 && crossings <= kVisMaxCrossings && to_light >= 3) blocked = true;
-            if (blocked || (!all_empty && crossings > kVisMaxCrossings)) break;  // decided, or can no longer be decided
+            if (blocked || (!all_empty && crossings > kVisMaxCrossings)) break;  // this lane's layers: decided, or can no longer decide
         }
         cls = blocked ? kVisShadow : (all_empty ? kVisLit : kVisUnknown);
     }
-    out[r] = cls;
+    // join the group: any lane blocked -> SHADOW; every lane all-empty -> LIT; else UNKNOWN.  (A voxel out of range has
+    // cls == kVisUnknown in every lane.)
+    unsigned any_shadow = cls == kVisShadow ? 1u : 0u, all_lit = cls == kVisLit ? 1u : 0u;
+#pragma unroll
+    for (int m = 1; m < kVisLanes; m <<= 1)
+    {
+        any_shadow |= static_cast<unsigned>(__shfl_xor(static_cast<int>(any_shadow), m));
+        all_lit &= static_cast<unsigned>(__shfl_xor(static_cast<int>(all_lit), m));
+    }
+    if (live && sub == 0) out[r] = any_shadow ? kVisShadow : (all_lit ? kVisLit : kVisUnknown);
 }
 
-hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], uint8_t* out, int n_vox, hipStream_t stream)
+hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], const int32_t* list, int n_list, uint8_t* out, hipStream_t stream)
 {
-    if (n_vox <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_light_visibility, dim3((n_vox + 255) / 256), dim3(256), 0, stream, scene, static_cast<double>(light_pos[0]), static_cast<double>(light_pos[1]),
-                       static_cast<double>(light_pos[2]), out, n_vox);
+    if (n_list <= 0) return hipSuccess;
+    const size_t lds = static_cast<size_t>(scene.nwords) * sizeof(uint32_t);
+    const int per_block = 256 / kVisLanes;  // voxels per 256-thread block
+    if (lds <= 64 * 1024)
+        hipLaunchKernelGGL(k_light_visibility<true>, dim3((n_list + per_block - 1) / per_block), dim3(256), lds, stream, scene, static_cast<double>(light_pos[0]), static_cast<double>(light_pos[1]),
+                           static_cast<double>(light_pos[2]), list, n_list, out);
+    else
+        hipLaunchKernelGGL(k_light_visibility<false>, dim3((n_list + per_block - 1) / per_block), dim3(256), 0, stream, scene, static_cast<double>(light_pos[0]), static_cast<double>(light_pos[1]),
+                           static_cast<double>(light_pos[2]), list, n_list, out);
     return hipGetLastError();
 }
 
