@@ -197,14 +197,32 @@ DDGI_D void stage_tile(float* stage, const f16v& acc, int col, int half)
 }
 
 // depth: workgroup = 7 waves, wave m = depth tile m of the 16 probes of a group; B columns = moment * 16 + probe
-__global__ __launch_bounds__(kBlendWaves * 64) void k_probe_blend_depth(const BlendArgs A, const float* __restrict__ rad_dd, const float* __restrict__ w_tiles,
-                                                                        const float* __restrict__ w_sum)
+struct DepthShared
+{
+    float4 b_stage[2][256];  // the group's records, 16 ray pairs (256 float4) at a time, double buffered: all seven waves
+                             // consume the same B operand — fetched from L2 once per workgroup, not once per wave
+    float stage_all[kBlendWaves][32 * kStageStride];
+    uint32_t slot_sh[16];  // tile slots of the group's probes (through LDS, not readlane: the epilogue runs under a partial exec mask)
+};
+struct IrrShared
+{
+    float stage_all[kIrrMTiles][3][32 * kStageStride];
+    uint32_t slot_sh[32];
+};
+union BlendShared
+{
+    DepthShared dep;
+    IrrShared irr;
+};
+
+// depth groups: block = first_block + k * n_blocks handles groups k
+DDGI_D void blend_depth_role(const BlendArgs& A, const float* __restrict__ rad_dd, const float* __restrict__ w_tiles, const float* __restrict__ w_sum, DepthShared& sh,
+                             uint32_t first_task, uint32_t task_stride)
 {
     static_assert(kRecRayPad % 32 == 0, "the contraction consumes 16 ray pairs per chunk");
-    __shared__ float stage_all[kBlendWaves][32 * kStageStride];
-    __shared__ uint32_t slot_sh[16];  // tile slots of the group's probes (through LDS, not readlane: the epilogue runs under a partial exec mask)
-    __shared__ float4 b_stage[2][256];  // the group's records, 16 ray pairs (256 float4) at a time, double buffered: all seven waves
-                                        // consume the same B operand — fetched from L2 once per workgroup, not once per wave
+    auto& stage_all = sh.stage_all;
+    auto& slot_sh = sh.slot_sh;
+    auto& b_stage = sh.b_stage;
     const GridK& G = A.grid;
     const int n_pad = static_cast<int>(rec_ray_pad(static_cast<uint32_t>(G.n))), q_pairs = n_pad / 2;
     const int mt = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -221,7 +239,7 @@ __global__ __launch_bounds__(kBlendWaves * 64) void k_probe_blend_depth(const Bl
         blend_destinations(1 + c % (kDepTile - 2), 1 + c / (kDepTile - 2), kDepTile, dst);
         sw = w_sum[c];
     }
-    for (uint32_t task = blockIdx.x; task < n_tasks; task += gridDim.x)
+    for (uint32_t task = first_task; task < n_tasks; task += task_stride)
     {
         // ---- contraction: acc = W tile x records, ray pairs in order ----
         f16v acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -289,11 +307,11 @@ __global__ __launch_bounds__(kBlendWaves * 64) void k_probe_blend_depth(const Bl
 // stores.  (Six waves per group — one per (channel, tile) — were slower: 55 us against 38 us on 16 384 probes; the
 // contraction is bound by requests in flight to L2 / HBM, not by the matrix pipe.)
 constexpr int kIrrWaves = kIrrMTiles;
-__global__ __launch_bounds__(kIrrWaves * 64) void k_probe_blend_irr(const BlendArgs A, const float* __restrict__ rad_rgb, const float* __restrict__ w_tiles,
-                                                                    const float* __restrict__ w_sum)
+DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb, const float* __restrict__ w_tiles, const float* __restrict__ w_sum, IrrShared& sh,
+                           uint32_t first_task, uint32_t task_stride)
 {
-    __shared__ float stage_all[kIrrMTiles][3][32 * kStageStride];
-    __shared__ uint32_t slot_sh[32];
+    auto& stage_all = sh.stage_all;
+    auto& slot_sh = sh.slot_sh;
     const GridK& G = A.grid;
     const int n_pad = static_cast<int>(rec_ray_pad(static_cast<uint32_t>(G.n))), q_pairs = n_pad / 2;
     const int mi = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -310,7 +328,7 @@ __global__ __launch_bounds__(kIrrWaves * 64) void k_probe_blend_irr(const BlendA
         blend_destinations(1 + c % (kIrrTile - 2), 1 + c / (kIrrTile - 2), kIrrTile, dst);
         sw = w_sum[kDepInterior + c];
     }
-    for (uint32_t task = blockIdx.x; task < n_tasks; task += gridDim.x)
+    for (uint32_t task = first_task; task < n_tasks; task += task_stride)
     {
         const float* wa = w_tiles + static_cast<size_t>(kDepMTiles + mi) * n_pad * 32 + lane * 4;
         const float* vb = rad_rgb + static_cast<size_t>(task) * 3 * n_pad * 32 + lane * 4;
@@ -339,6 +357,36 @@ __global__ __launch_bounds__(kIrrWaves * 64) void k_probe_blend_irr(const BlendA
                     if (dst[k] >= 0) *reinterpret_cast<float4*>(tile + dst[k] * 4) = out;
             }
     }
+}
+
+// Many probes: one launch each (the irradiance workgroups are two waves).
+__global__ __launch_bounds__(kBlendWaves * 64) void k_probe_blend_depth(const BlendArgs A, const float* __restrict__ rad_dd, const float* __restrict__ w_tiles,
+                                                                        const float* __restrict__ w_sum)
+{
+    __shared__ DepthShared sh;
+    blend_depth_role(A, rad_dd, w_tiles, w_sum, sh, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(kIrrWaves * 64) void k_probe_blend_irr(const BlendArgs A, const float* __restrict__ rad_rgb, const float* __restrict__ w_tiles,
+                                                                    const float* __restrict__ w_sum)
+{
+    __shared__ IrrShared sh;
+    blend_irr_role(A, rad_rgb, w_tiles, w_sum, sh, blockIdx.x, gridDim.x);
+}
+
+// Few probes (one rank's slab of a sharded grid: fewer groups than the chip has room for): one launch for both — blocks
+// [0, irr_blocks) take irradiance groups with their first two waves (the other five leave at once), the rest take depth
+// groups: the two contractions are bound by their own latency there and overlap instead of running one after the other
+// (2 048 probes: 51 -> 28 us; with 16 384 probes the half-empty irradiance workgroups cost more than the overlap gains).
+__global__ __launch_bounds__(kBlendWaves * 64) void k_probe_blend_mfma(const BlendArgs A, const float* __restrict__ rad_rgb, const float* __restrict__ rad_dd,
+                                                                       const float* __restrict__ w_tiles, const float* __restrict__ w_sum, const uint32_t irr_blocks)
+{
+    __shared__ BlendShared sh;
+    if (blockIdx.x < irr_blocks)
+    {
+        if (threadIdx.x < kIrrWaves * 64) blend_irr_role(A, rad_rgb, w_tiles, w_sum, sh.irr, blockIdx.x, irr_blocks);
+    }
+    else
+        blend_depth_role(A, rad_dd, w_tiles, w_sum, sh.dep, blockIdx.x - irr_blocks, gridDim.x - irr_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -476,10 +524,17 @@ hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t st
     if (args.w && args.w_sum)
     {
         const uint32_t dep_tasks = (args.n_local_probes + 15u) / 16u, irr_tasks = (args.n_local_probes + 31u) / 32u;
-        hipLaunchKernelGGL(k_probe_blend_depth, dim3(std::min<uint32_t>(dep_tasks, static_cast<uint32_t>(num_cus) * 8u)), dim3(kBlendWaves * 64), 0, stream, args, args.rad_dd,
-                           static_cast<const float*>(args.w), static_cast<const float*>(args.w_sum));
-        hipLaunchKernelGGL(k_probe_blend_irr, dim3(std::min<uint32_t>(irr_tasks, static_cast<uint32_t>(num_cus) * 16u)), dim3(kIrrWaves * 64), 0, stream, args, args.rad_rgb,
-                           static_cast<const float*>(args.w), static_cast<const float*>(args.w_sum));
+        const uint32_t dep_blocks = std::min<uint32_t>(dep_tasks, static_cast<uint32_t>(num_cus) * 8u), irr_blocks = std::min<uint32_t>(irr_tasks, static_cast<uint32_t>(num_cus) * 16u);
+        if (dep_tasks <= static_cast<uint32_t>(num_cus) * 2u)
+            hipLaunchKernelGGL(k_probe_blend_mfma, dim3(irr_blocks + dep_blocks), dim3(kBlendWaves * 64), 0, stream, args, args.rad_rgb, args.rad_dd, static_cast<const float*>(args.w),
+                               static_cast<const float*>(args.w_sum), irr_blocks);
+        else
+        {
+            hipLaunchKernelGGL(k_probe_blend_depth, dim3(dep_blocks), dim3(kBlendWaves * 64), 0, stream, args, args.rad_dd, static_cast<const float*>(args.w),
+                               static_cast<const float*>(args.w_sum));
+            hipLaunchKernelGGL(k_probe_blend_irr, dim3(irr_blocks), dim3(kIrrWaves * 64), 0, stream, args, args.rad_rgb, static_cast<const float*>(args.w),
+                               static_cast<const float*>(args.w_sum));
+        }
         return hipGetLastError();
     }
     const size_t lds = (static_cast<size_t>(7) * n + kIrrTile * kIrrTile * 4 + kDepTile * kDepTile * 2) * sizeof(float);
