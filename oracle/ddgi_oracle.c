@@ -1318,6 +1318,10 @@ int oracle_grid_march(const float* o, const float* d, int scene, float* out, int
     return block;
 }
 
+/* KAT helpers for tests/test_independent_restatement.py: the two chaotic pieces on their own */
+float oracle_fbm(float x, float y) { return fbm(x, y); }
+float oracle_interp_noise2d(float x, float y) { return interpNoise2D(x, y); }
+
 /* KAT helper: getColorAt */
 void oracle_get_color_at(const float* point, int type, const float* normal, float* rgb)
 {
