@@ -1245,6 +1245,7 @@ int ddgi_render_device(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_
     r.pinhole_w = 1.0f / (pm::sinf_pinned(half) / pm::cosf_pinned(half));  // P6: tan := sin / cos
     r.camera_mode = st->camera_mode;
     r.render_mode = st->render_mode;
+    r.visualize_probes = st->visualize_probes;
     r.width = st->screen_width;
     r.height = st->screen_height;
     if (e->mode == DDGI_MODE_DDGI)

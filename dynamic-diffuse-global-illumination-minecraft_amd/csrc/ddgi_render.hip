@@ -4,7 +4,11 @@
 // integrators (integrators.glsl:27-271, dispatched by compute_pass.comp:58-87): 0 DDGI (direct +
 // probe-field indirect), 1 direct, 2 indirect, 3 colour, 4 normal, 5 reciprocal depth.  The
 // indirect term is the same per-point cage sample the batched kernels use (ddgi_sampler.h), in
-// whichever mode the engine is in.  Probe visualisation (intersect_probes) is not implemented.
+// whichever mode the engine is in.  RenderSettings::visualize_probes draws the probes as spheres
+// (intersect_probes, intersection.glsl:1102-1128, for integrators 0 and 2, integrators.glsl:45-65, 180-199).
+// Debug views: render_mode 6 = the whole probe texture on screen (the reference's dormant
+// get_probe_image_coords blit, compute_pass.comp:116-124, 185-190), 7 = the cage's first probe index as a colour
+// (README.md:89-91).
 #include "ddgi_device.h"
 #include "ddgi_sampler.h"
 
@@ -87,6 +91,36 @@ DDGI_D int direct_light(const Hit& info, const TraceArgs& T, const uint32_t* s_b
     return nvis;
 }
 
+// sceneSDF / opRepLim (intersection.glsl:333-347): distance to the nearest probe sphere (radius 0.2) of the clamped
+// lattice c * clamp(round(p / c), -l, l), l = vec3(probeCount / 2) (integer division); round(): nearest-even (pinned)
+DDGI_D float probes_sdf(const GridK& G, f3 point)
+{
+    const f3 p = point - f3{G.origin[0], G.origin[1], G.origin[2]};
+    const float c = static_cast<float>(G.side);
+    const float qx = p.x - c * gl_clamp(rintf(p.x / c), -static_cast<float>(G.cx / 2), static_cast<float>(G.cx / 2));
+    const float qy = p.y - c * gl_clamp(rintf(p.y / c), -static_cast<float>(G.cy / 2), static_cast<float>(G.cy / 2));
+    const float qz = p.z - c * gl_clamp(rintf(p.z / c), -static_cast<float>(G.cz / 2), static_cast<float>(G.cz / 2));
+    return length3(f3{qx, qy, qz}) - 0.2f;
+}
+
+// implicit_surface (intersection.glsl:367-392): sphere tracing while curr_t < 100 along normalize(direction)
+DDGI_D bool probes_hit(const GridK& G, f3 o, f3 d, float& t_out)
+{
+    const f3 dir = normalize3(d);
+    float t = 0.0f;
+    while (t < 100.0f)
+    {
+        const float dist = probes_sdf(G, ray_at(o, dir, t));
+        if (dist < 0.001f)
+        {
+            t_out = t;
+            return true;
+        }
+        t += dist;
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(256) void k_render_primary(const RenderArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t render_lds[];
@@ -123,15 +157,51 @@ __global__ __launch_bounds__(256) void k_render_primary(const RenderArgs A)
         rd = normalize3(mul(u, v, A.pinhole_w, 0.0f));
     }
 
+    if (A.render_mode == 6)  // the probe texture on screen (REF mode; get_probe_image_coords works on the unflipped pixel)
+    {
+        f3 texel = mk3(0, 0, 0);
+        const GridK& G = T.grid;
+        const int W = G.cx * G.cz * G.sx, H = G.cy * G.sy;
+        const int tx = gl_int((static_cast<float>(px) * static_cast<float>(W)) / static_cast<float>(A.width));
+        const int ty = gl_int((static_cast<float>(py) * static_cast<float>(H)) / static_cast<float>(A.height));
+        if (A.albedo && tx >= 0 && tx < W && ty >= 0 && ty < H)
+        {
+            // raster (tx, ty) -> probe p = row * cx*cz + column, texel inside its tile -> the slab-major buffer
+            const int p = (ty / G.sy) * (G.cx * G.cz) + tx / G.sx;
+            texel = load_rgb(A.albedo, static_cast<size_t>(slab_slot(G, p)) * G.n + (ty % G.sy) * G.sx + tx % G.sx, s_unorm);
+        }
+        A.rgba8[k] = unorm8(texel.x) | (unorm8(texel.y) << 8) | (unorm8(texel.z) << 16) | (255u << 24);
+        if (A.rgb_f32) A.rgb_f32[3 * k] = texel.x, A.rgb_f32[3 * k + 1] = texel.y, A.rgb_f32[3 * k + 2] = texel.z;
+        return;
+    }
     const Hit info = intersect_scene_dev(ro, rd, T, s_bits, true);
     f3 out = mk3(0, 0, 0);
     int cage[8];
+    bool probe_seen = false;
+    if (A.visualize_probes && (A.render_mode == 0 || A.render_mode == 2))
+    {
+        float pt;
+        probe_seen = probes_hit(T.grid, ro, rd, pt) && pt < info.t;  // (info.t is INF when nothing was hit)
+    }
     auto gi = [&]() {
         return A.irradiance ? diffuse_gi_ddgi(T.grid, A.irradiance, A.depth, info.pos, info.normal, cage)
                             : diffuse_gi_ref(T.grid, A.albedo, info.pos, info.normal, s_unorm, cage);
     };
-    switch (A.render_mode)
+    if (probe_seen) out = mk3(0, 1, 1);  // probe colour, integrators.glsl:65,199
+    else switch (A.render_mode)
     {
+        case 7:  // the cage's first probe index as a colour; magenta outside the field
+            if (info.any)
+            {
+                (void)gi();
+                if (cage[0] < 0) out = mk3(1, 0, 1);
+                else
+                {
+                    const uint32_t h = (static_cast<uint32_t>(cage[0]) * 2654435761u) & 0xffffffu;
+                    out = f3{static_cast<float>((h >> 16) & 255u) / 255.0f, static_cast<float>((h >> 8) & 255u) / 255.0f, static_cast<float>(h & 255u) / 255.0f};
+                }
+            }
+            break;
         case 1:
         {
             f3 direct;

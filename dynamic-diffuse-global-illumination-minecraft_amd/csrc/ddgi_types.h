@@ -162,7 +162,8 @@ struct RenderArgs
     float cam_params[4];   // aspect, hfov, ortho scale, 0
     float pinhole_w;       // 1 / tan(hfov / 2), pinned tan = sin / cos, evaluated on the host
     int camera_mode;       // 0 pinhole, 1 ortho
-    int render_mode;       // integrator index, compute_pass.comp:58-87
+    int render_mode;       // integrator index, compute_pass.comp:58-87; 6 probe-texture blit, 7 cage-index colours (debug views)
+    int visualize_probes;  // RenderSettings::visualize_probes: probes drawn as spheres (integrators.glsl:45-65)
     int width, height;
     const uint32_t* albedo;   // REF mode probe texture (slab-major)
     const float* irradiance;  // DDGI mode tiles; null in REF mode

@@ -36,7 +36,8 @@ def dump_probe_textures(engine, prefix):
 
 
 def cage_debug_image(cage_idx8, height, width):
-    """Colour each shading point by its cage's base probe index (corner 0); magenta outside the field."""
+    """Colour each shading point by its cage's base probe index (corner 0); magenta outside the field.
+    (Host-side twin of ddgi_render's render_mode 7, for cage indices that come from ddgi_sample.)"""
     base = np.asarray(cage_idx8, dtype=np.int64).reshape(height, width, 8)[..., 0]
     h = (base * 2654435761) & 0xFFFFFF
     img = np.stack([(h >> 16) & 255, (h >> 8) & 255, h & 255, np.full_like(h, 255)], axis=-1).astype(np.uint8)

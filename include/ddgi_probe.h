@@ -53,10 +53,10 @@ typedef struct ddgi_render_settings
     int32_t screen_height;    /* unused by the probe path */
     int32_t max_bounces;      /* default 8 */
     int32_t camera_mode;      /* unused */
-    int32_t render_mode;      /* unused */
+    int32_t render_mode;      /* unused by the probe update; ddgi_render: the integrator */
     int32_t scene;            /* 0 cave, 1 Cornell box, 2 house */
     float time;               /* +2 per frame (rvpt.cpp:281); only animated lights read it */
-    int32_t visualize_probes; /* unused */
+    int32_t visualize_probes; /* unused by the probe update; ddgi_render: probes drawn as spheres */
 } ddgi_render_settings;
 
 /* struct ProbeRay, src/rvpt/probe.h:5-19 == structs.glsl:22-27 (std430), 48 B */
@@ -270,8 +270,13 @@ typedef struct ddgi_camera
  * (camera.glsl:29-74; settings->camera_mode 0 pinhole, 1 ortho) + eval_integrator
  * (compute_pass.comp:58-87; settings->render_mode 0 DDGI, 1 direct, 2 indirect, 3 colour, 4 normal,
  * 5 depth) over a screen_width x screen_height image, using the handle's current probe textures in
- * its current mode.  Output: rgba8 (the reference's result_image format), row 0 = top; optional
- * unquantised rgb (3 floats per pixel).  Probe visualisation is not implemented.  Synchronises. */
+ * its current mode.  settings->visualize_probes != 0 draws the probes as spheres in modes 0 and 2
+ * (intersect_probes, intersection.glsl:1102-1128; integrators.glsl:45-65, 180-199).  Two debug views
+ * (SURVEY.md 8(f) row 2): render_mode 6 = the whole REF probe texture stretched over the screen (the
+ * reference's dormant get_probe_image_coords blit, compute_pass.comp:116-124, 185-190), render_mode 7 =
+ * the first probe index of every pixel's cage as a colour, magenta outside the field (README.md:89-91).
+ * Output: rgba8 (the reference's result_image format), row 0 = top; optional unquantised rgb
+ * (3 floats per pixel).  Synchronises. */
 int ddgi_render(ddgi_handle h, const ddgi_camera* camera, const ddgi_render_settings* settings,
                 uint8_t* rgba8_out, float* rgb_f32_out);
 /* Same on device pointers, asynchronous on the handle's stream. */

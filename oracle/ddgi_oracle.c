@@ -2001,14 +2001,88 @@ static int render_direct(const TraceCtx* cx, const Isect* info, v3* direct)
     return nvis;
 }
 
-/* eval_integrator, compute_pass.comp:58-87 */
-static v3 eval_integrator(const TraceCtx* cx, const RenderProbes* rp, int idx, Ray ray)
+/* Probe visualisation (render_settings.visualize_probes; integrators.glsl:45-65, 180-199): the probes as spheres of
+ * radius 0.2, sphere-traced.  sceneSDF / opRepLim, intersection.glsl:333-347: the nearest probe of the (clamped)
+ * lattice  c * clamp(round(p / c), -l, l),  l = vec3(probeCount / 2) (integer division).  GLSL leaves round()'s
+ * handling of .5 to the implementation: pinned to nearest-even. */
+static float probes_sdf(const o_field* f, v3 point)
 {
+    v3 p = vsub(point, V3(f->field_origin[0], f->field_origin[1], f->field_origin[2]));
+    float c = (float)f->side_length;
+    float l[3] = {(float)(f->probe_count[0] / 2), (float)(f->probe_count[1] / 2), (float)(f->probe_count[2] / 2)};
+    float pv[3] = {p.x, p.y, p.z}, q[3];
+    for (int k = 0; k < 3; k++)
+    {
+        float r = rintf(pv[k] / c);
+        r = gclamp(r, -l[k], l[k]);
+        q[k] = pv[k] - c * r;
+    }
+    return length3(V3(q[0], q[1], q[2])) - 0.2f;
+}
+
+/* implicit_surface, intersection.glsl:367-392: marches while curr_t < 100 along normalize(direction) */
+static int probes_hit(const o_field* f, Ray ray, float* t_out)
+{
+    v3 dir = normalize3(ray.d);
+    float t = 0.0f;
+    while (t < 100.0f)
+    {
+        float dist = probes_sdf(f, ray_at(ray.o, dir, t));
+        if (dist < 0.001f)
+        {
+            *t_out = t;
+            return 1;
+        }
+        t += dist;
+    }
+    return 0;
+}
+
+/* eval_integrator, compute_pass.comp:58-87; render modes 6 and 7 are the debug views of SURVEY.md 8(f) row 2 */
+static v3 eval_integrator(const TraceCtx* cx, const RenderProbes* rp, const o_settings* st, Ray ray, int px, int py)
+{
+    int idx = st->render_mode;
+    if (idx == 6)
+    {
+        /* the whole probe texture on screen: get_probe_image_coords + imageLoad(probe_image_albedo), compute_pass.comp:116-124,
+         * 185-190 (dormant in the reference: "change sampled to probe ... if you want to see the texture") */
+        if (rp->ddgi_mode) return V3(0, 0, 0);
+        int W = rp->f->probe_count[0] * rp->f->probe_count[2] * tile_w(rp->f), H = rp->f->probe_count[1] * tile_h(rp->f);
+        int tx = gint(((float)px * (float)W) / (float)st->screen_width), ty = gint(((float)py * (float)H) / (float)st->screen_height);
+        if (tx < 0 || tx >= W || ty < 0 || ty >= H) return V3(0, 0, 0);
+        return image_load(rp->albedo, W, tx, ty);
+    }
     Isect info;
     int hit = intersect_scene(cx, ray, &info);
     v3 direct;
+    if (st->visualize_probes && (idx == 0 || idx == 2))
+    {
+        float pt;
+        if (probes_hit(rp->f, ray, &pt) && pt < info.t) return V3(0, 1, 1); /* probe colour, integrators.glsl:65,199 */
+    }
     switch (idx)
     {
+        case 7: /* the cage's first probe index as a colour (README.md:89-91, "probe_vicinity_debug"); magenta outside the field */
+        {
+            if (!hit) return V3(0, 0, 0);
+            int32_t cage[8];
+            if (rp->ddgi_mode)
+            {
+                float p[3] = {info.pos.x, info.pos.y, info.pos.z}, n[3] = {info.normal.x, info.normal.y, info.normal.z}, out[3];
+                oracle_ddgi_sample(rp->f, rp->irradiance, rp->depth, p, n, 1, out, cage);
+            }
+            else
+            {
+                SampleCtx sc;
+                sc.f = rp->f, sc.albedo = rp->albedo, sc.distance = rp->distance;
+                sc.W = rp->f->probe_count[0] * rp->f->probe_count[2] * tile_w(rp->f);
+                sc.H = rp->f->probe_count[1] * tile_h(rp->f);
+                get_diffuse_gi(&sc, info.pos, info.normal, cage);
+            }
+            if (cage[0] < 0) return V3(1, 0, 1);
+            uint32_t h = ((uint32_t)cage[0] * 2654435761u) & 0xffffffu;
+            return V3((float)((h >> 16) & 255u) / 255.0f, (float)((h >> 8) & 255u) / 255.0f, (float)(h & 255u) / 255.0f);
+        }
         case 1: /* integrator_direct :108-158 */
         {
             if (!hit) return V3(0, 0, 0);
@@ -2066,7 +2140,7 @@ void oracle_render(const o_field* f, const o_settings* st, const o_camera* cam, 
         float cxn = (float)px / (float)width;
         float cyn = 1.0f - (float)py / (float)height; /* flip image vertically */
         Ray ray = camera_ray(cam, st->camera_mode, cxn, cyn);
-        v3 c = eval_integrator(&cx, &rp, st->render_mode, ray);
+        v3 c = eval_integrator(&cx, &rp, st, ray, px, py);
         if (rgb_f32) rgb_f32[3 * k] = c.x, rgb_f32[3 * k + 1] = c.y, rgb_f32[3 * k + 2] = c.z;
         rgba8[4 * k] = unorm8(c.x), rgba8[4 * k + 1] = unorm8(c.y), rgba8[4 * k + 2] = unorm8(c.z), rgba8[4 * k + 3] = 255;
     }
