@@ -492,8 +492,9 @@ __global__ __launch_bounds__(kBlendBlock) void k_probe_blend(const BlendArgs A)
 
 __global__ __launch_bounds__(256) void k_probe_sample_ddgi(const SampleArgs A)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n) return;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n) return;
+    const uint32_t i = A.perm ? A.perm[k] : k;
     int cage[8];
     const f3 out = diffuse_gi_ddgi(A.grid, A.irradiance, A.depth, f3{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]},
                                    f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]}, cage);

@@ -36,6 +36,8 @@ hipError_t launch_blend_weights(const BlendArgs& args, hipStream_t stream);
 hipError_t launch_carry_tiles(void* dst, const void* src, const int32_t* map, uint32_t n_probes, uint32_t words_per_tile, hipStream_t stream);
 hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream);
 hipError_t launch_render_primary(const RenderArgs& args, hipStream_t stream);
+size_t sample_group_scratch_words(uint32_t n, uint32_t n_probes);
+hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t n, uint32_t* scratch, const uint32_t** perm_out, hipStream_t stream);
 hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], const int32_t* list, int n_list, uint8_t* out, hipStream_t stream);
 
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes)
@@ -79,6 +81,7 @@ static const TuningKey kTuningKeys[] = {
     {"wf_drain", &Tuning::wf_drain, "DDGI_WF_DRAIN"},
     {"wait_threshold", &Tuning::wait_threshold, "DDGI_WAIT_THRESHOLD"},
     {"light_vis", &Tuning::light_vis, "DDGI_LIGHT_VIS"},
+    {"sample_group", &Tuning::sample_group, "DDGI_SAMPLE_GROUP"},
     {"noise_lut", &Tuning::noise_lut, nullptr},
     {"lut_off", &Tuning::lut_off, "DDGI_LUT_OFF"},
     {"verbose", &Tuning::verbose, "DDGI_VERBOSE"},
@@ -385,6 +388,7 @@ int ddgi_destroy(ddgi_handle e)
         if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_stats) (void)hipFree(e->d_stats);
+    if (e->d_sample_scratch) (void)hipFree(e->d_sample_scratch);
     if (e->d_blend_w) (void)hipFree(e->d_blend_w);
     if (e->d_work) (void)hipFree(e->d_work);
     if (e->d_wf_cold) (void)hipFree(e->d_wf_cold);
@@ -1158,6 +1162,19 @@ int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, si
     a.rgb = d_rgb;
     a.cage = d_cage;
     a.n = static_cast<uint32_t>(n);
+    if (e->tuning.sample_group && n >= 4096)  // a batch worth grouping by cage (small ones are launch-latency bound anyway)
+    {
+        const size_t words = sample_group_scratch_words(a.n, static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.cz);
+        if (words > e->sample_scratch_words)
+        {
+            HIP_TRY(hipStreamSynchronize(e->stream));  // (an earlier batch may still be using the old scratch)
+            if (e->d_sample_scratch) (void)hipFree(e->d_sample_scratch);
+            e->d_sample_scratch = nullptr, e->sample_scratch_words = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_sample_scratch), words * sizeof(uint32_t)));
+            e->sample_scratch_words = words;
+        }
+        HIP_TRY(launch_sample_grouping(a.grid, d_pos, a.n, e->d_sample_scratch, &a.perm, e->stream));
+    }
     if (e->mode == DDGI_MODE_DDGI)
     {
         a.irradiance = static_cast<const float*>(e->tex[0]);

@@ -25,6 +25,7 @@ struct Tuning
     int aq_pool = 0, wf_pool = 0, wf_maxpool = 0, wf_threads = 1024;
     int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
     int light_vis = 1;      // per-voxel light-feeler classes (k_light_visibility): 0 = march every feeler
+    int sample_group = 1;   // ddgi_sample*: handle the points of a batch cage by cage (0: in the order given)
     int noise_lut = 1;      // memoised lattice hashes (0: compute every hash)
     int lut_off = 0;        // profiling: 1 = no wall table, 2 = no random1 table
     int verbose = 0;
@@ -130,6 +131,8 @@ struct ddgi_engine
         int cur = 0;               // pair written by the most recent update
         unsigned long long k = 0;  // updates issued since ddgi_exchange_init
     } xch;
+    uint32_t* d_sample_scratch = nullptr;   // ddgi_sample_device: grouping of a batch by cage (ddgi_kernels.hip: k_sample_*)
+    size_t sample_scratch_words = 0;
     unsigned long long* d_stats = nullptr;  // profiling aid, allocated on first ddgi_trace_stats(enable)
 };
 

@@ -261,8 +261,9 @@ __global__ __launch_bounds__(256) void k_probe_sample_ref(const SampleArgs A)
     __shared__ float s_unorm[256];
     s_unorm[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;  // blockDim.x == 256
     __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= A.n) return;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= A.n) return;
+    const uint32_t i = A.perm ? A.perm[k] : k;
     int cage[8];
     const f3 out = diffuse_gi_ref(A.grid, A.albedo, f3{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]},
                                   f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]}, s_unorm, cage);
@@ -271,6 +272,60 @@ __global__ __launch_bounds__(256) void k_probe_sample_ref(const SampleArgs A)
     A.rgb[3 * i + 2] = out.z;
     if (A.cage)
         for (int k = 0; k < 8; ++k) A.cage[8 * i + k] = cage[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouping a batch of shading points by probe cage (a counting sort by the cage's first probe; order inside and
+// between the groups is arbitrary).  Points scattered over the grid share nothing between neighbouring lanes:
+// every lane pulls its own 8 tiles — 40 64-byte sectors per point in REF mode — through L2.  Handled cage by cage,
+// a group's lanes read the same 8 tiles out of L1.  Results do not depend on the order: each point's output is
+// written to its own index.
+//   k_sample_keys     key = slab-major slot of the cage's corner-0 probe (n_probes: outside the field); histogram
+//   k_sample_bins     every bin reserves a contiguous range of the permutation (one atomic per bin — no scan needed)
+//   k_sample_scatter  perm[range start + arrival number] = point
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample_keys(const GridK G, const float* __restrict__ pos, uint32_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ hist)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float side = static_cast<float>(G.side);
+    // (grouping only: any point lands in SOME bin; the sample kernels redo get_diffuse_gi's arithmetic exactly)
+    const int bx = gl_int(floorf((pos[3 * i] - G.origin[0]) / side)) + G.cx / 2;
+    const int by = gl_int(floorf((pos[3 * i + 1] - G.origin[1]) / side)) + G.cy / 2;
+    const int bz = gl_int(floorf((pos[3 * i + 2] - G.origin[2]) / side)) + G.cz / 2;
+    uint32_t key = static_cast<uint32_t>(G.cx) * G.cy * G.cz;
+    if (bx >= 0 && bx < G.cx && by >= 0 && by < G.cy && bz >= 0 && bz < G.cz) key = static_cast<uint32_t>((bz * G.cy + by) * G.cx + bx);
+    keys[i] = key;
+    atomicAdd(&hist[key], 1u);
+}
+__global__ __launch_bounds__(256) void k_sample_bins(uint32_t n_bins, const uint32_t* __restrict__ hist, uint32_t* __restrict__ start, uint32_t* __restrict__ cursor)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bins) return;
+    const uint32_t c = hist[b];
+    start[b] = c ? atomicAdd(cursor, c) : 0u;
+}
+__global__ __launch_bounds__(256) void k_sample_scatter(uint32_t n, const uint32_t* __restrict__ keys, uint32_t* __restrict__ start, uint32_t* __restrict__ perm)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    perm[atomicAdd(&start[keys[i]], 1u)] = i;  // (start doubles as the bin's fill pointer)
+}
+
+// scratch: keys[n] | perm[n] | hist[n_bins] | start[n_bins] | cursor[1]   (uint32 each)
+size_t sample_group_scratch_words(uint32_t n, uint32_t n_probes) { return 2 * static_cast<size_t>(n) + 2 * (static_cast<size_t>(n_probes) + 1) + 1; }
+
+hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t n, uint32_t* scratch, const uint32_t** perm_out, hipStream_t stream)
+{
+    const uint32_t n_bins = static_cast<uint32_t>(grid.cx) * grid.cy * grid.cz + 1u;
+    uint32_t *keys = scratch, *perm = keys + n, *hist = perm + n, *start = hist + n_bins, *cursor = start + n_bins;
+    hipError_t e = hipMemsetAsync(hist, 0, (2 * static_cast<size_t>(n_bins) + 1) * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sample_keys, dim3((n + 255u) / 256u), dim3(256), 0, stream, grid, pos, n, keys, hist);
+    hipLaunchKernelGGL(k_sample_bins, dim3((n_bins + 255u) / 256u), dim3(256), 0, stream, n_bins, hist, start, cursor);
+    hipLaunchKernelGGL(k_sample_scatter, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, keys, start, perm);
+    *perm_out = perm;
+    return hipGetLastError();
 }
 
 // ---- launchers (called from ddgi_engine.cpp) -----------------------------------------------------

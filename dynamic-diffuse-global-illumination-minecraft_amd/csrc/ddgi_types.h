@@ -152,6 +152,7 @@ struct SampleArgs
     uint32_t n;
     const float* irradiance;  // DDGI mode tiles (slab-major), else null
     const float* depth;
+    const uint32_t* perm;     // processing order: lane k handles point perm[k] (points grouped by cage, see k_sample_*), or null
 };
 
 // k_render_primary: camera rays + integrators over the probe field
