@@ -719,12 +719,13 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
                     for (int x = bk.lo[0]; x <= bk.hi[0]; ++x)
                     {
                         if (bk.block_at(x, y, z) > 0) continue;
-                        if (bk.block_at(x - 1, y, z) > 0 || bk.block_at(x + 1, y, z) > 0 || bk.block_at(x, y - 1, z) > 0 || bk.block_at(x, y + 1, z) > 0 ||
-                            bk.block_at(x, y, z - 1) > 0 || bk.block_at(x, y, z + 1) > 0)
-                            list.push_back(((z - bk.lo[2]) * bk.dim[1] + (y - bk.lo[1])) * bk.dim[0] + (x - bk.lo[0]));
+                        const int r = ((z - bk.lo[2]) * bk.dim[1] + (y - bk.lo[1])) * bk.dim[0] + (x - bk.lo[0]);
+                        const int nb[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};  // face = 2 axis + (+ side)
+                        for (int fc = 0; fc < 6; ++fc)
+                            if (bk.block_at(x + nb[fc][0], y + nb[fc][1], z + nb[fc][2]) > 0) list.push_back(r * 8 + fc);
                     }
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis), static_cast<size_t>(n_vox)));
-            HIP_TRY(hipMemsetAsync(d.vis, 0, static_cast<size_t>(n_vox), e->stream));
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis), static_cast<size_t>(n_vox) * 8));  // one class byte per (voxel, face)
+            HIP_TRY(hipMemsetAsync(d.vis, 0, static_cast<size_t>(n_vox) * 8, e->stream));
             d.n_vis_list = static_cast<int>(list.size());
             if (d.n_vis_list > 0)
             {

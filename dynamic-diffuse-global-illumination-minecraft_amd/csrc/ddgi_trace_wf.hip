@@ -233,15 +233,37 @@ struct CfgPlain
     static DDGI_D bool ddgi(const TraceArgs&) { return kMode != 0; }
 };
 
-// The first kInlineSteps voxel steps are taken right here, by the event lane that sets the march up: 59 % of
-// the cave workload's marches end within 3 steps (probes inside rock, rays that start in a corner), and for
-// those a trip through the march queue and a 16-step burst is almost all overhead.  Returns -1 when the march
-// goes on (the slot is ready for the march queue, resuming at (t, iterations) like a parked march), else the
-// event bucket of the finished march (the slot is in its event state).
+// The first kInlineSteps voxel steps are taken right here, by the event lane that sets the march up: 57 % of the cave
+// workload's marches end with their FIRST step (probes inside rock, rays that start in a corner of the surface's relief),
+// and for those a trip through the march queue and a 24-step burst is all overhead.  More than one inline step does not
+// pay: only another 4 % of the marches end within steps 2..4, and those steps run at 18 of 64 lanes (ddgi_trace_stats,
+// sections "inline step"; 4 steps: 2.134 ms, 2: 2.136, 1: 2.109 on C3).  Returns -1 when the march goes on (the slot is
+// ready for the march queue, resuming at (t, iterations) like a parked march), else the event bucket of the finished march
+// (the slot is in its event state).
 #ifndef DDGI_INLINE_STEPS
-#define DDGI_INLINE_STEPS 4
+#define DDGI_INLINE_STEPS 1
 #endif
 constexpr int kInlineSteps = DDGI_INLINE_STEPS;
+
+// Profiling aid of the counters build of the queue kernel (kStats): how many lanes are active where.  at(id) is called
+// at the start of a section of event code: every active lane counts itself, the first active lane counts the visit.
+constexpr int kProbeSections = 12;
+struct LaneProbe
+{
+    uint32_t lanes[kProbeSections] = {};
+    uint32_t visits[kProbeSections] = {};
+    DDGI_D void at(int id)
+    {
+        const unsigned long long m = __ballot(true);
+        lanes[id] += 1u;
+        if ((__ffsll(static_cast<long long>(m)) - 1) == static_cast<int>(threadIdx.x & 63)) visits[id] += 1u;
+    }
+};
+#define DDGI_PROBE(lp, id) \
+    do                    \
+    {                     \
+        if (lp) (lp)->at(id); \
+    } while (0)
 
 struct InlineEnd  // how a march that ended within its first (inline) steps ended
 {
@@ -251,8 +273,9 @@ struct InlineEnd  // how a march that ended within its first (inline) steps ende
 
 template <class Cfg>
 DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, bool feeler, const TraceArgs& A, const uint32_t* s_bits, InlineEnd* end = nullptr,
-                         bool have_spheres = false, float tl_in = 0.0f, int lid_in = -1)
+                         bool have_spheres = false, float tl_in = 0.0f, int lid_in = -1, LaneProbe* lp = nullptr)
 {
+    DDGI_PROBE(lp, feeler ? 2 : 6);  // sections 2 / 6: a feeler's / a primary march's set-up
     // have_spheres: the caller has already evaluated light_spheres(o, d) -> (tl_in, lid_in)
     float tl = tl_in;
     int lid = lid_in;
@@ -283,6 +306,7 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
         for (int k = 0; k < kInlineSteps; ++k)
             if (!fin)
             {
+                DDGI_PROBE(lp, 8 + (k < 3 ? k : 3));  // sections 8..11: inline steps 1, 2, 3, 4+
                 occ = march_step_burst(m, A.scene, s_bits, hi);
                 fin = occ | (m.t >= m.tl);
             }
@@ -335,8 +359,9 @@ DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst
 // Returns true when the ray bounces; the caller then posts the march (o, d) — every path of an event
 // group shares ONE wf_post_march call site, so divergent lanes do not run its code twice.
 template <class Cfg>
-DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A, f3& o, f3& d)
+DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A, f3& o, f3& d, LaneProbe* lp = nullptr)
 {
+    DDGI_PROBE(lp, 5);  // section 5: accumulate + hemisphere sample
     const f3 color = v3of(c.col) + contribution;
     const uint32_t bounce = (cnt & 255u) + 1u;
     if (static_cast<int>(bounce) < A.max_bounces)
@@ -351,21 +376,27 @@ DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contr
     return false;
 }
 
-// The feeler class of the voxel a feeler would start in (k_light_visibility; ddgi_visibility.hip), or kVisUnknown
-// when there is no table, the origin is outside the baked box, or it is not at least 5e-4 inside its voxel on
-// every axis (the table's guarantee is for the voxel's interior; the origin is 1e-3 off the face that was hit).
-DDGI_D uint32_t light_vis_class(const TraceArgs& A, f3 o)
+// The feeler class of the (voxel, face) a feeler would start from (k_light_visibility; ddgi_visibility.hip), or kVisUnknown
+// when there is no table, the origin is outside the baked box, or it is not where the table's guarantee holds: 5e-4 ..
+// 1.5e-3 off the face that was hit (it is put 1e-3 off it) and at least 5e-4 inside the voxel on the two other axes.
+// n: the hit's axis normal (points from the block that was hit into the voxel the feeler starts in).
+DDGI_D uint32_t light_vis_class(const TraceArgs& A, f3 o, f3 n)
 {
     if (!A.vis) return kVisUnknown;
     const SceneK& S = A.scene;
     const f3 cell = cell_id(o);
     const float ux = cell.x - o.x, uy = cell.y - o.y, uz = cell.z - o.z;  // in [0, 1): distance to the voxel's upper faces
-    const float lo = fminf(ux, fminf(uy, uz)), hi = fmaxf(ux, fmaxf(uy, uz));
-    const bool inside = lo >= 5.0e-4f && hi <= 1.0f - 5.0e-4f && cell.x >= S.lo_f[0] && cell.x <= S.hi_f[0] && cell.y >= S.lo_f[1] && cell.y <= S.hi_f[1] &&
-                        cell.z >= S.lo_f[2] && cell.z <= S.hi_f[2];  // (false for NaN)
+    // along the normal's axis: distance to the face that was hit; along the others: distance to the nearer face
+    const float fx = n.x > 0.0f ? 1.0f - ux : ux, fy = n.y > 0.0f ? 1.0f - uy : uy, fz = n.z > 0.0f ? 1.0f - uz : uz;
+    const bool ax = n.x != 0.0f, ay = n.y != 0.0f;
+    const float off = ax ? fx : (ay ? fy : fz);
+    const float l1 = ax ? uy : ux, l2 = (ax || ay) ? uz : uy;
+    const bool inside = off >= 5.0e-4f && off <= 1.5e-3f && fminf(l1, l2) >= 5.0e-4f && fmaxf(l1, l2) <= 1.0f - 5.0e-4f && cell.x >= S.lo_f[0] && cell.x <= S.hi_f[0] &&
+                        cell.y >= S.lo_f[1] && cell.y <= S.hi_f[1] && cell.z >= S.lo_f[2] && cell.z <= S.hi_f[2];  // (false for NaN)
     if (!inside) return kVisUnknown;
     const int idx = static_cast<int>(fmaf(cell.z, S.nxy_f, fmaf(cell.y, S.nx_f, cell.x))) - S.bias;
-    return A.vis[idx];
+    const int face = (ax ? 0 : (ay ? 2 : 4)) + ((n.x + n.y + n.z) < 0.0f ? 1 : 0);  // 2 axis + (the block that was hit is on the + side)
+    return A.vis[idx * 8 + face];
 }
 
 // get_direct_lighting's loop body for the light L once its feeler's outcome is known (probe_pass.comp:194-207):
@@ -397,8 +428,9 @@ DDGI_D void feeler_outcome(const LightK& L, f3 hpos, f3 nh, f3 hcol, bool any_hi
 // march already ended within its first steps (return 2 + the event bucket it now waits in), or 0 when the ray
 // is finished (it has written its output and left the slot empty).
 template <class Cfg>
-DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits, uint32_t b, uint32_t slot, uint32_t r, bool r_valid)
+DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits, uint32_t b, uint32_t slot, uint32_t r, bool r_valid, LaneProbe* lp = nullptr)
 {
+    DDGI_PROBE(lp, 0);  // section 0: the event (all lanes of the group)
     const GridK& G = A.grid;
     const int rays_per_probe = G.n;
     const float inf = __builtin_inff();
@@ -440,7 +472,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             c.cnt = 0u;
             set3(c.col, mk3(0, 0, 0));
             set3(c.hn, mk3(0, 0, 0));
-            const int pb = wf_post_march<Cfg>(P, slot, c, ray_o, ray_d, false, A, s_bits);
+            const int pb = wf_post_march<Cfg>(P, slot, c, ray_o, ray_d, false, A, s_bits, nullptr, false, 0.0f, -1, lp);
             store_cold(P, slot, c, false);
             return pb < 0 ? 1 : 2 + pb;
         }
@@ -534,6 +566,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     const f3 nh = axis_normal ? hnrm : normalize3(hnrm);
                     const bool lambert_zero = Cfg::nl(A) == 1 && dot3(nh, to_light) <= 0.0f && !(Cfg::ablate(A) & 4);
                     const bool ordinary = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))) < 0x1.0p20f;
+                    if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary)) DDGI_PROBE(lp, 1);  // section 1: albedo
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary))
                         hcol = ((Cfg::ablate(A) & 1) || (DDGI_EXP & 8)) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
                     const bool finite_albedo = fabsf(hcol.x) < inf && fabsf(hcol.y) < inf && fabsf(hcol.z) < inf;
@@ -541,8 +574,8 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     // Is the feeler's outcome certain (k_light_visibility)?  Then its march, queue trip and event are
                     // skipped: the light-sphere test it would start with (does the ray reach the sphere at all) and
                     // get_direct_lighting's arithmetic are evaluated right here, on the same values.
-                    const uint32_t vis = (Cfg::nl(A) == 1 && block_wins && axis_normal && !(lambert_zero && finite_albedo)) ? light_vis_class(A, hpos) : kVisUnknown;
-                    if ((Cfg::ablate(A) & 16) && A.stats && block_wins) atomicAdd(&A.stats[(lambert_zero && finite_albedo) ? 43 : 40 + vis], 1ull);  // profiling build: feeler classes
+                    const uint32_t vis = (Cfg::nl(A) == 1 && block_wins && axis_normal && !(lambert_zero && finite_albedo)) ? light_vis_class(A, hpos, hnrm) : kVisUnknown;
+                    if ((Cfg::ablate(A) & 16) && A.stats && block_wins) atomicAdd(&A.stats[(lambert_zero && finite_albedo) ? 59 : 56 + vis], 1ull);  // profiling build: feeler classes
                     ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt;
                     if (lambert_zero && finite_albedo)
                         lit_done = true;  // contributes +0
@@ -552,6 +585,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                         // sphere at all, and where) is evaluated once, for the table's "lit" class and for the feeler's march.
                         float ftl = inf;
                         int flid = -1;
+                        if (vis != kVisShadow) DDGI_PROBE(lp, 3);  // section 3: sphere test of the feeler
                         if (vis != kVisShadow) light_spheres<Cfg::kNl>(hpos, to_light, A, ftl, flid);
                         bool feeler_any = true, feeler_block = true;  // kVisShadow: a block before the light (t_block < t_light, or no sphere hit at all)
                         if (vis == kVisLit) feeler_block = false, feeler_any = ftl < inf;
@@ -562,7 +596,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                             // trip, no second event.  A feeler that has to be marched takes the slot to the march queue.
                             c.cnt = cnt;
                             InlineEnd fe;
-                            if (wf_post_march<Cfg>(P, slot, c, hpos, to_light, true, A, s_bits, &fe, true, ftl, flid) < 0)
+                            if (wf_post_march<Cfg>(P, slot, c, hpos, to_light, true, A, s_bits, &fe, true, ftl, flid, lp) < 0)
                             {
                                 store_cold(P, slot, c, true);  // (hn and the albedo travel with the marched feeler)
                                 return 1;
@@ -573,6 +607,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                         f3 direct = mk3(0, 0, 0), contribution = mk3(0, 0, 0);
                         int nvis = 0;
                         bool early = false;
+                        DDGI_PROBE(lp, 4);  // section 4: the light's contribution for a decided feeler
                         feeler_outcome(L, hpos, nh, hcol, feeler_any, feeler_block, direct, nvis, contribution, early);
                         if (!early && nvis != 0) contribution = hcol * direct;  // one visible light: x / 1.0f == x
                         ld_contribution = contribution, lit_done = true;
@@ -607,7 +642,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             }
             f3 contribution = mk3(0, 0, 0);
             bool early = false;
-            if ((Cfg::ablate(A) & 16) && A.stats) atomicAdd(&A.stats[block_wins ? 45 : (any_hit ? 44 : 46)], 1ull);  // profiling build: outcomes of marched feelers
+            if ((Cfg::ablate(A) & 16) && A.stats) atomicAdd(&A.stats[block_wins ? 61 : (any_hit ? 60 : 62)], 1ull);  // profiling build: outcomes of marched feelers
             {
                 const bool is_axis = (fabsf(hnrm.x) + fabsf(hnrm.y) + fabsf(hnrm.z) == 1.0f) &&
                                      (fabsf(hnrm.x) == 1.0f || fabsf(hnrm.y) == 1.0f || fabsf(hnrm.z) == 1.0f);
@@ -629,10 +664,10 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 ld_contribution = contribution, ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt, lit_done = true;
             }
         }
-        if (lit_done) posted = wf_lighting_done<Cfg>(P, slot, c, ld_contribution, ld_hpos, ld_hnrm, ld_cnt, A, mo, md);
+        if (lit_done) posted = wf_lighting_done<Cfg>(P, slot, c, ld_contribution, ld_hpos, ld_hnrm, ld_cnt, A, mo, md, lp);
         if (posted)
         {
-            const int pb = wf_post_march<Cfg>(P, slot, c, mo, md, as_feeler, A, s_bits);
+            const int pb = wf_post_march<Cfg>(P, slot, c, mo, md, as_feeler, A, s_bits, nullptr, false, 0.0f, -1, lp);
             store_cold(P, slot, c, as_feeler);  // the slot lives on: write its shading state back
             return pb < 0 ? 1 : 2 + pb;
         }
@@ -1058,6 +1093,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     const float inf = __builtin_inff();
     unsigned int guard = 0;  // safety net: consecutive polls without work (about 1 s of them trips it); never spin forever on the GPU
     unsigned long long st_a = 0, st_b = 0;  // utilisation counters: trips / groups, and the lanes that had work in them
+    LaneProbe probe;                        // (counters build only)
 
     if (wave < march_waves)
     {
@@ -1231,7 +1267,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if (r_valid)
                 {
-                    const int rc = wf_event<Cfg>(A, P, s_bits, kBucketRefill, slot, r, true);
+                    const int rc = wf_event<Cfg>(A, P, s_bits, kBucketRefill, slot, r, true, kStats ? &probe : nullptr);
                     posted = rc == 1;
                     if (rc >= 2) ev_bucket = rc - 2;
                 }
@@ -1249,7 +1285,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 {
                     slot = aq_take(ring_eq + b * kAqCap, base + lane, &sh->abort);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const int rc = wf_event<Cfg>(A, P, s_bits, b, slot, 0u, false);
+                    const int rc = wf_event<Cfg>(A, P, s_bits, b, slot, 0u, false, kStats ? &probe : nullptr);
                     posted = rc == 1;
                     if (rc >= 2) ev_bucket = rc - 2;  // the new march ended within its first steps: straight to its event queue
                     freed = rc == 0;                  // the ray is finished: its output is written, the slot is empty
@@ -1270,6 +1306,13 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             }
         }
     }
+    if (kStats && A.stats)  // ddgi_trace_stats [32 + 2 s], [33 + 2 s]: visits of / lanes active in section s of the event code (LaneProbe)
+        for (int s = 0; s < kProbeSections; ++s)
+        {
+            unsigned long long v = probe.visits[s], l = probe.lanes[s];
+            for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m), l += __shfl_xor(l, m);
+            if (lane == 0 && l) atomicAdd(&A.stats[32 + 2 * s], v), atomicAdd(&A.stats[33 + 2 * s], l);
+        }
     if (kStats && A.stats && lane == 0)  // ddgi_trace_stats: [0] march trips, [1] lanes marching in them, [2] event groups, [3] lanes in them, [4] waves
     {
         atomicAdd(&A.stats[wave < march_waves ? 0 : 2], st_a);

@@ -96,7 +96,7 @@ struct TraceArgs
     float rot[9];
     float* rad_rgb;  // ray records, see RayRecords
     float* rad_dd;
-    const uint8_t* vis;  // single light: per-voxel feeler classes over the baked box (k_light_visibility), or null
+    const uint8_t* vis;  // single light: feeler classes per (voxel of the baked box, face): [voxel * 8 + face] (k_light_visibility), or null
 };
 
 // DDGI-mode ray records, laid out as the B operand of the blend's MFMA contraction (ddgi_blend_sample.hip): for local

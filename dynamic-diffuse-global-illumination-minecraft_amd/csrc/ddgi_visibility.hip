@@ -1,5 +1,5 @@
-// ddgi_visibility.hip — k_light_visibility: per voxel and light, is a light feeler that starts in this voxel
-// CERTAIN to reach the light, CERTAIN to be blocked, or neither?
+// ddgi_visibility.hip — k_light_visibility: per (voxel, face) and light, is a light feeler that starts just off this
+// face of the voxel CERTAIN to reach the light, CERTAIN to be blocked, or neither?
 //
 // A light feeler (get_direct_lighting, probe_pass.comp:186-207 -> intersect_scene -> grid_march) only decides a
 // boolean: does the march land in an occupied voxel before it reaches the light sphere.  For most surface
@@ -8,9 +8,10 @@
 // reference's float march provably comes to that outcome for EVERY start point in the voxel's interior — so
 // results are bit-identical with and without it (tests: trace with/without table agree; both equal the oracle).
 //
-// Voxel id n covers (n-1, n] per axis (voxel id = ceil(p)).  Start points o: the voxel shrunk by
-// kShrink on every face (wf_event only uses the table for a hit position at least kInside = 5e-4 from every
-// face; the feeler origin is 1e-3 off the face that was hit).  Rays run from o to the light centre L; the march
+// Voxel id n covers (n-1, n] per axis (voxel id = ceil(p)).  A feeler starts 1e-3 off the face of the
+// block that was hit, inside the empty voxel on the other side of that face.  Start points o of table entry
+// (voxel, face): between 4e-4 and 1.6e-3 off that face, and at least kShrink inside the voxel on the two other axes
+// (wf_event only uses the entry for an origin 5e-4 .. 1.5e-3 off the face and 5e-4 inside laterally).  Rays run from o to the light centre L; the march
 // positions p_k = fma(dn, t_k, o) stay within ~3e-5 of that segment for t_k <= t_light (binary32 rounding at
 // |p| < 2^10 and a unit direction good to 1e-7), so every voxel the march looks up intersects the kEps-tube
 // around the bundle B = hull(shrunk voxel, L).  Cross-sections of B are axis-aligned boxes
@@ -31,7 +32,8 @@
 
 namespace ddgi {
 
-constexpr double kVisShrink = 4.0e-4;  // start points: the voxel shrunk by this much (wf_event requires 5e-4)
+constexpr double kVisShrink = 4.0e-4;  // start points: the voxel shrunk by this much laterally (wf_event requires 5e-4)
+constexpr double kVisFaceNear = 4.0e-4, kVisFaceFar = 1.6e-3;  // ... and this far off the face that was hit (wf_event: 5e-4 .. 1.5e-3)
 constexpr double kVisEps = 1.0e-4;     // tube around the exact bundle that contains every march position
 constexpr int kVisMaxCrossings = 110;  // boundary crossings to a blocking layer (grid_march: 125 iterations)
 constexpr double kVisMinRange = 4.0;   // lights closer than this along the dominant axis: not classified
@@ -44,8 +46,9 @@ DDGI_D bool vis_occupied(const SceneK& S, const uint32_t* __restrict__ bits, int
     return ((bits[(idx >> 5) - (S.bias32 >> 5)] >> (idx & 31)) & 1u) != 0u;
 }
 
-// list: the voxels that can hold a feeler origin — empty, with an occupied face neighbour (the origin is 1e-3 off the face
-// that was hit); built once per scene on the host (ddgi_engine.cpp: ensure_scene).  Every other voxel keeps class 0.
+// list: the (voxel, face) pairs that can hold a feeler origin — an empty voxel and a face whose other side is occupied (the
+// origin is 1e-3 off the face that was hit); entry = voxel * 8 + face, built once per scene on the host (ddgi_engine.cpp:
+// plan_trace).  Every other table entry keeps class 0.
 // kLds: the occupancy bitmap is copied to LDS first (a thread makes several hundred dependent lookups)
 template <bool kLds>
 __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const double lx, const double ly, const double lz, const int32_t* __restrict__ list,
@@ -63,7 +66,8 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
     // lanes of a group and joined with an OR / AND across the group (a single lane walking ~60 layers was 150 us per update)
     const int t = (blockIdx.x * blockDim.x + threadIdx.x) / kVisLanes, sub = threadIdx.x % kVisLanes;
     const bool live = t < n_list;  // (no early return: the group shuffles below need every lane)
-    const int r = list[live ? t : n_list - 1];
+    const int entry = list[live ? t : n_list - 1];  // voxel * 8 + face; face = 2 axis + (the solid neighbour is on the + side)
+    const int r = entry >> 3, face = entry & 7, face_axis = face >> 1;
     const int ny = S.nxy / S.nx;
     int v[3] = {S.lo[0] + r % S.nx, S.lo[1] + (r / S.nx) % ny, S.lo[2] + r / S.nxy};
     uint8_t cls = kVisUnknown;
@@ -76,6 +80,11 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
     {
         lo0[k] = static_cast<double>(v[k] - 1) + kVisShrink;
         hi0[k] = static_cast<double>(v[k]) - kVisShrink;
+        if (k == face_axis)  // a thin slab 4e-4 .. 1.6e-3 off the face
+        {
+            if (face & 1) lo0[k] = static_cast<double>(v[k]) - kVisFaceFar, hi0[k] = static_cast<double>(v[k]) - kVisFaceNear;
+            else lo0[k] = static_cast<double>(v[k] - 1) + kVisFaceNear, hi0[k] = static_cast<double>(v[k] - 1) + kVisFaceFar;
+        }
         const double d = fabs(L[k] - (static_cast<double>(v[k]) - 0.5));
         if (d > best) best = d, a = k;
     }
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
         any_shadow |= static_cast<unsigned>(__shfl_xor(static_cast<int>(any_shadow), m));
         all_lit &= static_cast<unsigned>(__shfl_xor(static_cast<int>(all_lit), m));
     }
-    if (live && sub == 0) out[r] = any_shadow ? kVisShadow : (all_lit ? kVisLit : kVisUnknown);
+    if (live && sub == 0) out[entry] = any_shadow ? kVisShadow : (all_lit ? kVisLit : kVisUnknown);
 }
 
 hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], const int32_t* list, int n_list, uint8_t* out, hipStream_t stream)

@@ -9,6 +9,8 @@ from bench import WORKLOAD as w
 eng = ddgi_amd.ProbeEngine(ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"]), ddgi_amd.make_settings(w["scene"], w["max_bounces"]))
 eng.generate_probe_rays(seed=1)
 eng.probe_update(); eng.synchronize()
+if os.environ.get("DDGI_LIB", "").endswith("_prof.so"):
+    eng.set_tuning("ablate", 16)  # profiling build: count the feeler classes too (slow: global atomics per event)
 eng.trace_stats(True)
 eng.probe_update(); eng.synchronize()
 st = eng.trace_stats(False)
@@ -16,5 +18,7 @@ rays = eng.num_rays
 trips, lanes, groups, glanes = st["trips"], st["lane_steps"], st["event_rounds"], st["lane_events"]
 print("march: %.1f lane-trips/ray, %.1f of 64 lanes busy per trip;  events: %.2f per ray, %.1f of 64 lanes per group;  kernel %.3f ms" % (
     lanes / rays, lanes / max(trips, 1), glanes / rays, glanes / max(groups, 1), eng.last_update_ms()["trace_ms"]))
-print("feelers per ray:", {k: round(v / rays, 3) for k, v in st["feeler_classes"].items()})
-print("idle polls:", st["idle_polls"], " march trips", trips, " event groups", groups)
+print("feelers per ray (profiling build, ablate 16):", {k: round(v / rays, 3) for k, v in st["feeler_classes"].items()})
+for nm, (visits, lanes) in st["sections"].items():
+    if visits:
+        print("  section %-34s visits %8d  lanes/visit %5.1f  lane-visits/ray %6.2f" % (nm, visits, lanes / visits, lanes / rays))
