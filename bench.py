@@ -289,6 +289,7 @@ def main():
             "note": "the trace kernel is VALU-issue bound (dependent voxel steps + hit shading), not HBM bound: `issue` = the VALU's occupancy from profiles/ (rocprofv3 --pmc), see DESIGN.md section 4",
         },
     }
+    out["tuning"] = {"march_waves": eng.get_tuning("march_waves_measured"), "note": "waves of a 16-wave workgroup that march (the rest shade); measured by the first update of the configuration"}
     if ddgi_mode:
         # the blend kernels on their own: what THEY must move is the ray records the trace left (20 B per ray: r, g, b, d, d*d;
         # an intermediate of the pass, so not part of `roofline`) + the f32 tiles in and out (6144 B per probe)

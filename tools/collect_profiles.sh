@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collects the round's evidence on the GPU box into gpurun_out/profiles_out/ (copy what is to be kept into profiles/):
+#   tools/collect_profiles.sh <round> <tag>      e.g. r02 k
+R=${1:-r02}; T=${2:-x}
+ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/profiles_out; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# bench lines (REF: the headline; DDGI: trace + blend)
+timeout 300 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/${R}_${T}_bench.json 2> /dev/null
+timeout 200 python $ROOT/bench.py --mode ddgi --steps 20 --warmup 5 > $OUT/${R}_${T}_ddgi_bench.json 2> /dev/null
+# kernel traces of the same commands (the march/event split pinned to what the first update measured, so that every launch is the steady-state kernel)
+MW=$(python -c "import json;print(json.load(open('$OUT/${R}_${T}_bench.json')).get('tuning',{}).get('march_waves',5))" 2>/dev/null || echo 5)
+DDGI_AQ_MARCH=$MW timeout 200 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$T -o ref --output-format csv -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+python $ROOT/tools/profile_summary.py $ROOT/gpurun_out/prof_$T/ref "bench.py --steps 20 --warmup 5 (REF) with DDGI_AQ_MARCH=$MW, the split the first update measures for this workload" > $OUT/${R}_${T}_ref_kernel_stats.txt
+timeout 200 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$T -o ddgi --output-format csv -- python $ROOT/bench.py --mode ddgi --steps 20 --warmup 5 > /dev/null 2>&1
+python $ROOT/tools/profile_summary.py $ROOT/gpurun_out/prof_$T/ddgi "bench.py --mode ddgi --steps 20 --warmup 5" > $OUT/${R}_${T}_ddgi_kernel_stats.txt
+# counters (separate passes, kernel trace only)
+cd $ROOT
+timeout 300 bash tools/pmc_icache.sh $T > /dev/null 2>&1; python tools/pmc_issue.py $T $OUT/${R}_pmc_${T}_issue.txt > /dev/null
+timeout 400 bash tools/pmc_run.sh $T > /dev/null 2>&1; python tools/pmc_traffic.py $T $R > /dev/null
+# slab scaling, sampler throughput, lane statistics
+timeout 200 python tools/slab_timing.py > $OUT/${R}_${T}_slab_scaling.txt 2>/dev/null
+timeout 200 python tools/sample_bench.py 2>/dev/null | grep mode > $OUT/${R}_${T}_sample_bench.txt
+timeout 200 python tools/aq_stats.py 2>/dev/null | grep -v amdgpu > $OUT/${R}_${T}_lane_stats.txt
+ls -la $OUT

@@ -42,9 +42,11 @@ def main(tag, rnd="r01", workload="c3_cave_32x16x32_probes_x256_rays_ref"):
             lines.append(f"# VALU busy ~ SQ_ACTIVE_INST_VALU*4/(1024 SIMDs)/cycles = {allc['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / cyc:.3f}")
     lines.append(f"# HBM read  : FETCH_SIZE {fetch_b / 1e6:.1f} MB raw, {2 * fetch_b / 1e6:.1f} MB with the gfx950 x2 correction")
     lines.append(f"# HBM write : WRITE_SIZE {write_b / 1e6:.1f} MB")
-    txt = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{tag}.txt")
+    outdir = os.path.join(ROOT, "gpurun_out", "profiles_out")  # merged back by gpurun; copy what is to be kept into profiles/
+    os.makedirs(outdir, exist_ok=True)
+    txt = os.path.join(outdir, f"{rnd}_pmc_{tag}.txt")
     open(txt, "w").write("\n".join(lines) + "\n")
-    js = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{tag}.json")
+    js = os.path.join(outdir, f"{rnd}_traffic_{tag}.json")
     json.dump({"workload": workload, "kernel": "k_probe_trace_aq", "fetch_size_bytes_raw": fetch_b,
                "fetch_size_bytes_corrected": 2 * fetch_b, "write_size_bytes": write_b,
                "hbm_bytes_per_launch": 2 * fetch_b + write_b,
