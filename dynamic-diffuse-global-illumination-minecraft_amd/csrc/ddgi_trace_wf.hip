@@ -247,17 +247,37 @@ constexpr int kInlineSteps = DDGI_INLINE_STEPS;
 
 // Profiling aid of the counters build of the queue kernel (kStats): how many lanes are active where.  at(id) is called
 // at the start of a section of event code: every active lane counts itself, the first active lane counts the visit.
+#ifdef DDGI_LAP  // analysis build: the probes are lap timers (cycles per section of a wave's instruction stream)
+constexpr int kProbeSections = 16;
+#else
 constexpr int kProbeSections = 12;
+#endif
 struct LaneProbe
 {
     uint32_t lanes[kProbeSections] = {};
     uint32_t visits[kProbeSections] = {};
+#ifdef DDGI_LAP
+    uint32_t* lap = nullptr;  // this wave's LDS scratch: [0] section it is in, [1] clock at its start, [2 + s] cycles spent in section s
+    DDGI_D void at(int id)
+    {
+        const unsigned long long m = __ballot(true);
+        lanes[id] += 1u;
+        if ((__ffsll(static_cast<long long>(m)) - 1) == static_cast<int>(threadIdx.x & 63))
+        {
+            const uint32_t now = static_cast<uint32_t>(__builtin_readcyclecounter());
+            lap[2 + lap[0]] += now - lap[1];
+            lap[0] = static_cast<uint32_t>(id);
+            lap[1] = static_cast<uint32_t>(__builtin_readcyclecounter());
+        }
+    }
+#else
     DDGI_D void at(int id)
     {
         const unsigned long long m = __ballot(true);
         lanes[id] += 1u;
         if ((__ffsll(static_cast<long long>(m)) - 1) == static_cast<int>(threadIdx.x & 63)) visits[id] += 1u;
     }
+#endif
 };
 #define DDGI_PROBE(lp, id) \
     do                    \
@@ -569,6 +589,9 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary)) DDGI_PROBE(lp, 1);  // section 1: albedo
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary))
                         hcol = ((Cfg::ablate(A) & 1) || (DDGI_EXP & 8)) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
+#ifdef DDGI_LAP
+                    DDGI_PROBE(lp, 7);  // after the albedo: visibility class, feeler decision
+#endif
                     const bool finite_albedo = fabsf(hcol.x) < inf && fabsf(hcol.y) < inf && fabsf(hcol.z) < inf;
                     set3(c.hc, hcol);
                     // Is the feeler's outcome certain (k_light_visibility)?  Then its march, queue trip and event are
@@ -668,6 +691,9 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
         if (posted)
         {
             const int pb = wf_post_march<Cfg>(P, slot, c, mo, md, as_feeler, A, s_bits, nullptr, false, 0.0f, -1, lp);
+#ifdef DDGI_LAP
+            DDGI_PROBE(lp, 12);  // write-back
+#endif
             store_cold(P, slot, c, as_feeler);  // the slot lives on: write its shading state back
             return pb < 0 ? 1 : 2 + pb;
         }
@@ -1094,6 +1120,15 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     unsigned int guard = 0;  // safety net: consecutive polls without work (about 1 s of them trips it); never spin forever on the GPU
     unsigned long long st_a = 0, st_b = 0;  // utilisation counters: trips / groups, and the lanes that had work in them
     LaneProbe probe;                        // (counters build only)
+#ifdef DDGI_LAP
+    if (kStats)
+    {
+        probe.lap = reinterpret_cast<uint32_t*>(ring_eq + kAqCap * kAqEventQueues) + wave * 32;
+        if (lane < 32) probe.lap[lane] = lane == 0 ? 15u : (lane == 1 ? static_cast<uint32_t>(__builtin_readcyclecounter()) : 0u);
+    }
+#endif
+    unsigned long long st_q[8] = {};        // counters build: [0] samples [1..3] sum of MQ / FQ / EQ depths at an event wave's poll, [4] idle polls,
+                                            // [5] march bursts, [6] fetches that found MQ short of the idle lanes, [7] lanes in flight at burst start
 
     if (wave < march_waves)
     {
@@ -1116,6 +1151,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 uint32_t base = 0, k = 0;
                 if (lane == 0) k = aq_claim(&sh->mq_head, &sh->mq_tail, static_cast<uint32_t>(n_idle), base);
                 k = __shfl(k, 0), base = __shfl(base, 0);
+                if (kStats && static_cast<int>(k) < n_idle) st_q[6] += 1;
                 const uint32_t rank = static_cast<uint32_t>(__popcll(idle_mask & ((1ull << lane) - 1ull)));
                 if (!have && rank < k)
                 {
@@ -1152,6 +1188,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             bool finished = false;
             uint32_t bucket = 0;
             if (kStats) st_a += 1, st_b += static_cast<unsigned long long>(__popcll(__ballot(have)));
+            if (kStats) st_q[5] += 1, st_q[7] += static_cast<unsigned long long>(__popcll(__ballot(have)));
             if (have)
             {
                 const int left = kMarchIters - m.it;
@@ -1205,6 +1242,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             if (avail > kAqCap) avail = 0;  // a claim in flight can make tail - head wrap for an instant
             const unsigned long long full = __ballot(avail >= 64u);
             const bool no_more = aq_load(&sh->no_more) != 0u;
+
             if (full != 0ull)
             {
                 // 1) a full group, dearest bucket first
@@ -1242,12 +1280,20 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             if (k == 0u)
             {
                 if ((no_more && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
+                if (kStats) st_q[4] += 1;
                 __builtin_amdgcn_s_sleep(2);
                 continue;
             }
             const bool valid = static_cast<uint32_t>(lane) < k;
             guard = 0;
             if (kStats) st_a += 1, st_b += k;
+            if (kStats)  // queue depths, sampled when a group starts (so weighted by work, not by idle polls)
+            {
+                uint32_t eq_sum = lane < kAqEventQueues ? avail : 0u;
+                for (int mm = 4; mm >= 1; mm >>= 1) eq_sum += __shfl_xor(eq_sum, mm);
+                const uint32_t mqd = aq_load(&sh->mq_tail) - aq_load(&sh->mq_head), fqd = aq_load(&sh->fq_tail) - aq_load(&sh->fq_head);
+                st_q[0] += 1, st_q[1] += mqd <= kAqCap ? mqd : 0u, st_q[2] += fqd <= kAqCap ? fqd : 0u, st_q[3] += eq_sum;
+            }
             uint32_t slot = 0;
             bool posted = false, freed = false;
             int ev_bucket = -1;
@@ -1291,6 +1337,9 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                     freed = rc == 0;                  // the ray is finished: its output is written, the slot is empty
                 }
             }
+#ifdef DDGI_LAP
+            if (kStats) probe.at(15);  // outside the event code: queue traffic, polling
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             aq_push(ring_mq, &sh->mq_tail, posted && !(Cfg::ablate(A) & 8), slot, lane);  // DDGI_ABLATE=8: fault injection for the safety-net test
             aq_push(ring_fq, &sh->fq_tail, freed, slot, lane);
@@ -1306,10 +1355,16 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             }
         }
     }
+#ifdef DDGI_LAP
+    if (kStats && lane == 0 && wave >= march_waves) probe.at(15);  // close the last lap
+#endif
     if (kStats && A.stats)  // ddgi_trace_stats [32 + 2 s], [33 + 2 s]: visits of / lanes active in section s of the event code (LaneProbe)
         for (int s = 0; s < kProbeSections; ++s)
         {
             unsigned long long v = probe.visits[s], l = probe.lanes[s];
+#ifdef DDGI_LAP
+            v = (lane == 0 && probe.lap && wave >= march_waves) ? probe.lap[2 + s] : 0ull;
+#endif
             for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m), l += __shfl_xor(l, m);
             if (lane == 0 && l) atomicAdd(&A.stats[32 + 2 * s], v), atomicAdd(&A.stats[33 + 2 * s], l);
         }
@@ -1318,11 +1373,19 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
         atomicAdd(&A.stats[wave < march_waves ? 0 : 2], st_a);
         atomicAdd(&A.stats[wave < march_waves ? 1 : 3], st_b);
         atomicAdd(&A.stats[4], 1ull);
+        for (int q = 0; q < 8; ++q) atomicAdd(&A.stats[8 + q], st_q[q]);  // (the slots of the round kernel's cycle counters)
     }
     if (status && lane == 0 && aq_load(&sh->abort) != 0u) atomicOr(status, 1u);  // the safety net tripped: the output is not valid
 }
 
-static size_t aq_lds_bytes(int nwords, int pool) { return (32 + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * kPoolDwords * 4 + kAqCap * 2 * (2 + kAqEventQueues) + 16; }
+static size_t aq_lds_bytes(int nwords, int pool)
+{
+    size_t extra = 16;
+#ifdef DDGI_LAP
+    extra += 16 * 32 * 4;  // the lap timers' scratch, one row per wave
+#endif
+    return (32 + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * kPoolDwords * 4 + kAqCap * 2 * (2 + kAqEventQueues) + extra;
+}
 
 int aq_pool_size(int nwords, size_t lds_limit)
 {

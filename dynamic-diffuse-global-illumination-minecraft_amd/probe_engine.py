@@ -446,17 +446,17 @@ class ProbeEngine:
         out = np.zeros(64, dtype=np.uint64)
         _check(self._lib.ddgi_trace_stats(self._h, 1 if enable else 0, _ptr(out)))
         keys = ("trips", "lane_steps", "event_rounds", "lane_events", "waves", "rounds", "fetches", "_7",
-                "cyc_scan", "cyc_march", "cyc_march_wait", "cyc_list", "cyc_events", "cyc_events_wait")
-        st = dict(zip(keys, (int(v) for v in out[:14])))
+                "cyc_scan", "cyc_march", "cyc_march_wait", "cyc_list", "cyc_events", "cyc_events_wait", "_14", "_15")
+        st = dict(zip(keys, (int(v) for v in out[:16])))
         st["bucket_cycles"] = [int(v) for v in out[16:24]]   # event groups by bucket (ddgi_trace_wf.hip: shade_bucket)
         st["bucket_groups"] = [int(v) for v in out[24:32]]
         # light feelers of block hits: decided by the visibility table (unknown = marched / lit / shadow), dead (Lambert 0), and
         # what the marched ones found (reached the light / hit a block / neither)
         st["feeler_classes"] = dict(zip(("unknown", "table_lit", "table_shadow", "dead", "marched_lit", "marched_shadow", "marched_none"), (int(v) for v in out[56:63])))
         # queue kernel, counters build: (visits, active lanes) per section of the event code (ddgi_trace_wf.hip: LaneProbe)
-        names = ("event", "albedo", "feeler set-up", "feeler sphere test", "light contribution", "bounce: accumulate + hemisphere", "primary set-up", "-",
-                 "inline step 1", "inline step 2", "inline step 3", "inline step 4")
-        st["sections"] = {nm: (int(out[32 + 2 * s]), int(out[33 + 2 * s])) for s, nm in enumerate(names) if nm != "-"}
+        names = ("event", "albedo", "feeler set-up", "feeler sphere test", "light contribution", "bounce: accumulate + hemisphere", "primary set-up", "after albedo",
+                 "inline step 1", "inline step 2", "inline step 3", "inline step 4", "write-back", "-", "-", "outside events")
+        st["sections"] = {nm: (int(out[32 + 2 * s]), int(out[33 + 2 * s])) for s, nm in enumerate(names) if nm != "-" and 33 + 2 * s < 64}
         return st
 
     # -- outputs -------------------------------------------------------------------------------

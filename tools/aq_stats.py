@@ -18,6 +18,11 @@ rays = eng.num_rays
 trips, lanes, groups, glanes = st["trips"], st["lane_steps"], st["event_rounds"], st["lane_events"]
 print("march: %.1f lane-trips/ray, %.1f of 64 lanes busy per trip;  events: %.2f per ray, %.1f of 64 lanes per group;  kernel %.3f ms" % (
     lanes / rays, lanes / max(trips, 1), glanes / rays, glanes / max(groups, 1), eng.last_update_ms()["trace_ms"]))
+q = [st[k] for k in ("cyc_scan", "cyc_march", "cyc_march_wait", "cyc_list", "cyc_events", "cyc_events_wait")] + [st["_14"], st["_15"]]
+if q[0]:
+    print("queues at an event wave's poll: MQ %.0f  FQ %.0f  EQ (all buckets) %.0f slots;  idle polls %.2f of %d;  march bursts: %.2f per ray, "
+          "%.1f lanes in flight at the start, %.2f of the fetches found MQ short" % (q[1] / q[0], q[2] / q[0], q[3] / q[0], q[4] / q[0], q[0],
+          q[5] / rays, q[7] / max(q[5], 1), q[6] / max(q[5], 1)))
 print("feelers per ray (profiling build, ablate 16):", {k: round(v / rays, 3) for k, v in st["feeler_classes"].items()})
 for nm, (visits, lanes) in st["sections"].items():
     if visits:
