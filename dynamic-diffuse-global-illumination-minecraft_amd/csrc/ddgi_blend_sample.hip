@@ -186,6 +186,57 @@ DDGI_D f16v blend_contract(const float* __restrict__ wa, const float* __restrict
     return acc;
 }
 
+// The same for three B streams (the colour channels, `b_stride` floats apart) against ONE pass over the A stream: three
+// independent chains, each in ray order; the weights are read once instead of three times.
+DDGI_D void blend_contract3(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, int q_pairs, f16v (&acc)[3])
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = f16v{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const float4* __restrict__ pa = reinterpret_cast<const float4*>(wa);
+    const float4* __restrict__ pb[3] = {reinterpret_cast<const float4*>(vb), reinterpret_cast<const float4*>(vb + b_stride), reinterpret_cast<const float4*>(vb + 2 * b_stride)};
+    const int n4 = q_pairs / 4;
+    float4 a0[2], b0[3][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+    {
+        a0[u] = pa[static_cast<size_t>(min(u, n4 - 1)) * 64];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b0[c][u] = pb[c][static_cast<size_t>(min(u, n4 - 1)) * 64];
+    }
+    for (int k = 0; k < n4; k += 2)
+    {
+        float4 a1[2], b1[3][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+        {
+            const int kn = min(k + 2 + u, n4 - 1);  // past the end: re-read the last one (dropped)
+            a1[u] = pa[static_cast<size_t>(kn) * 64];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) b1[c][u] = pb[c][static_cast<size_t>(kn) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (k + u < n4)  // wave-uniform
+            {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].x, b0[c][u].x, acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].y, b0[c][u].y, acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].z, b0[c][u].z, acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].w, b0[c][u].w, acc[c], 0, 0, 0);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+        {
+            a0[u] = a1[u];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) b0[c][u] = b1[c][u];
+        }
+    }
+}
+
 // Epilogue staging: a wave parks its accumulator tile in LDS as [texel row][column] (row stride 33 words: conflict-free
 // for a fixed column) and then walks it with lanes = texels, so that a probe's texels are written as runs of
 // consecutive addresses and everything that depends on the texel only (wrap destinations, weight sum) is set up once.
@@ -302,6 +353,144 @@ DDGI_D void blend_depth_role(const BlendArgs& A, const float* __restrict__ rad_d
     }
 }
 
+// depth, 256 rays per probe: ONE persistent workgroup per CU.  Its seven contraction waves keep their whole weight tile —
+// 32 texel rows x 256 rays = 128 VGPRs — in registers across the groups they handle, so a group costs its own records and
+// nothing else (the kernel above re-reads the 7 x 32 KB of tiles from L2 for every 32 KB of records).  With one workgroup
+// per CU nothing else hides latency, so the work is pipelined by hand, one barrier per group:
+//   contraction waves   contract this group out of LDS (two whole-group record buffers) and park the accumulators in LDS
+//                       (two staging sets)
+//   five service waves  meanwhile fetch the NEXT group's records (32 KB) into the other buffer, and four of them turn the
+//                       PREVIOUS group's accumulators into texels: lanes = 64 consecutive texels of a tile, border texels
+//                       computed from their octahedral-wrap source's sums (the same arithmetic on the same values), every
+//                       load / store instruction moves 512 consecutive bytes.  (Storing from the contraction waves —
+//                       4-byte stores, lanes = interior texels, borders as extra partial stores — took longer than the
+//                       contraction itself: 40 us of the kernel's 80 on 16 384 probes.)
+// A texel is mixed with the old value AT ITS OWN PLACE (the update may run in place, and a border's source is another lane's
+// output): for a border texel that is its source's old value because every tile this engine writes has its borders equal
+// to their sources, and fresh tiles are zero — tiles brought in through ddgi_bind_textures must keep that (ddgi_probe.h).
+constexpr int kResN4 = 32;                          // float4 per lane of a resident tile: 128 ray pairs
+constexpr int kResGroupF4 = kResN4 * 64;            // float4 of one group's records (16 probes x 2 moments x 256 rays)
+constexpr int kResServiceWaves = 5;
+constexpr int kResWaves = kBlendWaves + kResServiceWaves;
+constexpr int kResLoads = (kResGroupF4 + kResServiceWaves * 64 - 1) / (kResServiceWaves * 64);  // per service thread: 7
+struct DepthResShared
+{
+    float4 b_all[2][kResGroupF4];
+    float stage_all[2][kBlendWaves][32 * kStageStride];
+};
+DDGI_D void blend_depth_resident(const BlendArgs& A, const float* __restrict__ rad_dd, const float* __restrict__ w_tiles, const float* __restrict__ w_sum, DepthResShared& sh,
+                                 uint32_t first_task, uint32_t task_stride)
+{
+    const GridK& G = A.grid;
+    constexpr int n_pad = 256;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t n_tasks = (A.n_local_probes + 15u) / 16u;
+    const uint32_t my_tasks = first_task < n_tasks ? (n_tasks - first_task + task_stride - 1u) / task_stride : 0u;
+    if (wave < kBlendWaves)
+    {
+        // ================= contraction waves: wave = depth tile =================
+        float4 a_res[kResN4];
+        {
+            const float4* __restrict__ pa = reinterpret_cast<const float4*>(w_tiles + static_cast<size_t>(wave) * n_pad * 32) + lane;
+#pragma unroll
+            for (int k = 0; k < kResN4; ++k) a_res[k] = pa[static_cast<size_t>(k) * 64];
+        }
+        __syncthreads();
+        for (uint32_t it = 0; it <= my_tasks; ++it)
+        {
+            if (it < my_tasks)
+            {
+                const int cur = static_cast<int>(it & 1u);
+                f16v acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < kResN4; ++k)
+                {
+                    const float4 bv = sh.b_all[cur][k * 64 + lane];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_res[k].x, bv.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_res[k].y, bv.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_res[k].z, bv.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_res[k].w, bv.w, acc, 0, 0, 0);
+                }
+                stage_tile(sh.stage_all[cur][wave], acc, lane & 31, lane >> 5);
+            }
+            __syncthreads();
+        }
+    }
+    else
+    {
+        // ================= service waves =================
+        const int sw_id = wave - kBlendWaves, st_tid = static_cast<int>(threadIdx.x) - kBlendWaves * 64;
+        auto fetch_records = [&](uint32_t it, float4 (&r)[kResLoads]) {
+            const float4* __restrict__ gb = reinterpret_cast<const float4*>(rad_dd + static_cast<size_t>(first_task + it * task_stride) * n_pad * 32);
+#pragma unroll
+            for (int k = 0; k < kResLoads; ++k)
+            {
+                const int idx = st_tid + k * kResServiceWaves * 64;
+                r[k] = idx < kResGroupF4 ? gb[idx] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        };
+        auto park_records = [&](int buf, const float4 (&r)[kResLoads]) {
+#pragma unroll
+            for (int k = 0; k < kResLoads; ++k)
+            {
+                const int idx = st_tid + k * kResServiceWaves * 64;
+                if (idx < kResGroupF4) sh.b_all[buf][idx] = r[k];
+            }
+        };
+        // texel waves (the first four): lane's output texel e = 64 sw_id + lane of a 16x16 tile, the staging offset of the interior
+        // texel it takes its sums from, and that texel's weight sum
+        const bool texel_wave = sw_id < 4;
+        const int e = 64 * (sw_id & 3) + lane, tx = e & (kDepTile - 1), ty = e / kDepTile;
+        int sx = tx, sy = ty;
+        if (tx == 0 || ty == 0 || tx == kDepTile - 1 || ty == kDepTile - 1) border_source(tx, ty, kDepTile, sx, sy);
+        const int c = (sy - 1) * (kDepTile - 2) + (sx - 1);
+        const int stage_off = (c >> 5) * (32 * kStageStride) + (c & 31) * kStageStride;
+        const float sw = w_sum[c];
+        const float hyst = G.hysteresis;
+        {
+            float4 r[kResLoads];
+            if (my_tasks > 0u)
+            {
+                fetch_records(0u, r);
+                park_records(0, r);
+            }
+        }
+        __syncthreads();
+        for (uint32_t it = 0; it <= my_tasks; ++it)
+        {
+            const bool more = it + 1u < my_tasks;
+            float4 r[kResLoads];
+            if (more) fetch_records(it + 1u, r);
+            if (it >= 1u && texel_wave)
+            {
+                const uint32_t task = first_task + (it - 1u) * task_stride;
+                const float* __restrict__ st = &sh.stage_all[(it - 1u) & 1u][0][0];
+                const uint32_t np = min(16u, A.n_local_probes - task * 16u);
+                const uint32_t my_slot = static_cast<uint32_t>(blend_tile_slot(G, min(task * 16u + static_cast<uint32_t>(lane & 15), A.n_local_probes - 1u)));
+                float2 old[16];
+#pragma unroll
+                for (uint32_t p = 0; p < 16u; ++p)
+                {
+                    const size_t tile_off = static_cast<size_t>(__builtin_amdgcn_readlane(my_slot, p)) * (kDepTile * kDepTile * 2);
+                    old[p] = p < np ? *reinterpret_cast<const float2*>(A.depth_old + tile_off + e * 2) : float2{0.0f, 0.0f};
+                }
+#pragma unroll
+                for (uint32_t p = 0; p < 16u; ++p)
+                    if (p < np)  // (wave-uniform)
+                    {
+                        const size_t tile_off = static_cast<size_t>(__builtin_amdgcn_readlane(my_slot, p)) * (kDepTile * kDepTile * 2);
+                        const float s0 = st[stage_off + static_cast<int>(p)], s1 = st[stage_off + 16 + static_cast<int>(p)];
+                        float r0 = 0.0f, r1 = 0.0f;
+                        if (sw > 1e-6f) r0 = s0 / sw, r1 = s1 / sw;
+                        *reinterpret_cast<float2*>(A.depth + tile_off + e * 2) = float2{gl_mix(old[p].x, r0, hyst), gl_mix(old[p].y, r1, hyst)};
+                    }
+            }
+            if (more) park_records(static_cast<int>((it + 1u) & 1u), r);  // (that buffer was read last in the previous iteration)
+            __syncthreads();
+        }
+    }
+}
+
 // irradiance: workgroup = 2 waves, wave m = irradiance tile m, the three colour channels one after the other, for the
 // 32 probes of a group; B columns = probe.  The epilogue joins a texel's three channels: rgba texels leave as 16-byte
 // stores.  (Six waves per group — one per (channel, tile) — were slower: 55 us against 38 us on 16 384 probes; the
@@ -317,45 +506,52 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
     const int mi = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float hyst = G.hysteresis;
     const uint32_t n_tasks = (A.n_local_probes + 31u) / 32u;
-    // epilogue role: texel c = 32 mi + (lane & 31), probes of parity lane >> 5
-    const int trow = lane & 31, c = mi * 32 + trow;
-    const uint32_t p_first = static_cast<uint32_t>(lane >> 5);
-    const bool texel_valid = c < kIrrInterior;
-    int dst[4] = {0, -1, -1, -1};
-    float sw = 0.0f;
-    if (texel_valid)
-    {
-        blend_destinations(1 + c % (kIrrTile - 2), 1 + c / (kIrrTile - 2), kIrrTile, dst);
-        sw = w_sum[kDepInterior + c];
-    }
+    // epilogue role: lane = output texel e of the 8x8 tile (borders included: computed from their octahedral-wrap source's
+    // sums — the same arithmetic on the same values), wave mi takes the group's probes of parity mi: a probe's tile is one
+    // 1 KB load and one 1 KB store.  (Old value at the texel's own place: see blend_depth_resident.)
+    const int e = lane, tx = e & (kIrrTile - 1), ty = e / kIrrTile;
+    int sx = tx, sy = ty;
+    if (tx == 0 || ty == 0 || tx == kIrrTile - 1 || ty == kIrrTile - 1) border_source(tx, ty, kIrrTile, sx, sy);
+    const int c = (sy - 1) * (kIrrTile - 2) + (sx - 1);
+    const float sw = w_sum[kDepInterior + c];
+    const float* stage_src = &stage_all[c >> 5][0][(c & 31) * kStageStride];
     for (uint32_t task = first_task; task < n_tasks; task += task_stride)
     {
         const float* wa = w_tiles + static_cast<size_t>(kDepMTiles + mi) * n_pad * 32 + lane * 4;
         const float* vb = rad_rgb + static_cast<size_t>(task) * 3 * n_pad * 32 + lane * 4;
         f16v acc[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) acc[k] = blend_contract(wa, vb + static_cast<size_t>(k) * n_pad * 32, q_pairs);
+        blend_contract3(wa, vb, static_cast<size_t>(n_pad) * 32, q_pairs, acc);
         __syncthreads();  // (the previous task's staging has been read)
 #pragma unroll
         for (int k = 0; k < 3; ++k) stage_tile(stage_all[mi][k], acc[k], lane & 31, lane >> 5);
         if (threadIdx.x < 32) slot_sh[threadIdx.x] = static_cast<uint32_t>(blend_tile_slot(G, min(task * 32u + threadIdx.x, A.n_local_probes - 1u)));
         __syncthreads();
         const uint32_t np = min(32u, A.n_local_probes - task * 32u);
-        if (texel_valid)
-            for (uint32_t p = p_first; p < np; p += 2u)
+        constexpr uint32_t kBatch = 8;  // old tiles in flight per wave
+        for (uint32_t p0 = static_cast<uint32_t>(mi); p0 < np; p0 += 2u * kBatch)
+        {
+            float4 old[kBatch];
+#pragma unroll
+            for (uint32_t b = 0; b < kBatch; ++b)
             {
-                const size_t tile_off = static_cast<size_t>(slot_sh[p]) * (kIrrTile * kIrrTile * 4);
-                float* tile = A.irradiance + tile_off;
-                float res[3] = {0.0f, 0.0f, 0.0f};
-                if (sw > 1e-6f)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) res[k] = stage_all[mi][k][trow * kStageStride + static_cast<int>(p)] / sw;
-                const float4 old = *reinterpret_cast<const float4*>(A.irradiance_old + tile_off + dst[0] * 4);
-                const float4 out{gl_mix(old.x, res[0], hyst), gl_mix(old.y, res[1], hyst), gl_mix(old.z, res[2], hyst), 1.0f};
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (dst[k] >= 0) *reinterpret_cast<float4*>(tile + dst[k] * 4) = out;
+                const uint32_t p = min(p0 + 2u * b, 31u);
+                old[b] = *reinterpret_cast<const float4*>(A.irradiance_old + static_cast<size_t>(slot_sh[p]) * (kIrrTile * kIrrTile * 4) + e * 4);
             }
+#pragma unroll
+            for (uint32_t b = 0; b < kBatch; ++b)
+            {
+                const uint32_t p = p0 + 2u * b;
+                if (p < np)  // (wave-uniform)
+                {
+                    float res[3] = {0.0f, 0.0f, 0.0f};
+                    if (sw > 1e-6f)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) res[k] = stage_src[k * (32 * kStageStride) + static_cast<int>(p)] / sw;
+                    *reinterpret_cast<float4*>(A.irradiance + static_cast<size_t>(slot_sh[p]) * (kIrrTile * kIrrTile * 4) + e * 4) =
+                        float4{gl_mix(old[b].x, res[0], hyst), gl_mix(old[b].y, res[1], hyst), gl_mix(old[b].z, res[2], hyst), 1.0f};
+                }
+            }
+        }
     }
 }
 
@@ -365,6 +561,12 @@ __global__ __launch_bounds__(kBlendWaves * 64) void k_probe_blend_depth(const Bl
 {
     __shared__ DepthShared sh;
     blend_depth_role(A, rad_dd, w_tiles, w_sum, sh, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(kResWaves * 64) void k_probe_blend_depth_res(const BlendArgs A, const float* __restrict__ rad_dd, const float* __restrict__ w_tiles,
+                                                                            const float* __restrict__ w_sum)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char blend_dyn_lds[];
+    blend_depth_resident(A, rad_dd, w_tiles, w_sum, *reinterpret_cast<DepthResShared*>(blend_dyn_lds), blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(kIrrWaves * 64) void k_probe_blend_irr(const BlendArgs A, const float* __restrict__ rad_rgb, const float* __restrict__ w_tiles,
                                                                     const float* __restrict__ w_sum)
@@ -531,8 +733,16 @@ hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t st
                                static_cast<const float*>(args.w_sum), irr_blocks);
         else
         {
-            hipLaunchKernelGGL(k_probe_blend_depth, dim3(dep_blocks), dim3(kBlendWaves * 64), 0, stream, args, args.rad_dd, static_cast<const float*>(args.w),
-                               static_cast<const float*>(args.w_sum));
+            if (rec_ray_pad(static_cast<uint32_t>(n)) == 256u)  // the weight tiles fit the register file: persistent workgroups, one per CU
+            {
+                hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_probe_blend_depth_res), sizeof(DepthResShared));
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k_probe_blend_depth_res, dim3(std::min<uint32_t>(dep_tasks, static_cast<uint32_t>(num_cus))), dim3(kResWaves * 64), sizeof(DepthResShared), stream, args,
+                                   args.rad_dd, static_cast<const float*>(args.w), static_cast<const float*>(args.w_sum));
+            }
+            else
+                hipLaunchKernelGGL(k_probe_blend_depth, dim3(dep_blocks), dim3(kBlendWaves * 64), 0, stream, args, args.rad_dd, static_cast<const float*>(args.w),
+                                   static_cast<const float*>(args.w_sum));
             hipLaunchKernelGGL(k_probe_blend_irr, dim3(irr_blocks), dim3(kIrrWaves * 64), 0, stream, args, args.rad_rgb, static_cast<const float*>(args.w),
                                static_cast<const float*>(args.w_sum));
         }

@@ -1013,7 +1013,13 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
 // the entry to become valid (!= 0xffff) and invalidate it.
 // =================================================================================================
 constexpr uint32_t kAqCap = 2048, kAqMask = kAqCap - 1;
-constexpr int kAqThinTrip = 32;     // a march wave with fewer lanes in flight (and nothing queued) yields for a moment
+#ifndef DDGI_AQ_THIN
+#define DDGI_AQ_THIN 32
+#endif
+#ifndef DDGI_AQ_THIN_WAITS
+#define DDGI_AQ_THIN_WAITS 4
+#endif
+constexpr int kAqThinTrip = DDGI_AQ_THIN;     // a march wave with fewer lanes in flight (and nothing queued) yields for a moment
 constexpr int kAqEventQueues = 7;  // buckets 0..6 (kBucketRefill is served from FQ)
 
 struct AqShared  // control block at the start of dynamic LDS (32 dwords)
@@ -1177,7 +1183,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             }
             // a thin trip costs the SIMD as many issue slots as a full one: with few marches in flight and
             // none queued, give the slots to the event waves for a moment and look again (bounded)
-            if (__popcll(__ballot(have)) < kAqThinTrip && thin_waits < 4)
+            if (__popcll(__ballot(have)) < kAqThinTrip && thin_waits < DDGI_AQ_THIN_WAITS)
             {
                 ++thin_waits;
                 __builtin_amdgcn_s_sleep(4);

@@ -300,7 +300,11 @@ int ddgi_device_textures(ddgi_handle h, void** tex0, size_t* tex0_bytes, void** 
 /* Makes the handle use caller-allocated full-grid device buffers (same layout/size as above)
  * instead of its own, so that e.g. torch.distributed.all_gather_into_tensor can run in place.
  * The caller keeps ownership and must keep them alive while bound.  NULLs rebind the internal
- * buffers. */
+ * buffers.
+ * DDGI mode: the update mixes every texel with the old value at its own place, and a tile's border
+ * texels are copies of interior texels (octahedral wrap).  Buffers bound here must therefore hold
+ * either zeros (fresh tiles) or tiles this library has written (whose borders equal their sources);
+ * tiles with inconsistent borders would keep the inconsistency, decaying with the hysteresis. */
 int ddgi_bind_textures(ddgi_handle h, void* tex0, void* tex1);
 
 /* ddgi_sample on device pointers, asynchronous on the handle's stream. */

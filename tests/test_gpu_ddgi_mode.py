@@ -119,3 +119,28 @@ def test_blend_kernels_agree_on_ragged_shapes(ddgi, oracle, counts, s):
     for kernel, (irr, dep) in results.items():
         assert np.array_equal(_bits(irr), _bits(o_irr)), kernel
         assert np.array_equal(_bits(dep), _bits(o_dep)), kernel
+
+
+@pytest.mark.gpu
+def test_persistent_depth_blend_agrees_with_the_per_probe_kernel_on_a_large_grid(ddgi):
+    """More than 8 192 probes x 256 rays: the depth tiles are blended by the persistent kernel that keeps its weight tile in
+    registers (k_probe_blend_depth_res), 576 groups over one workgroup per CU (so the workgroups' loops end unevenly).  The
+    one-probe-per-workgroup kernel (DDGI_BLEND_KERNEL=probe; checked against the oracle above) must give the same bits,
+    with hysteresis over two frames."""
+    import os
+    counts, side, s, origin, scene = (24, 16, 24), 2, 16, (0.0, 0.0, 0.0), 0
+    results = {}
+    for kernel in ("mfma", "probe"):
+        if kernel == "probe":
+            os.environ["DDGI_BLEND_KERNEL"] = "probe"
+        try:
+            with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin, hysteresis=0.7), ddgi.make_settings(scene, 3)) as eng:
+                eng.set_mode(ddgi.MODE_DDGI)
+                for _ in range(2):
+                    eng.probe_update()
+                results[kernel] = eng.read_tiles()
+        finally:
+            os.environ.pop("DDGI_BLEND_KERNEL", None)
+    assert results["mfma"][1].any() and results["mfma"][0].any()
+    assert np.array_equal(_bits(results["mfma"][0]), _bits(results["probe"][0]))
+    assert np.array_equal(_bits(results["mfma"][1]), _bits(results["probe"][1]))
