@@ -37,11 +37,16 @@ WORKLOAD = {
     "counts": (32, 16, 32),
     "side": 2,
     "s": 16,
+    "tile": (16, 16),
     "origin": (1.4, 0.0, 1.0),
     "scene": 0,
     "max_bounces": 8,
     "seed": 1,
 }
+# BASELINE.json configs[3] (the 8-GPU shard configuration), runnable on one GPU with --workload c4: 131 072 probes x 512 rays
+# (a 32 x 16 ray tile, ddgi_set_ray_tile) = 67 108 864 probe rays, 3.2 GB of ProbeRay records resident in HBM
+WORKLOAD_C4 = dict(WORKLOAD, name="c4_cave_64x32x64_probes_x512_rays_ref", counts=(64, 32, 64), side=1, tile=(32, 16))
+WORKLOADS = {"c3": WORKLOAD, "c4": WORKLOAD_C4}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_RAY = 56        # 48 B ProbeRay read + two 4 B rgba8 texel writes
 
@@ -67,7 +72,7 @@ def _issue_from_profiles():
     return out or None
 
 
-def _traffic_from_profiles():
+def _traffic_from_profiles(workload=None):
     """Per-launch HBM bytes of k_probe_trace_ref from the committed rocprofv3 --pmc passes
     (profiles/*_traffic.json, written by tools/pmc_traffic.py); None if not collected."""
     import glob
@@ -77,14 +82,14 @@ def _traffic_from_profiles():
         try:
             with open(path) as fh:
                 d = json.load(fh)
-            if d.get("workload") == WORKLOAD["name"] and d.get("kernel", "").startswith("k_probe_trace"):
+            if d.get("workload") == (workload or WORKLOAD["name"]) and d.get("kernel", "").startswith("k_probe_trace"):
                 best = d.get("hbm_bytes_per_launch", best)
         except Exception:
             pass
     return best
 
 
-def cpu_baseline(n_probes=96, gpu_albedo=None):
+def cpu_baseline(n_probes=96, gpu_albedo=None, w=WORKLOAD, rays=None):
     """The oracle (a CPU restatement of the reference's algorithm: procedural getBlockAt per march
     step, exactly what the reference's shader does) over a bounded, evenly spread sample of the
     workload's probes, all host threads.  The texels it computes are also compared, byte for byte, with
@@ -92,10 +97,14 @@ def cpu_baseline(n_probes=96, gpu_albedo=None):
     from oracle import oracle_py as O
 
     O.set_arith(True)
-    w = WORKLOAD
+    tx, ty = w["tile"]
+    O.set_ray_tile(*((0, 0) if tx == ty == w["s"] else (tx, ty)))
     f = O.make_field(w["counts"], w["side"], w["s"], w["origin"])
     st = O.make_settings(w["scene"], w["max_bounces"])
-    rays = O.generate_probe_rays(f, O.new_rand_state(w["seed"]))
+    if rays is None:  # (the engine's own ray buffer when the caller passes it: the host generator's output, checked against the oracle's in tests/)
+        rays = O.generate_probe_rays(f, O.new_rand_state(w["seed"]))
+    else:
+        rays = rays.view(O.RAY_DTYPE)
     total = w["counts"][0] * w["counts"][1] * w["counts"][2]
     # calibrate on a small spread sample, then size the timed sample for ~12 s of wall time
     # (bounded by the whole grid)
@@ -108,7 +117,8 @@ def cpu_baseline(n_probes=96, gpu_albedo=None):
     t0 = time.perf_counter()
     want = O.probe_update_probes(f, st, rays, probes)
     dt = time.perf_counter() - t0
-    nrays = len(probes) * w["s"] ** 2
+    nrays = len(probes) * tx * ty
+    O.set_ray_tile(0, 0)
     out = {
         "value": nrays / dt,
         "unit": "rays/s",
@@ -118,14 +128,15 @@ def cpu_baseline(n_probes=96, gpu_albedo=None):
     }
     if gpu_albedo is not None:
         # the probes of the sample as tile masks of the reference raster (tile of probe p at ((p mod cx*cz)*s, (p div cx*cz)*s))
-        s, cxz = w["s"], w["counts"][0] * w["counts"][2]
+        cxz = w["counts"][0] * w["counts"][2]
         mask = np.zeros((w["counts"][1], cxz), dtype=bool)
         mask[np.unique(probes) // cxz, np.unique(probes) % cxz] = True
-        tiles_gpu = gpu_albedo.reshape(w["counts"][1], s, cxz, s, 4).transpose(0, 2, 1, 3, 4)[mask]
-        tiles_cpu = want.reshape(w["counts"][1], s, cxz, s, 4).transpose(0, 2, 1, 3, 4)[mask]
+        tiles_gpu = gpu_albedo.reshape(w["counts"][1], ty, cxz, tx, 4).transpose(0, 2, 1, 3, 4)[mask]
+        tiles_cpu = want.reshape(w["counts"][1], ty, cxz, tx, 4).transpose(0, 2, 1, 3, 4)[mask]
         differ = int((tiles_gpu != tiles_cpu).any(axis=-1).sum())
-        n_tex = int(mask.sum()) * s * s
-        scope = "c3 full grid" if int(mask.sum()) == total else f"{int(mask.sum())} of {total} probes of c3"
+        n_tex = int(mask.sum()) * tx * ty
+        cfg = w["name"][:2]
+        scope = f"{cfg} full grid" if int(mask.sum()) == total else f"{int(mask.sum())} of {total} probes of {cfg}"
         out["parity_checked"] = f"{scope}, {n_tex - differ} of {n_tex} texels equal (HIP vs oracle, rgba8 bytes)"
         out["parity_texels_differing"] = differ
     return out
@@ -152,6 +163,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-probes", type=int, default=96)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3",
+                    help="c3 (default): the configuration the metric is quoted on; c4: BASELINE's 8-GPU shard configuration "
+                         "(64x32x64 probes x 512 rays) on however many GPUs are given")
     ap.add_argument("--mode", choices=["ref", "ddgi"], default="ref",
                     help="ref (default): the reference's live behaviour, the headline metric; ddgi: in-kernel Fibonacci rays + "
                          "octahedral irradiance/depth blend with hysteresis (trace + blend per step)")
@@ -179,10 +193,12 @@ def main():
         with _c_stdout_to_stderr():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    w = WORKLOAD
+    w = WORKLOADS[args.workload]
     field = ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"])
     settings = ddgi_amd.make_settings(w["scene"], w["max_bounces"])
     eng = ddgi_amd.ProbeEngine(field, settings, device=local_rank, rank=rank, world=world)
+    if w["tile"] != (w["s"], w["s"]):
+        eng.set_ray_tile(*w["tile"])
     stream = torch.cuda.current_stream()
     eng.set_stream(stream.cuda_stream)          # kernels + collectives share torch's stream
     ddgi_mode = args.mode == "ddgi"
@@ -268,7 +284,7 @@ def main():
         "config": {
             "workload": w["name"],
             "probes": list(w["counts"]),
-            "rays_per_probe": w["s"] ** 2,
+            "rays_per_probe": w["tile"][0] * w["tile"][1],
             "probe_rays": total_rays,
             "scene": "minecraft_cave",
             "max_bounces": w["max_bounces"],
@@ -282,10 +298,10 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None if ddgi_mode else _traffic_from_profiles(),
+            "traffic": None if ddgi_mode else _traffic_from_profiles(w["name"]),
             "algorithmic_bytes_per_launch": algo_bytes,
             "kernel_ms": kernel_ms,
-            "issue": None if ddgi_mode else _issue_from_profiles(),
+            "issue": None if (ddgi_mode or args.workload != "c3") else _issue_from_profiles(),
             "note": "the trace kernel is VALU-issue bound (dependent voxel steps + hit shading), not HBM bound: `issue` = the VALU's occupancy from profiles/ (rocprofv3 --pmc), see DESIGN.md section 4",
         },
     }
@@ -299,7 +315,8 @@ def main():
         out["blend"] = {"kernel": "k_blend_weights+k_probe_blend", "kernel_ms": bms, "kernel_io_bytes_per_launch": bbytes,
                         "achieved_GBps": bbytes / (bms * 1e-3) / 1e9, "frac_of_hbm_peak": bbytes / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not ddgi_mode:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_probes, gpu_albedo=eng.read_textures()[0])
+        out["cpu_baseline"] = cpu_baseline(args.cpu_probes, gpu_albedo=eng.read_textures()[0], w=w,
+                                           rays=None if args.workload == "c3" else eng.get_probe_rays())
     if comm is not None:
         eng.exchange_init(None)
     eng.close()
