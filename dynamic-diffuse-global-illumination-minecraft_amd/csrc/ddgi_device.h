@@ -56,7 +56,12 @@ struct March
     int cell;  // linear (clamped) cell index reached by the last step
 };
 
-DDGI_D float axis_inv(float d) { return d == 0.0f ? __builtin_inff() : 1.0f / d; }
+// d: a component of a normalised direction a * (1 / sqrt(dot(a, a))): |d| <= 1 + 2^-22, or 0 / inf / NaN for a degenerate a
+// (dot under- or overflowed) — inside pm::rcp_upto_2p62's domain
+DDGI_D float axis_inv(float d) { return d == 0.0f ? __builtin_inff() : pm::rcp_upto_2p62(d); }
+// normalize3 (P3) of a direction that is itself the output of a normalisation or of hemisphere_dir: dot(d, d) is about 1,
+// or 0 / inf / NaN when that normalisation was degenerate — never in (0, 2^-96), the part of the line pm::rcp_sqrt_core gets wrong
+DDGI_D f3 normalize3_of_unit(f3 d) { return d * pm::rcp_sqrt_core(dot3(d, d)); }
 
 // The light-sphere half of intersect_scene (intersection.glsl:1264-1279): nearest hit of the ray
 // (o, d) with the radius-0.1 spheres around the lights; +inf / -1 if none.
@@ -208,8 +213,9 @@ DDGI_D f3 hemisphere_dir(f3 n, uint32_t& rng)
 {
     const float kTwoPi = 6.2831853071795864769252867665590057683943f;
     const float kSqrtThird = 0.5773502691896257645091487805019574556476f;
-    const float up = sqrtf(rng_next(rng));
-    const float over = sqrtf(1.0f - up * up);
+    // rng_next is 0 or in [2^-32, 1], 1 - up * up is 0 or in [2^-24, 1]: inside pm::sqrt_core's exact range, no range test
+    const float up = pm::sqrt_core(rng_next(rng));
+    const float over = pm::sqrt_core(1.0f - up * up);
     const float around = rng_next(rng) * kTwoPi;
     f3 other;
     if (fabsf(n.x) < kSqrtThird) other = mk3(1, 0, 0);

@@ -131,5 +131,38 @@ DDGI_HD float acosf_pinned(float xf)
     return static_cast<float>(neg ? (kPi - 2.0 * a) : (2.0 * a));
 }
 
+// ---- IEEE 1/x and sqrt(x) in fewer instructions, on arguments known to lie in a domain (device) -----------------------
+// The compiler's correctly rounded binary32 1/x is 11 instructions and its sqrt 16 (scaling for the ends of the exponent
+// range, fix-ups for the special values); a ray segment runs one of them a dozen times (normalisation, the three axis
+// reciprocals of a march, the hemisphere sample).  Where the argument's range is known by construction, shorter BRANCH-FREE
+// sequences give the same bits (a version that tested the range and branched to the compiler's sequence saved 3.4 % of the
+// trace kernel's VALU instructions and lost 1.8 % of its time to the branches' scalar work):
+//   sqrt_core(x)      v_sqrt_f32 + the compiler's own +-1 ulp fix            == sqrtf(x)          for x in {+0} u [2^-96, +inf] u NaN
+//   rcp_sqrt_core(x)  ... + v_rcp_f32, one Newton step in fma, v_div_fixup   == 1.0f / sqrtf(x)   on the same domain
+//   rcp_upto_2p62(x)  the same reciprocal behind a power-of-two pre-scale     == 1.0f / x          for |x| <= 2^62 (zero and
+//                     subnormals included), +-inf and NaN
+// bit for bit: tests/exact_rcp_sqrt_check.hip walks all 2^32 arguments on the GPU and checks every one that lies in the
+// stated domain (tests/test_gpu_device_math.py).  Each use site says why its arguments are in the domain.
+__device__ __forceinline__ float sqrt_core(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-sd, s, x), ru = fmaf(-su, s, x);
+    s = rd <= 0.0f ? sd : s;
+    s = ru > 0.0f ? su : s;
+    return s;
+}
+__device__ __forceinline__ float rcp_fixed(float x)  // 1.0f / x for x = 0, 2^-126 <= |x| <= 2^126, +-inf, NaN
+{
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_amdgcn_div_fixupf(fmaf(fmaf(-x, r, 1.0f), r, r), x, 1.0f);
+}
+__device__ __forceinline__ float rcp_sqrt_core(float x) { return rcp_fixed(sqrt_core(x)); }  // sqrt_core's range maps into rcp_fixed's
+__device__ __forceinline__ float rcp_upto_2p62(float x)
+{
+    const float s = fabsf(x) < 0x1.0p-64f ? 0x1.0p64f : 1.0f;  // (exact: a power of two; a quotient that overflows does so in r * s)
+    return rcp_fixed(x * s) * s;
+}
+
 }  // namespace pm
 }  // namespace ddgi

@@ -291,7 +291,9 @@ struct InlineEnd  // how a march that ended within its first (inline) steps ende
     bool occ;
 };
 
-template <class Cfg>
+// kUnitDir: d is the output of a normalisation or of hemisphere_dir (every march an event posts; not the rays of a refill,
+// which are the caller's) — see normalize3_of_unit
+template <class Cfg, bool kUnitDir = false>
 DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, bool feeler, const TraceArgs& A, const uint32_t* s_bits, InlineEnd* end = nullptr,
                          bool have_spheres = false, float tl_in = 0.0f, int lid_in = -1, LaneProbe* lp = nullptr)
 {
@@ -300,7 +302,7 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
     float tl = tl_in;
     int lid = lid_in;
     if (!have_spheres) light_spheres<Cfg::kNl>(o, d, A, tl, lid);
-    const f3 dn = normalize3(d);
+    const f3 dn = kUnitDir ? normalize3_of_unit(d) : normalize3(d);
     st3(P.ro, slot, o);
     st3(P.dn, slot, dn);
     if (!feeler) set3(c.hc, d);  // the hit albedo is dead until this march is shaded
@@ -619,7 +621,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                             // trip, no second event.  A feeler that has to be marched takes the slot to the march queue.
                             c.cnt = cnt;
                             InlineEnd fe;
-                            if (wf_post_march<Cfg>(P, slot, c, hpos, to_light, true, A, s_bits, &fe, true, ftl, flid, lp) < 0)
+                            if (wf_post_march<Cfg, true>(P, slot, c, hpos, to_light, true, A, s_bits, &fe, true, ftl, flid, lp) < 0)
                             {
                                 store_cold(P, slot, c, true);  // (hn and the albedo travel with the marched feeler)
                                 return 1;
@@ -690,7 +692,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
         if (lit_done) posted = wf_lighting_done<Cfg>(P, slot, c, ld_contribution, ld_hpos, ld_hnrm, ld_cnt, A, mo, md, lp);
         if (posted)
         {
-            const int pb = wf_post_march<Cfg>(P, slot, c, mo, md, as_feeler, A, s_bits, nullptr, false, 0.0f, -1, lp);
+            const int pb = wf_post_march<Cfg, true>(P, slot, c, mo, md, as_feeler, A, s_bits, nullptr, false, 0.0f, -1, lp);  // md: to_light or a hemisphere sample
 #ifdef DDGI_LAP
             DDGI_PROBE(lp, 12);  // write-back
 #endif

@@ -1,0 +1,68 @@
+// Exhaustive check, on the GPU, of the short branch-free 1/x and sqrt(x) sequences the kernels use on arguments of known
+// range (csrc/ddgi_pinned_math.h: pm::sqrt_core, rcp_sqrt_core, rcp_fixed, rcp_upto_2p62) against the compiler's correctly
+// rounded `/` and sqrtf: every one of the 2^32 binary32 arguments that lies in a function's stated domain, bit for bit.
+// Prints OK or the mismatch counts.  Run by tests/test_gpu_device_math.py.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "../dynamic-diffuse-global-illumination-minecraft_amd/csrc/ddgi_pinned_math.h"
+
+using namespace ddgi;
+
+__device__ __forceinline__ bool same(float a, float b) { return __float_as_uint(a) == __float_as_uint(b); }
+// the references, kept out of line so that nothing of the sequences under test can be folded into them
+__device__ __attribute__((noinline)) float ref_rcp(float x) { return 1.0f / x; }
+__device__ __attribute__((noinline)) float ref_sqrt(float x) { return sqrtf(x); }
+
+__global__ void k_check(unsigned long long* bad, unsigned long long* checked)
+{
+    const uint64_t tid = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x, stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long b[4] = {0, 0, 0, 0}, n[4] = {0, 0, 0, 0};
+    for (uint64_t u = tid; u < (1ull << 32); u += stride)
+    {
+        const float x = __uint_as_float(static_cast<uint32_t>(u));
+        const float ax = fabsf(x);
+        const bool nan = x != x;
+        const float want_r = ref_rcp(x), want_s = ref_sqrt(x);
+        // sqrt_core / rcp_sqrt_core: {+0} u [2^-96, +inf] u NaN
+        if (u == 0u || nan || (x >= 0x1.0p-96f))
+        {
+            n[0]++, n[1]++;
+            if (!same(pm::sqrt_core(x), want_s)) b[0]++;
+            if (!same(pm::rcp_sqrt_core(x), ref_rcp(want_s))) b[1]++;
+        }
+        // rcp_fixed: +-0, 2^-126 <= |x| <= 2^126, +-inf, NaN
+        if (ax == 0.0f || nan || ax == __builtin_inff() || (ax >= 0x1.0p-126f && ax <= 0x1.0p126f))
+        {
+            n[2]++;
+            if (!same(pm::rcp_fixed(x), want_r)) b[2]++;
+        }
+        // rcp_upto_2p62: |x| <= 2^62 (zero, subnormals), +-inf, NaN
+        if (nan || ax == __builtin_inff() || ax <= 0x1.0p62f)
+        {
+            n[3]++;
+            if (!same(pm::rcp_upto_2p62(x), want_r)) b[3]++;
+        }
+    }
+    for (int i = 0; i < 4; ++i)
+    {
+        if (b[i]) atomicAdd(&bad[i], b[i]);
+        atomicAdd(&checked[i], n[i]);
+    }
+}
+
+int main()
+{
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, 8 * sizeof(unsigned long long)) != hipSuccess || hipMemset(d, 0, 8 * sizeof(unsigned long long)) != hipSuccess) return 2;
+    hipLaunchKernelGGL(k_check, dim3(4096), dim3(256), 0, 0, d, d + 4);
+    unsigned long long h[8] = {1, 1, 1, 1, 0, 0, 0, 0};
+    if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+    const char* names[4] = {"sqrt_core", "rcp_sqrt_core", "rcp_fixed", "rcp_upto_2p62"};
+    for (int i = 0; i < 4; ++i) std::printf("%-14s %llu mismatches in %llu arguments of its domain\n", names[i], h[i], h[4 + i]);
+    const bool ok = !(h[0] | h[1] | h[2] | h[3]) && h[4] > (1ull << 30) && h[6] > (1ull << 31) && h[7] > (1ull << 31);
+    std::printf(ok ? "OK\n" : "FAILED\n");
+    return ok ? 0 : 1;
+}

@@ -24,3 +24,14 @@ def test_f32_mfma_accumulates_in_k_order_like_an_fmaf_chain(tmp_path):
                     "-fno-fast-math", os.path.join(HERE, "mfma_order_check.hip"), "-o", str(exe)], check=True)
     res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
+
+
+def test_short_reciprocal_and_square_root_sequences_are_ieee_on_their_whole_domains(tmp_path):
+    """pm::sqrt_core / rcp_sqrt_core / rcp_fixed / rcp_upto_2p62 (v_sqrt_f32 + a +-1 ulp fix; v_rcp_f32 + one Newton step +
+    v_div_fixup; the same behind a power-of-two pre-scale) against sqrtf(x) and `1.0f / x`: every binary32 argument of each
+    function's stated domain, on the GPU, bit for bit."""
+    exe = tmp_path / "exact_rcp_sqrt_check"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                    "-fno-fast-math", os.path.join(HERE, "exact_rcp_sqrt_check.hip"), "-o", str(exe)], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
