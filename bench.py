@@ -144,7 +144,8 @@ def cpu_baseline(n_probes=96, gpu_albedo=None, w=WORKLOAD, rays=None):
 
 class _c_stdout_to_stderr:
     """RCCL prints its version banner to the C-level stdout when a communicator is created; bench.py's stdout
-    must carry exactly one JSON line, so file descriptor 1 points at stderr while communicators are made."""
+    must carry exactly one JSON line, so file descriptor 1 points at stderr while communicators are made (and the C stdio
+    buffer, which a pipe makes block-buffered, is flushed before fd 1 is restored)."""
 
     def __enter__(self):
         sys.stdout.flush()
@@ -152,6 +153,9 @@ class _c_stdout_to_stderr:
         os.dup2(2, 1)
 
     def __exit__(self, *exc):
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)  # RCCL printf()s into the C stdio buffer: empty it while fd 1 still points at stderr
         os.dup2(self._saved, 1)
         os.close(self._saved)
 
