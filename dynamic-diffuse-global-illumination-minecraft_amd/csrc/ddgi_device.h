@@ -57,8 +57,8 @@ struct March
 };
 
 // d: a component of a normalised direction a * (1 / sqrt(dot(a, a))): |d| <= 1 + 2^-22, or 0 / inf / NaN for a degenerate a
-// (dot under- or overflowed) — inside pm::rcp_upto_2p62's domain
-DDGI_D float axis_inv(float d) { return d == 0.0f ? __builtin_inff() : pm::rcp_upto_2p62(d); }
+// (dot under- or overflowed) — inside pm::rcp_upto_2p94's domain
+DDGI_D float axis_inv(float d) { return d == 0.0f ? __builtin_inff() : pm::rcp_upto_2p94(d); }
 // normalize3 (P3) of a direction that is itself the output of a normalisation or of hemisphere_dir: dot(d, d) is about 1,
 // or 0 / inf / NaN when that normalisation was degenerate — never in (0, 2^-96), the part of the line pm::rcp_sqrt_core gets wrong
 DDGI_D f3 normalize3_of_unit(f3 d) { return d * pm::rcp_sqrt_core(dot3(d, d)); }

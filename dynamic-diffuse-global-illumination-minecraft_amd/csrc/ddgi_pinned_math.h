@@ -139,7 +139,7 @@ DDGI_HD float acosf_pinned(float xf)
 // trace kernel's VALU instructions and lost 1.8 % of its time to the branches' scalar work):
 //   sqrt_core(x)      v_sqrt_f32 + the compiler's own +-1 ulp fix            == sqrtf(x)          for x in {+0} u [2^-96, +inf] u NaN
 //   rcp_sqrt_core(x)  ... + v_rcp_f32, one Newton step in fma, v_div_fixup   == 1.0f / sqrtf(x)   on the same domain
-//   rcp_upto_2p62(x)  the same reciprocal behind a power-of-two pre-scale     == 1.0f / x          for |x| <= 2^62 (zero and
+//   rcp_upto_2p94(x)  the same reciprocal of x * 2^32, times 2^32             == 1.0f / x          for |x| <= 2^94 (zero and
 //                     subnormals included), +-inf and NaN
 // bit for bit: tests/exact_rcp_sqrt_check.hip walks all 2^32 arguments on the GPU and checks every one that lies in the
 // stated domain (tests/test_gpu_device_math.py).  Each use site says why its arguments are in the domain.
@@ -158,10 +158,11 @@ __device__ __forceinline__ float rcp_fixed(float x)  // 1.0f / x for x = 0, 2^-1
     return __builtin_amdgcn_div_fixupf(fmaf(fmaf(-x, r, 1.0f), r, r), x, 1.0f);
 }
 __device__ __forceinline__ float rcp_sqrt_core(float x) { return rcp_fixed(sqrt_core(x)); }  // sqrt_core's range maps into rcp_fixed's
-__device__ __forceinline__ float rcp_upto_2p62(float x)
+__device__ __forceinline__ float rcp_upto_2p94(float x)
 {
-    const float s = fabsf(x) < 0x1.0p-64f ? 0x1.0p64f : 1.0f;  // (exact: a power of two; a quotient that overflows does so in r * s)
-    return rcp_fixed(x * s) * s;
+    // x * 2^32 is exact and normal for every nonzero |x| <= 2^94 (subnormals included) and lies in rcp_fixed's range; scaling
+    // the correctly rounded quotient back by 2^32 is exact again, or overflows exactly where 1.0f / x does
+    return rcp_fixed(x * 0x1.0p32f) * 0x1.0p32f;
 }
 
 }  // namespace pm

@@ -1,5 +1,5 @@
 // Exhaustive check, on the GPU, of the short branch-free 1/x and sqrt(x) sequences the kernels use on arguments of known
-// range (csrc/ddgi_pinned_math.h: pm::sqrt_core, rcp_sqrt_core, rcp_fixed, rcp_upto_2p62) against the compiler's correctly
+// range (csrc/ddgi_pinned_math.h: pm::sqrt_core, rcp_sqrt_core, rcp_fixed, rcp_upto_2p94) against the compiler's correctly
 // rounded `/` and sqrtf: every one of the 2^32 binary32 arguments that lies in a function's stated domain, bit for bit.
 // Prints OK or the mismatch counts.  Run by tests/test_gpu_device_math.py.
 #include <hip/hip_runtime.h>
@@ -39,11 +39,11 @@ __global__ void k_check(unsigned long long* bad, unsigned long long* checked)
             n[2]++;
             if (!same(pm::rcp_fixed(x), want_r)) b[2]++;
         }
-        // rcp_upto_2p62: |x| <= 2^62 (zero, subnormals), +-inf, NaN
-        if (nan || ax == __builtin_inff() || ax <= 0x1.0p62f)
+        // rcp_upto_2p94: |x| <= 2^94 (zero, subnormals), +-inf, NaN
+        if (nan || ax == __builtin_inff() || ax <= 0x1.0p94f)
         {
             n[3]++;
-            if (!same(pm::rcp_upto_2p62(x), want_r)) b[3]++;
+            if (!same(pm::rcp_upto_2p94(x), want_r)) b[3]++;
         }
     }
     for (int i = 0; i < 4; ++i)
@@ -60,7 +60,7 @@ int main()
     hipLaunchKernelGGL(k_check, dim3(4096), dim3(256), 0, 0, d, d + 4);
     unsigned long long h[8] = {1, 1, 1, 1, 0, 0, 0, 0};
     if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return 2;
-    const char* names[4] = {"sqrt_core", "rcp_sqrt_core", "rcp_fixed", "rcp_upto_2p62"};
+    const char* names[4] = {"sqrt_core", "rcp_sqrt_core", "rcp_fixed", "rcp_upto_2p94"};
     for (int i = 0; i < 4; ++i) std::printf("%-14s %llu mismatches in %llu arguments of its domain\n", names[i], h[i], h[4 + i]);
     const bool ok = !(h[0] | h[1] | h[2] | h[3]) && h[4] > (1ull << 30) && h[6] > (1ull << 31) && h[7] > (1ull << 31);
     std::printf(ok ? "OK\n" : "FAILED\n");

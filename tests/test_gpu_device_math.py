@@ -27,7 +27,7 @@ def test_f32_mfma_accumulates_in_k_order_like_an_fmaf_chain(tmp_path):
 
 
 def test_short_reciprocal_and_square_root_sequences_are_ieee_on_their_whole_domains(tmp_path):
-    """pm::sqrt_core / rcp_sqrt_core / rcp_fixed / rcp_upto_2p62 (v_sqrt_f32 + a +-1 ulp fix; v_rcp_f32 + one Newton step +
+    """pm::sqrt_core / rcp_sqrt_core / rcp_fixed / rcp_upto_2p94 (v_sqrt_f32 + a +-1 ulp fix; v_rcp_f32 + one Newton step +
     v_div_fixup; the same behind a power-of-two pre-scale) against sqrtf(x) and `1.0f / x`: every binary32 argument of each
     function's stated domain, on the GPU, bit for bit."""
     exe = tmp_path / "exact_rcp_sqrt_check"
