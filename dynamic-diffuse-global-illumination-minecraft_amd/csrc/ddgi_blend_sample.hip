@@ -188,6 +188,7 @@ DDGI_D f16v blend_contract(const float* __restrict__ wa, const float* __restrict
 
 // The same for three B streams (the colour channels, `b_stride` floats apart) against ONE pass over the A stream: three
 // independent chains, each in ray order; the weights are read once instead of three times.
+template <int kDepth>
 DDGI_D void blend_contract3(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, int q_pairs, f16v (&acc)[3])
 {
 #pragma unroll
@@ -195,44 +196,46 @@ DDGI_D void blend_contract3(const float* __restrict__ wa, const float* __restric
     const float4* __restrict__ pa = reinterpret_cast<const float4*>(wa);
     const float4* __restrict__ pb[3] = {reinterpret_cast<const float4*>(vb), reinterpret_cast<const float4*>(vb + b_stride), reinterpret_cast<const float4*>(vb + 2 * b_stride)};
     const int n4 = q_pairs / 4;
-    float4 a0[2], b0[3][2];
+    // Operands are requested kDepth float4 (4 ray pairs each = 12 MFMAs = 768 matrix-pipe cycles) ahead of the MFMAs that consume
+    // them: an irradiance workgroup's two waves sit alone on their SIMDs, so the prefetch distance is all that hides the
+    // records' way from HBM (two float4 ahead, the kernel waited a microsecond per 8 ray pairs: 38 us, of which 10 are MFMAs).
+    // (kDepth = 8 costs 128 VGPRs: for the stand-alone irradiance kernel; the merged small-grid kernel, whose workgroups
+    // share a CU with depth workgroups, keeps 2)
+    float4 ab[kDepth], bb[3][kDepth];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < kDepth; ++u)
     {
-        a0[u] = pa[static_cast<size_t>(min(u, n4 - 1)) * 64];
+        const size_t at = static_cast<size_t>(min(u, n4 - 1)) * 64;
+        ab[u] = pa[at];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) b0[c][u] = pb[c][static_cast<size_t>(min(u, n4 - 1)) * 64];
+        for (int c = 0; c < 3; ++c) bb[c][u] = pb[c][at];
     }
-    for (int k = 0; k < n4; k += 2)
+    for (int k = 0; k < n4; k += kDepth)
     {
-        float4 a1[2], b1[3][2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < kDepth; ++u)
         {
-            const int kn = min(k + 2 + u, n4 - 1);  // past the end: re-read the last one (dropped)
-            a1[u] = pa[static_cast<size_t>(kn) * 64];
+            const float4 a = ab[u];
+            float4 b[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) b1[c][u] = pb[c][static_cast<size_t>(kn) * 64];
-        }
+            for (int c = 0; c < 3; ++c) b[c] = bb[c][u];
+            {
+                const size_t at = static_cast<size_t>(min(k + kDepth + u, n4 - 1)) * 64;  // past the end: re-read the last one (dropped)
+                ab[u] = pa[at];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+                for (int c = 0; c < 3; ++c) bb[c][u] = pb[c][at];
+            }
             if (k + u < n4)  // wave-uniform
             {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].x, b0[c][u].x, acc[c], 0, 0, 0);
+                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[c].x, acc[c], 0, 0, 0);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].y, b0[c][u].y, acc[c], 0, 0, 0);
+                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[c].y, acc[c], 0, 0, 0);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].z, b0[c][u].z, acc[c], 0, 0, 0);
+                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[c].z, acc[c], 0, 0, 0);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u].w, b0[c][u].w, acc[c], 0, 0, 0);
+                for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[c].w, acc[c], 0, 0, 0);
             }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-        {
-            a0[u] = a1[u];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) b0[c][u] = b1[c][u];
         }
     }
 }
@@ -496,6 +499,7 @@ DDGI_D void blend_depth_resident(const BlendArgs& A, const float* __restrict__ r
 // stores.  (Six waves per group — one per (channel, tile) — were slower: 55 us against 38 us on 16 384 probes; the
 // contraction is bound by requests in flight to L2 / HBM, not by the matrix pipe.)
 constexpr int kIrrWaves = kIrrMTiles;
+template <int kDepth>
 DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb, const float* __restrict__ w_tiles, const float* __restrict__ w_sum, IrrShared& sh,
                            uint32_t first_task, uint32_t task_stride)
 {
@@ -520,7 +524,7 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
         const float* wa = w_tiles + static_cast<size_t>(kDepMTiles + mi) * n_pad * 32 + lane * 4;
         const float* vb = rad_rgb + static_cast<size_t>(task) * 3 * n_pad * 32 + lane * 4;
         f16v acc[3];
-        blend_contract3(wa, vb, static_cast<size_t>(n_pad) * 32, q_pairs, acc);
+        blend_contract3<kDepth>(wa, vb, static_cast<size_t>(n_pad) * 32, q_pairs, acc);
         __syncthreads();  // (the previous task's staging has been read)
 #pragma unroll
         for (int k = 0; k < 3; ++k) stage_tile(stage_all[mi][k], acc[k], lane & 31, lane >> 5);
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(kIrrWaves * 64) void k_probe_blend_irr(const BlendA
                                                                     const float* __restrict__ w_sum)
 {
     __shared__ IrrShared sh;
-    blend_irr_role(A, rad_rgb, w_tiles, w_sum, sh, blockIdx.x, gridDim.x);
+    blend_irr_role<8>(A, rad_rgb, w_tiles, w_sum, sh, blockIdx.x, gridDim.x);
 }
 
 // Few probes (one rank's slab of a sharded grid: fewer groups than the chip has room for): one launch for both — blocks
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(kBlendWaves * 64) void k_probe_blend_mfma(const Ble
     __shared__ BlendShared sh;
     if (blockIdx.x < irr_blocks)
     {
-        if (threadIdx.x < kIrrWaves * 64) blend_irr_role(A, rad_rgb, w_tiles, w_sum, sh.irr, blockIdx.x, irr_blocks);
+        if (threadIdx.x < kIrrWaves * 64) blend_irr_role<2>(A, rad_rgb, w_tiles, w_sum, sh.irr, blockIdx.x, irr_blocks);
     }
     else
         blend_depth_role(A, rad_dd, w_tiles, w_sum, sh.dep, blockIdx.x - irr_blocks, gridDim.x - irr_blocks);
