@@ -422,6 +422,10 @@ DDGI_D void blend_depth_resident(const BlendArgs& A, const float* __restrict__ r
     else
     {
         // ================= service waves =================
+        // (In-kernel clocks: a texel wave that shares its SIMD with two contraction waves needs 27 000 cycles per group for work
+        // that takes 5 000 alone — while an f32 MFMA of another wave runs, this wave's VALU instructions mostly wait — and is the
+        // critical path, not the 16 400 cycles of the two contractions.  Priority over the contraction waves buys 1 us of 55.)
+        __builtin_amdgcn_s_setprio(2);
         const int sw_id = wave - kBlendWaves, st_tid = static_cast<int>(threadIdx.x) - kBlendWaves * 64;
         auto fetch_records = [&](uint32_t it, float4 (&r)[kResLoads]) {
             const float4* __restrict__ gb = reinterpret_cast<const float4*>(rad_dd + static_cast<size_t>(first_task + it * task_stride) * n_pad * 32);
