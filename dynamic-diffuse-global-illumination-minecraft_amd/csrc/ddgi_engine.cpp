@@ -764,7 +764,7 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     p.use_async = p.pool > 0 && !force_rounds && aq_pool_size(a.scene.nwords, 160 * 1024) > 0;
     if (p.use_async)
     {
-        p.pool = std::min(1344, aq_pool_size(a.scene.nwords, 160 * 1024));  // more slots than ~1300 buy nothing (C3: 1024: 3.64 ms, 1280: 3.36, 1536: 3.35, 2048: 3.39); 1344 x 72 B is what fits next to the cave's bitmap
+        p.pool = std::min(1344, aq_pool_size(a.scene.nwords, 160 * 1024));  // what fits next to the cave's bitmap at 72 B per slot; more buys nothing (C3: 1024: 2.56 ms, 1152: 2.37, 1344: 2.11, 1472: 2.13)
         if (tn.aq_pool > 0) p.pool = std::min(aq_pool_size(a.scene.nwords, 160 * 1024), std::max(1024, tn.aq_pool / 64 * 64));
     }
     if (p.ddgi_mode && p.pool <= 0) return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode: the ray pool does not fit in LDS next to the scene bitmap");
