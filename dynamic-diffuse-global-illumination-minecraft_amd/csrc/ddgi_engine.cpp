@@ -38,7 +38,7 @@ hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream);
 hipError_t launch_render_primary(const RenderArgs& args, hipStream_t stream);
 size_t sample_group_scratch_words(uint32_t n, uint32_t n_probes);
 hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t n, uint32_t* scratch, const uint32_t** perm_out, hipStream_t stream);
-hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], const int32_t* list, int n_list, uint8_t* out, hipStream_t stream);
+hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], const int32_t* list, int n_list, uint8_t* out, uint32_t* out_occ, hipStream_t stream);
 
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes)
 {
@@ -401,6 +401,7 @@ int ddgi_destroy(ddgi_handle e)
         if (d.bits) (void)hipFree(d.bits);
         if (d.types) (void)hipFree(d.types);
         if (d.vis) (void)hipFree(d.vis);
+        if (d.vis_occ) (void)hipFree(d.vis_occ);
         if (d.vis_list) (void)hipFree(d.vis_list);
     }
     for (auto& triple : e->ev)
@@ -726,6 +727,8 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
                     }
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis), static_cast<size_t>(n_vox) * 8));  // one class byte per (voxel, face)
             HIP_TRY(hipMemsetAsync(d.vis, 0, static_cast<size_t>(n_vox) * 8, e->stream));
+            // (the lists are written and read only for entries of class kVisListed: no initialisation)
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis_occ), static_cast<size_t>(n_vox) * 8 * kVisListMax * sizeof(uint32_t)));
             d.n_vis_list = static_cast<int>(list.size());
             if (d.n_vis_list > 0)
             {
@@ -735,11 +738,12 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
         }
         if (!d.vis_valid || std::memcmp(d.vis_light, a.lights[0].pos, sizeof(d.vis_light)) != 0)
         {
-            HIP_TRY(launch_light_visibility(a.scene, a.lights[0].pos, d.vis_list, d.n_vis_list, d.vis, e->stream));
+            HIP_TRY(launch_light_visibility(a.scene, a.lights[0].pos, d.vis_list, d.n_vis_list, d.vis, d.vis_occ, e->stream));
             std::memcpy(d.vis_light, a.lights[0].pos, sizeof(d.vis_light));
             d.vis_valid = true;
         }
         a.vis = d.vis;
+        a.vis_occ = d.vis_occ;
     }
     a.albedo = static_cast<uint32_t*>(e->tex[0]);
     a.distance = static_cast<uint32_t*>(e->tex[1]);
@@ -1451,6 +1455,7 @@ static int fill_user_scene(ddgi_engine* e, const int lo[3], const int dim[3], co
     if (d.bits) (void)hipFree(d.bits);
     if (d.types) (void)hipFree(d.types);
     if (d.vis) (void)hipFree(d.vis);
+    if (d.vis_occ) (void)hipFree(d.vis_occ);
     if (d.vis_list) (void)hipFree(d.vis_list);
     d = ddgi_engine::DevScene{};
     e->user_scene = std::move(b);

@@ -76,6 +76,7 @@ struct ddgi_engine
         SceneK k{};
         bool ready = false;
         uint8_t* vis = nullptr;             // k_light_visibility table for the scene's single light
+        uint32_t* vis_occ = nullptr;        // ... its listed voxels (kVisListed), kVisListMax per (voxel, face)
         int32_t* vis_list = nullptr;        // the (voxel, face) pairs it classifies: empty voxel, occupied on the face's other side
         int n_vis_list = 0;
         float vis_light[3] = {0, 0, 0};     // ... computed for this light position

@@ -402,8 +402,9 @@ DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contr
 // when there is no table, the origin is outside the baked box, or it is not where the table's guarantee holds: 5e-4 ..
 // 1.5e-3 off the face that was hit (it is put 1e-3 off it) and at least 5e-4 inside the voxel on the two other axes.
 // n: the hit's axis normal (points from the block that was hit into the voxel the feeler starts in).
-DDGI_D uint32_t light_vis_class(const TraceArgs& A, f3 o, f3 n)
+DDGI_D uint32_t light_vis_class(const TraceArgs& A, f3 o, f3 n, int& entry)
 {
+    entry = 0;
     if (!A.vis) return kVisUnknown;
     const SceneK& S = A.scene;
     const f3 cell = cell_id(o);
@@ -418,7 +419,45 @@ DDGI_D uint32_t light_vis_class(const TraceArgs& A, f3 o, f3 n)
     if (!inside) return kVisUnknown;
     const int idx = static_cast<int>(fmaf(cell.z, S.nxy_f, fmaf(cell.y, S.nx_f, cell.x))) - S.bias;
     const int face = (ax ? 0 : (ay ? 2 : 4)) + ((n.x + n.y + n.z) < 0.0f ? 1 : 0);  // 2 axis + (the block that was hit is on the + side)
-    return A.vis[idx * 8 + face];
+    entry = idx * 8 + face;
+    return A.vis[entry];
+}
+
+// A feeler that starts in a patch of class kVisListed (ddgi_visibility.hip) and did not end within its first step: its own ray
+// (o, unit direction dn, light sphere at t_light) against the patch's list of occupied voxels — everything else its march can look
+// up is empty.  True: the march certainly lands in no occupied voxel (it reaches the light); false: undecided, march it.  The
+// arithmetic here decides nothing about the result's bits, it only has to be CONSERVATIVE: a march looks up the voxel that holds
+// its position, positions lie within 3e-5 of the line o + t dn (|p| < 2^10), so a line that misses a voxel grown by kListGrow on
+// every side (ten times that) never has a position inside it; every "misses" needs a comparison that comes out true (a NaN
+// decides nothing).
+constexpr float kListGrow = 4.0e-4f;
+DDGI_D bool listed_feeler_clear(const TraceArgs& A, int entry, f3 o, f3 dn, float t_light)
+{
+    const uint4 packed4 = *reinterpret_cast<const uint4*>(A.vis_occ + static_cast<size_t>(entry) * kVisListMax);
+    const uint32_t packed[kVisListMax] = {packed4.x, packed4.y, packed4.z, packed4.w};
+    const f3 cell = cell_id(o);  // the start voxel
+    const f3 inv{__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y), __builtin_amdgcn_rcpf(dn.z)};
+    bool all_clear = true;
+#pragma unroll
+    for (int k = 0; k < kVisListMax; ++k)
+    {
+        const uint32_t u = packed[k];
+        if (u == kVisListEnd) continue;
+        const int dx = static_cast<int>(u & 1023u) - 512, dy = static_cast<int>((u >> 10) & 1023u) - 512, dz = static_cast<int>(u >> 20) - 512;
+        const f3 hi{cell.x + static_cast<float>(dx), cell.y + static_cast<float>(dy), cell.z + static_cast<float>(dz)};  // the voxel covers (hi - 1, hi]
+        // slab parameters of the faces (lo - o) / dn, (hi - o) / dn; a zero component gives +-inf or NaN, and NaN decides nothing
+        const f3 ta{(hi.x - 1.0f - o.x) * inv.x, (hi.y - 1.0f - o.y) * inv.y, (hi.z - 1.0f - o.z) * inv.z};
+        const f3 tb{(hi.x - o.x) * inv.x, (hi.y - o.y) * inv.y, (hi.z - o.z) * inv.z};
+        // growing / shrinking the box by m moves a face's parameter by m / |dn_axis|
+        const f3 ai{fabsf(inv.x), fabsf(inv.y), fabsf(inv.z)};
+        const f3 tn{fminf(ta.x, tb.x), fminf(ta.y, tb.y), fminf(ta.z, tb.z)}, tf{fmaxf(ta.x, tb.x), fmaxf(ta.y, tb.y), fmaxf(ta.z, tb.z)};
+        // grown box: [tn - g, tf + g] per axis
+        const float g_in = fmaxf(fmaxf(tn.x - kListGrow * ai.x, tn.y - kListGrow * ai.y), tn.z - kListGrow * ai.z);
+        const float g_out = fminf(fminf(tf.x + kListGrow * ai.x, tf.y + kListGrow * ai.y), tf.z + kListGrow * ai.z);
+        const bool clear = (g_in > g_out) || (g_out < 0.0f) || (g_in > t_light);
+        all_clear = all_clear && clear;
+    }
+    return all_clear;
 }
 
 // get_direct_lighting's loop body for the light L once its feeler's outcome is known (probe_pass.comp:194-207):
@@ -599,8 +638,9 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     // Is the feeler's outcome certain (k_light_visibility)?  Then its march, queue trip and event are
                     // skipped: the light-sphere test it would start with (does the ray reach the sphere at all) and
                     // get_direct_lighting's arithmetic are evaluated right here, on the same values.
-                    const uint32_t vis = (Cfg::nl(A) == 1 && block_wins && axis_normal && !(lambert_zero && finite_albedo)) ? light_vis_class(A, hpos, hnrm) : kVisUnknown;
-                    if ((Cfg::ablate(A) & 16) && A.stats && block_wins) atomicAdd(&A.stats[(lambert_zero && finite_albedo) ? 59 : 56 + vis], 1ull);  // profiling build: feeler classes
+                    int vis_entry = 0;
+                    const uint32_t vis = (Cfg::nl(A) == 1 && block_wins && axis_normal && !(lambert_zero && finite_albedo)) ? light_vis_class(A, hpos, hnrm, vis_entry) : kVisUnknown;
+                    if ((Cfg::ablate(A) & 16) && A.stats && block_wins) atomicAdd(&A.stats[(lambert_zero && finite_albedo) ? 59 : (vis == kVisListed ? 63 : 56 + vis)], 1ull);  // profiling build: feeler classes
                     ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt;
                     if (lambert_zero && finite_albedo)
                         lit_done = true;  // contributes +0
@@ -614,20 +654,29 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                         if (vis != kVisShadow) light_spheres<Cfg::kNl>(hpos, to_light, A, ftl, flid);
                         bool feeler_any = true, feeler_block = true;  // kVisShadow: a block before the light (t_block < t_light, or no sphere hit at all)
                         if (vis == kVisLit) feeler_block = false, feeler_any = ftl < inf;
-                        else if (vis == kVisUnknown)
+                        else if (vis == kVisUnknown || vis == kVisListed)
                         {
                             // The feeler is set up right here.  Most shadowed feelers end within their first steps (on the
                             // surface's own relief); then get_direct_lighting goes on in this event as well — no record round
                             // trip, no second event.  A feeler that has to be marched takes the slot to the march queue.
                             c.cnt = cnt;
                             InlineEnd fe;
-                            if (wf_post_march<Cfg, true>(P, slot, c, hpos, to_light, true, A, s_bits, &fe, true, ftl, flid, lp) < 0)
+                            // (a listed patch: the feeler's own ray against the few occupied voxels of its bundle, before it is queued)
+                            bool clear = false;
+                            const bool inline_end = wf_post_march<Cfg, true>(P, slot, c, hpos, to_light, true, A, s_bits, &fe, true, ftl, flid, lp) >= 0;
+                            if (!inline_end && vis == kVisListed) clear = listed_feeler_clear(A, vis_entry, hpos, normalize3_of_unit(to_light), ftl);
+                            if (!inline_end && !clear)
                             {
                                 store_cold(P, slot, c, true);  // (hn and the albedo travel with the marched feeler)
                                 return 1;
                             }
-                            feeler_block = fe.occ && (fe.t < fe.tl);
-                            feeler_any = feeler_block || (fe.tl < inf);
+                            if (inline_end)
+                            {
+                                feeler_block = fe.occ && (fe.t < fe.tl);
+                                feeler_any = feeler_block || (fe.tl < inf);
+                            }
+                            else
+                                feeler_block = false, feeler_any = ftl < inf;  // (clear of every listed voxel: as for the class kVisLit)
                         }
                         f3 direct = mk3(0, 0, 0), contribution = mk3(0, 0, 0);
                         int nvis = 0;

@@ -64,7 +64,13 @@ enum : uint8_t
     kVisUnknown = 0,  // march it
     kVisLit = 1,      // reaches the light
     kVisShadow = 2,   // lands in an occupied voxel before the light
+    kVisListed = 3,   // neither for the whole start patch, but the bundle holds at most kVisListMax occupied voxels: they are listed,
+                      // and the event tests the feeler's own ray against them (wf_event: listed_feeler_outcome)
 };
+constexpr int kVisListMax = 4;
+constexpr uint32_t kVisListEnd = 0xffffffffu;
+// a listed voxel: its id minus the start voxel's, per axis, biased by 512 into 10 bits (the table's range is 400 voxels)
+inline __host__ __device__ uint32_t vis_pack_offset(int dx, int dy, int dz) { return static_cast<uint32_t>(dx + 512) | (static_cast<uint32_t>(dy + 512) << 10) | (static_cast<uint32_t>(dz + 512) << 20); }
 
 struct TraceArgs
 {
@@ -97,6 +103,7 @@ struct TraceArgs
     float* rad_rgb;  // ray records, see RayRecords
     float* rad_dd;
     const uint8_t* vis;  // single light: feeler classes per (voxel of the baked box, face): [voxel * 8 + face] (k_light_visibility), or null
+    const uint32_t* vis_occ;  // ... and for class kVisListed the occupied voxels of the bundle: [(voxel * 8 + face) * kVisListMax + k]
 };
 
 // DDGI-mode ray records, laid out as the B operand of the blend's MFMA contraction (ddgi_blend_sample.hip): for local

@@ -20,13 +20,25 @@
 // of X(s_in) and X(s_out), the cross-sections where the bundle enters and leaves the layer (+- kEps).
 //   LIT     every voxel (other than the start voxel) in every layer's bounding box, from the start layer to
 //           the light's, is empty: no march position can be in an occupied voxel.
-//   SHADOW  some layer strictly between (>= 3 layers before the light's: t_hit < t_light with a margin far above
-//           the error of the sphere quadratic) has its bounding box fully occupied, and is reached within
+//   SHADOW  TWO consecutive layers strictly between (>= 3 layers before the light's: t_hit < t_light with a margin far above
+//           the error of the sphere quadratic) have their bounding boxes fully occupied, and are reached within
 //           grid_march's 125 iterations: an iteration ends 1e-4 past the NEXT voxel boundary on its way, so it
 //           crosses at least one boundary, and a ray of the bundle crosses at most (layers + lateral voxel offsets
 //           of the bounding box) boundaries before it is inside the layer; kVisMaxCrossings leaves 15 iterations
-//           for the rare step that starts exactly on a boundary.  A march cannot step over a layer, so it lands
+//           for the rare step that starts exactly on a boundary.  A march cannot step over two layers, so it lands
 //           in an occupied voxel there or earlier — and the outcome "blocked" does not depend on where.
+//           (Why two: a march CAN step over one.  grid_march takes the next boundary from fract(p); a position that
+//           lands EXACTLY on an integer plane while travelling in the positive direction belongs to the voxel below
+//           the plane (id = ceil(p)) and its next boundary along that axis is a whole voxel further on — the voxel above
+//           the plane is never looked up if that boundary comes first, however long the ray's stretch inside it.  One
+//           landing in a million is exact; a C3 update has half a billion landings.  The landing after a skipped layer
+//           is 1e-4 past a plane, not on one, so the second layer is looked up.)
+//   LISTED  neither, but every layer was examined and the bundle's bounding boxes hold at most kVisListMax occupied voxels: they
+//           are written out (relative to the start voxel) and wf_event tests the feeler's OWN ray against them — a ray that clears
+//           them all with a margin cannot land in an occupied voxel: everything else the march can look up is empty
+//           (ddgi_trace_wf.hip: listed_feeler_outcome).  Three quarters of the feelers that used to be marched start in such a
+//           patch.  (The converse — "the ray runs through the inside of a listed voxel, so the march lands in it" — is false for
+//           the same reason one full layer is not enough for SHADOW; tried, and one feeler of a C3 update's 33 million differed.)
 //   UNKNOWN otherwise: the feeler is marched.
 #include "ddgi_device.h"
 
@@ -52,7 +64,7 @@ DDGI_D bool vis_occupied(const SceneK& S, const uint32_t* __restrict__ bits, int
 // kLds: the occupancy bitmap is copied to LDS first (a thread makes several hundred dependent lookups)
 template <bool kLds>
 __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const double lx, const double ly, const double lz, const int32_t* __restrict__ list,
-                                                          const int n_list, uint8_t* __restrict__ out)
+                                                          const int n_list, uint8_t* __restrict__ out, uint32_t* __restrict__ out_occ)
 {
     extern __shared__ uint32_t vis_lds[];
     const uint32_t* __restrict__ bits = S.bits;
@@ -71,6 +83,9 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
     const int ny = S.nxy / S.nx;
     int v[3] = {S.lo[0] + r % S.nx, S.lo[1] + (r / S.nx) % ny, S.lo[2] + r / S.nxy};
     uint8_t cls = kVisUnknown;
+    uint32_t found[kVisListMax];  // this lane's occupied voxels (its layers), packed offsets from the start voxel
+    int n_found = 0;
+    bool complete = false;        // this lane has examined every one of its layers up to the light's
     const bool relevant = true;
     const double L[3] = {lx, ly, lz};
     double lo0[3], hi0[3];
@@ -94,9 +109,10 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
         const int sgn = L[a] > hi0[a] ? 1 : -1;
         const int n_a = v[a], m_a = static_cast<int>(ceil(L[a]));
         bool all_empty = true, blocked = false;
-        for (int i = n_a + sgn * sub; sgn > 0 ? i <= m_a : i >= m_a; i += sgn * kVisLanes)
-        {
-            // s-range over which the cross-section X(s) reaches into layer i = (i-1, i] (widened by kVisEps)
+        complete = true;
+        // voxel-id range (along b and c) of the bounding box of the bundle's cross-sections inside layer i = (i-1, i]
+        auto layer_box = [&](int i, int (&w0)[2], int (&w1)[2]) {
+            // s-range over which the cross-section X(s) reaches into the layer (widened by kVisEps)
             double s_in, s_out;
             if (sgn > 0)
             {
@@ -109,7 +125,6 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
                 s_out = (hi0[a] - (static_cast<double>(i - 1) - kVisEps)) / (hi0[a] - L[a]);
             }
             s_in = fmin(fmax(s_in, 0.0), 1.0), s_out = fmin(fmax(s_out, 0.0), 1.0);
-            int w0[2], w1[2];  // voxel-id range of the bounding box along b and c
             const int ax2[2] = {b, c};
             for (int q = 0; q < 2; ++q)
             {
@@ -119,6 +134,11 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
                 w0[q] = static_cast<int>(ceil(fmin(lo_in, lo_out) - kVisEps));
                 w1[q] = static_cast<int>(ceil(fmax(hi_in, hi_out) + kVisEps));
             }
+        };
+        for (int i = n_a + sgn * sub; sgn > 0 ? i <= m_a : i >= m_a; i += sgn * kVisLanes)
+        {
+            int w0[2], w1[2];
+            layer_box(i, w0, w1);
             bool layer_full = true;
             for (int wb = w0[0]; wb <= w1[0]; ++wb)
                 for (int wc = w0[1]; wc <= w1[1]; ++wc)
@@ -133,12 +153,39 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
                     const bool occ = vis_occupied(S, bits, w[0], w[1], w[2]);
                     all_empty = all_empty && !occ;
                     layer_full = layer_full && occ;
+                    if (occ)
+                    {
+                        const uint32_t packed = vis_pack_offset(w[0] - v[0], w[1] - v[1], w[2] - v[2]);
+                        if (n_found == 0) found[0] = packed;
+                        else if (n_found == 1) found[1] = packed;
+                        else if (n_found == 2) found[2] = packed;
+                        else if (n_found == 3) found[3] = packed;
+                        ++n_found;
+                    }
                 }
             const int from_start = sgn * (i - n_a), to_light = sgn * (m_a - i);
             const int lat_b = max(abs(w0[0] - v[b]), abs(w1[0] - v[b])), lat_c = max(abs(w0[1] - v[c]), abs(w1[1] - v[c]));
             const int crossings = from_start + lat_b + lat_c + 2;
-            if (layer_full && from_start >= 1 && crossings <= kVisMaxCrossings && to_light >= 3) blocked = true;
-            if (blocked || (!all_empty && crossings > kVisMaxCrossings)) break;  // this lane's layers: decided, or can no longer decide
+            if (layer_full && from_start >= 1 && crossings <= kVisMaxCrossings && to_light >= 4)
+            {
+                // ... and the layer behind it (see SHADOW above)
+                int x0[2], x1[2];
+                layer_box(i + sgn, x0, x1);
+                bool next_full = true;
+                for (int wb = x0[0]; wb <= x1[0] && next_full; ++wb)
+                    for (int wc = x0[1]; wc <= x1[1] && next_full; ++wc)
+                    {
+                        int w[3];
+                        w[a] = i + sgn, w[b] = wb, w[c] = wc;
+                        next_full = vis_occupied(S, bits, w[0], w[1], w[2]);
+                    }
+                if (next_full) blocked = true;
+            }
+            if (blocked || (!all_empty && crossings > kVisMaxCrossings))  // this lane's layers: decided, or can no longer decide
+            {
+                complete = false;
+                break;
+            }
         }
         cls = blocked ? kVisShadow : (all_empty ? kVisLit : kVisUnknown);
     }
@@ -151,20 +198,41 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
         any_shadow |= static_cast<unsigned>(__shfl_xor(static_cast<int>(any_shadow), m));
         all_lit &= static_cast<unsigned>(__shfl_xor(static_cast<int>(all_lit), m));
     }
-    if (live && sub == 0) out[entry] = any_shadow ? kVisShadow : (all_lit ? kVisLit : kVisUnknown);
+    // the group's occupied voxels: how many, and where this lane's go in the entry's list
+    int incl = n_found;
+    unsigned all_complete = complete ? 1u : 0u;
+#pragma unroll
+    for (int m = 1; m < kVisLanes; m <<= 1)
+    {
+        const int up = __shfl_up(incl, m, kVisLanes);
+        if (sub >= m) incl += up;
+        all_complete &= static_cast<unsigned>(__shfl_xor(static_cast<int>(all_complete), m));
+    }
+    const int total = __shfl(incl, kVisLanes - 1, kVisLanes), excl = incl - n_found;
+    const bool listed = !any_shadow && !all_lit && all_complete && total >= 1 && total <= kVisListMax;
+    if (live && listed)
+    {
+        uint32_t* dst = out_occ + static_cast<size_t>(entry) * kVisListMax;
+        if (n_found >= 1) dst[excl] = found[0];
+        if (n_found >= 2) dst[excl + 1] = found[1];
+        if (n_found >= 3) dst[excl + 2] = found[2];
+        if (n_found >= 4) dst[excl + 3] = found[3];
+        if (sub < kVisListMax && sub >= total) dst[sub] = kVisListEnd;  // (every slot has exactly one writer)
+    }
+    if (live && sub == 0) out[entry] = any_shadow ? kVisShadow : (all_lit ? kVisLit : (listed ? kVisListed : kVisUnknown));
 }
 
-hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], const int32_t* list, int n_list, uint8_t* out, hipStream_t stream)
+hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], const int32_t* list, int n_list, uint8_t* out, uint32_t* out_occ, hipStream_t stream)
 {
     if (n_list <= 0) return hipSuccess;
     const size_t lds = static_cast<size_t>(scene.nwords) * sizeof(uint32_t);
     const int per_block = 256 / kVisLanes;  // voxels per 256-thread block
     if (lds <= 64 * 1024)
         hipLaunchKernelGGL(k_light_visibility<true>, dim3((n_list + per_block - 1) / per_block), dim3(256), lds, stream, scene, static_cast<double>(light_pos[0]), static_cast<double>(light_pos[1]),
-                           static_cast<double>(light_pos[2]), list, n_list, out);
+                           static_cast<double>(light_pos[2]), list, n_list, out, out_occ);
     else
         hipLaunchKernelGGL(k_light_visibility<false>, dim3((n_list + per_block - 1) / per_block), dim3(256), 0, stream, scene, static_cast<double>(light_pos[0]), static_cast<double>(light_pos[1]),
-                           static_cast<double>(light_pos[2]), list, n_list, out);
+                           static_cast<double>(light_pos[2]), list, n_list, out, out_occ);
     return hipGetLastError();
 }
 

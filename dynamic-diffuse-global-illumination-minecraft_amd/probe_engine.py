@@ -452,7 +452,7 @@ class ProbeEngine:
         st["bucket_groups"] = [int(v) for v in out[24:32]]
         # light feelers of block hits: decided by the visibility table (unknown = marched / lit / shadow), dead (Lambert 0), and
         # what the marched ones found (reached the light / hit a block / neither)
-        st["feeler_classes"] = dict(zip(("unknown", "table_lit", "table_shadow", "dead", "marched_lit", "marched_shadow", "marched_none"), (int(v) for v in out[56:63])))
+        st["feeler_classes"] = dict(zip(("unknown", "table_lit", "table_shadow", "dead", "marched_lit", "marched_shadow", "marched_none", "listed"), (int(v) for v in out[56:64])))
         # queue kernel, counters build: (visits, active lanes) per section of the event code (ddgi_trace_wf.hip: LaneProbe)
         names = ("event", "albedo", "feeler set-up", "feeler sphere test", "light contribution", "bounce: accumulate + hemisphere", "primary set-up", "after albedo",
                  "inline step 1", "inline step 2", "inline step 3", "inline step 4", "write-back", "-", "-", "outside events")
