@@ -20,19 +20,22 @@
 // of X(s_in) and X(s_out), the cross-sections where the bundle enters and leaves the layer (+- kEps).
 //   LIT     every voxel (other than the start voxel) in every layer's bounding box, from the start layer to
 //           the light's, is empty: no march position can be in an occupied voxel.
-//   SHADOW  TWO consecutive layers strictly between (>= 3 layers before the light's: t_hit < t_light with a margin far above
-//           the error of the sphere quadratic) have their bounding boxes fully occupied, and are reached within
+//   SHADOW  some layer strictly between (>= 3 layers before the light's: t_hit < t_light with a margin far above
+//           the error of the sphere quadratic) has its bounding box fully occupied, and is reached within
 //           grid_march's 125 iterations: an iteration ends 1e-4 past the NEXT voxel boundary on its way, so it
 //           crosses at least one boundary, and a ray of the bundle crosses at most (layers + lateral voxel offsets
 //           of the bounding box) boundaries before it is inside the layer; kVisMaxCrossings leaves 15 iterations
-//           for the rare step that starts exactly on a boundary.  A march cannot step over two layers, so it lands
-//           in an occupied voxel there or earlier — and the outcome "blocked" does not depend on where.
-//           (Why two: a march CAN step over one.  grid_march takes the next boundary from fract(p); a position that
-//           lands EXACTLY on an integer plane while travelling in the positive direction belongs to the voxel below
-//           the plane (id = ceil(p)) and its next boundary along that axis is a whole voxel further on — the voxel above
-//           the plane is never looked up if that boundary comes first, however long the ray's stretch inside it.  One
-//           landing in a million is exact; a C3 update has half a billion landings.  The landing after a skipped layer
-//           is 1e-4 past a plane, not on one, so the second layer is looked up.)
+//           for the rare step that starts exactly on a boundary.  The march lands in an occupied voxel there or
+//           earlier — and the outcome "blocked" does not depend on where — PROVIDED it cannot step over the layer:
+//           it can, when the bundle travels in the POSITIVE direction of the dominant axis.  grid_march takes the next
+//           boundary from fract(p): a position that lands EXACTLY on an integer plane while travelling in the positive
+//           direction belongs to the voxel below the plane (id = ceil(p)) and its next boundary along that axis is a whole
+//           voxel further on — if that boundary comes first, the layer above the plane is never looked up, however long
+//           the ray's stretch inside it.  (One landing in a million is exact; a C3 update has half a billion landings.)
+//           The landing after such a step is at most 1e-4 past the layer's far plane, and not on a plane: so for a
+//           positive dominant direction the voxels of the NEXT layer that the bundle touches within kVisSkipDepth of
+//           that plane must be occupied as well.  In the negative direction a position on a plane belongs to the voxel it
+//           is about to cross and nothing is stepped over.
 //   LISTED  neither, but every layer was examined and the bundle's bounding boxes hold at most kVisListMax occupied voxels: they
 //           are written out (relative to the start voxel) and wf_event tests the feeler's OWN ray against them — a ray that clears
 //           them all with a margin cannot land in an occupied voxel: everything else the march can look up is empty
@@ -51,6 +54,7 @@ constexpr int kVisMaxCrossings = 110;  // boundary crossings to a blocking layer
 constexpr double kVisMinRange = 4.0;   // lights closer than this along the dominant axis: not classified
 constexpr double kVisMaxRange = 400.0;
 constexpr int kVisLanes = 16;          // lanes that share one voxel's layers
+constexpr double kVisSkipDepth = 1.0e-3;  // SHADOW, positive direction: how deep into the next layer a march that stepped over the full one can land
 
 DDGI_D bool vis_occupied(const SceneK& S, const uint32_t* __restrict__ bits, int x, int y, int z)
 {
@@ -110,19 +114,20 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
         const int n_a = v[a], m_a = static_cast<int>(ceil(L[a]));
         bool all_empty = true, blocked = false;
         complete = true;
-        // voxel-id range (along b and c) of the bounding box of the bundle's cross-sections inside layer i = (i-1, i]
-        auto layer_box = [&](int i, int (&w0)[2], int (&w1)[2]) {
-            // s-range over which the cross-section X(s) reaches into the layer (widened by kVisEps)
+        // voxel-id range (along b and c) of the bounding box of the bundle's cross-sections inside layer i = (i-1, i], from the plane
+        // the bundle enters it through to `depth` behind that plane (1: the whole layer)
+        auto layer_box = [&](int i, double depth, int (&w0)[2], int (&w1)[2]) {
+            // s-range over which the cross-section X(s) reaches into that slab (widened by kVisEps)
             double s_in, s_out;
             if (sgn > 0)
             {
                 s_in = (static_cast<double>(i - 1) - kVisEps - hi0[a]) / (L[a] - hi0[a]);
-                s_out = (static_cast<double>(i) + kVisEps - lo0[a]) / (L[a] - lo0[a]);
+                s_out = (static_cast<double>(i - 1) + depth + kVisEps - lo0[a]) / (L[a] - lo0[a]);
             }
             else
             {
                 s_in = (lo0[a] - (static_cast<double>(i) + kVisEps)) / (lo0[a] - L[a]);
-                s_out = (hi0[a] - (static_cast<double>(i - 1) - kVisEps)) / (hi0[a] - L[a]);
+                s_out = (hi0[a] - (static_cast<double>(i) - depth - kVisEps)) / (hi0[a] - L[a]);
             }
             s_in = fmin(fmax(s_in, 0.0), 1.0), s_out = fmin(fmax(s_out, 0.0), 1.0);
             const int ax2[2] = {b, c};
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
         for (int i = n_a + sgn * sub; sgn > 0 ? i <= m_a : i >= m_a; i += sgn * kVisLanes)
         {
             int w0[2], w1[2];
-            layer_box(i, w0, w1);
+            layer_box(i, 1.0, w0, w1);
             bool layer_full = true;
             for (int wb = w0[0]; wb <= w1[0]; ++wb)
                 for (int wc = w0[1]; wc <= w1[1]; ++wc)
@@ -168,10 +173,11 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
             const int crossings = from_start + lat_b + lat_c + 2;
             if (layer_full && from_start >= 1 && crossings <= kVisMaxCrossings && to_light >= 4)
             {
-                // ... and the layer behind it (see SHADOW above)
+                // ... and, in the positive direction, where a march that stepped over it lands (see SHADOW above)
                 int x0[2], x1[2];
-                layer_box(i + sgn, x0, x1);
                 bool next_full = true;
+                if (sgn > 0) layer_box(i + 1, kVisSkipDepth, x0, x1);
+                else x0[0] = x0[1] = 0, x1[0] = x1[1] = -1;  // (nothing to examine)
                 for (int wb = x0[0]; wb <= x1[0] && next_full; ++wb)
                     for (int wc = x0[1]; wc <= x1[1] && next_full; ++wc)
                     {
