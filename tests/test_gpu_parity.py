@@ -175,6 +175,25 @@ def test_full_size_c3_full_grid_vs_oracle(ddgi, oracle):
     assert not want_d.any()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [2, 3])
+def test_full_size_c3_full_grid_other_ray_sets(ddgi, oracle, seed):
+    """The full C3 grid again with differently seeded probe rays: every texel against the oracle.  The work the kernels skip
+    (feelers decided by k_light_visibility's classes and lists, dead feelers) rests on arguments about the reference's float
+    march; a hole in one shows as a handful of texels in 4 million (a SHADOW rule that overlooked grid_march stepping over a
+    voxel whose entry plane it lands on exactly differed in ONE texel), so more than one ray set is compared."""
+    counts, side, s, origin, scene = CONFIGS["c3_cave"]
+    with _engine(ddgi, "c3_cave") as eng:
+        eng.generate_probe_rays(seed=seed)
+        eng.probe_update()
+        a1, _ = eng.read_textures()
+    f = oracle.make_field(counts, side, s, origin)
+    rays = oracle.generate_probe_rays(f, oracle.new_rand_state(seed))
+    want, _ = oracle.probe_update(f, oracle.make_settings(scene, 8), rays)
+    nbad = int((a1 != want).any(axis=-1).sum())
+    assert nbad == 0, f"seed {seed}: {nbad} of {a1.shape[0] * a1.shape[1]} texels of the full C3 grid differ from the oracle"
+
+
 def test_torch_owned_textures_and_stream(ddgi, oracle):
     """The multi-GPU plumbing at world size 1: textures allocated by torch and bound into the
     engine (ddgi_bind_textures), kernels on torch's current stream (ddgi_set_stream), the in-place
