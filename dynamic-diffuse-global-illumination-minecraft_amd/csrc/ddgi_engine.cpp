@@ -727,8 +727,10 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
                     }
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis), static_cast<size_t>(n_vox) * 8));  // one class byte per (voxel, face)
             HIP_TRY(hipMemsetAsync(d.vis, 0, static_cast<size_t>(n_vox) * 8, e->stream));
-            // (the lists are written and read only for entries of class kVisListed: no initialisation)
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis_occ), static_cast<size_t>(n_vox) * 8 * kVisListMax * sizeof(uint32_t)));
+            // (the lists are written and read only for entries of class kVisListed: no initialisation; 128 B per voxel — a user scene
+            // of more than 4 M voxels goes without lists, i.e. without the class)
+            const size_t occ_bytes = static_cast<size_t>(n_vox) * 8 * kVisListMax * sizeof(uint32_t);
+            if (occ_bytes <= (static_cast<size_t>(512) << 20)) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis_occ), occ_bytes));
             d.n_vis_list = static_cast<int>(list.size());
             if (d.n_vis_list > 0)
             {

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_light_visibility(const SceneK S, const 
         all_complete &= static_cast<unsigned>(__shfl_xor(static_cast<int>(all_complete), m));
     }
     const int total = __shfl(incl, kVisLanes - 1, kVisLanes), excl = incl - n_found;
-    const bool listed = !any_shadow && !all_lit && all_complete && total >= 1 && total <= kVisListMax;
+    const bool listed = out_occ != nullptr && !any_shadow && !all_lit && all_complete && total >= 1 && total <= kVisListMax;
     if (live && listed)
     {
         uint32_t* dst = out_occ + static_cast<size_t>(entry) * kVisListMax;
