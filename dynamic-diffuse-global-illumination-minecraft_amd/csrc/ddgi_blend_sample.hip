@@ -1,5 +1,5 @@
 // ddgi_blend_sample.hip — DDGI-mode kernels (the reference's dormant pieces switched on):
-//   k_blend_weights + k_probe_blend_s (and the one-probe-per-workgroup k_probe_blend)
+//   k_blend_weights + k_probe_blend_depth[_res] / k_probe_blend_irr / k_probe_blend_mfma (and the one-probe-per-workgroup k_probe_blend)
 //                        octahedral irradiance (8x8 rgba f32) + depth-moment (16x16 rg f32) tile update
 //                        with temporal hysteresis — the dormant line probe_pass.comp:298-299
 //                        `color = mix(old, new, hysteresis)` applied to DDGI-paper tiles
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kBlendWaves * 64) void k_probe_blend_mfma(const Ble
 // ------------------------------------------------------------------------------------------------
 // k_probe_blend — the same blend with one 256-lane workgroup per probe, lane = texel, weights
 // evaluated in place and the ray records staged in LDS.  Used for ray counts whose direction table
-// does not fit k_blend_weights' LDS, and as the cross-check of k_probe_blend_s
+// does not fit k_blend_weights' LDS, and as the cross-check of the MFMA blend kernels
 // (DDGI_BLEND_KERNEL=probe, tests/test_gpu_ddgi_mode.py).
 // ------------------------------------------------------------------------------------------------
 constexpr int kBlendBlock = 256;

@@ -93,7 +93,7 @@ def test_ddgi_sharded_slabs(ddgi, oracle):
 @pytest.mark.parametrize("counts,s", [((3, 3, 3), 5), ((2, 1, 3), 3), ((5, 2, 2), 8), ((1, 1, 1), 1)])
 def test_blend_kernels_agree_on_ragged_shapes(ddgi, oracle, counts, s):
     """Probe counts that are not a multiple of the 8-probe record group and odd ray counts: the
-    scalar-operand blend (k_blend_weights + k_probe_blend_s), the one-probe-per-workgroup blend
+    MFMA blend (k_blend_weights + k_probe_blend_depth / _irr / _mfma), the one-probe-per-workgroup blend
     (DDGI_BLEND_KERNEL=probe) and the oracle give the same tiles, bit for bit, over three frames."""
     import os
     side, origin, scene = 6, (0.0, 0.0, 15.0), 1
