@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--mode", choices=["ref", "ddgi"], default="ref",
                     help="ref (default): the reference's live behaviour, the headline metric; ddgi: in-kernel Fibonacci rays + "
                          "octahedral irradiance/depth blend with hysteresis (trace + blend per step)")
+    ap.add_argument("--exchange", choices=["rccl", "p2p"], default="rccl",
+                    help="N > 1: how the ranks' slabs are exchanged — rccl (default): one in-place ncclAllGather per texture; "
+                         "p2p: every rank pushes its slab into its peers' textures (ddgi_exchange_p2p_*, IPC-mapped buffers)")
     args = ap.parse_args()
 
     import torch
@@ -187,15 +190,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    # DDGI_BENCH_ONE_GPU=1: every rank uses device 0 (a functional run of the N > 1 path on a one-GPU box — not a measurement:
+    # the ranks share the chip; RCCL refuses two ranks on one device, so this needs --exchange p2p and the gloo backend)
+    one_gpu = os.environ.get("DDGI_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
+        if world > 1 and args.exchange != "p2p":
+            raise SystemExit("DDGI_BENCH_ONE_GPU=1 needs --exchange p2p (RCCL refuses two ranks on one device)")
     torch.cuda.set_device(local_rank)
-    # DDGI_BENCH_FORCE_DIST=1: run the N > 1 code path (RCCL group, torch-owned textures, pipelined
-    # exchange) with a single rank — a smoke test of that path on a one-GPU box
+    # DDGI_BENCH_FORCE_DIST=1: run the N > 1 code path (RCCL group, pipelined exchange) with a single rank — a smoke test of
+    # that path on a one-GPU box
     sharded = world > 1 or os.environ.get("DDGI_BENCH_FORCE_DIST") == "1"
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         with _c_stdout_to_stderr():
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if one_gpu:
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     w = WORKLOADS[args.workload]
     field = ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"])
@@ -212,7 +225,8 @@ def main():
         eng.generate_probe_rays(seed=w["seed"])  # ray buffer resident in HBM from here on
 
     comm = None
-    if sharded:
+    exchanging = False
+    if sharded and (args.exchange == "rccl" or world == 1):
         # the engine issues the RCCL all-gather itself (include/ddgi_probe.h: ddgi_exchange_*): rank 0 makes the
         # 128-byte RCCL id, torch.distributed carries it to the other ranks, every rank joins the communicator
         with _c_stdout_to_stderr():
@@ -221,6 +235,14 @@ def main():
             comm = ddgi_amd.comm_create(ids[0], world, rank, local_rank)
         # pipelined: the exchange of update k overlaps the kernels of update k+1 (two texture pairs inside the engine)
         eng.exchange_init(comm, pipelined=True)
+        exchanging = True
+    elif sharded:
+        # peer-to-peer: every rank publishes its buffers (512 bytes), torch.distributed carries the addresses around
+        mine = eng.exchange_p2p_export(pipelined=True)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        eng.exchange_p2p_init(everyone)
+        exchanging = True
 
     frame_time = [0.0]
 
@@ -231,11 +253,11 @@ def main():
             eng.probe_update(settings)
         else:
             eng.probe_update()
-        if comm is not None:
+        if exchanging:
             eng.exchange()
 
     def fence():
-        if comm is not None:
+        if exchanging:
             eng.exchange_finish()               # the stream waits for every exchange issued so far
         if sharded:
             dist.barrier()
@@ -250,7 +272,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if sharded:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -293,7 +315,7 @@ def main():
             "scene": "minecraft_cave",
             "max_bounces": w["max_bounces"],
             "mode": "DDGI" if ddgi_mode else "REF",
-            "parallelism": f"zslab{world}" + ("+allgather" if world > 1 else ""),
+            "parallelism": f"zslab{world}" + ((f"+allgather_{args.exchange}" + ("_all_ranks_on_one_gpu" if one_gpu else "")) if world > 1 else ""),
         },
         "roofline": {
             "kernel": {"lane": "k_probe_trace_ref", "rounds": "k_probe_trace_wf"}.get(os.environ.get("DDGI_TRACE_KERNEL", ""), "k_probe_trace_aq"),
@@ -321,7 +343,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not ddgi_mode:
         out["cpu_baseline"] = cpu_baseline(args.cpu_probes, gpu_albedo=eng.read_textures()[0], w=w,
                                            rays=None if args.workload == "c3" else eng.get_probe_rays())
-    if comm is not None:
+    if exchanging:
+        if sharded:
+            dist.barrier()                      # every rank has stopped pushing before any rank unmaps / frees
         eng.exchange_init(None)
     eng.close()
     if comm is not None:

@@ -479,6 +479,13 @@ int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const dd
     if (int rc = alloc_texture_pair(e, bytes, fresh)) return rc;
     if (carried > 0)
     {
+        // (a pipelined exchange may still be writing the other ranks' slabs into the pair the carry reads)
+        if (int rc = ddgi_exchange_wait_latest(e))
+        {
+            (void)hipFree(fresh[0]);
+            (void)hipFree(fresh[1]);
+            return rc;
+        }
         int32_t* d_map = nullptr;
         hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_map), map.size() * sizeof(int32_t));
         if (he == hipSuccess) he = hipMemcpyAsync(d_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
@@ -725,18 +732,31 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
                         for (int fc = 0; fc < 6; ++fc)
                             if (bk.block_at(x + nb[fc][0], y + nb[fc][1], z + nb[fc][2]) > 0) list.push_back(r * 8 + fc);
                     }
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis), static_cast<size_t>(n_vox) * 8));  // one class byte per (voxel, face)
-            HIP_TRY(hipMemsetAsync(d.vis, 0, static_cast<size_t>(n_vox) * 8, e->stream));
+            // allocated into locals and committed together: a failure half way (a large user scene) must not leave a table
+            // without its lists behind for the next update to trip over
+            uint8_t* vis = nullptr;
+            uint32_t* vis_occ = nullptr;
+            int32_t* vis_list = nullptr;
+            hipError_t he = hipMalloc(reinterpret_cast<void**>(&vis), static_cast<size_t>(n_vox) * 8);  // one class byte per (voxel, face)
+            if (he == hipSuccess) he = hipMemsetAsync(vis, 0, static_cast<size_t>(n_vox) * 8, e->stream);
             // (the lists are written and read only for entries of class kVisListed: no initialisation; 128 B per voxel — a user scene
             // of more than 4 M voxels goes without lists, i.e. without the class)
             const size_t occ_bytes = static_cast<size_t>(n_vox) * 8 * kVisListMax * sizeof(uint32_t);
-            if (occ_bytes <= (static_cast<size_t>(512) << 20)) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis_occ), occ_bytes));
-            d.n_vis_list = static_cast<int>(list.size());
-            if (d.n_vis_list > 0)
+            if (he == hipSuccess && occ_bytes <= (static_cast<size_t>(512) << 20)) he = hipMalloc(reinterpret_cast<void**>(&vis_occ), occ_bytes);
+            if (he == hipSuccess && !list.empty())
             {
-                HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis_list), list.size() * sizeof(int32_t)));
-                HIP_TRY(hipMemcpy(d.vis_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                he = hipMalloc(reinterpret_cast<void**>(&vis_list), list.size() * sizeof(int32_t));
+                if (he == hipSuccess) he = hipMemcpy(vis_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice);
             }
+            if (he != hipSuccess)
+            {
+                if (vis) (void)hipFree(vis);
+                if (vis_occ) (void)hipFree(vis_occ);
+                if (vis_list) (void)hipFree(vis_list);
+                return fail(he == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY : DDGI_ERR_HIP, "allocating the light-feeler classes failed: %s", hipGetErrorString(he));
+            }
+            d.vis = vis, d.vis_occ = vis_occ, d.vis_list = vis_list;
+            d.n_vis_list = static_cast<int>(list.size());
         }
         if (!d.vis_valid || std::memcmp(d.vis_light, a.lights[0].pos, sizeof(d.vis_light)) != 0)
         {
@@ -917,6 +937,17 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     }
     HIP_TRY(hipSetDevice(e->device));
     if (int rc = ddgi_exchange_before_update(e)) return rc;  // pipelined exchange: which texture pair this update writes
+    // ... committed only once the update's kernels are on the stream: a plan or launch that fails (NOT_READY, out of memory,
+    // unsupported) leaves the handle on the pair it had — consumers keep reading the latest finished update
+    struct PairSwitch
+    {
+        ddgi_engine* e;
+        bool launched = false;
+        ~PairSwitch()
+        {
+            if (!launched) ddgi_exchange_update_failed(e);
+        }
+    } pair_switch{e};
     TracePlan p;
     if (int rc = plan_trace(e, p)) return rc;
     const TraceArgs& a = p.a;
@@ -968,6 +999,7 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         HIP_TRY(launch_probe_blend(b, e->num_cus, e->stream));
         e->frame += 1;
     }
+    pair_switch.launched = true;
     HIP_TRY(hipEventRecord(ev[2], e->stream));
     e->updates += 1;
     return DDGI_OK;
@@ -1342,7 +1374,7 @@ int ddgi_bind_textures(ddgi_handle e, void* tex0, void* tex1)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     if ((tex0 == nullptr) != (tex1 == nullptr)) return fail(DDGI_ERR_INVALID_ARGUMENT, "bind both textures or neither");
-    if (e->xch.pipelined) return fail(DDGI_ERR_INVALID_ARGUMENT, "the pipelined exchange owns the texture pairs: ddgi_exchange_init(h, NULL, 0) first");
+    if (e->xch.pipelined || e->xch.p2p) return fail(DDGI_ERR_INVALID_ARGUMENT, "the pipelined / peer-to-peer exchange owns the texture pairs: ddgi_exchange_init(h, NULL, 0) first");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->tex[0] = tex0 ? tex0 : e->own_tex[0];

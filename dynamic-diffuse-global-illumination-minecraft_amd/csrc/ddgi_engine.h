@@ -119,18 +119,21 @@ struct ddgi_engine
     unsigned scene_epoch = 0;                    // bumped when the user scene changes (part of the configuration key)
     float* d_blend_w = nullptr;  // k_blend_weights output: [256 sums][n][256]
     size_t d_blend_w_floats = 0;
-    // multi-GPU exchange of the blended textures through RCCL (ddgi_exchange.cpp)
+    // multi-GPU exchange of the blended textures (ddgi_exchange.cpp): one interface, two transports
+    struct P2P;  // peer-to-peer transport state (ddgi_exchange.cpp)
     struct Exchange
     {
-        void* comm = nullptr;   // ncclComm_t; caller-owned unless made by ddgi_comm_create
+        int transport = 0;      // 0 none, 1 RCCL all-gather, 2 peer-to-peer pushes (DDGI_EXCHANGE_*)
+        void* comm = nullptr;   // RCCL: ncclComm_t; caller-owned unless made by ddgi_comm_create
+        P2P* p2p = nullptr;     // peer-to-peer: mapped peer buffers, flags, per-peer streams
         bool pipelined = false;
         void* pair[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // pipelined: two engine-owned texture pairs, used alternately
         hipStream_t comm_stream = nullptr;
         hipEvent_t written = nullptr;           // handle's stream: the update's kernels have finished
-        hipEvent_t sent[2] = {nullptr, nullptr};  // comm stream: pair i's last exchange is over
+        hipEvent_t sent[2] = {nullptr, nullptr};  // comm stream: pair i's last exchange is over (RCCL) / this rank's slab has left (p2p)
         bool sent_valid[2] = {false, false};
         int cur = 0;               // pair written by the most recent update
-        unsigned long long k = 0;  // updates issued since ddgi_exchange_init
+        unsigned long long k = 0;  // updates issued since the exchange was set up
     } xch;
     uint32_t* d_sample_scratch = nullptr;   // ddgi_sample_device: grouping of a batch by cage (ddgi_kernels.hip: k_sample_*)
     size_t sample_scratch_words = 0;
@@ -143,5 +146,6 @@ void ddgi_texture_bytes(int mode, const ddgi_irradiance_field& f, int rays_per_p
 int ddgi_alloc_texture_pair(ddgi_engine* e, const size_t bytes[2], void* out[2]);
 // exchange hooks called by the engine (no-ops without an initialised exchange)
 int ddgi_exchange_before_update(ddgi_engine* e);   // pipelined: pick + bind the pair the update writes, wait for its last exchange
+void ddgi_exchange_update_failed(ddgi_engine* e);  // ... and take that back: the update was not launched (the handle keeps the pair it had)
 int ddgi_exchange_wait_latest(ddgi_engine* e);     // consumers: the handle's stream waits until the latest pair is complete
 void ddgi_exchange_release(ddgi_engine* e);        // configuration changed / handle destroyed: drop pairs, stream, events

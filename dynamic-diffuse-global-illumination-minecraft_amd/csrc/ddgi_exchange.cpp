@@ -15,10 +15,25 @@
 // RCCL is resolved at run time (dlopen of the librccl.so.1 already in the process — e.g. the one PyTorch
 // loaded — else the system's): a host that never shards needs no RCCL, and the communicator handed to
 // ddgi_exchange_init and the collectives issued here always come from the same library instance.
+//
+// Two transports behind the same calls (ddgi_exchange / _finish, the engine's hooks):
+//   RCCL  ddgi_exchange_init(h, comm, pipelined): one ncclAllGather per texture.  The default on a node.
+//   P2P   ddgi_exchange_p2p_export + ddgi_exchange_p2p_init: SURVEY.md §8e's one-shot alternative — every rank
+//         pushes its contiguous slab straight into every other rank's buffers (hipMemcpyAsync into memory mapped
+//         with hipIpcOpenMemHandle; one process per rank), one stream per peer,
+//         so all 7 xGMI links of a GPU carry one slab each at the same time instead of a ring's 7 sequential
+//         hops.  Rendezvous is two flag words per peer pair in device memory, written by the peer and waited for
+//         by the command processor (hipStreamWaitValue32: no CU is held, nothing spins):
+//             ready[q]    rank q has finished reading what the pair held and may be written to  (receiver -> sender)
+//             arrived[r]  rank r's slab of exchange number `seq` has landed                      (sender -> receiver)
+//         It needs no RCCL, and — unlike RCCL, which refuses two ranks on one device — it runs with several
+//         ranks on ONE GPU, which is how the one-GPU test box executes a rank > 0 at all.
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "ddgi_engine.h"
 
@@ -94,21 +109,176 @@ int rccl_ready()
         if (r_ != 0) return fail(DDGI_ERR_HIP, "%s failed: %s", #expr, rccl().GetErrorString ? rccl().GetErrorString(r_) : "?"); \
     } while (0)
 
+
+// ---- peer-to-peer transport ----------------------------------------------------------------------------------
+
+constexpr uint32_t kP2PMagic = 0x32503244u;  // "D2P2"
+constexpr int kP2PMaxWorld = 64;
+
+// What a rank publishes (ddgi_exchange_p2p_export): where its buffers are, as IPC handles for its peers' processes.
+// Fits DDGI_P2P_ADDRESS_BYTES.
+struct P2PAddress
+{
+    uint32_t magic, rank, world, pipelined;
+    int32_t pid, device;
+    uint64_t tex_bytes[2];
+    hipIpcMemHandle_t pair[2][2];
+    hipIpcMemHandle_t flags;
+};
+static_assert(sizeof(P2PAddress) <= DDGI_P2P_ADDRESS_BYTES, "the published address must fit the ABI's blob");
+
+}  // namespace
+
+struct ddgi_engine::P2P
+{
+    struct Peer
+    {
+        void* pair[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+        uint32_t* flags = nullptr;
+        bool ipc = false;  // mapped with hipIpcOpenMemHandle (to be closed)
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;  // this peer's copy of the latest exchange has been issued and finished
+    };
+    uint32_t* flags = nullptr;   // own: [q] = ready, written by rank q; [kP2PMaxWorld + r] = arrived, written by rank r
+    std::vector<Peer> peers;     // [world]; the own rank's entry is unused
+    uint32_t seq = 0;            // exchanges issued
+    uint32_t pair_seq[2] = {0, 0};  // exchange number that last filled pair i
+    bool exported_pipelined = false;
+    bool connected = false;
+    bool write_value_ok = true;  // hipStreamWriteValue32 accepts peer memory (else a one-word fill)
+};
+
+namespace {
+
+// one flag word of a peer := v, in stream order
+int p2p_write_flag(ddgi_engine::P2P& p, hipStream_t s, uint32_t* flag, uint32_t v)
+{
+    if (p.write_value_ok)
+    {
+        if (hipStreamWriteValue32(s, flag, v, 0) == hipSuccess) return DDGI_OK;
+        (void)hipGetLastError();
+        p.write_value_ok = false;
+    }
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flag), static_cast<int>(v), 1, s));
+    return DDGI_OK;
+}
+
+int p2p_wait_flag(hipStream_t s, uint32_t* flag, uint32_t v)
+{
+    HIP_TRY(hipStreamWaitValue32(s, flag, v, hipStreamWaitValueGte, 0xffffffffu));
+    return DDGI_OK;
+}
+
+void p2p_release(ddgi_engine* e)
+{
+    ddgi_engine::P2P* p = e->xch.p2p;
+    if (!p) return;
+    for (auto& peer : p->peers)
+    {
+        if (peer.stream) (void)hipStreamSynchronize(peer.stream);
+        if (peer.ipc)
+        {
+            for (auto& pr : peer.pair)
+                for (void* q : pr)
+                    if (q) (void)hipIpcCloseMemHandle(q);
+            if (peer.flags) (void)hipIpcCloseMemHandle(peer.flags);
+        }
+        if (peer.done) (void)hipEventDestroy(peer.done);
+        if (peer.stream) (void)hipStreamDestroy(peer.stream);
+    }
+    if (p->flags) (void)hipFree(p->flags);
+    delete p;
+    e->xch.p2p = nullptr;
+}
+
+// The consumers of exchange number `seq` may run once every other rank's slab of it has landed.
+int p2p_wait_arrived(ddgi_engine* e, uint32_t seq)
+{
+    ddgi_engine::P2P& p = *e->xch.p2p;
+    if (seq == 0) return DDGI_OK;
+    for (int r = 0; r < e->world; ++r)
+        if (r != e->rank)
+            if (int rc = p2p_wait_flag(e->stream, p.flags + kP2PMaxWorld + r, seq)) return rc;
+    return DDGI_OK;
+}
+
+int p2p_exchange(ddgi_engine* e)
+{
+    ddgi_engine::Exchange& x = e->xch;
+    ddgi_engine::P2P& p = *x.p2p;
+    const uint32_t seq = ++p.seq;
+    const int cur = x.pipelined ? x.cur : 0;
+    p.pair_seq[cur] = seq;
+    HIP_TRY(hipEventRecord(x.written, e->stream));
+    // REF mode: the reference never assigns its `distances` image — every rank's copy is all zeros already
+    const int n_tex = e->mode == DDGI_MODE_DDGI ? 2 : 1;
+    // Phase 1, receiver -> every sender: everything this rank enqueued that reads the pair is done (`written` follows it in
+    // stream order), the peers may write their slabs of exchange `seq` into it.  ALL of these go out before the first wait
+    // below: HIP may map several streams onto one hardware queue, where a waiting packet holds back whatever is queued
+    // behind it — with every rank's "ready" already on its way, no chain of ranks waiting for each other can close.
+    for (int step = 1; step < e->world; ++step)
+    {
+        const int q = (e->rank + step) % e->world;  // every rank starts with a different peer
+        ddgi_engine::P2P::Peer& peer = p.peers[static_cast<size_t>(q)];
+        HIP_TRY(hipStreamWaitEvent(peer.stream, x.written, 0));
+        if (int rc = p2p_write_flag(p, peer.stream, peer.flags + e->rank, seq)) return rc;
+    }
+    // Phase 2, sender: once q is ready, push the slab and tell q that it has landed
+    for (int step = 1; step < e->world; ++step)
+    {
+        const int q = (e->rank + step) % e->world;
+        ddgi_engine::P2P::Peer& peer = p.peers[static_cast<size_t>(q)];
+        if (int rc = p2p_wait_flag(peer.stream, p.flags + q, seq)) return rc;
+        for (int i = 0; i < n_tex; ++i)
+        {
+            const size_t slab = e->tex_bytes[i] / static_cast<size_t>(e->world);
+            const size_t off = slab * static_cast<size_t>(e->rank);
+            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(peer.pair[cur][i]) + off, static_cast<const uint8_t*>(e->tex[i]) + off, slab, hipMemcpyDeviceToDevice, peer.stream));
+        }
+        if (int rc = p2p_write_flag(p, peer.stream, peer.flags + kP2PMaxWorld + e->rank, seq)) return rc;
+        HIP_TRY(hipEventRecord(peer.done, peer.stream));
+        HIP_TRY(hipStreamWaitEvent(x.comm_stream, peer.done, 0));
+    }
+    HIP_TRY(hipEventRecord(x.sent[cur], x.comm_stream));  // this rank's slab has left: the update after next may overwrite it
+    x.sent_valid[cur] = true;
+    if (!x.pipelined)
+    {
+        // in order: what follows on the handle's stream sees the whole field, and does not touch the slab before it has left
+        HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[cur], 0));
+        if (int rc = p2p_wait_arrived(e, seq)) return rc;
+    }
+    return DDGI_OK;
+}
+
 }  // namespace
 
 // ---- hooks for the engine -------------------------------------------------------------------------------
 
+namespace {
+// One process driving several handles brackets a frame's ddgi_exchange calls with ddgi_exchange_group_begin/end
+// (≙ ncclGroupStart/End).  Inside the bracket RCCL only RECORDS the collectives; they reach their streams at the
+// outermost ncclGroupEnd — so "this exchange is over" (Exchange::sent) can only be recorded there, not in
+// ddgi_exchange.  The bracket is per thread, like RCCL's.
+struct PendingSent
+{
+    ddgi_engine* e;
+    int pair;
+};
+thread_local int g_group_depth = 0;
+thread_local std::vector<PendingSent> g_group_pending;
+}  // namespace
+
 int ddgi_exchange_before_update(ddgi_engine* e)
 {
     ddgi_engine::Exchange& x = e->xch;
-    if (!x.comm || !x.pipelined)
+    if (!x.transport || !x.pipelined)
     {
         e->tex_prev[0] = e->tex_prev[1] = nullptr;
         return DDGI_OK;
     }
     const int cur = static_cast<int>(x.k & 1ull);
-    x.k += 1;
     if (x.sent_valid[cur]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[cur], 0));  // its previous exchange has left the buffers
+    x.k += 1;
     for (int i = 0; i < 2; ++i)
     {
         e->tex[i] = x.pair[cur][i];
@@ -118,10 +288,29 @@ int ddgi_exchange_before_update(ddgi_engine* e)
     return DDGI_OK;
 }
 
+// The update that ddgi_exchange_before_update prepared was not launched (planning or a launch failed): the handle
+// goes back to the pair it had, so that consumers keep reading the latest finished update and the next update
+// mixes with the right tiles.
+void ddgi_exchange_update_failed(ddgi_engine* e)
+{
+    ddgi_engine::Exchange& x = e->xch;
+    if (!x.transport || !x.pipelined || x.k == 0) return;
+    x.k -= 1;
+    const int prev = static_cast<int>((x.k & 1ull) ^ 1ull);  // the pair the update before wrote (pair 0 before the first)
+    const int cur = x.k == 0 ? 0 : prev;
+    for (int i = 0; i < 2; ++i)
+    {
+        e->tex[i] = x.pair[cur][i];
+        e->tex_prev[i] = x.pair[cur ^ 1][i];
+    }
+    x.cur = cur;
+}
+
 int ddgi_exchange_wait_latest(ddgi_engine* e)
 {
     ddgi_engine::Exchange& x = e->xch;
-    if (!x.comm || !x.pipelined) return DDGI_OK;  // in-order exchange: stream order already covers it
+    if (!x.transport || !x.pipelined) return DDGI_OK;  // in-order exchange: stream order already covers it
+    if (x.transport == DDGI_EXCHANGE_P2P) return p2p_wait_arrived(e, x.p2p->pair_seq[x.cur]);
     if (x.sent_valid[x.cur]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[x.cur], 0));
     return DDGI_OK;
 }
@@ -129,7 +318,10 @@ int ddgi_exchange_wait_latest(ddgi_engine* e)
 void ddgi_exchange_release(ddgi_engine* e)
 {
     ddgi_engine::Exchange& x = e->xch;
+    for (auto it = g_group_pending.begin(); it != g_group_pending.end();)
+        it = it->e == e ? g_group_pending.erase(it) : it + 1;
     if (x.comm_stream) (void)hipStreamSynchronize(x.comm_stream);
+    p2p_release(e);
     if (x.pipelined)
     {
         // pair[0] is the handle's own pair; pair[1] was allocated by ddgi_exchange_init
@@ -146,6 +338,43 @@ void ddgi_exchange_release(ddgi_engine* e)
         if (ev) (void)hipEventDestroy(ev);
     x = ddgi_engine::Exchange{};
 }
+
+namespace {
+// Streams, events and (pipelined) the second texture pair, common to both transports.  On failure everything is released.
+int exchange_common_setup(ddgi_engine* e, bool pipelined, bool always_streams)
+{
+    ddgi_engine::Exchange& x = e->xch;
+    if (pipelined)
+    {
+        if (e->tex[0] != e->own_tex[0]) return fail(DDGI_ERR_INVALID_ARGUMENT, "the pipelined exchange alternates the handle's own texture pairs: unbind caller textures first");
+        void* second[2];
+        if (int rc = ddgi_alloc_texture_pair(e, e->tex_bytes, second)) return rc;
+        for (int i = 0; i < 2; ++i)
+        {
+            x.pair[0][i] = e->own_tex[i];
+            x.pair[1][i] = second[i];
+        }
+        x.pipelined = true;
+    }
+    if (pipelined || always_streams)
+    {
+        hipError_t he = hipStreamCreateWithFlags(&x.comm_stream, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&x.written, hipEventDisableTiming);
+        for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&x.sent[i], hipEventDisableTiming);
+        if (he != hipSuccess)
+        {
+            const int rc = fail(DDGI_ERR_HIP, "exchange stream/event creation failed: %s", hipGetErrorString(he));
+            ddgi_exchange_release(e);
+            return rc;
+        }
+    }
+    if (pipelined)
+        // the first update writes pair 0 (the tiles so far), mixing with pair 1: start pair 1 as a copy, so that a
+        // DDGI field that has already converged carries on
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipMemcpyAsync(x.pair[1][i], x.pair[0][i], e->tex_bytes[i], hipMemcpyDeviceToDevice, e->stream));
+    return DDGI_OK;
+}
+}  // namespace
 
 // ---- C ABI -------------------------------------------------------------------------------------------------
 
@@ -192,13 +421,29 @@ int ddgi_exchange_group_begin(void)
 {
     if (int rc = rccl_ready()) return rc;
     NCCL_TRY(rccl().GroupStart());
+    g_group_depth += 1;
     return DDGI_OK;
 }
 
 int ddgi_exchange_group_end(void)
 {
     if (int rc = rccl_ready()) return rc;
+    if (g_group_depth > 0) g_group_depth -= 1;
     NCCL_TRY(rccl().GroupEnd());
+    if (g_group_depth == 0)
+    {
+        // the collectives recorded inside the bracket are on their streams NOW: this is where "exchange over" is in stream order
+        std::vector<PendingSent> pending;
+        pending.swap(g_group_pending);
+        for (const PendingSent& ps : pending)
+        {
+            ddgi_engine::Exchange& x = ps.e->xch;
+            if (x.transport != DDGI_EXCHANGE_RCCL || !x.pipelined) continue;
+            HIP_TRY(hipSetDevice(ps.e->device));
+            HIP_TRY(hipEventRecord(x.sent[ps.pair], x.comm_stream));
+            x.sent_valid[ps.pair] = true;
+        }
+    }
     return DDGI_OK;
 }
 
@@ -215,33 +460,112 @@ int ddgi_exchange_init(ddgi_handle e, void* nccl_comm, int pipelined)
     NCCL_TRY(rccl().CommUserRank(nccl_comm, &rank));
     if (count != e->world || rank != e->rank)
         return fail(DDGI_ERR_INVALID_ARGUMENT, "communicator is rank %d of %d, the handle is slab %d of %d", rank, count, e->rank, e->world);
+    if (int rc = exchange_common_setup(e, pipelined != 0, false)) return rc;
+    e->xch.comm = nccl_comm;
+    e->xch.transport = DDGI_EXCHANGE_RCCL;
+    return DDGI_OK;
+}
+
+int ddgi_exchange_p2p_export(ddgi_handle e, int pipelined, uint8_t address[DDGI_P2P_ADDRESS_BYTES])
+{
+    if (!e || !address) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/address");
+    if (e->world > kP2PMaxWorld) return fail(DDGI_ERR_UNSUPPORTED, "the peer-to-peer exchange serves at most %d ranks", kP2PMaxWorld);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    ddgi_exchange_release(e);
+    if (e->tex[0] != e->own_tex[0]) return fail(DDGI_ERR_INVALID_ARGUMENT, "the peer-to-peer exchange publishes the handle's own textures: unbind caller textures first");
+    if (int rc = exchange_common_setup(e, pipelined != 0, true)) return rc;
     ddgi_engine::Exchange& x = e->xch;
-    if (pipelined)
+    if (!x.pipelined)
+        for (int i = 0; i < 2; ++i) x.pair[0][i] = e->own_tex[i];
+    x.p2p = new (std::nothrow) ddgi_engine::P2P();
+    if (!x.p2p)
     {
-        if (e->tex[0] != e->own_tex[0]) return fail(DDGI_ERR_INVALID_ARGUMENT, "the pipelined exchange alternates the handle's own texture pairs: unbind caller textures first");
-        void* second[2];
-        if (int rc = ddgi_alloc_texture_pair(e, e->tex_bytes, second)) return rc;
-        int rc = DDGI_OK;
-        hipError_t he = hipStreamCreateWithFlags(&x.comm_stream, hipStreamNonBlocking);
-        if (he == hipSuccess) he = hipEventCreateWithFlags(&x.written, hipEventDisableTiming);
-        for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&x.sent[i], hipEventDisableTiming);
-        if (he != hipSuccess) rc = fail(DDGI_ERR_HIP, "exchange stream/event creation failed: %s", hipGetErrorString(he));
-        for (int i = 0; i < 2; ++i)
-        {
-            x.pair[0][i] = e->own_tex[i];
-            x.pair[1][i] = second[i];
-        }
-        x.pipelined = true;
-        if (rc)
-        {
-            ddgi_exchange_release(e);
-            return rc;
-        }
-        // the first update writes pair 0 (the tiles so far), mixing with pair 1: start pair 1 as a copy, so that a
-        // DDGI field that has already converged carries on
-        for (int i = 0; i < 2; ++i) HIP_TRY(hipMemcpyAsync(x.pair[1][i], x.pair[0][i], e->tex_bytes[i], hipMemcpyDeviceToDevice, e->stream));
+        ddgi_exchange_release(e);
+        return fail(DDGI_ERR_OUT_OF_MEMORY, "host allocation failed");
     }
-    x.comm = nccl_comm;
+    ddgi_engine::P2P& p = *x.p2p;
+    p.exported_pipelined = x.pipelined;
+    P2PAddress a;
+    std::memset(&a, 0, sizeof a);
+    a.magic = kP2PMagic, a.rank = static_cast<uint32_t>(e->rank), a.world = static_cast<uint32_t>(e->world), a.pipelined = x.pipelined ? 1u : 0u;
+    a.pid = static_cast<int32_t>(getpid()), a.device = e->device;
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&p.flags), 2 * kP2PMaxWorld * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMemset(p.flags, 0, 2 * kP2PMaxWorld * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);  // (the second pair's first contents)
+    if (he == hipSuccess) he = hipIpcGetMemHandle(&a.flags, p.flags);
+    for (int pr = 0; pr < (x.pipelined ? 2 : 1) && he == hipSuccess; ++pr)
+        for (int i = 0; i < 2 && he == hipSuccess; ++i)
+            he = hipIpcGetMemHandle(&a.pair[pr][i], x.pair[pr][i]);
+    for (int i = 0; i < 2; ++i) a.tex_bytes[i] = e->tex_bytes[i];
+    if (he != hipSuccess)
+    {
+        const int rc = fail(DDGI_ERR_HIP, "publishing the probe textures for peer access failed: %s", hipGetErrorString(he));
+        ddgi_exchange_release(e);
+        return rc;
+    }
+    std::memset(address, 0, DDGI_P2P_ADDRESS_BYTES);
+    std::memcpy(address, &a, sizeof a);
+    return DDGI_OK;
+}
+
+int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
+{
+    if (!e || !addresses) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/addresses");
+    ddgi_engine::Exchange& x = e->xch;
+    if (!x.p2p || x.p2p->connected) return fail(DDGI_ERR_NOT_READY, "ddgi_exchange_p2p_init needs a fresh ddgi_exchange_p2p_export on this handle");
+    if (world != e->world) return fail(DDGI_ERR_INVALID_ARGUMENT, "%d addresses for a handle that is slab %d of %d", world, e->rank, e->world);
+    HIP_TRY(hipSetDevice(e->device));
+    ddgi_engine::P2P& p = *x.p2p;
+    p.peers.assign(static_cast<size_t>(world), ddgi_engine::P2P::Peer{});
+    const int n_pairs = x.pipelined ? 2 : 1;
+    int rc = DDGI_OK;
+    for (int q = 0; q < world && rc == DDGI_OK; ++q)
+    {
+        P2PAddress a;
+        std::memcpy(&a, addresses + static_cast<size_t>(q) * DDGI_P2P_ADDRESS_BYTES, sizeof a);
+        if (a.magic != kP2PMagic || static_cast<int>(a.rank) != q || static_cast<int>(a.world) != world || (a.pipelined != 0) != x.pipelined || a.tex_bytes[0] != e->tex_bytes[0] ||
+            a.tex_bytes[1] != e->tex_bytes[1])
+        {
+            rc = fail(DDGI_ERR_INVALID_ARGUMENT, "address %d does not describe rank %d of %d with this handle's textures and pipelining", q, q, world);
+            break;
+        }
+        if (q == e->rank) continue;
+        ddgi_engine::P2P::Peer& peer = p.peers[static_cast<size_t>(q)];
+        hipError_t he = hipSuccess;
+        if (a.pid == static_cast<int32_t>(getpid()))
+        {
+            // The rendezvous is a flag another rank writes LATER, waited for by the command processor.  Between processes each
+            // rank's queues make progress on their own; inside one process the host enqueues rank after rank, and two handles'
+            // streams may share a hardware queue — rank 0's wait would sit in front of the very write it waits for.
+            rc = fail(DDGI_ERR_UNSUPPORTED, "rank %d lives in this process: the peer-to-peer exchange is one process per rank (one process driving several handles uses the RCCL transport with ddgi_exchange_group_begin/end)", q);
+            break;
+        }
+        peer.ipc = true;
+        void* fl = nullptr;
+        he = hipIpcOpenMemHandle(&fl, a.flags, hipIpcMemLazyEnablePeerAccess);
+        peer.flags = static_cast<uint32_t*>(fl);
+        for (int pr = 0; pr < n_pairs && he == hipSuccess; ++pr)
+            for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipIpcOpenMemHandle(&peer.pair[pr][i], a.pair[pr][i], hipIpcMemLazyEnablePeerAccess);
+        if (he == hipSuccess) he = hipStreamCreateWithFlags(&peer.stream, hipStreamNonBlocking);
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&peer.done, hipEventDisableTiming);
+        if (he != hipSuccess && rc == DDGI_OK) rc = fail(DDGI_ERR_HIP, "mapping rank %d's probe textures failed: %s", q, hipGetErrorString(he));
+    }
+    if (rc)
+    {
+        ddgi_exchange_release(e);
+        return rc;
+    }
+    p.connected = true;
+    x.transport = DDGI_EXCHANGE_P2P;
+    return DDGI_OK;
+}
+
+int ddgi_exchange_transport(ddgi_handle e, int* transport, int* pipelined)
+{
+    if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    if (transport) *transport = e->xch.transport;
+    if (pipelined) *pipelined = e->xch.pipelined ? 1 : 0;
     return DDGI_OK;
 }
 
@@ -249,8 +573,9 @@ int ddgi_exchange(ddgi_handle e)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     ddgi_engine::Exchange& x = e->xch;
-    if (!x.comm) return fail(DDGI_ERR_NOT_READY, "ddgi_exchange before ddgi_exchange_init");
+    if (!x.transport) return fail(DDGI_ERR_NOT_READY, "ddgi_exchange before ddgi_exchange_init / ddgi_exchange_p2p_init");
     HIP_TRY(hipSetDevice(e->device));
+    if (x.transport == DDGI_EXCHANGE_P2P) return p2p_exchange(e);
     hipStream_t s = e->stream;
     if (x.pipelined)
     {
@@ -271,8 +596,19 @@ int ddgi_exchange(ddgi_handle e)
     NCCL_TRY(rccl().GroupEnd());
     if (x.pipelined)
     {
-        HIP_TRY(hipEventRecord(x.sent[x.cur], x.comm_stream));
-        x.sent_valid[x.cur] = true;
+        if (g_group_depth > 0)
+        {
+            // inside ddgi_exchange_group_begin/end the all-gather is not on comm_stream yet: an event recorded now would fire
+            // before it.  Until the bracket closes the pair counts as "exchange not over" for nobody — consumers and the next
+            // update only come after ddgi_exchange_group_end, which records it.
+            x.sent_valid[x.cur] = false;
+            g_group_pending.push_back(PendingSent{e, x.cur});
+        }
+        else
+        {
+            HIP_TRY(hipEventRecord(x.sent[x.cur], x.comm_stream));
+            x.sent_valid[x.cur] = true;
+        }
     }
     return DDGI_OK;
 }
@@ -281,8 +617,15 @@ int ddgi_exchange_finish(ddgi_handle e)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     ddgi_engine::Exchange& x = e->xch;
-    if (!x.comm || !x.pipelined) return DDGI_OK;
+    if (!x.transport) return DDGI_OK;
     HIP_TRY(hipSetDevice(e->device));
+    if (x.transport == DDGI_EXCHANGE_P2P)
+    {
+        for (int i = 0; i < 2; ++i)
+            if (x.sent_valid[i]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[i], 0));
+        return p2p_wait_arrived(e, x.p2p->seq);
+    }
+    if (!x.pipelined) return DDGI_OK;
     for (int i = 0; i < 2; ++i)
         if (x.sent_valid[i]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[i], 0));
     return DDGI_OK;

@@ -15,6 +15,7 @@ from .build import build_library, library_path
 
 MODE_REF = 0
 MODE_DDGI = 1
+P2P_ADDRESS_BYTES = 512  # DDGI_P2P_ADDRESS_BYTES
 
 
 class DDGIError(RuntimeError):
@@ -135,6 +136,9 @@ _SIGNATURES = {
     "ddgi_exchange_init": (C.c_int, [_VP, _VP, C.c_int]),
     "ddgi_exchange": (C.c_int, [_VP]),
     "ddgi_exchange_finish": (C.c_int, [_VP]),
+    "ddgi_exchange_p2p_export": (C.c_int, [_VP, C.c_int, _VP]),
+    "ddgi_exchange_p2p_init": (C.c_int, [_VP, _VP, C.c_int]),
+    "ddgi_exchange_transport": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ddgi_exchange_group_begin": (C.c_int, []),
     "ddgi_exchange_group_end": (C.c_int, []),
     "ddgi_comm_unique_id": (C.c_int, [_VP]),
@@ -421,6 +425,24 @@ class ProbeEngine:
     def exchange_init(self, nccl_comm, pipelined=False):
         """nccl_comm: an ncclComm_t as an integer address (comm_create below), or None to detach."""
         _check(self._lib.ddgi_exchange_init(self._h, C.c_void_p(nccl_comm), 1 if pipelined else 0))
+
+    def exchange_p2p_export(self, pipelined=False):
+        """Publishes this handle's buffers for the peer-to-peer exchange: 512 opaque bytes to hand to every rank."""
+        blob = (C.c_uint8 * P2P_ADDRESS_BYTES)()
+        _check(self._lib.ddgi_exchange_p2p_export(self._h, 1 if pipelined else 0, blob))
+        return bytes(blob)
+
+    def exchange_p2p_init(self, addresses):
+        """addresses: every rank's exchange_p2p_export() bytes, in rank order."""
+        raw = b"".join(addresses)
+        assert len(raw) == P2P_ADDRESS_BYTES * len(addresses)
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        _check(self._lib.ddgi_exchange_p2p_init(self._h, buf, len(addresses)))
+
+    def exchange_transport(self):
+        t, pl = C.c_int(), C.c_int()
+        _check(self._lib.ddgi_exchange_transport(self._h, C.byref(t), C.byref(pl)))
+        return {0: "none", 1: "rccl", 2: "p2p"}[t.value], bool(pl.value)
 
     def exchange(self):
         _check(self._lib.ddgi_exchange(self._h))

@@ -335,8 +335,31 @@ int ddgi_exchange(ddgi_handle h);
 /* Makes the handle's stream wait for every exchange issued so far (needed only before work the caller
  * enqueues itself on that stream, e.g. a timing fence; the handle's own consumers wait by themselves). */
 int ddgi_exchange_finish(ddgi_handle h);
+/* One process driving several handles brackets the ddgi_exchange calls of a frame (≙ ncclGroupStart/End; per
+ * thread).  Inside the bracket RCCL only records the collectives: consumers of the exchanged textures and the next
+ * ddgi_probe_update come after ddgi_exchange_group_end. */
 int ddgi_exchange_group_begin(void);
 int ddgi_exchange_group_end(void);
+
+/* The same exchange without RCCL: every rank pushes its slab straight into every other rank's textures (SURVEY.md
+ * §8e's one-shot alternative to a ring; one copy stream per peer, rendezvous through flag words in device memory
+ * that the command processor waits on).  One process per rank (the peers' textures are mapped with
+ * hipIpcOpenMemHandle); several ranks may share ONE device — which RCCL refuses.  Set-up, on every rank:
+ *     ddgi_exchange_p2p_export(h, pipelined, mine);          publish this handle's buffers (512 opaque bytes)
+ *     ... the host gathers every rank's 512 bytes, in rank order, by whatever channel it has ...
+ *     ddgi_exchange_p2p_init(h, all, world);                 map the peers' buffers
+ * then ddgi_probe_update / ddgi_exchange / consumers exactly as with RCCL (`pipelined` means the same).  The ranks
+ * must all still be alive when any of them detaches (ddgi_exchange_init(h, NULL, 0), reconfiguration, destroy):
+ * put a host barrier before tearing down, as before ncclCommDestroy. */
+#define DDGI_P2P_ADDRESS_BYTES 512
+int ddgi_exchange_p2p_export(ddgi_handle h, int pipelined, uint8_t address[DDGI_P2P_ADDRESS_BYTES]);
+int ddgi_exchange_p2p_init(ddgi_handle h, const uint8_t* addresses_rank_major, int world);
+
+#define DDGI_EXCHANGE_NONE 0
+#define DDGI_EXCHANGE_RCCL 1
+#define DDGI_EXCHANGE_P2P 2
+/* Which transport the handle's exchange uses (DDGI_EXCHANGE_*), and whether it is pipelined. */
+int ddgi_exchange_transport(ddgi_handle h, int* transport, int* pipelined);
 
 /* Communicator bootstrap through the same RCCL instance (thin wrappers of ncclGetUniqueId /
  * ncclCommInitRank / ncclCommInitAll / ncclCommDestroy), for hosts that do not link RCCL themselves:

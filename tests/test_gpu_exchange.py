@@ -87,6 +87,51 @@ def test_ddgi_mode_exchange_keeps_the_temporal_blend(ddgi, oracle, comm1, pipeli
             assert np.array_equal(_bits(g_dep), _bits(dep)), f"depth tiles differ at frame {frame}"
 
 
+def test_grouped_exchange_records_its_end_at_the_group_end(ddgi, comm1):
+    """Inside ddgi_exchange_group_begin/end RCCL only records the all-gather; it reaches the communication stream at the
+    outermost group end, and only there can "this exchange is over" be recorded (an event recorded in ddgi_exchange would fire
+    before the collective).  One rank is enough to run that path: new rays every frame, a consumer after every bracket."""
+    counts, side, s, origin, scene = CONFIGS["c1_cornell"]
+    lib = ddgi.load_library()
+    with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8)) as ref, \
+            ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8)) as eng:
+        eng.exchange_init(comm1, pipelined=True)
+        for frame in range(5):
+            for e in (ref, eng):
+                e.generate_probe_rays(seed=frame + 1, reseed=True)
+                e.probe_update()
+            assert lib.ddgi_exchange_group_begin() == 0
+            assert lib.ddgi_exchange_group_begin() == 0      # nested brackets: only the outermost end counts
+            eng.exchange()
+            assert lib.ddgi_exchange_group_end() == 0
+            assert lib.ddgi_exchange_group_end() == 0
+            if frame != 2:
+                assert np.array_equal(eng.read_textures()[0], ref.read_textures()[0]), f"frame {frame}"
+        eng.exchange_finish()
+        eng.synchronize()
+
+
+def test_a_failed_update_keeps_the_pair(ddgi, comm1):
+    """ddgi_probe_update picks the texture pair it will write before it plans the launch; when the plan fails the handle must
+    still point at the pair of the latest finished update (consumers and the next update depend on it)."""
+    counts, side, s, origin, scene = CONFIGS["c1_cornell"]
+    with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8)) as eng:
+        eng.exchange_init(comm1, pipelined=True)
+        eng.generate_probe_rays(seed=1)
+        eng.probe_update()
+        eng.exchange()
+        want = eng.read_textures()[0]
+        before = eng.device_textures()["tex0"]
+        with pytest.raises(ddgi.DDGIError):
+            eng.probe_update(ddgi.make_settings(3, 8))       # scene 3 without a user scene loaded: NOT_READY
+        assert eng.device_textures()["tex0"] == before
+        assert np.array_equal(eng.read_textures()[0], want)
+        eng.probe_update(ddgi.make_settings(scene, 8))       # the next update alternates as if nothing had happened
+        eng.exchange()
+        assert eng.device_textures()["tex0"] != before
+        assert np.array_equal(eng.read_textures()[0], want)
+
+
 def test_communicator_must_match_the_shard(ddgi, comm1):
     counts, side, s, origin, scene = CONFIGS["cave_small"]
     with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8), rank=1, world=2) as eng:
@@ -110,20 +155,22 @@ def test_one_process_drives_every_visible_gpu(ddgi, oracle):
     assert lib.ddgi_comm_create_all(world, devs, comms) == 0, lib.ddgi_last_error()
     engines = [ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8), device=r, rank=r, world=world) for r in range(world)]
     try:
+        f = oracle.make_field(counts, side, s, origin)
         for r, eng in enumerate(engines):
             eng.exchange_init(comms[r], pipelined=True)
-            eng.generate_probe_rays(seed=1)
-        for _ in range(3):
+        for frame in range(4):
+            # new rays every frame: a consumer that ran ahead of the all-gather would read the previous frame's texels
             for eng in engines:
+                eng.generate_probe_rays(seed=frame + 1, reseed=True)
                 eng.probe_update()
             assert lib.ddgi_exchange_group_begin() == 0
             for eng in engines:
                 eng.exchange()
             assert lib.ddgi_exchange_group_end() == 0
-        f = oracle.make_field(counts, side, s, origin)
-        want, _ = oracle.probe_update(f, oracle.make_settings(scene, 8), oracle.generate_probe_rays(f, oracle.new_rand_state(1)))
-        for eng in engines:
-            assert np.array_equal(eng.read_textures()[0], want)
+            if frame in (1, 3):   # (frames 0 and 2: the next update is issued while the exchange is still in flight)
+                want, _ = oracle.probe_update(f, oracle.make_settings(scene, 8), oracle.generate_probe_rays(f, oracle.new_rand_state(frame + 1)))
+                for r, eng in enumerate(engines):
+                    assert np.array_equal(eng.read_textures()[0], want), f"rank {r}, frame {frame}"
     finally:
         for eng in engines:
             eng.close()
