@@ -174,6 +174,81 @@ DDGI_D bool march_step_burst(March& m, const SceneK& S, const uint32_t* __restri
     return __builtin_amdgcn_ubfe(base[idx >> 5], static_cast<uint32_t>(idx), 1u) != 0u;
 }
 
+// ---- the fast march (tolerance mode, opt-in: ddgi_set_tuning "fast_march") -----------------------------------------
+// grid_march (intersection.glsl:1051-1100) re-derives every step from the position it has reached — t += (distance to
+// the next voxel boundary) + 1e-4 — so the position after crossing a given plane is that plane's t + 1e-4 whatever came
+// before it, up to rounding.  A march may therefore cross several planes in ONE step when the voxels in between are
+// known to be empty, land where grid_march would have landed after as many unit steps, and go on exactly as grid_march
+// does: same hit voxel, hit position equal to a few ulp — except for rays that graze a voxel edge within those ulp.
+// What is known comes from the scene's skip field (ddgi_host.h: build_skip_field): code 0 = occupied, else every voxel
+// within Chebyshev distance code - 1 is empty, so the next boundary that matters is `code` voxels away on each axis:
+//     t_axis = (code - f) / |d_axis| going up,  (code - 1 + f) / |d_axis| going down,   f = fract(p_axis)
+// (code = 1 is grid_march's own step).  grid_march's limit of 125 iterations is kept as a limit on the planes crossed
+// (fast_march_planes): per axis the position moves one way only, so the planes crossed since the origin are the
+// Manhattan distance between the voxel ids — no counter travels with the march.
+// Results are NOT bit-equal to the exact march; tests/test_gpu_fast_march.py states and checks the tolerance.
+struct FastMarch
+{
+    f3 ro, dn;
+    f3 ainv;  // 1 / |dn| per axis (1e30 where dn == 0)
+    f3 nsgn;  // -1 where dn >= 0 else +1
+    f3 c1;    //  0 where dn >= 0 else  1
+    f3 p;
+    float t, tl;
+    float code;  // skip code of the voxel that holds p, as a float (>= 1 while the march is going)
+    int cell;
+};
+
+DDGI_D float fast_axis_ainv(float d) { return d == 0.0f ? 1.0e30f : __builtin_amdgcn_rcpf(fabsf(d)); }
+
+DDGI_D void fast_march_begin(FastMarch& m, f3 ro, f3 dn, float t, float tl)
+{
+    m.ro = ro, m.dn = dn;
+    m.ainv = f3{fast_axis_ainv(dn.x), fast_axis_ainv(dn.y), fast_axis_ainv(dn.z)};
+    m.nsgn = f3{dn.x >= 0.0f ? -1.0f : 1.0f, dn.y >= 0.0f ? -1.0f : 1.0f, dn.z >= 0.0f ? -1.0f : 1.0f};
+    m.c1 = f3{dn.x >= 0.0f ? 0.0f : 1.0f, dn.y >= 0.0f ? 0.0f : 1.0f, dn.z >= 0.0f ? 0.0f : 1.0f};
+    m.t = t, m.tl = tl;
+    m.p = ray_at(ro, dn, t);
+    m.code = 1.0f;  // nothing known about the start voxel: the first step is grid_march's
+    m.cell = 0;
+}
+
+// One step; returns the skip code of the voxel reached (0: occupied).  s_skip: the skip field (LDS).
+// Distance to the boundary `code` voxels on, per axis, with f = fract(p):  going up (code - f) / |d|, going down
+// (code - 1 + f) / |d| — for code = 1 exactly grid_march's max(-f / d, (1 - f) / d), INCLUDING its zero-length step from a
+// position that sits on a plane and goes down (f = 0): probes stand on integer coordinates, and what grid_march looks up
+// after that step (the voxel diagonally across) is part of the reference's result.
+DDGI_D uint32_t fast_march_step(FastMarch& m, const SceneK& S, const uint32_t* __restrict__ s_skip, f3 hi)
+{
+    const float fx = gl_fract(m.p.x);
+    const f2v fyz = f2v{gl_fract(m.p.y), gl_fract(m.p.z)};
+    const float tx = fmaf(m.nsgn.x, fx, m.code - m.c1.x) * m.ainv.x;
+    const f2v nyz = f2v{fmaf(m.nsgn.y, fyz.x, m.code - m.c1.y), fmaf(m.nsgn.z, fyz.y, m.code - m.c1.z)};
+    const f2v tyz = nyz * f2v{m.ainv.y, m.ainv.z};
+    m.t += fminf(fminf(tx, tyz.x), tyz.y) + 0.0001f;
+    m.p = ray_at(m.ro, m.dn, m.t);
+    const float kx = __builtin_amdgcn_fmed3f(ceilf(m.p.x), S.lo_f[0], hi.x);
+    const float ky = __builtin_amdgcn_fmed3f(ceilf(m.p.y), S.lo_f[1], hi.y);
+    const float kz = __builtin_amdgcn_fmed3f(ceilf(m.p.z), S.lo_f[2], hi.z);
+    const int idx = static_cast<int>(fmaf(kz, S.nxy_f, fmaf(ky, S.nx_f, kx)));
+    m.cell = idx;
+    const uint32_t* __restrict__ base = s_skip - (S.bias32 >> 4);
+    const uint32_t code = __builtin_amdgcn_ubfe(base[idx >> 4], static_cast<uint32_t>(idx) << 1, 2u);
+#if defined(DDGI_FAST_DEBUG) && (DDGI_FAST_DEBUG & 1)
+    m.code = code ? 1.0f : 0.0f;  // debug: never skip
+#else
+    m.code = static_cast<float>(code);
+#endif
+    return code;
+}
+
+// Planes crossed between the march's origin and its position = the iterations grid_march would have spent to get here
+// (one plane per iteration; two planes within 1e-4 of each other count twice here, once there).
+DDGI_D float fast_march_planes(const FastMarch& m)
+{
+    return fabsf(ceilf(m.p.x) - ceilf(m.ro.x)) + fabsf(ceilf(m.p.y) - ceilf(m.ro.y)) + fabsf(ceilf(m.p.z) - ceilf(m.ro.z));
+}
+
 // Block type of the voxel a march ended in (its id `cell` = ceil(p), raw linear index `raw`).  The
 // baked table is exact inside the box and for everything that is an extrusion of its border layer;
 // the one exception is the cave's floor band (y < -15): there getBlockAt decides 11/12/13 from an
@@ -194,7 +269,8 @@ DDGI_D int hit_block_type(const SceneK& S, int scene_id, f3 cell, int raw)
 // True when the march can no longer hit a block: the position is outside the baked box on some
 // axis, moving away from it, and the border layer it left through is entirely empty (so the whole
 // half space beyond is empty).  Skipping the remaining iterations does not change any result.
-DDGI_D bool march_escaped(const March& m, const SceneK& S)
+template <class M>
+DDGI_D bool march_escaped(const M& m, const SceneK& S)
 {
     const int x = static_cast<int>(ceilf(m.p.x)), y = static_cast<int>(ceilf(m.p.y)), z = static_cast<int>(ceilf(m.p.z));
     const unsigned fe = S.face_empty;

@@ -30,6 +30,7 @@ int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads, in
 hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream);
 hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t stream);
 int aq_pool_size(int nwords, size_t lds_limit);
+int aq_pool_size_fast(int nwords_skip, size_t lds_limit, bool plain);
 hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream);
 size_t blend_weights_floats(int n);
 hipError_t launch_blend_weights(const BlendArgs& args, hipStream_t stream);
@@ -80,6 +81,7 @@ static const TuningKey kTuningKeys[] = {
     {"wf_chunk", &Tuning::wf_chunk, "DDGI_WF_CHUNK"},
     {"wf_drain", &Tuning::wf_drain, "DDGI_WF_DRAIN"},
     {"wait_threshold", &Tuning::wait_threshold, "DDGI_WAIT_THRESHOLD"},
+    {"fast_march", &Tuning::fast_march, "DDGI_FAST_MARCH"},
     {"light_vis", &Tuning::light_vis, "DDGI_LIGHT_VIS"},
     {"sample_group", &Tuning::sample_group, "DDGI_SAMPLE_GROUP"},
     {"noise_lut", &Tuning::noise_lut, nullptr},
@@ -240,6 +242,13 @@ static int ensure_scene(ddgi_engine* e, int scene)
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.types), b.types.size()));
     HIP_TRY(hipMemcpy(d.bits, shifted.data(), shifted.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d.types, b.types.data(), b.types.size(), hipMemcpyHostToDevice));
+    // the fast march's skip field (2 bits per voxel, addressed like the bitmap); built with the scene, used only on request
+    std::vector<uint32_t> skip;
+    build_skip_field(b, shift, skip);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.skip), skip.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(d.skip, skip.data(), skip.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    d.k.skip = d.skip;
+    d.k.nwords_skip = static_cast<int>(skip.size());
     for (int a = 0; a < 3; ++a)
     {
         d.k.lo[a] = b.lo[a];
@@ -400,6 +409,7 @@ int ddgi_destroy(ddgi_handle e)
     {
         if (d.bits) (void)hipFree(d.bits);
         if (d.types) (void)hipFree(d.types);
+        if (d.skip) (void)hipFree(d.skip);
         if (d.vis) (void)hipFree(d.vis);
         if (d.vis_occ) (void)hipFree(d.vis_occ);
         if (d.vis_list) (void)hipFree(d.vis_list);
@@ -645,7 +655,7 @@ static unsigned long long aq_config_key(const ddgi_engine* e, const TraceArgs& a
     }
     mix(static_cast<unsigned>(a.scene_id)), mix(static_cast<unsigned>(a.max_bounces)), mix(static_cast<unsigned>(a.nl));
     mix(ddgi_mode ? 1u : 0u), mix(static_cast<unsigned>(e->rank)), mix(static_cast<unsigned>(e->world)), mix(a.n_rays);
-    mix(e->scene_epoch);
+    mix(e->scene_epoch), mix(static_cast<unsigned>(a.fast_march));
     return h | 1ull;
 }
 
@@ -657,6 +667,7 @@ struct TracePlan
     bool ddgi_mode = false;
     int pool = 0;            // ray pool of the wavefront kernels; 0: the ray-per-lane kernel
     bool use_async = false;  // k_probe_trace_aq (queues) rather than k_probe_trace_wf (rounds)
+    bool fast = false;       // ... its tolerance-mode build (tuning "fast_march")
     int wf_threads = 1024;
     uint32_t grid = 0;
     size_t rec_rgb = 0;      // DDGI mode: floats in the rgb part of the ray-record buffer (the (d, d*d) part follows)
@@ -788,7 +799,21 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     // round-based k_probe_trace_wf (cross-check), which also serves the utilisation counters
     const bool force_rounds = tn.trace_kernel == 1 || (a.stats != nullptr && tn.trace_kernel != 3) || p.wf_threads != 1024;
     p.use_async = p.pool > 0 && !force_rounds && aq_pool_size(a.scene.nwords, 160 * 1024) > 0;
-    if (p.use_async)
+    // "fast_march": the tolerance-mode march (ddgi_device.h: fast_march_step) — the queue kernel only, and only when its pool
+    // fits next to the scene's skip field; otherwise the update runs the exact march ("fast_march_active" tells)
+    p.fast = false;
+    if (p.use_async && tn.fast_march && a.stats == nullptr && tn.ablate == 0)
+    {
+        const int fast_pool = aq_pool_size_fast(a.scene.nwords_skip, 160 * 1024, a.nl == 1);
+        if (fast_pool > 0)
+        {
+            p.fast = true;
+            p.pool = fast_pool;
+            a.fast_march = 1;
+        }
+    }
+    e->fast_march_active = p.fast;
+    if (p.use_async && !p.fast)
     {
         p.pool = std::min(1344, aq_pool_size(a.scene.nwords, 160 * 1024));  // what fits next to the cave's bitmap at 72 B per slot; more buys nothing (C3: 1024: 2.56 ms, 1152: 2.37, 1344: 2.11, 1472: 2.13)
         if (tn.aq_pool > 0) p.pool = std::min(aq_pool_size(a.scene.nwords, 160 * 1024), std::max(1024, tn.aq_pool / 64 * 64));
@@ -1166,6 +1191,11 @@ int ddgi_get_tuning(ddgi_handle e, const char* name, int* value)
     if (!std::strcmp(name, "march_waves_measured"))  // the split in use for the last planned configuration (0: none yet)
     {
         *value = e->aq_last;
+        return DDGI_OK;
+    }
+    if (!std::strcmp(name, "fast_march_active"))  // did the most recent update run the fast march ("fast_march" is a request)
+    {
+        *value = e->fast_march_active ? 1 : 0;
         return DDGI_OK;
     }
     for (const TuningKey& k : kTuningKeys)

@@ -24,6 +24,7 @@ struct Tuning
     int blend_kernel = 0;   // DDGI blend: 0 auto, 1 one probe per workgroup (cross-check)
     int aq_pool = 0, wf_pool = 0, wf_maxpool = 0, wf_threads = 1024;
     int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
+    int fast_march = 0;     // tolerance mode: marches skip empty space (NOT bit-exact; tests/test_gpu_fast_march.py states the tolerance)
     int light_vis = 1;      // per-voxel light-feeler classes (k_light_visibility): 0 = march every feeler
     int sample_group = 1;   // ddgi_sample*: handle the points of a batch cage by cage (0: in the order given)
     int noise_lut = 1;      // memoised lattice hashes (0: compute every hash)
@@ -73,6 +74,7 @@ struct ddgi_engine
     {
         uint32_t* bits = nullptr;
         uint8_t* types = nullptr;
+        uint32_t* skip = nullptr;           // the fast march's skip field (ddgi_host.h: build_skip_field)
         SceneK k{};
         bool ready = false;
         uint8_t* vis = nullptr;             // k_light_visibility table for the scene's single light
@@ -114,6 +116,7 @@ struct ddgi_engine
     int d_radiance_rays = 0;                // rays per probe the buffer was zeroed for (its padding layout)
     uint32_t frame = 0;                     // DDGI mode: updates done so far (seeds the ray rotation)
     Tuning tuning;
+    bool fast_march_active = false;              // the most recent update ran the fast march
     std::map<unsigned long long, int> aq_split;  // configuration key -> measured march/event wave split of the queue kernel
     int aq_last = 0;                             // the most recently measured split (starting point of the next measurement)
     unsigned scene_epoch = 0;                    // bumped when the user scene changes (part of the configuration key)

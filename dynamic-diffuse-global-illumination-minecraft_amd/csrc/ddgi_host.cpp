@@ -93,6 +93,47 @@ int SceneBake::block_at(int x, int y, int z) const
     return types[i];
 }
 
+void build_skip_field(const SceneBake& b, int shift, std::vector<uint32_t>& words)
+{
+    const int nx = b.dim[0], ny = b.dim[1], nz = b.dim[2];
+    const size_t n = b.types.size();
+    // occupancy dilated by Chebyshev radius 1 and 2: three separable 3-wide maxima per radius, edges replicated (a lookup
+    // outside the box reads the border layer, so the neighbour beyond an edge is the edge voxel itself)
+    std::vector<uint8_t> lvl[3];
+    lvl[0].resize(n);
+    for (size_t i = 0; i < n; ++i) lvl[0][i] = b.types[i] ? 1 : 0;
+    std::vector<uint8_t> tmp(n);
+    auto dilate_axis = [&](const std::vector<uint8_t>& src, std::vector<uint8_t>& dst, int axis) {
+        const int dim[3] = {nx, ny, nz};
+        const size_t stride[3] = {1, static_cast<size_t>(nx), static_cast<size_t>(nx) * ny};
+        for (int z = 0; z < nz; ++z)
+            for (int y = 0; y < ny; ++y)
+                for (int x = 0; x < nx; ++x)
+                {
+                    const int c[3] = {x, y, z};
+                    const size_t i = (static_cast<size_t>(z) * ny + y) * nx + x;
+                    uint8_t v = src[i];
+                    if (c[axis] > 0) v |= src[i - stride[axis]];
+                    if (c[axis] + 1 < dim[axis]) v |= src[i + stride[axis]];
+                    dst[i] = v;
+                }
+    };
+    for (int r = 1; r <= 2; ++r)
+    {
+        lvl[r].resize(n);
+        dilate_axis(lvl[r - 1], lvl[r], 0);
+        dilate_axis(lvl[r], tmp, 1);
+        dilate_axis(tmp, lvl[r], 2);
+    }
+    words.assign((n + static_cast<size_t>(shift) + 15) / 16, 0u);
+    for (size_t i = 0; i < n; ++i)
+    {
+        const uint32_t code = lvl[0][i] ? 0u : (lvl[1][i] ? 1u : (lvl[2][i] ? 2u : 3u));
+        const size_t k = i + static_cast<size_t>(shift);
+        words[k >> 4] |= code << ((k & 15) * 2);
+    }
+}
+
 const SceneBake& baked_scene(int scene)
 {
     static std::array<SceneBake, 3> cache;

@@ -23,6 +23,12 @@ struct SceneBake
 
 const SceneBake& baked_scene(int scene);  // cached, thread-safe; scene in {0,1,2}
 
+// The fast (tolerance-mode) march's per-voxel skip field, 2 bits per voxel in the bitmap's order: 0 = occupied, else
+// 1 + min(r, 2) with r the voxel's free Chebyshev radius — every voxel within r of it, in the world the kernels see
+// (clamped lookups: outside the box the border layer repeats), is empty.  Stored shifted by `shift` entries like the
+// occupancy bitmap (ddgi_engine.cpp: ensure_scene), 16 entries per word.
+void build_skip_field(const SceneBake& b, int shift, std::vector<uint32_t>& words);
+
 // glibc rand() (random_r TYPE_3) restated: the reference draws its ray jitter from the unseeded C
 // library generator (src/rvpt/rvpt.cpp:1161-1162).
 struct GlibcRand

@@ -108,7 +108,8 @@ struct WfPool
     uint16_t* event_list;
 };
 
-constexpr int kPoolDwords = 18;  // LDS per slot: ro, dn, t, tl, flags + col, rd, rng, cnt, dst
+constexpr int kPoolDwords = 18;      // LDS per slot: ro, dn, t, tl, flags + col, rd, rng, cnt, dst
+constexpr int kPoolDwordsFast = 16;  // ... the fast build keeps |rd| only
 constexpr int wf_dwords_per_ray(bool) { return kPoolDwords; }
 
 DDGI_D f3 ld3(float* const* a, uint32_t i) { return f3{a[0][i], a[1][i], a[2][i]}; }
@@ -120,6 +121,8 @@ DDGI_D void st3(float* const* a, uint32_t i, f3 v)
 }
 
 // A slot's shading state in and out of an event.  with_hn: the hit normal travels too (a marched feeler is in flight).
+// kFast: while a primary march is in flight only hc[0] = |ray direction as given| is kept (the direction itself is dn).
+template <bool kFast = false>
 DDGI_D WfCold load_cold(const WfPool& P, uint32_t slot, bool with_hn)
 {
     WfCold c;
@@ -131,12 +134,15 @@ DDGI_D WfCold load_cold(const WfPool& P, uint32_t slot, bool with_hn)
         c.hc[0] = __uint_as_float(a.x), c.hc[1] = __uint_as_float(a.y), c.hc[2] = __uint_as_float(a.z);
         c.hn[0] = __uint_as_float(b.x), c.hn[1] = __uint_as_float(b.y), c.hn[2] = __uint_as_float(b.z);
     }
+    else if (kFast)
+        c.hc[0] = P.rd[0][slot], c.hc[1] = c.hc[2] = 0.0f;
     else
         c.hc[0] = P.rd[0][slot], c.hc[1] = P.rd[1][slot], c.hc[2] = P.rd[2][slot];
     c.col[0] = P.col[0][slot], c.col[1] = P.col[1][slot], c.col[2] = P.col[2][slot];
     c.rng = P.rng[slot], c.cnt = P.cnt[slot], c.dst = P.dst[slot];
     return c;
 }
+template <bool kFast = false>
 DDGI_D void store_cold(const WfPool& P, uint32_t slot, const WfCold& c, bool with_hn)
 {
     if (with_hn)
@@ -145,6 +151,8 @@ DDGI_D void store_cold(const WfPool& P, uint32_t slot, const WfCold& c, bool wit
         q[0] = uint4{__float_as_uint(c.hc[0]), __float_as_uint(c.hc[1]), __float_as_uint(c.hc[2]), 0u};
         q[1] = uint4{__float_as_uint(c.hn[0]), __float_as_uint(c.hn[1]), __float_as_uint(c.hn[2]), 0u};
     }
+    else if (kFast)
+        P.rd[0][slot] = c.hc[0];
     else
         P.rd[0][slot] = c.hc[0], P.rd[1][slot] = c.hc[1], P.rd[2][slot] = c.hc[2];
     P.col[0][slot] = c.col[0], P.col[1][slot] = c.col[1], P.col[2][slot] = c.col[2];
@@ -213,9 +221,13 @@ DDGI_D uint32_t primary_bucket(uint32_t fl) { return (fl & kFlagDeadHint) ? kBuc
 // What the shared event code may know at compile time.  CfgRuntime reads everything from the arguments;
 // CfgPlain<kMode> is the common case — one light, no profiling switches, REF (0) or DDGI (1) output —
 // whose light loops and mode branches fold away (fewer instructions, far fewer scalar registers to spill).
-struct CfgRuntime
+// kFast: the tolerance-mode build (ddgi_device.h: fast_march_step) — the scene in LDS is the 2-bit skip field instead of the
+// occupancy bitmap, a slot keeps |rd| instead of rd (16 dwords), the rings hold 1536 entries.
+template <bool kFastT>
+struct CfgRuntimeT
 {
     static constexpr int kNl = 0;
+    static constexpr bool kFast = kFastT;
     static DDGI_D int nl(const TraceArgs& A) { return A.nl; }
 #ifdef DDGI_PROFILING  // the ablation / fault-injection switches exist only in the profiling build (make prof)
     static DDGI_D int ablate(const TraceArgs& A) { return A.ablate; }
@@ -224,10 +236,12 @@ struct CfgRuntime
 #endif
     static DDGI_D bool ddgi(const TraceArgs& A) { return A.ddgi != 0; }
 };
-template <int kMode>
+using CfgRuntime = CfgRuntimeT<false>;
+template <int kMode, bool kFastT = false>
 struct CfgPlain
 {
     static constexpr int kNl = 1;
+    static constexpr bool kFast = kFastT;
     static DDGI_D int nl(const TraceArgs&) { return 1; }
     static DDGI_D int ablate(const TraceArgs&) { return 0; }
     static DDGI_D bool ddgi(const TraceArgs&) { return kMode != 0; }
@@ -305,7 +319,11 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
     const f3 dn = kUnitDir ? normalize3_of_unit(d) : normalize3(d);
     st3(P.ro, slot, o);
     st3(P.dn, slot, dn);
-    if (!feeler) set3(c.hc, d);  // the hit albedo is dead until this march is shaded
+    if (!feeler)  // the hit albedo is dead until this march is shaded
+    {
+        if (Cfg::kFast) c.hc[0] = kUnitDir ? 1.0f : __builtin_sqrtf(dot3(d, d));  // (hemisphere samples and directions to the light are unit to an ulp)
+        else set3(c.hc, d);
+    }
     P.tl[slot] = tl;
     const uint32_t base_flags = (feeler ? kFlagFeeler : 0u) | (static_cast<uint32_t>(lid + 1) << 12);
     if ((DDGI_EXP & 16) && feeler)  // timing experiment: a feeler "reaches the light" without being marched
@@ -316,30 +334,47 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
     }
     if (kInlineSteps > 0)
     {
-        March m;
-        m.ro = o, m.rd = d, m.dn = dn;
-        m.inv = f3{axis_inv(dn.x), axis_inv(dn.y), axis_inv(dn.z)};
-        m.cc = f3{dn.x >= 0.0f ? 1.0f : 0.0f, dn.y >= 0.0f ? 1.0f : 0.0f, dn.z >= 0.0f ? 1.0f : 0.0f};
-        m.t = 0.0f, m.tl = tl, m.it = 0, m.lid = lid, m.cell = 0;
-        m.p = ray_at(o, dn, 0.0f);
         const f3 hi = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
         bool occ = false, fin = false;
+        float t_end;
+        f3 p_end;
+        int cell_end;
+        if (Cfg::kFast)
+        {
+            // (s_bits is the skip field here; the first step is grid_march's own — nothing is known about the start voxel yet)
+            FastMarch m;
+            fast_march_begin(m, o, dn, 0.0f, tl);
+            DDGI_PROBE(lp, 8);
+            occ = fast_march_step(m, A.scene, s_bits, hi) == 0u;
+            fin = occ | (m.t >= m.tl);
+            t_end = m.t, p_end = m.p, cell_end = m.cell;
+        }
+        else
+        {
+            March m;
+            m.ro = o, m.rd = d, m.dn = dn;
+            m.inv = f3{axis_inv(dn.x), axis_inv(dn.y), axis_inv(dn.z)};
+            m.cc = f3{dn.x >= 0.0f ? 1.0f : 0.0f, dn.y >= 0.0f ? 1.0f : 0.0f, dn.z >= 0.0f ? 1.0f : 0.0f};
+            m.t = 0.0f, m.tl = tl, m.it = 0, m.lid = lid, m.cell = 0;
+            m.p = ray_at(o, dn, 0.0f);
 #pragma unroll
-        for (int k = 0; k < kInlineSteps; ++k)
-            if (!fin)
-            {
-                DDGI_PROBE(lp, 8 + (k < 3 ? k : 3));  // sections 8..11: inline steps 1, 2, 3, 4+
-                occ = march_step_burst(m, A.scene, s_bits, hi);
-                fin = occ | (m.t >= m.tl);
-            }
-        P.t[slot] = m.t;
+            for (int k = 0; k < kInlineSteps; ++k)
+                if (!fin)
+                {
+                    DDGI_PROBE(lp, 8 + (k < 3 ? k : 3));  // sections 8..11: inline steps 1, 2, 3, 4+
+                    occ = march_step_burst(m, A.scene, s_bits, hi);
+                    fin = occ | (m.t >= m.tl);
+                }
+            t_end = m.t, p_end = m.p, cell_end = m.cell;
+        }
+        P.t[slot] = t_end;
         if (fin)
         {
             // (a feeler only asks whether a block was hit, not which)
-            const uint32_t hf = !occ ? 0u : (feeler ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
+            const uint32_t hf = !occ ? 0u : (feeler ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(p_end), cell_end)), p_end, false));
             P.flags[slot] = base_flags | (feeler ? kSlotEvFeeler : kSlotEvPrimary) | hf;
-            if (end) end->t = m.t, end->tl = tl, end->occ = occ;
-            const bool block_wins = occ && (m.t < tl);
+            if (end) end->t = t_end, end->tl = tl, end->occ = occ;
+            const bool block_wins = occ && (t_end < tl);
             return static_cast<int>(feeler ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock));
         }
         P.flags[slot] = kSlotMarch | base_flags | (static_cast<uint32_t>(kInlineSteps) << 4);
@@ -534,13 +569,13 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             set3(c.col, mk3(0, 0, 0));
             set3(c.hn, mk3(0, 0, 0));
             const int pb = wf_post_march<Cfg>(P, slot, c, ray_o, ray_d, false, A, s_bits, nullptr, false, 0.0f, -1, lp);
-            store_cold(P, slot, c, false);
+            store_cold<Cfg::kFast>(P, slot, c, false);
             return pb < 0 ? 1 : 2 + pb;
         }
     }
     else
     {
-        WfCold c = load_cold(P, slot, b == kBucketFeeler);
+        WfCold c = load_cold<Cfg::kFast>(P, slot, b == kBucketFeeler);
         f3 mo = mk3(0, 0, 0), md = mk3(0, 0, 0);  // the march this event posts, if any
         bool as_feeler = false;
         // Every path on which get_direct_lighting has come to its end for this hit sets these and meets at ONE
@@ -564,7 +599,8 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             }
             else
             {
-                const f3 rd = v3of(c.hc);  // the ray direction as given (see WfCold::hc)
+                // the ray direction as given (see WfCold::hc); the fast build keeps its length only
+                const f3 rd = Cfg::kFast ? ld3(P.dn, slot) * c.hc[0] : v3of(c.hc);
                 f3 nraw, hcol = mk3(0, 0, 0);  // (light-sphere hit: Q12, unassigned Material pinned to zero)
                 f3 p = mk3(0, 0, 0), nn = mk3(0, 0, 0);  // block hit: march position and block normal, for the albedo
                 const int type = static_cast<int>((fl >> 16) & 15u);
@@ -667,7 +703,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                             if (!inline_end && vis == kVisListed) clear = listed_feeler_clear(A, vis_entry, hpos, normalize3_of_unit(to_light), ftl);
                             if (!inline_end && !clear)
                             {
-                                store_cold(P, slot, c, true);  // (hn and the albedo travel with the marched feeler)
+                                store_cold<Cfg::kFast>(P, slot, c, true);  // (hn and the albedo travel with the marched feeler)
                                 return 1;
                             }
                             if (inline_end)
@@ -745,7 +781,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
 #ifdef DDGI_LAP
             DDGI_PROBE(lp, 12);  // write-back
 #endif
-            store_cold(P, slot, c, as_feeler);  // the slot lives on: write its shading state back
+            store_cold<Cfg::kFast>(P, slot, c, as_feeler);  // the slot lives on: write its shading state back
             return pb < 0 ? 1 : 2 + pb;
         }
     }
@@ -1063,7 +1099,12 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
 // write the entries; consumers claim indices below `tail` with a compare-and-swap on `head`, wait for
 // the entry to become valid (!= 0xffff) and invalidate it.
 // =================================================================================================
-constexpr uint32_t kAqCap = 2048, kAqMask = kAqCap - 1;
+constexpr uint32_t kAqCap = 2048;
+constexpr uint32_t kAqCapFast = 1536;  // the fast build's compile-time pool (1280) + slack: a ring index is reused only after 256 later claims
+#ifndef DDGI_AQ_FAST_STEPS
+#define DDGI_AQ_FAST_STEPS 8
+#endif
+constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast build's march waves
 #ifndef DDGI_AQ_SLEEP
 #define DDGI_AQ_SLEEP 2  // an idle wave's nap between two looks at the queues, in units of 64 cycles
 #endif
@@ -1099,10 +1140,12 @@ DDGI_D uint32_t aq_claim(uint32_t* head, const uint32_t* tail, uint32_t want, ui
     return 0u;
 }
 
-// Reads (and invalidates) ring entry idx; waits until its producer has written it.
+// Reads (and invalidates) ring entry idx; waits until its producer has written it.  kCap: the ring's capacity (a power of
+// two folds the modulo into a mask; the fast build's rings hold kAqCapFast entries).
+template <uint32_t kCap>
 DDGI_D uint32_t aq_take(uint16_t* ring, uint32_t idx, uint32_t* abort)
 {
-    volatile uint16_t* p = ring + (idx & kAqMask);
+    volatile uint16_t* p = ring + (idx % kCap);
     uint32_t v = *p;
     for (int spins = 0; v == 0xffffu; ++spins)
     {
@@ -1118,10 +1161,11 @@ DDGI_D uint32_t aq_take(uint16_t* ring, uint32_t idx, uint32_t* abort)
 }
 
 // Every lane with pred appends `value` to a ring.
+template <uint32_t kCap>
 DDGI_D void aq_push(uint16_t* ring, uint32_t* tail, bool pred, uint32_t value, int lane)
 {
     const uint32_t at = wave_append(pred, tail, lane);
-    if (pred) ring[at & kAqMask] = static_cast<uint16_t>(value);
+    if (pred) ring[at % kCap] = static_cast<uint16_t>(value);
 }
 
 // kPool > 0: the pool size is a compile-time constant, so every pool array is the LDS base plus a constant
@@ -1138,10 +1182,13 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     const uint32_t PS = kPool > 0 ? static_cast<uint32_t>(kPool) : static_cast<uint32_t>(pool_size);
     const int fetch_lanes = A.wf_fetch > 0 ? A.wf_fetch : kWfFetchLanes;
 
-    // ---- carve LDS: control block | occupancy bitmap | pool arrays | rings ----
+    // ---- carve LDS: control block | occupancy bitmap (fast build: the skip field) | pool arrays | rings ----
+    constexpr uint32_t kCap = (Cfg::kFast && kPool > 0) ? kAqCapFast : kAqCap;  // ring capacity > pool
+    const int scene_words = Cfg::kFast ? A.scene.nwords_skip : A.scene.nwords;
+    const uint32_t* __restrict__ scene_src = Cfg::kFast ? A.scene.skip : A.scene.bits;
     AqShared* sh = reinterpret_cast<AqShared*>(wf_lds);
     uint32_t* s_bits = wf_lds + 32;
-    uint32_t* cursor = s_bits + ((A.scene.nwords + 3) & ~3);
+    uint32_t* cursor = s_bits + ((scene_words + 3) & ~3);
     WfPool P;
     auto takef = [&]() { float* p = reinterpret_cast<float*>(cursor); cursor += PS; return p; };
     auto takeu = [&]() { uint32_t* p = cursor; cursor += PS; return p; };
@@ -1151,18 +1198,20 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     P.tl = takef();
     P.flags = takeu();
     for (int a = 0; a < 3; ++a) P.col[a] = takef();
-    for (int a = 0; a < 3; ++a) P.rd[a] = takef();
+    P.rd[0] = takef();
+    P.rd[1] = Cfg::kFast ? P.rd[0] : takef();  // (the fast build keeps |rd| in rd[0] and never touches the others)
+    P.rd[2] = Cfg::kFast ? P.rd[0] : takef();
     P.rng = takeu(), P.cnt = takeu(), P.dst = takeu();
     P.cold = static_cast<WfColdGlobal*>(A.wf_cold) + static_cast<size_t>(blockIdx.x) * PS;
     P.dirbuf = Cfg::nl(A) > 1 ? A.wf_dir + static_cast<size_t>(blockIdx.x) * PS : nullptr;
     P.march_list[0] = P.march_list[1] = P.event_list = nullptr;
     uint16_t* ring_mq = reinterpret_cast<uint16_t*>(cursor);
-    uint16_t* ring_fq = ring_mq + kAqCap;
-    uint16_t* ring_eq = ring_fq + kAqCap;  // kAqEventQueues rings
+    uint16_t* ring_fq = ring_mq + kCap;
+    uint16_t* ring_eq = ring_fq + kCap;  // kAqEventQueues rings
 
-    for (int i = tid; i < A.scene.nwords; i += T) s_bits[i] = A.scene.bits[i];
+    for (int i = tid; i < scene_words; i += T) s_bits[i] = scene_src[i];
     for (uint32_t i = tid; i < PS; i += T) P.flags[i] = kSlotEmpty;
-    for (uint32_t i = tid; i < kAqCap * (2 + kAqEventQueues); i += T) ring_mq[i] = 0xffffu;
+    for (uint32_t i = tid; i < kCap * (2 + kAqEventQueues); i += T) ring_mq[i] = 0xffffu;
     __syncthreads();
     for (uint32_t i = tid; i < PS; i += T) ring_fq[i] = static_cast<uint16_t>(i);  // every slot starts free
     if (tid < 32) wf_lds[tid] = 0u;
@@ -1177,14 +1226,102 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
 #ifdef DDGI_LAP
     if (kStats)
     {
-        probe.lap = reinterpret_cast<uint32_t*>(ring_eq + kAqCap * kAqEventQueues) + wave * 32;
+        probe.lap = reinterpret_cast<uint32_t*>(ring_eq + kCap * kAqEventQueues) + wave * 32;
         if (lane < 32) probe.lap[lane] = lane == 0 ? 15u : (lane == 1 ? static_cast<uint32_t>(__builtin_readcyclecounter()) : 0u);
     }
 #endif
     unsigned long long st_q[8] = {};        // counters build: [0] samples [1..3] sum of MQ / FQ / EQ depths at an event wave's poll, [4] idle polls,
                                             // [5] march bursts, [6] fetches that found MQ short of the idle lanes, [7] lanes in flight at burst start
 
-    if (wave < march_waves)
+    if (Cfg::kFast && wave < march_waves)
+    {
+        // ================= march waves, fast build =================
+        // The same loop as below around fast_march_step: a lane's march skips through voxels the skip field calls empty.
+        // Marches are a third as many steps long, so a burst is kAqFastSteps steps.
+        FastMarch m;
+        m.ro = m.dn = m.ainv = m.nsgn = m.c1 = m.p = mk3(0, 0, 0);
+        m.t = 0.0f, m.tl = inf, m.code = 1.0f, m.cell = 0;
+        uint32_t slot = 0, fl = 0;
+        f3 hi_v = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
+        asm volatile("" : "+v"(hi_v.x), "+v"(hi_v.y), "+v"(hi_v.z));
+        bool have = false;
+        int trips = 0, thin_waits = 0;
+        for (;;)
+        {
+            if (++guard > (1u << 23)) sh->abort = 1u;
+            const unsigned long long idle_mask = __ballot(!have);
+            const int n_idle = __popcll(idle_mask);
+            if (n_idle >= fetch_lanes)
+            {
+                uint32_t base = 0, k = 0;
+                if (lane == 0) k = aq_claim(&sh->mq_head, &sh->mq_tail, static_cast<uint32_t>(n_idle), base);
+                k = __shfl(k, 0), base = __shfl(base, 0);
+                const uint32_t rank = static_cast<uint32_t>(__popcll(idle_mask & ((1ull << lane) - 1ull)));
+                if (!have && rank < k)
+                {
+                    slot = aq_take<kCap>(ring_mq, base + rank, &sh->abort);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    fl = P.flags[slot];
+                    fast_march_begin(m, ld3(P.ro, slot), ld3(P.dn, slot), P.t[slot], P.tl[slot]);
+                    have = true;
+                }
+            }
+            if (__ballot(have) == 0ull)
+            {
+                if ((aq_load(&sh->no_more) != 0u && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
+                __builtin_amdgcn_s_sleep(DDGI_AQ_SLEEP);
+                continue;
+            }
+            if (__popcll(__ballot(have)) < kAqThinTrip && thin_waits < 4 && aq_load(&sh->no_more) == 0u)
+            {
+                ++thin_waits;
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            thin_waits = 0;
+            guard = 0;
+            bool finished = false;
+            uint32_t bucket = 0;
+            if (have)
+            {
+                bool fin = (fast_march_step(m, A.scene, s_bits, hi_v) == 0u) | (m.t >= m.tl);
+#pragma unroll
+                for (int sub = 1; sub < kAqFastSteps; ++sub)
+                    if (!fin) fin = (fast_march_step(m, A.scene, s_bits, hi_v) == 0u) | (m.t >= m.tl);
+                bool occ = m.code == 0.0f;
+                // grid_march's 125 iterations, as planes crossed: a voxel reached after more of them is never looked at, and a
+                // march that has used them up is over
+                const float planes = fast_march_planes(m);
+                if (planes >= static_cast<float>(kMarchIters))
+                {
+                    fin = true;
+                    if (planes > static_cast<float>(kMarchIters)) occ = false;
+                }
+                if (!fin && (trips & 1)) fin = march_escaped(m, A.scene);
+                if (fin)
+                {
+                    const uint32_t hf = !occ ? 0u : ((fl & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
+                    P.t[slot] = m.t;
+                    P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | hf;
+                    const bool block_wins = occ && (m.t < m.tl);
+                    bucket = (fl & kFlagFeeler) ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock);
+                    have = false;
+                    finished = true;
+                }
+            }
+            ++trips;
+            if (__ballot(finished) != 0ull)
+            {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (finished)
+                {
+                    const uint32_t at = atomicAdd(&sh->eq_tail[bucket], 1u);
+                    (ring_eq + bucket * kCap)[at % kCap] = static_cast<uint16_t>(slot);
+                }
+            }
+        }
+    }
+    else if (wave < march_waves)
     {
         // ================= march waves =================
         March m;
@@ -1209,7 +1346,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 const uint32_t rank = static_cast<uint32_t>(__popcll(idle_mask & ((1ull << lane) - 1ull)));
                 if (!have && rank < k)
                 {
-                    slot = aq_take(ring_mq, base + rank, &sh->abort);
+                    slot = aq_take<kCap>(ring_mq, base + rank, &sh->abort);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     fl = P.flags[slot];
                     m.ro = ld3(P.ro, slot);
@@ -1296,7 +1433,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 if (finished)
                 {
                     const uint32_t at = atomicAdd(&sh->eq_tail[bucket], 1u);
-                    (ring_eq + bucket * kAqCap)[at & kAqMask] = static_cast<uint16_t>(slot);
+                    (ring_eq + bucket * kCap)[at % kCap] = static_cast<uint16_t>(slot);
                 }
             }
         }
@@ -1312,7 +1449,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             uint32_t b = 0, base = 0, k = 0;
             uint32_t avail = 0;
             if (lane < kAqEventQueues) avail = aq_load(&sh->eq_tail[lane]) - aq_load(&sh->eq_head[lane]);
-            if (avail > kAqCap) avail = 0;  // a claim in flight can make tail - head wrap for an instant
+            if (avail > kCap) avail = 0;  // a claim in flight can make tail - head wrap for an instant
             const unsigned long long full = __ballot(avail >= 64u);
             const bool no_more = aq_load(&sh->no_more) != 0u;
 
@@ -1365,7 +1502,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 uint32_t eq_sum = lane < kAqEventQueues ? avail : 0u;
                 for (int mm = 4; mm >= 1; mm >>= 1) eq_sum += __shfl_xor(eq_sum, mm);
                 const uint32_t mqd = aq_load(&sh->mq_tail) - aq_load(&sh->mq_head), fqd = aq_load(&sh->fq_tail) - aq_load(&sh->fq_head);
-                st_q[0] += 1, st_q[1] += mqd <= kAqCap ? mqd : 0u, st_q[2] += fqd <= kAqCap ? fqd : 0u, st_q[3] += eq_sum;
+                st_q[0] += 1, st_q[1] += mqd <= kCap ? mqd : 0u, st_q[2] += fqd <= kCap ? fqd : 0u, st_q[3] += eq_sum;
             }
             uint32_t slot = 0;
             bool posted = false, freed = false;
@@ -1382,7 +1519,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 rbase = __shfl(rbase, 0);
                 const uint32_t r = rbase + static_cast<uint32_t>(lane);
                 const bool r_valid = valid && r < A.n_rays;
-                if (valid) slot = aq_take(ring_fq, base + lane, &sh->abort);
+                if (valid) slot = aq_take<kCap>(ring_fq, base + lane, &sh->abort);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if (r_valid)
                 {
@@ -1402,7 +1539,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             {
                 if (valid)
                 {
-                    slot = aq_take(ring_eq + b * kAqCap, base + lane, &sh->abort);
+                    slot = aq_take<kCap>(ring_eq + b * kCap, base + lane, &sh->abort);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     const int rc = wf_event<Cfg>(A, P, s_bits, b, slot, 0u, false, kStats ? &probe : nullptr);
                     posted = rc == 1;
@@ -1414,12 +1551,12 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             if (kStats) probe.at(15);  // outside the event code: queue traffic, polling
 #endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            aq_push(ring_mq, &sh->mq_tail, posted && !(Cfg::ablate(A) & 8), slot, lane);  // DDGI_ABLATE=8: fault injection for the safety-net test
-            aq_push(ring_fq, &sh->fq_tail, freed, slot, lane);
+            aq_push<kCap>(ring_mq, &sh->mq_tail, posted && !(Cfg::ablate(A) & 8), slot, lane);  // DDGI_ABLATE=8: fault injection for the safety-net test
+            aq_push<kCap>(ring_fq, &sh->fq_tail, freed, slot, lane);
             if (ev_bucket >= 0)
             {
                 const uint32_t at = atomicAdd(&sh->eq_tail[ev_bucket], 1u);
-                (ring_eq + ev_bucket * kAqCap)[at & kAqMask] = static_cast<uint16_t>(slot);
+                (ring_eq + ev_bucket * kCap)[at % kCap] = static_cast<uint16_t>(slot);
             }
             if (b != kBucketRefill)
             {
@@ -1451,13 +1588,17 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     if (status && lane == 0 && aq_load(&sh->abort) != 0u) atomicOr(status, 1u);  // the safety net tripped: the output is not valid
 }
 
-static size_t aq_lds_bytes(int nwords, int pool)
+constexpr int kAqPool = 1344;      // the usual pool (ddgi_engine.cpp); other sizes take the generic instantiation
+constexpr int kAqPoolFast = 1280;  // the fast build's: 16 dwords per slot and rings of 1536 entries next to the cave's 52 KB skip field
+
+// fast: nwords = the skip field's, 16 dwords per slot; ring_cap: entries per ring (k_probe_trace_aq: kCap)
+static size_t aq_lds_bytes(int nwords, int pool, bool fast = false, size_t ring_cap = kAqCap)
 {
     size_t extra = 16;
 #ifdef DDGI_LAP
     extra += 16 * 32 * 4;  // the lap timers' scratch, one row per wave
 #endif
-    return (32 + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * kPoolDwords * 4 + kAqCap * 2 * (2 + kAqEventQueues) + extra;
+    return (32 + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * (fast ? kPoolDwordsFast : kPoolDwords) * 4 + ring_cap * 2 * (2 + kAqEventQueues) + extra;
 }
 
 int aq_pool_size(int nwords, size_t lds_limit)
@@ -1467,10 +1608,21 @@ int aq_pool_size(int nwords, size_t lds_limit)
     return pool >= 1024 ? pool : 0;
 }
 
+// The fast build's pool for a skip field of nwords_skip words.  plain (one light: the compile-time instantiation, whose
+// rings hold kAqCapFast entries): kAqPoolFast when that fits.  Otherwise the largest pool that fits next to rings of kAqCap
+// entries; 0: the fast march is not available for this scene.
+int aq_pool_size_fast(int nwords_skip, size_t lds_limit, bool plain)
+{
+    if (plain && aq_lds_bytes(nwords_skip, kAqPoolFast, true, kAqCapFast) <= lds_limit) return kAqPoolFast;
+    int pool = kAqPoolFast - 64;
+    while (pool >= 1024 && aq_lds_bytes(nwords_skip, pool, true) > lds_limit) pool -= 64;
+    return pool >= 1024 ? pool : 0;
+}
+
 template <bool kStats, int kPool, class Cfg>
 static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
 {
-    const size_t lds = aq_lds_bytes(args.scene.nwords, pool);
+    const size_t lds = Cfg::kFast ? aq_lds_bytes(args.scene.nwords_skip, pool, true, kPool > 0 ? kAqCapFast : kAqCap) : aq_lds_bytes(args.scene.nwords, pool);
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_probe_trace_aq<kStats, kPool, Cfg>), 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
@@ -1479,10 +1631,16 @@ static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, in
     return hipGetLastError();
 }
 
-constexpr int kAqPool = 1344;  // the usual pool (ddgi_engine.cpp); other sizes take the generic instantiation
-
 hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
 {
+    if (args.fast_march)
+    {
+        // (the tolerance-mode build: no counters kernel, no ablation switches)
+        if (pool == kAqPoolFast && args.nl == 1)
+            return args.ddgi ? launch_aq<false, kAqPoolFast, CfgPlain<1, true>>(args, pool, grid_blocks, march_waves, work_counter, status, stream)
+                             : launch_aq<false, kAqPoolFast, CfgPlain<0, true>>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+        return launch_aq<false, 0, CfgRuntimeT<true>>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+    }
     if (args.stats) return launch_aq<true, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
     if (pool == kAqPool && args.nl == 1 && args.ablate == 0)
         return args.ddgi ? launch_aq<false, kAqPool, CfgPlain<1>>(args, pool, grid_blocks, march_waves, work_counter, status, stream)

@@ -39,6 +39,8 @@ struct SceneK
     unsigned face_empty;   // bit (2*axis + side): that border layer is entirely empty
     const uint32_t* bits;  // device
     const uint8_t* types;  // device
+    const uint32_t* skip;  // device: the fast march's skip field, 2 bits per voxel, addressed like `bits` (ddgi_host.h: build_skip_field)
+    int nwords_skip;       // 32-bit words in it (16 voxels each)
 };
 
 // Probe-grid geometry shared by all kernels.
@@ -102,6 +104,7 @@ struct TraceArgs
     float rot[9];
     float* rad_rgb;  // ray records, see RayRecords
     float* rad_dd;
+    int fast_march;      // tolerance mode (ddgi_set_tuning "fast_march"): marches skip empty space (ddgi_device.h: fast_march_step)
     const uint8_t* vis;  // single light: feeler classes per (voxel of the baked box, face): [voxel * 8 + face] (k_light_visibility), or null
     const uint32_t* vis_occ;  // ... and for class kVisListed the occupied voxels of the bundle: [(voxel * 8 + face) * kVisListMax + k]
 };
