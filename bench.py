@@ -17,8 +17,15 @@ torch.distributed only hands the 128-byte RCCL id around and provides the barrie
 Total work is fixed, so `scaling` is "strong".
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
-dominant kernel (k_probe_trace_ref) and, at N = 1, `cpu_baseline` (the CPU oracle timed on the
-box's host cores over a bounded sample of the same workload).
+dominant kernel (k_probe_trace_aq, the queue-driven wavefront tracer) and, at N = 1, `cpu_baseline`
+(the CPU oracle timed on the box's host cores over a bounded sample of the same workload; its texels
+are compared with the GPU's byte for byte, and — `literal_within_1_255` — within the stated tolerance
+against the oracle's LITERAL arithmetic) and `fast_march` (the opt-in tolerance-mode march timed on the
+same workload next to the exact headline number, with its texel agreement against both arithmetics).
+
+  --workload c5 --mode ddgi   SURVEY.md section 8d's S-Dyn: 128x64x128 probes x 256 rays, the reference's
+                              4-light cave table animated by update_lights, hysteresis 0.9, time = 2 frame;
+                              frames 8.. are the timed steady state (--warmup defaults to 8 there)
 """
 import argparse
 import json
@@ -46,7 +53,11 @@ WORKLOAD = {
 # BASELINE.json configs[3] (the 8-GPU shard configuration), runnable on one GPU with --workload c4: 131 072 probes x 512 rays
 # (a 32 x 16 ray tile, ddgi_set_ray_tile) = 67 108 864 probe rays, 3.2 GB of ProbeRay records resident in HBM
 WORKLOAD_C4 = dict(WORKLOAD, name="c4_cave_64x32x64_probes_x512_rays_ref", counts=(64, 32, 64), side=1, tile=(32, 16))
-WORKLOADS = {"c3": WORKLOAD, "c4": WORKLOAD_C4}
+# BASELINE.json configs[4] = SURVEY.md 8d S-Dyn: 1 048 576 probes x 256 rays = 268 435 456 probe rays per frame, DDGI mode, 4 animated lights
+WORKLOAD_C5 = dict(WORKLOAD, name="c5_cave_128x64x128_probes_x256_rays_4_dynamic_lights", counts=(128, 64, 128), side=1,
+                   lights=[(20.0, (1.0, 1.0, 1.0), (4, 17.5, 8.5)), (10.0, (1.0, 0.5, 0.1), (0, 2, 0)),      # assets/shaders/structs.glsl:65-68
+                           (10.0, (0.1, 1.1, 1.0), (5, 0, 0)), (10.0, (1.1, 0.0, 1.1), (0, 5, 0))])
+WORKLOADS = {"c3": WORKLOAD, "c4": WORKLOAD_C4, "c5": WORKLOAD_C5}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_RAY = 56        # 48 B ProbeRay read + two 4 B rgba8 texel writes
 
@@ -66,34 +77,50 @@ def _issue_from_profiles():
             insts = re.search(r"SQ_INSTS_VALU\s+([0-9.e+]+)", txt)
             if busy and lanes:
                 out = {"valu_busy": float(busy.group(1)), "valu_lane_use": float(lanes.group(1)),
-                       "valu_wave_instructions_per_launch": float(insts.group(1)) if insts else None, "source": os.path.basename(path)}
+                       "valu_wave_instructions_per_launch": float(insts.group(1)) if insts else None,
+                       "replayed_from": "profiles/" + os.path.basename(path)}
         except Exception:
             pass
     return out or None
 
 
 def _traffic_from_profiles(workload=None):
-    """Per-launch HBM bytes of k_probe_trace_ref from the committed rocprofv3 --pmc passes
-    (profiles/*_traffic.json, written by tools/pmc_traffic.py); None if not collected."""
+    """Per-launch HBM bytes of the trace kernel from the committed rocprofv3 --pmc passes (profiles/*_traffic.json,
+    written by tools/pmc_traffic.py) and the file they come from; (None, None) if not collected.  REPLAYED, not measured
+    by this run: counters need their own rocprofv3 passes."""
     import glob
 
-    best = None
+    best, src = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             with open(path) as fh:
                 d = json.load(fh)
-            if d.get("workload") == (workload or WORKLOAD["name"]) and d.get("kernel", "").startswith("k_probe_trace"):
-                best = d.get("hbm_bytes_per_launch", best)
+            if d.get("workload") == (workload or WORKLOAD["name"]) and d.get("kernel", "").startswith("k_probe_trace") and d.get("hbm_bytes_per_launch"):
+                best, src = d["hbm_bytes_per_launch"], "profiles/" + os.path.basename(path)
         except Exception:
             pass
-    return best
+    return best, src
 
 
-def cpu_baseline(n_probes=96, gpu_albedo=None, w=WORKLOAD, rays=None):
+def _tile_view(raster, w, mask):
+    """The tiles of the masked probes out of a reference-layout raster: [n_probes, ty, tx, 4]."""
+    tx, ty = w["tile"]
+    cxz = w["counts"][0] * w["counts"][2]
+    return raster.reshape(w["counts"][1], ty, cxz, tx, 4).transpose(0, 2, 1, 3, 4)[mask]
+
+
+def _tolerance(a, b):
+    d = np.abs(a[..., :3].astype(np.int32) - b[..., :3].astype(np.int32))
+    return {"within_1_255": float((d <= 1).mean()), "mean_abs_diff_255": float(d.mean()), "texels_differing": int((d.max(axis=-1) > 0).sum())}
+
+
+def cpu_baseline(n_probes=96, gpu_albedo=None, w=WORKLOAD, rays=None, fast_albedo=None):
     """The oracle (a CPU restatement of the reference's algorithm: procedural getBlockAt per march
     step, exactly what the reference's shader does) over a bounded, evenly spread sample of the
     workload's probes, all host threads.  The texels it computes are also compared, byte for byte, with
-    the ones the GPU produced in the timed run (`parity_checked`)."""
+    the ones the GPU produced in the timed run (`parity_checked`); the same probes are then evaluated in the
+    oracle's LITERAL arithmetic (one IEEE operation per GLSL operator, libm) for the stated tolerance
+    (`literal_within_1_255`), and the fast march's texels (fast_albedo) are held against both."""
     from oracle import oracle_py as O
 
     O.set_arith(True)
@@ -118,7 +145,6 @@ def cpu_baseline(n_probes=96, gpu_albedo=None, w=WORKLOAD, rays=None):
     want = O.probe_update_probes(f, st, rays, probes)
     dt = time.perf_counter() - t0
     nrays = len(probes) * tx * ty
-    O.set_ray_tile(0, 0)
     out = {
         "value": nrays / dt,
         "unit": "rays/s",
@@ -126,20 +152,34 @@ def cpu_baseline(n_probes=96, gpu_albedo=None, w=WORKLOAD, rays=None):
         "kind": "port",
         "sample": f"{len(probes)} of {total} probes evenly spread over the grid ({nrays} rays), {dt:.1f} s",
     }
+    fast = None
     if gpu_albedo is not None:
         # the probes of the sample as tile masks of the reference raster (tile of probe p at ((p mod cx*cz)*s, (p div cx*cz)*s))
         cxz = w["counts"][0] * w["counts"][2]
         mask = np.zeros((w["counts"][1], cxz), dtype=bool)
         mask[np.unique(probes) // cxz, np.unique(probes) % cxz] = True
-        tiles_gpu = gpu_albedo.reshape(w["counts"][1], ty, cxz, tx, 4).transpose(0, 2, 1, 3, 4)[mask]
-        tiles_cpu = want.reshape(w["counts"][1], ty, cxz, tx, 4).transpose(0, 2, 1, 3, 4)[mask]
+        tiles_gpu, tiles_cpu = _tile_view(gpu_albedo, w, mask), _tile_view(want, w, mask)
         differ = int((tiles_gpu != tiles_cpu).any(axis=-1).sum())
         n_tex = int(mask.sum()) * tx * ty
         cfg = w["name"][:2]
         scope = f"{cfg} full grid" if int(mask.sum()) == total else f"{int(mask.sum())} of {total} probes of {cfg}"
         out["parity_checked"] = f"{scope}, {n_tex - differ} of {n_tex} texels equal (HIP vs oracle, rgba8 bytes)"
         out["parity_texels_differing"] = differ
-    return out
+        # the same probes in LITERAL arithmetic: the stated tolerance (|d| <= 1/255 on >= 99.9 % of the rgb channels, mean < 0.05/255)
+        O.set_arith(False)
+        t0 = time.perf_counter()
+        lit = O.probe_update_probes(f, st, rays, probes)
+        O.set_arith(True)
+        tiles_lit = _tile_view(lit, w, mask)
+        tol = _tolerance(tiles_gpu, tiles_lit)
+        out["literal_within_1_255"] = tol["within_1_255"]
+        out["literal"] = dict(tol, scope=scope, seconds=round(time.perf_counter() - t0, 1),
+                              note="HIP (exact march, PINNED arithmetic) vs the oracle's LITERAL arithmetic: IEEE operations in GLSL source order, libm sin/cos/acos")
+        if fast_albedo is not None:
+            tiles_fast = _tile_view(fast_albedo, w, mask)
+            fast = {"vs_pinned_oracle": _tolerance(tiles_fast, tiles_cpu), "vs_literal_oracle": _tolerance(tiles_fast, tiles_lit), "scope": scope}
+    O.set_ray_tile(0, 0)
+    return out, fast
 
 
 class _c_stdout_to_stderr:
@@ -164,12 +204,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=None, help="default 5 (c5: 8 — SURVEY.md 8d times frames 8.. of S-Dyn)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-probes", type=int, default=96)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3",
                     help="c3 (default): the configuration the metric is quoted on; c4: BASELINE's 8-GPU shard configuration "
-                         "(64x32x64 probes x 512 rays) on however many GPUs are given")
+                         "(64x32x64 probes x 512 rays) on however many GPUs are given; c5 (with --mode ddgi): S-Dyn, 128x64x128 probes "
+                         "x 256 rays, 4 animated lights + hysteresis")
+    ap.add_argument("--no-fast-march", action="store_true", help="skip the extra timed run of the opt-in tolerance-mode march (N = 1, REF)")
     ap.add_argument("--mode", choices=["ref", "ddgi"], default="ref",
                     help="ref (default): the reference's live behaviour, the headline metric; ddgi: in-kernel Fibonacci rays + "
                          "octahedral irradiance/depth blend with hysteresis (trace + blend per step)")
@@ -177,6 +219,10 @@ def main():
                     help="N > 1: how the ranks' slabs are exchanged — rccl (default): one in-place ncclAllGather per texture; "
                          "p2p: every rank pushes its slab into its peers' textures (ddgi_exchange_p2p_*, IPC-mapped buffers)")
     args = ap.parse_args()
+    if args.workload == "c5" and args.mode != "ddgi":
+        raise SystemExit("--workload c5 is S-Dyn (4 dynamic lights + temporal hysteresis): run it with --mode ddgi")
+    if args.warmup is None:
+        args.warmup = 8 if args.workload == "c5" else 5
 
     import torch
     import torch.distributed as dist
@@ -223,6 +269,8 @@ def main():
         eng.set_mode(ddgi_amd.MODE_DDGI)        # rays are generated in the kernel; tiles start zeroed
     else:
         eng.generate_probe_rays(seed=w["seed"])  # ray buffer resident in HBM from here on
+    if w.get("lights"):
+        eng.set_lights(w["scene"], np.array(w["lights"], dtype=ddgi_amd.LIGHT_DTYPE))  # animated per update from RenderSettings::time
 
     comm = None
     exchanging = False
@@ -294,6 +342,7 @@ def main():
     else:
         algo_bytes = ALGO_BYTES_PER_RAY * local_rays
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src = (None, None) if (ddgi_mode or world > 1) else _traffic_from_profiles(w["name"])
     out = {
         "metric": "probe_rays_per_sec",
         "value": total_rays / (elapsed / args.steps),
@@ -324,11 +373,12 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None if ddgi_mode else _traffic_from_profiles(w["name"]),
+            "traffic": traffic,
+            "traffic_replayed_from": traffic_src,
             "algorithmic_bytes_per_launch": algo_bytes,
             "kernel_ms": kernel_ms,
             "issue": None if (ddgi_mode or args.workload != "c3") else _issue_from_profiles(),
-            "note": "the trace kernel is VALU-issue bound (dependent voxel steps + hit shading), not HBM bound: `issue` = the VALU's occupancy from profiles/ (rocprofv3 --pmc), see DESIGN.md section 4",
+            "note": "achieved / kernel_ms are measured by this run (HIP events on the launch stream); `traffic` and `issue` are REPLAYED from the committed rocprofv3 --pmc passes named beside them (counters need their own passes). The trace kernel is VALU-issue bound (dependent voxel steps + hit shading), not HBM bound, see DESIGN.md section 4",
         },
     }
     out["tuning"] = {"march_waves": eng.get_tuning("march_waves_measured"), "note": "waves of a 16-wave workgroup that march (the rest shade); measured by the first update of the configuration"}
@@ -340,9 +390,37 @@ def main():
         out["roofline"]["kernel"] += "+k_blend_weights+k_probe_blend"
         out["blend"] = {"kernel": "k_blend_weights+k_probe_blend", "kernel_ms": bms, "kernel_io_bytes_per_launch": bbytes,
                         "achieved_GBps": bbytes / (bms * 1e-3) / 1e9, "frac_of_hbm_peak": bbytes / (bms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if w.get("lights"):
+        out["config"]["lights"] = f"{len(w['lights'])} (assets/shaders/structs.glsl:65-68), animated by update_lights(time), time += 2 per frame"
+        out["config"]["hysteresis"] = 0.9
+        out["config"]["frames_timed"] = f"{args.warmup}..{args.warmup + args.steps - 1}"
+    exact_albedo = eng.read_textures()[0] if (rank == 0 and world == 1 and not ddgi_mode) else None
+    fast_albedo = None
+    if world == 1 and not ddgi_mode and not args.no_fast_march:
+        # the opt-in tolerance-mode march on the same workload, timed the same way (the headline `value` above is the exact march)
+        eng.set_tuning("fast_march", 1)
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        fast_elapsed = time.perf_counter() - t0
+        ftr, _ = eng.update_history_ms(min(args.steps, 64))
+        out["fast_march"] = {
+            "ms_per_step": fast_elapsed / args.steps * 1e3, "value": total_rays / (fast_elapsed / args.steps), "unit": "rays/s",
+            "kernel_ms": float(np.mean(ftr)), "active": bool(eng.get_tuning("fast_march_active")), "march_waves": eng.get_tuning("march_waves_measured"),
+            "speedup_vs_exact": kernel_ms / float(np.mean(ftr)),
+            "note": "ddgi_set_tuning(h, \"fast_march\", 1): empty-space skipping through a 2-bit per-voxel skip field in LDS; NOT bit-exact — tolerance below and in tests/test_gpu_fast_march.py",
+        }
+        fast_albedo = eng.read_textures()[0]
+        eng.set_tuning("fast_march", 0)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not ddgi_mode:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_probes, gpu_albedo=eng.read_textures()[0], w=w,
-                                           rays=None if args.workload == "c3" else eng.get_probe_rays())
+        out["cpu_baseline"], fast_tol = cpu_baseline(args.cpu_probes, gpu_albedo=exact_albedo, w=w,
+                                                     rays=None if args.workload == "c3" else eng.get_probe_rays(), fast_albedo=fast_albedo)
+        if fast_tol and "fast_march" in out:
+            out["fast_march"]["tolerance"] = fast_tol
     if exchanging:
         if sharded:
             dist.barrier()                      # every rank has stopped pushing before any rank unmaps / frees

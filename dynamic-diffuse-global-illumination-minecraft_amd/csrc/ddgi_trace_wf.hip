@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
 constexpr uint32_t kAqCap = 2048;
 constexpr uint32_t kAqCapFast = 1536;  // the fast build's compile-time pool (1280) + slack: a ring index is reused only after 256 later claims
 #ifndef DDGI_AQ_FAST_STEPS
-#define DDGI_AQ_FAST_STEPS 8
+#define DDGI_AQ_FAST_STEPS 12
 #endif
 constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast build's march waves
 #ifndef DDGI_AQ_SLEEP

@@ -24,3 +24,29 @@ def shading_points(rng, field_counts, side, origin, n):
     nrm = rng.normal(size=(n, 3)).astype(np.float32)
     nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     return pos.astype(np.float32), nrm.astype(np.float32)
+
+
+_C3_ORACLE = {}
+
+
+def c3_oracle_albedo(oracle, arith, seed=1):
+    """The oracle's albedo raster of the full C3 grid (4 194 304 texels; seconds on the GPU box's host threads), computed
+    once per test session and arithmetic: "pinned" (what the kernels implement bit for bit) or "literal" (one IEEE operation
+    per GLSL operator, libm — the closest this repository gets to the reference's own semantics)."""
+    key = (arith, seed)
+    if key not in _C3_ORACLE:
+        counts, side, s, origin, scene = CONFIGS["c3_cave"]
+        oracle.set_arith(arith == "pinned")
+        try:
+            f = oracle.make_field(counts, side, s, origin)
+            rays = oracle.generate_probe_rays(f, oracle.new_rand_state(seed))
+            _C3_ORACLE[key] = oracle.probe_update(f, oracle.make_settings(scene, 8), rays)[0]
+        finally:
+            oracle.set_arith(True)
+    return _C3_ORACLE[key]
+
+
+def texel_tolerance_stats(got, want):
+    """(fraction of rgb channels within one unorm8 step, mean |difference| in unorm8 steps, texels that differ at all)"""
+    d = np.abs(got[..., :3].astype(np.int32) - want[..., :3].astype(np.int32))
+    return float((d <= 1).mean()), float(d.mean()), int((d.max(axis=-1) > 0).sum())

@@ -12,7 +12,7 @@ Tolerances
 import numpy as np
 import pytest
 
-from tests.common import CONFIGS, shading_points
+from tests.common import CONFIGS, c3_oracle_albedo, shading_points, texel_tolerance_stats
 
 pytestmark = pytest.mark.gpu
 
@@ -167,12 +167,14 @@ def test_full_size_c3_full_grid_vs_oracle(ddgi, oracle):
     # get the 0.2*base*lambert term, so fully black tiles are rare
     tiles = a1[..., :3].reshape(16, 16, 1024, 16, 3).any(axis=(1, 3, 4))
     assert tiles.mean() > 0.9
-    f = oracle.make_field(counts, side, s, origin)
-    rays = oracle.generate_probe_rays(f, oracle.new_rand_state(1))
-    want, want_d = oracle.probe_update(f, oracle.make_settings(scene, 8), rays)
+    want = c3_oracle_albedo(oracle, "pinned")
     nbad = int((a1 != want).any(axis=-1).sum())
     assert nbad == 0, f"{nbad} of {a1.shape[0] * a1.shape[1]} texels of the full C3 grid differ from the oracle"
-    assert not want_d.any()
+    # ... and the stated tolerance against the LITERAL arithmetic (IEEE operations in GLSL source order, libm sin / cos / acos),
+    # the nearest thing to the reference's own semantics, on the headline configuration: |d| <= 1/255 on >= 99.9 % of the
+    # texel channels, mean |d| < 0.05/255
+    within, mean, differing = texel_tolerance_stats(a1, c3_oracle_albedo(oracle, "literal"))
+    assert within >= 0.999 and mean < 0.05, f"HIP vs LITERAL oracle on C3: {within * 100:.4f} % within 1/255, mean {mean:.5f}/255, {differing} texels differ"
 
 
 @pytest.mark.gpu

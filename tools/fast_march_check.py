@@ -31,6 +31,16 @@ def run(name, fast, mode="ref", steps=8):
         return out, float(np.min(tr)), active, eng.get_tuning("march_waves_measured")
 
 
+if os.environ.get("FAST_CHECK_DDGI"):
+    for name in sys.argv[1:] or ["cave_small", "c3_cave"]:
+        (ia, da), ta, _, _ = run(name, False, "ddgi", 3)
+        (ib, db), tb, active, _ = run(name, True, "ddgi", 3)
+        for label, x, y in (("irradiance", ia[..., :3], ib[..., :3]), ("depth", da, db)):
+            d = np.abs(x - y)
+            rel = d / np.maximum(np.abs(x), 1e-3)
+            print(f"{name} ddgi {label}: exact {ta:.3f} fast {tb:.3f} ms active={active}; equal {np.mean(d == 0) * 100:.3f} %  |d|<=1e-4+1e-3|x| {np.mean(d <= 1e-4 + 1e-3 * np.abs(x)) * 100:.4f} %  "
+                  f"|d|<=1e-3+1e-2|x| {np.mean(d <= 1e-3 + 1e-2 * np.abs(x)) * 100:.4f} %  mean |d| {d.mean():.2e}  mean |x| {np.abs(x).mean():.3f}  max |d| {d.max():.3f}")
+    sys.exit(0)
 for name in sys.argv[1:] or ["c2_cornell", "c3_cave"]:
     a, ta, _, mwa = run(name, False)
     b, tb, active, mwb = run(name, True)
