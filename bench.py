@@ -292,6 +292,7 @@ def main():
         eng.exchange_p2p_init(everyone)
         exchanging = True
 
+    eng.tune()                                  # the march/event wave split of this configuration, measured once (blocks; outside the timed region)
     frame_time = [0.0]
 
     def step():
@@ -381,7 +382,7 @@ def main():
             "note": "achieved / kernel_ms are measured by this run (HIP events on the launch stream); `traffic` and `issue` are REPLAYED from the committed rocprofv3 --pmc passes named beside them (counters need their own passes). The trace kernel is VALU-issue bound (dependent voxel steps + hit shading), not HBM bound, see DESIGN.md section 4",
         },
     }
-    out["tuning"] = {"march_waves": eng.get_tuning("march_waves_measured"), "note": "waves of a 16-wave workgroup that march (the rest shade); measured by the first update of the configuration"}
+    out["tuning"] = {"march_waves": eng.get_tuning("march_waves_measured"), "note": "waves of a 16-wave workgroup that march (the rest shade); measured by ddgi_tune() before the warm-up"}
     if ddgi_mode:
         # the blend kernels on their own: what THEY must move is the ray records the trace left (20 B per ray: r, g, b, d, d*d;
         # an intermediate of the pass, so not part of `roofline`) + the f32 tiles in and out (6144 B per probe)
@@ -399,6 +400,7 @@ def main():
     if world == 1 and not ddgi_mode and not args.no_fast_march:
         # the opt-in tolerance-mode march on the same workload, timed the same way (the headline `value` above is the exact march)
         eng.set_tuning("fast_march", 1)
+        eng.tune()
         for _ in range(args.warmup):
             step()
         fence()

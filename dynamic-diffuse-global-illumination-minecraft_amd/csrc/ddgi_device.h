@@ -12,13 +12,6 @@ namespace ddgi {
 
 #define DDGI_D __device__ __forceinline__
 
-// Timing experiments only (make alt ALTFLAGS=-DDDGI_EXP=<bits>): each bit swaps one piece of the trace kernels for a
-// cheap stand-in to measure what that piece costs.  Results are NOT exact with any bit set; the release build has 0.
-//   1 hemisphere sine/cosine  2 no light-sphere test  8 constant albedo  16 light feelers are not marched
-#ifndef DDGI_EXP
-#define DDGI_EXP 0
-#endif
-
 // ---- per-ray RNG: wang_hash seed + xorshift32 (probe_pass.comp:45-71) -------------------------
 
 DDGI_D uint32_t wang_hash(uint32_t seed)
@@ -72,7 +65,7 @@ DDGI_D void light_spheres(f3 o, f3 d, const TraceArgs& A, float& tl_out, int& li
 {
     float closest = __builtin_inff();
     int lid = -1;
-    const int nl = (DDGI_EXP & 2) ? 0 : (kNl > 0 ? kNl : A.nl);
+    const int nl = kNl > 0 ? kNl : A.nl;
     for (int i = 0; i < nl; ++i)
     {
         const f3 lp{A.lights[i].pos[0], A.lights[i].pos[1], A.lights[i].pos[2]};
@@ -234,11 +227,7 @@ DDGI_D uint32_t fast_march_step(FastMarch& m, const SceneK& S, const uint32_t* _
     m.cell = idx;
     const uint32_t* __restrict__ base = s_skip - (S.bias32 >> 4);
     const uint32_t code = __builtin_amdgcn_ubfe(base[idx >> 4], static_cast<uint32_t>(idx) << 1, 2u);
-#if defined(DDGI_FAST_DEBUG) && (DDGI_FAST_DEBUG & 1)
-    m.code = code ? 1.0f : 0.0f;  // debug: never skip
-#else
     m.code = static_cast<float>(code);
-#endif
     return code;
 }
 
@@ -304,13 +293,9 @@ DDGI_D f3 hemisphere_dir(f3 n, uint32_t& rng)
     if (!axis) p1 = normalize3(p1);
     f3 p2 = cross3(n, p1);
     if (!axis) p2 = normalize3(p2);
-#if DDGI_EXP & 1
-    const float ca = __cosf(around) * over, sa = __sinf(around) * over;
-#else
     float sn, cs;
     pm::sincos_small(around, sn, cs);  // P6b
     const float ca = cs * over, sa = sn * over;
-#endif
     return (n * up + p1 * ca) + p2 * sa;
 }
 

@@ -913,8 +913,8 @@ static int measure_march_waves(ddgi_engine* e, const TracePlan& p, int start, in
     return DDGI_OK;
 }
 
-// The split for plan p: pinned ("march_waves" tuning) > measured earlier for this configuration > measured now
-// (when `may_block` and "autotune" allow it) > the last measured value / 5.
+// The split for plan p: pinned ("march_waves" tuning) > measured earlier for this configuration (ddgi_tune, or "autotune") >
+// measured now (when `may_block` and "autotune" allow it) > the last measured value > 5 (the fast march: 4).
 static int choose_march_waves(ddgi_engine* e, const TracePlan& p, bool may_block, bool force_measure, int* out)
 {
     const Tuning& tn = e->tuning;
@@ -929,7 +929,7 @@ static int choose_march_waves(ddgi_engine* e, const TracePlan& p, bool may_block
         *out = it->second;
         return DDGI_OK;
     }
-    int mw = e->aq_last > 0 ? e->aq_last : 5;
+    int mw = e->aq_last > 0 ? e->aq_last : (p.fast ? 4 : 5);
     if (force_measure || (may_block && tn.autotune && tn.ablate == 0))
     {
         if (int rc = measure_march_waves(e, p, mw, &mw)) return rc;

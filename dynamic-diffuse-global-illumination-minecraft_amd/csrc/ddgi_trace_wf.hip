@@ -1,26 +1,30 @@
 // ddgi_trace_wf.hip — the probe update (assets/shaders/probe_pass.comp:main and everything it calls)
 // scheduled as a wavefront path tracer inside ONE persistent 1024-lane workgroup per CU:
-//   k_probe_trace_aq  slots travel through LDS queues, 8 waves march, 8 waves shade, no barrier  (default)
+//   k_probe_trace_aq  slots travel through LDS queues; m waves march, 16 - m waves shade (m per configuration, ddgi_tune);
+//                     no workgroup barrier after start-up                                                  (default)
 //   k_probe_trace_wf  the same work in synchronous rounds (sort / events / march) with barriers   (cross-check, counters)
 // Same per-ray arithmetic, in the same order, as the ray-per-lane k_probe_trace_ref (ddgi_kernels.hip),
-// hence bit-identical results; only the schedule differs.
+// hence bit-identical results; only the schedule differs.  (The opt-in fast march — Cfg::kFast, ddgi_device.h:
+// fast_march_step — is the one exception: a tolerance mode, see tests/test_gpu_fast_march.py.)
 //
 // Why a different schedule: per ray the path alternates ~13 voxel marches (1..125 dependent steps
 // each, heavy tailed) with hit shading whose cost depends on the block type hit.  With one ray
 // bound to one lane, a wave spends ~3/4 of its march-loop issue slots on parked lanes and every
 // shading round pays for every block type present in the wave.
 //
-// Here rays are NOT bound to lanes.  A pool of P rays lives in LDS as a structure of arrays (9 dwords
-// per ray: what a march needs; the shading state is a 48-byte record per slot in global memory) next
-// to the scene's occupancy bitmap.  Two kinds of work alternate on a slot:
-//   events  (wf_event) 64-lane groups of ONE bucket: hit shading per block-type class (the procedural
-//           albedo is a switch over 13 block types) + feeler set-up, light hit / miss, light-feeler
-//           result (+ bounce set-up, or texel store and slot release), refill (a new ray into a free
-//           slot: 48 B ProbeRay record in, first march set up)
-//   marches bursts of 16 predicated, fully unrolled voxel steps; a lane takes another march when its
-//           own ends
-// The round kernel alternates them in phases over compacted slot lists (C sort, D events, B march,
-// stragglers parked for the next round); the queue kernel lets every ray run at its own pace.
+// Here rays are NOT bound to lanes.  A pool of P rays lives in LDS as a structure of arrays, 18 dwords per ray
+// (WfPool: what a march needs — origin, unit direction, t, t_light, flags — and what an event needs — colour so far,
+// RNG, counters, destination, the ray direction as given) next to the scene's occupancy bitmap and the slot rings; only a
+// MARCHED light feeler parks its hit normal and albedo in a 32-byte global record (WfColdGlobal).  Two kinds of work
+// alternate on a slot:
+//   events  (wf_event) 64-lane groups of ONE bucket: hit shading per block-type class (the procedural albedo is a switch
+//           over 13 block types) + the single light's feeler decided on the spot where k_light_visibility's classes allow,
+//           light hit / miss, light-feeler result, bounce set-up (whose first voxel step the event lane takes itself), texel
+//           store and slot release, refill (a new ray into a free slot: 48 B ProbeRay record in, first march set up)
+//   marches bursts of 24 predicated, fully unrolled voxel steps (the fast march: 12); a lane takes another march when
+//           its own ends
+// The round kernel alternates them in phases over compacted slot lists (C sort, D events, B march, stragglers parked for
+// the next round); the queue kernel lets every ray run at its own pace.
 // ------------------------------------------------------------------------------------------------
 #include <algorithm>
 #include <cstdlib>
@@ -326,12 +330,6 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
     }
     P.tl[slot] = tl;
     const uint32_t base_flags = (feeler ? kFlagFeeler : 0u) | (static_cast<uint32_t>(lid + 1) << 12);
-    if ((DDGI_EXP & 16) && feeler)  // timing experiment: a feeler "reaches the light" without being marched
-    {
-        P.t[slot] = tl;
-        P.flags[slot] = base_flags | kSlotEvFeeler;
-        return static_cast<int>(kBucketFeeler);
-    }
     if (kInlineSteps > 0)
     {
         const f3 hi = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
@@ -665,7 +663,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     const bool ordinary = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))) < 0x1.0p20f;
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary)) DDGI_PROBE(lp, 1);  // section 1: albedo
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary))
-                        hcol = ((Cfg::ablate(A) & 1) || (DDGI_EXP & 8)) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
+                        hcol = (Cfg::ablate(A) & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
 #ifdef DDGI_LAP
                     DDGI_PROBE(lp, 7);  // after the albedo: visibility class, feeler decision
 #endif
@@ -1694,69 +1692,3 @@ hipError_t launch_probe_trace_wf(const TraceArgs& args_in, int threads, int pool
 }
 
 }  // namespace ddgi
-
-#ifdef DDGI_ISA_PROBE
-// instruction-count probes (hipcc -S -DDDGI_ISA_PROBE): the building blocks of an event as kernels of their own
-namespace ddgi {
-__global__ void k_isa_post_march(const TraceArgs A, float* io, uint32_t* lds_src)
-{
-    extern __shared__ uint32_t pl[];
-    WfPool P;
-    float* f = reinterpret_cast<float*>(pl);
-    for (int a = 0; a < 3; ++a) P.ro[a] = f + 1536 * a, P.dn[a] = f + 1536 * (3 + a);
-    P.t = f + 1536 * 6, P.tl = f + 1536 * 7, P.flags = pl + 1536 * 8;
-    for (int a = 0; a < 3; ++a) P.col[a] = f + 1536 * (10 + a), P.rd[a] = f + 1536 * (17 + a);
-    P.rng = pl + 1536 * 13, P.cnt = pl + 1536 * 14, P.dst = pl + 1536 * 15;
-    P.cold = reinterpret_cast<WfColdGlobal*>(io);
-    WfCold c = load_cold(P, threadIdx.x, true);
-    const f3 o = v3of(c.hn), d = v3of(c.hc);
-    const int r = wf_post_march<CfgPlain<0>>(P, threadIdx.x, c, o, d, c.cnt != 0, A, pl + 1536 * 16);
-    store_cold(P, threadIdx.x, c, true);
-    io[threadIdx.x] = static_cast<float>(r);
-}
-__global__ void k_isa_hemisphere(float* io)
-{
-    uint32_t rng = __float_as_uint(io[threadIdx.x + 512]);
-    const f3 d = hemisphere_dir(f3{io[threadIdx.x], io[threadIdx.x + 64], io[threadIdx.x + 128]}, rng);
-    io[threadIdx.x] = d.x, io[threadIdx.x + 64] = d.y, io[threadIdx.x + 128] = d.z, io[threadIdx.x + 512] = __uint_as_float(rng);
-}
-__global__ void k_isa_light_spheres(const TraceArgs A, float* io)
-{
-    float tl;
-    int lid;
-    light_spheres<1>(f3{io[threadIdx.x], io[threadIdx.x + 64], io[threadIdx.x + 128]}, f3{io[threadIdx.x + 192], io[threadIdx.x + 256], io[threadIdx.x + 320]}, A, tl, lid);
-    io[threadIdx.x] = tl, io[threadIdx.x + 64] = static_cast<float>(lid);
-}
-__global__ void k_isa_normalize(float* io)
-{
-    const f3 d = normalize3(f3{io[threadIdx.x], io[threadIdx.x + 64], io[threadIdx.x + 128]});
-    io[threadIdx.x] = d.x, io[threadIdx.x + 64] = d.y, io[threadIdx.x + 128] = d.z;
-}
-__global__ void k_isa_albedo_wall(const TraceArgs A, float* io)
-{
-    const f3 d = block_albedo(f3{io[threadIdx.x], io[threadIdx.x + 64], io[threadIdx.x + 128]}, 10, f3{1.0f, 0.0f, 0.0f}, A.noise);
-    io[threadIdx.x] = d.x, io[threadIdx.x + 64] = d.y, io[threadIdx.x + 128] = d.z;
-}
-__global__ void k_isa_step(const TraceArgs A, float* io, int n)
-{
-    extern __shared__ uint32_t pl[];
-    March m;
-    m.ro = f3{io[threadIdx.x], io[threadIdx.x + 64], io[threadIdx.x + 128]};
-    m.dn = f3{io[threadIdx.x + 192], io[threadIdx.x + 256], io[threadIdx.x + 320]};
-    m.inv = f3{io[threadIdx.x + 384], io[threadIdx.x + 448], io[threadIdx.x + 512]};
-    m.cc = f3{io[threadIdx.x + 576], io[threadIdx.x + 640], io[threadIdx.x + 704]};
-    m.t = 0, m.tl = io[threadIdx.x + 768], m.p = m.ro, m.it = 0, m.cell = 0, m.lid = 0, m.rd = m.dn;
-    f3 hi = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
-    asm volatile("" : "+v"(hi.x), "+v"(hi.y), "+v"(hi.z));
-    bool occ = false;
-    for (int i = 0; i < n; ++i)
-    {
-        asm volatile("; STEP BEGIN");
-        occ = march_step_burst(m, A.scene, pl, hi);
-        asm volatile("; STEP END");
-        if (occ | (m.t >= m.tl)) break;
-    }
-    io[threadIdx.x] = m.t + (occ ? 1.0f : 0.0f);
-}
-}  // namespace ddgi
-#endif

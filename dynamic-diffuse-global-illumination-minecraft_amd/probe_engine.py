@@ -478,7 +478,7 @@ class ProbeEngine:
         # queue kernel, counters build: (visits, active lanes) per section of the event code (ddgi_trace_wf.hip: LaneProbe)
         names = ("event", "albedo", "feeler set-up", "feeler sphere test", "light contribution", "bounce: accumulate + hemisphere", "primary set-up", "after albedo",
                  "inline step 1", "inline step 2", "inline step 3", "inline step 4", "write-back", "-", "-", "outside events")
-        st["sections"] = {nm: (int(out[32 + 2 * s]), int(out[33 + 2 * s])) for s, nm in enumerate(names) if nm != "-" and 33 + 2 * s < 64}
+        st["sections"] = {nm: (int(out[32 + 2 * s]), int(out[33 + 2 * s])) for s, nm in enumerate(names) if nm != "-" and s < 12}  # (slots 56.. hold feeler_classes; sections 12.. exist in the lap-timer build only)
         return st
 
     # -- outputs -------------------------------------------------------------------------------

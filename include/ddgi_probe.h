@@ -183,20 +183,25 @@ int ddgi_get_probe_rays(ddgi_handle h, ddgi_probe_ray* rays, size_t n);
  * record_compute_command_buffer (barrier + vkCmdDispatch, rvpt.cpp:1105-1129) + Queue::submit
  * (rvpt.cpp:378-380).  Asynchronous on the handle's stream.  `settings` may be NULL to reuse the
  * last one; the function does NOT add +2 to time (the caller's RVPT::update does, rvpt.cpp:281).
- * By default the first update of a configuration (grid, rays, scene, bounces, lights, mode) also measures
- * how the trace kernel should split its waves between marching and shading: a few extra launches of the
- * same trace (idempotent) and one host synchronisation, some tens of milliseconds, once per configuration
- * (the handle remembers up to 64 configurations).  A host that must never block in its frame loop calls
- * ddgi_tune() at load time, or turns it off: ddgi_set_tuning(h, "autotune", 0) [+ "march_waves", n]. */
+ * Never blocks the host.  How the trace kernel splits its waves between marching and shading depends on the
+ * configuration (grid, rays, scene, bounces, lights, mode): a host calls ddgi_tune() once at load time to
+ * measure it (worth 5-10 %), or sets "autotune" to let the first update of a configuration measure it. */
 int ddgi_probe_update(ddgi_handle h, const ddgi_render_settings* settings);
 
-/* Measures, now and blocking, the trace kernel's march/event wave split for the handle's CURRENT
- * configuration (what the first ddgi_probe_update of a configuration would do) and remembers it. */
+/* Measures, now and blocking, the trace kernel's march/event wave split for the handle's CURRENT configuration
+ * and remembers it (up to 64 configurations per handle): a few extra launches of the same trace (idempotent) and
+ * host synchronisations, some tens of milliseconds.  Call it after the rays are in place (REF mode). */
 int ddgi_tune(ddgi_handle h);
 
 /* Tuning switches of a handle, by name.  The environment variables in brackets are read ONCE, when the handle
  * is created, as initial values — never on the per-frame path.
- *   "autotune"      1 = measure the wave split on a configuration's first update (default), 0 = never block [DDGI_AUTOTUNE]
+ *   "autotune"      1 = the first update of a configuration measures the wave split itself (that one update blocks the
+ *                   host, as ddgi_tune does); 0 (default) = ddgi_probe_update never blocks                    [DDGI_AUTOTUNE]
+ *   "fast_march"    1 = TOLERANCE MODE: marches skip empty space through the scene's 2-bit skip field (csrc/ddgi_device.h:
+ *                   fast_march_step).  Not bit-exact with the exact march — REF texels: |d| <= 1/255 on >= 99.9 % of the
+ *                   channels, mean < 0.05/255 (measured on C3: 99.996 %, 0.0013/255); cage indices and the sampler are
+ *                   untouched (tests/test_gpu_fast_march.py).  A request: where the skip field does not fit in LDS the update
+ *                   runs the exact march; ddgi_get_tuning "fast_march_active" tells.  0 (default) = the exact march [DDGI_FAST_MARCH]
  *   "march_waves"   n > 0 pins the split (waves that march, of 16); 0 = per configuration            [DDGI_AQ_MARCH]
  *   "trace_kernel"  0 auto, 1 round-based, 2 ray per lane, 3 queues (cross-checks)   [DDGI_TRACE_KERNEL=rounds|lane|queues]
  *   "blend_kernel"  0 auto, 1 one probe per workgroup (cross-check)                                  [DDGI_BLEND_KERNEL]

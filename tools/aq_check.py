@@ -1,4 +1,6 @@
 """Queue kernel vs round kernel on two small scenes: same bytes? (GPU box)"""
+import os
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ddgi_amd

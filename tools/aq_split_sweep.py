@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Trace time of k_probe_trace_aq against the march/event wave split, per scene (GPU box)."""
 import os, sys
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import ddgi_amd

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Lane utilisation of k_probe_trace_aq's march trips and event groups on the bench workload (GPU box)."""
 import os, sys
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 os.environ["DDGI_TRACE_KERNEL"] = "queues"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ddgi_amd

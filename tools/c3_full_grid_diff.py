@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Every texel of the C3 update against the oracle (GPU box): prints the number that differ and the first few."""
 import os, sys
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, ddgi_amd
 from oracle import oracle_py as O

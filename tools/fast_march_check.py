@@ -2,6 +2,7 @@
 """Fast (tolerance-mode) march vs the exact march on the GPU: texel differences and kernel time.
    python tools/fast_march_check.py [c2_cornell|c3_cave|cave_small ...]"""
 import os
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 import sys
 
 import numpy as np

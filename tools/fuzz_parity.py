@@ -3,6 +3,8 @@
 mode, HIP (default kernels) against the pinned oracle, bit for bit.  Not part of the test suite (the
 oracle makes it slow); run after changes to the trace kernels.  The oracle is the checker here, as in tests/.
 Usage: tools/fuzz_parity.py [cases] [seed]"""
+import os
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -3,6 +3,7 @@
 DDGI_LIB=.../libddgi_probe_lap.so).  Cycles are wall cycles of the wave between two probes of its instruction stream, so they
 include the turns of the other waves on the SIMD: read them as shares."""
 import os, sys
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 os.environ["DDGI_TRACE_KERNEL"] = "queues"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ddgi_amd

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Time of k_render_primary for a 1600x900 frame (the reference's window) of the cave over the bench grid (GPU box)."""
+import os
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -2,6 +2,7 @@
 """End-to-end demo on the GPU box: probe update -> probe texture PNG -> rendered frames
 (integrator_DDGI / indirect / direct) of the Cornell box and the cave.  Writes under gpurun_out/demo/."""
 import os, sys
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ddgi_amd
 from ddgi_amd import imageio

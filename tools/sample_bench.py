@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Device-resident throughput of the cage-sample kernels (REF and DDGI mode) on the bench grid."""
+import os
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

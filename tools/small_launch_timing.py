@@ -2,6 +2,7 @@
 """Trace-kernel time of one rank's slab of the bench workload for large world sizes (GPU box, one GPU), and of the smallest
 slab with fewer bounces: the fixed part of the kernel's time — the latency of one ray's chain of marches and events."""
 import os, sys
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, ddgi_amd
 from bench import WORKLOAD as w

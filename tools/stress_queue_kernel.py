@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Repeats the bench workload's update many times and checks that the output never changes (GPU box):
 the queue kernel's execution order differs from run to run, its result must not."""
+import os
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

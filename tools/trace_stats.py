@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Prints the trace kernel's lane-utilisation counters for the bench workload (GPU box)."""
 import os, sys
+os.environ.setdefault("DDGI_AUTOTUNE", "1")  # tools measure the steady state: let the first update of a configuration pick the wave split
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ddgi_amd
 from bench import WORKLOAD as w
