@@ -102,11 +102,17 @@ DDGI_HD float noise2D(float px, float py)  // :402
 // The tables' extents are compile-time constants (ddgi_host.cpp: build_noise_lut fills exactly these): the
 // kernels compare against immediates instead of carrying two dozen scalars per launch.
 namespace lut {
-constexpr int kN2X0 = -2, kN2NX = 520, kN2Y0 = -2048, kN2NY = 4096;  // noise2D(ix, iy): ix in [x0, x0+nx), iy in [y0, y0+ny)
+// noise2D(ix, iy): ix in [x0, x0+nx), iy in [y0, y0+ny).  Wide enough for the cave's most expensive albedo as well: the mushroom
+// stems' fbm(5 u, z) reaches ix = 5 * 256 and |iy| = 22 * 256 in its last octave (stems stand at |z| <= 22); 60 MB, of which
+// the cave's other block types touch the few rows they always did
+constexpr int kN2X0 = -2, kN2NX = 1288, kN2Y0 = -5888, kN2NY = 11776;
 constexpr int kN1I0 = -8192, kN1N = 16384;                           // noise1(i)
 constexpr int kWpC0 = -16, kWpN = 32;                                // worley_point(cx, cy)
-constexpr int kR1Lo0 = -42, kR1Lo1 = -21, kR1Lo2 = -38;              // random1(cell) over the cave's bake box
-constexpr int kR1N0 = 75, kR1N1 = 40, kR1N2 = 70;
+// random1(cell) over the cave's bake box (-42..32, -21..18, -38..31) grown by 8 voxels: a probe grid that reaches past the box
+// (C3's last z layers stand in the rock beyond it) hits wall voxels out there — 0.7 % of C3's wall hits, but one such lane
+// sends its whole 64-lane group through the out-of-line albedo
+constexpr int kR1Lo0 = -50, kR1Lo1 = -29, kR1Lo2 = -46;
+constexpr int kR1N0 = 91, kR1N1 = 56, kR1N2 = 86;
 }  // namespace lut
 
 struct NoiseLut
@@ -119,6 +125,11 @@ struct NoiseLut
     // wall[o*ny + (iy-y0)] for octave o = 0..7 (freq 2..256) holds that value
     const float* wall = nullptr;
     const float* r1 = nullptr;    // random1(cell), x fastest
+    // Device hot paths only: where to note that a lattice point fell outside the tables INSTEAD of evaluating the hash in
+    // place (the value returned is then meaningless and the caller redoes the whole albedo out of line, ddgi_trace_wf.hip:
+    // block_albedo_computed).  A binary64 sine is an out-of-line call; inlined into every table miss of every block type
+    // it put 161 call sites into the trace kernel, and every one of them constrains the kernel's register allocation.
+    bool* miss = nullptr;
 };
 constexpr float kWallFbmX = 0.05f;
 DDGI_HD float random1_at(f3 cell, const NoiseLut& L)  // random1 of a voxel id (integer-valued floats)
@@ -127,6 +138,11 @@ DDGI_HD float random1_at(f3 cell, const NoiseLut& L)  // random1 of a voxel id (
                    uz = static_cast<unsigned>(gl_int(cell.z) - lut::kR1Lo2);
     if (L.r1 && ux < static_cast<unsigned>(lut::kR1N0) && uy < static_cast<unsigned>(lut::kR1N1) && uz < static_cast<unsigned>(lut::kR1N2))
         return L.r1[(uz * static_cast<unsigned>(lut::kR1N1) + uy) * static_cast<unsigned>(lut::kR1N0) + ux];
+    if (L.miss)
+    {
+        *L.miss = true;
+        return 0.0f;
+    }
     return random1(cell);
 }
 
@@ -141,6 +157,11 @@ DDGI_HD float interp_noise2D(float x, float y, const NoiseLut& L = NoiseLut())  
     {
         const float* q = L.n2 + static_cast<size_t>(ux) * lut::kN2NY + uy;
         a = q[0], c = q[1], b = q[lut::kN2NY], d = q[lut::kN2NY + 1];
+    }
+    else if (L.miss)
+    {
+        *L.miss = true;
+        a = b = c = d = 0.0f;
     }
     else
     {
@@ -190,6 +211,11 @@ DDGI_HD float noise1_at(float i, const NoiseLut& L)
 {
     const unsigned u = static_cast<unsigned>(gl_int(i) - lut::kN1I0);
     if (L.n1 && u < static_cast<unsigned>(lut::kN1N)) return L.n1[u];
+    if (L.miss)
+    {
+        *L.miss = true;
+        return 0.0f;
+    }
     return noise1(i);
 }
 DDGI_HD float interp_noise1D(float x, const NoiseLut& L = NoiseLut())  // :441-448
@@ -222,6 +248,11 @@ DDGI_HD f2 worley_point(f2 cell, const NoiseLut& L)
     {
         const float* q = L.wp + (static_cast<size_t>(ux) * lut::kWpN + uy) * 2;
         return f2{q[0], q[1]};
+    }
+    if (L.miss)
+    {
+        *L.miss = true;
+        return f2{0.0f, 0.0f};
     }
     return worley_point_eval(cell);
 }
