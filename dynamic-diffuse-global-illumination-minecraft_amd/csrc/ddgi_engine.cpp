@@ -38,6 +38,7 @@ hipError_t launch_carry_tiles(void* dst, const void* src, const int32_t* map, ui
 hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream);
 hipError_t launch_render_primary(const RenderArgs& args, hipStream_t stream);
 size_t sample_group_scratch_words(uint32_t n, uint32_t n_probes);
+hipError_t launch_sample_box_filter(const GridK& grid, const uint32_t* albedo, float4* box, int num_cus, hipStream_t stream);
 hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t n, uint32_t* scratch, const uint32_t** perm_out, hipStream_t stream);
 hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], const int32_t* list, int n_list, uint8_t* out, uint32_t* out_occ, hipStream_t stream);
 
@@ -84,6 +85,7 @@ static const TuningKey kTuningKeys[] = {
     {"fast_march", &Tuning::fast_march, "DDGI_FAST_MARCH"},
     {"light_vis", &Tuning::light_vis, "DDGI_LIGHT_VIS"},
     {"sample_group", &Tuning::sample_group, "DDGI_SAMPLE_GROUP"},
+    {"sample_box", &Tuning::sample_box, "DDGI_SAMPLE_BOX"},
     {"noise_lut", &Tuning::noise_lut, nullptr},
     {"lut_off", &Tuning::lut_off, "DDGI_LUT_OFF"},
     {"verbose", &Tuning::verbose, "DDGI_VERBOSE"},
@@ -209,6 +211,7 @@ int ddgi_alloc_texture_pair(ddgi_engine* e, const size_t bytes[2], void* out[2])
 // On failure the previous textures stay in place.
 static int alloc_textures(ddgi_engine* e)
 {
+    e->box_of = nullptr;
     ddgi_exchange_release(e);  // a new configuration: the exchange is set up again by ddgi_exchange_init
     size_t bytes[2];
     texture_bytes(e->mode, e->field, make_grid(e).n, bytes);
@@ -398,6 +401,7 @@ int ddgi_destroy(ddgi_handle e)
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->d_sample_scratch) (void)hipFree(e->d_sample_scratch);
+    if (e->d_box) (void)hipFree(e->d_box);
     if (e->d_blend_w) (void)hipFree(e->d_blend_w);
     if (e->d_work) (void)hipFree(e->d_work);
     if (e->d_wf_cold) (void)hipFree(e->d_wf_cold);
@@ -512,6 +516,7 @@ int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const dd
         }
     }
     // commit.  Caller-bound textures (ddgi_bind_textures) are unbound: the handle uses its own from here on.
+    e->box_of = nullptr;
     ddgi_exchange_release(e);
     for (int i = 0; i < 2; ++i)
     {
@@ -1025,6 +1030,7 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         e->frame += 1;
     }
     pair_switch.launched = true;
+    e->box_of = nullptr;  // the textures change: the sampler's per-texel table is stale
     HIP_TRY(hipEventRecord(ev[2], e->stream));
     e->updates += 1;
     return DDGI_OK;
@@ -1231,6 +1237,30 @@ int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, si
     a.rgb = d_rgb;
     a.cage = d_cage;
     a.n = static_cast<uint32_t>(n);
+    // REF mode, a large batch (or the table is there already): sample_probe comes from its per-texel table — built now if the
+    // textures have changed since it was last built (one pass over the texels, ~ the cost of sampling 100 000 points directly)
+    constexpr size_t kBoxMinPoints = 65536;
+    if (e->mode == DDGI_MODE_REF && e->tuning.sample_box && (n >= kBoxMinPoints || e->box_of == e->tex[0]))
+    {
+        const size_t texels = e->tex_bytes[0] / 4;
+        if (texels > e->box_texels)
+        {
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            if (e->d_box) (void)hipFree(e->d_box);
+            e->d_box = nullptr, e->box_texels = 0, e->box_of = nullptr;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_box), texels * sizeof(float4)));
+            e->box_texels = texels;
+        }
+        if (e->box_of != e->tex[0])
+        {
+            HIP_TRY(launch_sample_box_filter(a.grid, a.albedo, e->d_box, e->num_cus, e->stream));
+            e->box_of = e->tex[0];
+        }
+        a.box = e->d_box;
+        HIP_TRY(launch_probe_sample_ref(a, e->stream));  // 8 table entries per point: nothing to gain from grouping
+        if (e->tex[0] != e->own_tex[0] && !e->xch.pipelined) e->box_of = nullptr;  // caller-owned textures may change behind the handle's back: never reuse
+        return DDGI_OK;
+    }
     if (e->tuning.sample_group && n >= 4096)  // a batch worth grouping by cage (small ones are launch-latency bound anyway)
     {
         const size_t words = sample_group_scratch_words(a.n, static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.cz);
@@ -1409,6 +1439,7 @@ int ddgi_bind_textures(ddgi_handle e, void* tex0, void* tex1)
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->tex[0] = tex0 ? tex0 : e->own_tex[0];
     e->tex[1] = tex1 ? tex1 : e->own_tex[1];
+    e->box_of = nullptr;
     return DDGI_OK;
 }
 

@@ -27,6 +27,7 @@ struct Tuning
     int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
     int fast_march = 0;     // tolerance mode: marches skip empty space (NOT bit-exact; tests/test_gpu_fast_march.py states the tolerance)
     int light_vis = 1;      // per-voxel light-feeler classes (k_light_visibility): 0 = march every feeler
+    int sample_box = 1;     // REF ddgi_sample*: large batches go through the per-texel table of sample_probe (0: every point evaluates its 8 x 26 texels)
     int sample_group = 1;   // ddgi_sample*: handle the points of a batch cage by cage (0: in the order given)
     int noise_lut = 1;      // memoised lattice hashes (0: compute every hash)
     int lut_off = 0;        // profiling: 1 = no wall table, 2 = no random1 table
@@ -139,6 +140,9 @@ struct ddgi_engine
         int cur = 0;               // pair written by the most recent update
         unsigned long long k = 0;  // updates issued since the exchange was set up
     } xch;
+    float4* d_box = nullptr;                // REF mode: sample_probe per texel of the current textures (k_sample_box_filter), built on demand
+    size_t box_texels = 0;
+    const void* box_of = nullptr;           // ... the texture it was built from (null: stale — any update, exchange or rebind resets it)
     uint32_t* d_sample_scratch = nullptr;   // ddgi_sample_device: grouping of a batch by cage (ddgi_kernels.hip: k_sample_*)
     size_t sample_scratch_words = 0;
     unsigned long long* d_stats = nullptr;  // profiling aid, allocated on first ddgi_trace_stats(enable)

@@ -318,6 +318,7 @@ int ddgi_exchange_wait_latest(ddgi_engine* e)
 void ddgi_exchange_release(ddgi_engine* e)
 {
     ddgi_engine::Exchange& x = e->xch;
+    e->box_of = nullptr;
     for (auto it = g_group_pending.begin(); it != g_group_pending.end();)
         it = it->e == e ? g_group_pending.erase(it) : it + 1;
     if (x.comm_stream) (void)hipStreamSynchronize(x.comm_stream);
@@ -575,6 +576,7 @@ int ddgi_exchange(ddgi_handle e)
     ddgi_engine::Exchange& x = e->xch;
     if (!x.transport) return fail(DDGI_ERR_NOT_READY, "ddgi_exchange before ddgi_exchange_init / ddgi_exchange_p2p_init");
     HIP_TRY(hipSetDevice(e->device));
+    e->box_of = nullptr;  // the other ranks' slabs are about to change: the sampler's per-texel table is stale
     if (x.transport == DDGI_EXCHANGE_P2P) return p2p_exchange(e);
     hipStream_t s = e->stream;
     if (x.pipelined)

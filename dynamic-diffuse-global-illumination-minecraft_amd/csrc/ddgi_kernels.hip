@@ -266,12 +266,57 @@ __global__ __launch_bounds__(256) void k_probe_sample_ref(const SampleArgs A)
     const uint32_t i = A.perm ? A.perm[k] : k;
     int cage[8];
     const f3 out = diffuse_gi_ref(A.grid, A.albedo, f3{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]},
-                                  f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]}, s_unorm, cage);
+                                  f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]}, s_unorm, cage, A.box);
     A.rgb[3 * i] = out.x;
     A.rgb[3 * i + 1] = out.y;
     A.rgb[3 * i + 2] = out.z;
     if (A.cage)
         for (int k = 0; k < 8; ++k) A.cage[8 * i + k] = cage[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sample_box_filter — sample_probe for every texel of every tile, once per probe update.
+// What sample_probe returns depends on the probe and on the texel (rx, ry) the direction lands in, nothing else: the centre texel
+// plus its clipped 5x5 box, divided by the count (intersection.glsl:1213-1239).  get_diffuse_gi asks for it 8 times per shaded
+// point — 208 gathers and 624 rgba8 conversions per point, the same few thousand sums over and over.  This kernel evaluates it
+// ONCE per texel, in the reference's order of additions (so every value has the bits the per-point evaluation would give), into
+// a float4 table [slab slot][ry][rx]; the sampler then loads one table entry per cage corner (diffuse_gi_ref's `box`).
+// One workgroup per tile: the tile's texels are converted once into three float planes in LDS, every lane sums its own box.
+// The engine rebuilds the table lazily — the first large sample batch after a probe update pays for it (ddgi_engine.cpp).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample_box_filter(const GridK G, const uint32_t* __restrict__ albedo, float4* __restrict__ box, uint32_t n_probes)
+{
+    extern __shared__ __attribute__((aligned(16))) float box_lds[];
+    const int n = G.n, s = G.sx, sh = G.sy;
+    float* unorm = box_lds;
+    float *pr = box_lds + 256, *pg = pr + n, *pb = pg + n;
+    unorm[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;  // blockDim.x == 256
+    for (uint32_t slot = blockIdx.x; slot < n_probes; slot += gridDim.x)
+    {
+        __syncthreads();  // the previous tile's planes are no longer read (and the table is written)
+        const uint32_t* __restrict__ tile = albedo + static_cast<size_t>(slot) * n;
+        for (int t = threadIdx.x; t < n; t += 256)
+        {
+            const uint32_t v = tile[t];
+            pr[t] = unorm[v & 255u], pg[t] = unorm[(v >> 8) & 255u], pb[t] = unorm[(v >> 16) & 255u];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < n; t += 256)
+        {
+            const f3 v = sample_box_ref(s, sh, t % s, t / s, [&](int off) { return f3{pr[off], pg[off], pb[off]}; });
+            box[static_cast<size_t>(slot) * n + t] = float4{v.x, v.y, v.z, 0.0f};
+        }
+    }
+}
+
+hipError_t launch_sample_box_filter(const GridK& grid, const uint32_t* albedo, float4* box, int num_cus, hipStream_t stream)
+{
+    const uint32_t n_probes = static_cast<uint32_t>(grid.cx) * grid.cy * grid.cz;
+    const size_t lds = (256 + static_cast<size_t>(3) * grid.n) * sizeof(float);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_sample_box_filter), static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sample_box_filter, dim3(std::min<uint32_t>(n_probes, static_cast<uint32_t>(num_cus) * 8u)), dim3(256), lds, stream, grid, albedo, box, n_probes);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

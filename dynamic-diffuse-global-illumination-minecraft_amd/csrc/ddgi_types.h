@@ -163,6 +163,7 @@ struct SampleArgs
     const float* irradiance;  // DDGI mode tiles (slab-major), else null
     const float* depth;
     const uint32_t* perm;     // processing order: lane k handles point perm[k] (points grouped by cage, see k_sample_*), or null
+    const float4* box;        // REF mode: sample_probe tabulated per texel (k_sample_box_filter), or null: evaluate it per point
 };
 
 // k_render_primary: camera rays + integrators over the probe field

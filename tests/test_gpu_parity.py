@@ -124,6 +124,44 @@ def test_sample_bit_exact_vs_pinned_oracle(ddgi, oracle, name):
     assert np.array_equal(rgb[~inside], np.tile(np.float32([1, 0, 1]), ((~inside).sum(), 1)))
 
 
+@pytest.mark.parametrize("name", ["c2_cornell", "cave_odd"])
+def test_sample_paths_agree(ddgi, oracle, name):
+    """A large REF batch takes sample_probe from its per-texel table (k_sample_box_filter, rebuilt after every update), a
+    medium one is grouped by cage, a small one goes as it comes; "sample_box" / "sample_group" switch the first two off.  Every
+    path must equal the oracle bit for bit: points everywhere, crowded into one cage, on the field's last cage layer (whose corner
+    indices wrap, Q4) and outside."""
+    counts, side, s, origin, scene = CONFIGS[name]
+    rng = np.random.default_rng(23)
+    spread, nrm = shading_points(rng, counts, side, origin, 60000)          # everywhere, some outside
+    o = np.asarray(origin, dtype=np.float32)
+    crowd = (rng.uniform(0.05, 0.95, size=(9000, 3)) * side + o).astype(np.float32)
+    top = (rng.uniform(-0.5, 0.5, size=(6000, 3)) * np.float32(side) * np.asarray(counts, dtype=np.float32) + o).astype(np.float32)
+    top[:, 0] = o[0] + side * (counts[0] // 2 - 0.5)                                             # the last cage layer in x
+    pos = np.concatenate([spread, crowd, top]).astype(np.float32)
+    nrm = np.concatenate([nrm, rng.normal(size=(len(pos) - len(nrm), 3)).astype(np.float32)])
+    nrm[:4] = [[0, 0, 1], [0, 0, -1], [1, 0, 0], [0, 1, 0]]                                      # degenerate directions (Q8)
+    f = oracle.make_field(counts, side, s, origin)
+    with _engine(ddgi, name) as eng:
+        for seed in (1, 2):                                                 # the table must follow the textures
+            eng.generate_probe_rays(seed=seed, reseed=True)
+            eng.probe_update()
+            got = {}
+            for box, group in ((1, 1), (0, 1), (0, 0)):
+                eng.set_tuning("sample_box", box)
+                eng.set_tuning("sample_group", group)
+                got[(box, group)] = eng.sample(pos, nrm)
+            eng.set_tuning("sample_box", 1)
+            small = eng.sample(pos[:777], nrm[:777])                         # a small batch reuses the table that is there
+            albedo, distance = eng.read_textures()
+            want_rgb, want_cage = oracle.sample(f, albedo, distance, pos, nrm)
+            for key, (rgb, cage) in got.items():
+                assert np.array_equal(cage, want_cage), f"seed {seed}, (sample_box, sample_group) = {key}"
+                assert np.array_equal(rgb.view(np.uint32), want_rgb.view(np.uint32)), f"seed {seed}, (sample_box, sample_group) = {key}"
+            assert np.array_equal(small[0].view(np.uint32), want_rgb[:777].view(np.uint32)) and np.array_equal(small[1], want_cage[:777])
+    inside = want_cage[:, 0] >= 0
+    assert 0.02 < inside.mean() < 1.0, inside.mean()
+
+
 def test_sharded_slabs_equal_the_full_grid(ddgi, oracle):
     """z-slab sharding: rank r of 2 fills exactly its slab of the slab-major
     texture and nothing else; the union equals the unsharded result."""

@@ -9,7 +9,7 @@ timeout 300 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/${R}_${T}_bench.j
 timeout 200 python $ROOT/bench.py --mode ddgi --steps 20 --warmup 5 > $OUT/${R}_${T}_ddgi_bench.json 2> /dev/null
 # kernel traces of the same commands (the march/event split pinned to what the first update measured, so that every launch is the steady-state kernel)
 MW=$(python -c "import json;print(json.load(open('$OUT/${R}_${T}_bench.json')).get('tuning',{}).get('march_waves',5))" 2>/dev/null || echo 5)
-DDGI_AQ_MARCH=$MW timeout 200 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$T -o ref --output-format csv -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+DDGI_AQ_MARCH=$MW timeout 200 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$T -o ref --output-format csv -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fast-march > /dev/null 2>&1
 python $ROOT/tools/profile_summary.py $ROOT/gpurun_out/prof_$T/ref "bench.py --steps 20 --warmup 5 (REF) with DDGI_AQ_MARCH=$MW, the split the first update measures for this workload" > $OUT/${R}_${T}_ref_kernel_stats.txt
 timeout 200 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$T -o ddgi --output-format csv -- python $ROOT/bench.py --mode ddgi --steps 20 --warmup 5 > /dev/null 2>&1
 python $ROOT/tools/profile_summary.py $ROOT/gpurun_out/prof_$T/ddgi "bench.py --mode ddgi --steps 20 --warmup 5" > $OUT/${R}_${T}_ddgi_kernel_stats.txt

@@ -3,7 +3,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_blend
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --mode ddgi --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --mode ddgi --steps 3 --warmup 1 --no-cpu-baseline --no-fast-march"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU -d $OUT -o sq1 --output-format csv -- $BENCH > $OUT/sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SMEM SQ_WAVES SQ_INST_CYCLES_VMEM -d $OUT -o sq2 --output-format csv -- $BENCH > $OUT/sq2.log 2>&1
 python3 - <<PY

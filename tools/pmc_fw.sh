@@ -2,7 +2,7 @@
 # FETCH_SIZE / WRITE_SIZE per launch of the trace kernel for a given env (GPU box)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_fw
 mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-march"
 for c in FETCH_SIZE WRITE_SIZE; do
 rocprofv3 --kernel-trace --pmc $c -d $OUT -o $c --output-format csv -- $BENCH > $OUT/$c.log 2>&1
 python3 - <<PY

@@ -3,7 +3,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_mix
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fast-march"
 export DDGI_AQ_MARCH=5
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT64 -d $OUT -o m1 --output-format csv -- $BENCH > $OUT/m1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $OUT -o m2 --output-format csv -- $BENCH > $OUT/m2.log 2>&1

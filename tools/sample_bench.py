@@ -32,6 +32,16 @@ for mode in (ddgi_amd.MODE_REF, ddgi_amd.MODE_DDGI):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / K
     inside = float((cage[:, 0] >= 0).float().mean())
-    print("mode %d: %.3f ms for %d points (%.0f Mpoints/s), %.1f GB/s of point I/O (68 B/point), %.0f%% inside the grid" % (
-        mode, dt * 1e3, n, n / dt / 1e6, n * 68 / dt / 1e9, inside * 100))
+    # REF mode: a large batch reads sample_probe from a per-texel table that the FIRST batch after a probe update has to build
+    # (k_sample_box_filter) — time that first batch too: update, synchronise, one batch
+    first = []
+    for it in range(5):
+        eng.probe_update()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.sample_device(pos.data_ptr(), nrm.data_ptr(), n, rgb.data_ptr(), cage.data_ptr())
+        torch.cuda.synchronize()
+        first.append(time.perf_counter() - t1)
+    print("mode %d: %.3f ms for %d points (%.0f Mpoints/s), %.1f GB/s of point I/O (68 B/point), %.0f%% inside the grid; the first batch after a probe update: %.3f ms (%.0f Mpoints/s)" % (
+        mode, dt * 1e3, n, n / dt / 1e6, n * 68 / dt / 1e9, inside * 100, min(first) * 1e3, n / min(first) / 1e6))
     eng.close()
