@@ -1220,6 +1220,32 @@ int ddgi_set_frame(ddgi_handle e, uint32_t frame)
     return DDGI_OK;
 }
 
+// REF mode: the per-texel table of sample_probe for the handle's current textures (k_sample_box_filter), rebuilt when they have
+// changed since it was last built — one pass over the texels, about what sampling 100 000 points directly costs.
+static int ensure_sample_box(ddgi_engine* e, const GridK& grid)
+{
+    const size_t texels = e->tex_bytes[0] / 4;
+    if (texels > e->box_texels)
+    {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->d_box) (void)hipFree(e->d_box);
+        e->d_box = nullptr, e->box_texels = 0, e->box_of = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_box), texels * sizeof(float4)));
+        e->box_texels = texels;
+    }
+    if (e->box_of != e->tex[0])
+    {
+        HIP_TRY(launch_sample_box_filter(grid, static_cast<const uint32_t*>(e->tex[0]), e->d_box, e->num_cus, e->stream));
+        e->box_of = e->tex[0];
+    }
+    return DDGI_OK;
+}
+// caller-owned textures (ddgi_bind_textures) may change behind the handle's back: their table is never reused
+static void release_sample_box_if_borrowed(ddgi_engine* e)
+{
+    if (e->tex[0] != e->own_tex[0] && !e->xch.pipelined) e->box_of = nullptr;
+}
+
 int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, size_t n, float* d_rgb, int32_t* d_cage)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
@@ -1242,23 +1268,10 @@ int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, si
     constexpr size_t kBoxMinPoints = 65536;
     if (e->mode == DDGI_MODE_REF && e->tuning.sample_box && (n >= kBoxMinPoints || e->box_of == e->tex[0]))
     {
-        const size_t texels = e->tex_bytes[0] / 4;
-        if (texels > e->box_texels)
-        {
-            HIP_TRY(hipStreamSynchronize(e->stream));
-            if (e->d_box) (void)hipFree(e->d_box);
-            e->d_box = nullptr, e->box_texels = 0, e->box_of = nullptr;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_box), texels * sizeof(float4)));
-            e->box_texels = texels;
-        }
-        if (e->box_of != e->tex[0])
-        {
-            HIP_TRY(launch_sample_box_filter(a.grid, a.albedo, e->d_box, e->num_cus, e->stream));
-            e->box_of = e->tex[0];
-        }
+        if (int rc = ensure_sample_box(e, a.grid)) return rc;
         a.box = e->d_box;
         HIP_TRY(launch_probe_sample_ref(a, e->stream));  // 8 table entries per point: nothing to gain from grouping
-        if (e->tex[0] != e->own_tex[0] && !e->xch.pipelined) e->box_of = nullptr;  // caller-owned textures may change behind the handle's back: never reuse
+        release_sample_box_if_borrowed(e);
         return DDGI_OK;
     }
     if (e->tuning.sample_group && n >= 4096)  // a batch worth grouping by cage (small ones are launch-latency bound anyway)
@@ -1370,10 +1383,20 @@ int ddgi_render_device(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_
         r.depth = static_cast<const float*>(e->tex[1]);
     }
     else
+    {
         r.albedo = static_cast<const uint32_t*>(e->tex[0]);
+        // only for the views that read the probe field (integrator_DDGI, integrator_indirect, the cage colours): a frame's pixels are
+        // always worth the table
+        if (e->tuning.sample_box && !(st->render_mode == 1 || (st->render_mode >= 3 && st->render_mode <= 6)))
+        {
+            if (int rc = ensure_sample_box(e, r.trace.grid)) return rc;
+            r.box = e->d_box;
+        }
+    }
     r.rgba8 = d_rgba8;
     r.rgb_f32 = d_rgb_f32;
     HIP_TRY(launch_render_primary(r, e->stream));
+    if (r.box) release_sample_box_if_borrowed(e);
     return DDGI_OK;
 }
 

@@ -178,6 +178,7 @@ struct RenderArgs
     int visualize_probes;  // RenderSettings::visualize_probes: probes drawn as spheres (integrators.glsl:45-65)
     int width, height;
     const uint32_t* albedo;   // REF mode probe texture (slab-major)
+    const float4* box;        // ... and sample_probe tabulated per texel of it (k_sample_box_filter), or null
     const float* irradiance;  // DDGI mode tiles; null in REF mode
     const float* depth;
     uint32_t* rgba8;  // width*height
