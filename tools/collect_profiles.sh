@@ -22,3 +22,13 @@ timeout 200 python tools/slab_timing.py > $OUT/${R}_${T}_slab_scaling.txt 2>/dev
 timeout 200 python tools/sample_bench.py 2>/dev/null | grep mode > $OUT/${R}_${T}_sample_bench.txt
 timeout 200 python tools/aq_stats.py 2>/dev/null | grep -v amdgpu > $OUT/${R}_${T}_lane_stats.txt
 ls -la $OUT
+# round 3 additions: the fast-march kernel's issue counters, the blend kernels' counters, the sample kernels, the WRITE_SIZE calibration
+cd $ROOT
+DDGI_FAST_MARCH=1 DDGI_AQ_MARCH=4 timeout 300 bash tools/pmc_icache.sh ${T}fast > /dev/null 2>&1; DDGI_FAST_MARCH=1 DDGI_AQ_MARCH=4 python tools/pmc_issue.py ${T}fast $OUT/${R}_pmc_${T}_fast_march_issue.txt > /dev/null
+timeout 300 bash tools/pmc_blend.sh > $OUT/${R}_${T}_pmc_blend.txt 2>&1
+timeout 400 bash tools/pmc_sample.sh $R $T > /dev/null 2>&1
+timeout 200 bash tools/calib_write_size.sh $R > /dev/null 2>&1
+timeout 300 python bench.py --workload c4 --steps 5 --warmup 2 > $OUT/${R}_${T}_c4_bench.json 2> /dev/null
+timeout 300 python bench.py --workload c4 --mode ddgi --steps 5 --warmup 2 > $OUT/${R}_${T}_c4_ddgi_bench.json 2> /dev/null
+timeout 400 python bench.py --workload c5 --mode ddgi --steps 12 > $OUT/${R}_${T}_c5_sdyn_ddgi_bench.json 2> /dev/null
+ls -la $OUT

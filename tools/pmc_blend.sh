@@ -5,18 +5,21 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $GRAFT_REPO_ROOT/bench.py --mode ddgi --steps 3 --warmup 1 --no-cpu-baseline --no-fast-march"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU -d $OUT -o sq1 --output-format csv -- $BENCH > $OUT/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT -o mem --output-format csv -- $BENCH > $OUT/mem.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT -o memw --output-format csv -- $BENCH > $OUT/memw.log 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SMEM SQ_WAVES SQ_INST_CYCLES_VMEM -d $OUT -o sq2 --output-format csv -- $BENCH > $OUT/sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES -d $OUT -o mfma --output-format csv -- $BENCH > $OUT/mfma.log 2>&1
 python3 - <<PY
 import csv, collections
-for f in ["sq1","sq2"]:
+print("# rocprofv3 --pmc passes on `bench.py --mode ddgi --steps 3 --warmup 1`: per-launch means of the DDGI blend kernels (C3: 16 384 probes x 256 rays)")
+for f in ["sq1","sq2","mfma","mem","memw"]:
     agg=collections.defaultdict(list)
     try:
         rows = list(csv.DictReader(open("$OUT/"+f+"_counter_collection.csv")))
     except Exception as e:
-        print(f, "no data", e); continue
+        print("#", f, "no data", e); continue
     for r in rows:
-        if "blend_s" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k,v in sorted(agg.items()): print(f,k,"%.4g"%(sum(v)/len(v)))
+        if "blend" in r["Kernel_Name"]:
+            agg[(r["Kernel_Name"].split("(")[0].replace("ddgi::", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (k,c),v in sorted(agg.items()): print("%-28s %-24s %14.5g" % (k[:28], c, sum(v)/len(v)))
 PY
-tail -3 $OUT/sq2.log

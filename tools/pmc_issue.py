@@ -19,8 +19,8 @@ def main(tag, out):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         c.update({k: sum(v) / len(v) for k, v in agg.items()})
     lines = [f"# rocprofv3 --pmc passes (tools/pmc_icache.sh {tag}), bench workload c3_cave_32x16x32_probes_x256_rays_ref",
-             "# per-launch means over the k_probe_trace_aq dispatches of `bench.py --steps 3 --warmup 1` (they include the launches of the",
-             "# first update's wave-split measurement: same kernel, neighbouring splits)"]
+             "# per-launch means over the k_probe_trace_aq dispatches of `bench.py --steps 3 --warmup 1 --no-fast-march` with the march/event",
+             "# wave split pinned (DDGI_AQ_MARCH=%s)%s" % (os.environ.get("DDGI_AQ_MARCH", "5"), "; DDGI_FAST_MARCH=1: the tolerance-mode kernel" if os.environ.get("DDGI_FAST_MARCH") == "1" else "")]
     for k in sorted(c):
         lines.append(f"{k:28s} {c[k]:.6g}")
     busy = c["SQ_ACTIVE_INST_VALU"] / (c["SQ_WAVE_CYCLES"] / 4.0)

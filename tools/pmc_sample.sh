@@ -7,7 +7,7 @@ CMD="python $GRAFT_REPO_ROOT/tools/sample_bench.py"
 rocprofv3 --kernel-trace --stats -d $OUT -o kt --output-format csv -- $CMD > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU -d $OUT -o sq1 --output-format csv -- $CMD > $OUT/sq1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM -d $OUT -o sq2 --output-format csv -- $CMD > $OUT/sq2.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum -d $OUT -o mem --output-format csv -- $CMD > $OUT/mem.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT -o mem --output-format csv -- $CMD > $OUT/mem.log 2>&1
 python3 - <<PY > $GRAFT_REPO_ROOT/gpurun_out/profiles_out/${R}_${T}_sample_kernels.txt
 import csv, collections
 print("# tools/sample_bench.py: 1 440 000 scattered shading points over the C3 grid, REF then DDGI mode; rocprofv3 --kernel-trace and --pmc passes")
@@ -22,7 +22,7 @@ for f in ("sq1", "sq2", "mem"):
     a = collections.defaultdict(list)
     try:
         for r in csv.DictReader(open("$OUT/" + f + "_counter_collection.csv")):
-            if "probe_sample" in r["Kernel_Name"]: a[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if "sample" in r["Kernel_Name"]: a[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
     except Exception as e:
         print("#", f, "no data:", e); continue
     for (k, c), v in sorted(a.items()): print("%-40s %-26s %14.5g" % (k[:40], c, sum(v) / len(v)))
