@@ -108,11 +108,12 @@ namespace lut {
 constexpr int kN2X0 = -2, kN2NX = 1288, kN2Y0 = -5888, kN2NY = 11776;
 constexpr int kN1I0 = -8192, kN1N = 16384;                           // noise1(i)
 constexpr int kWpC0 = -16, kWpN = 32;                                // worley_point(cx, cy)
-// random1(cell) over the cave's bake box (-42..32, -21..18, -38..31) grown by 8 voxels: a probe grid that reaches past the box
-// (C3's last z layers stand in the rock beyond it) hits wall voxels out there — 0.7 % of C3's wall hits, but one such lane
-// sends its whole 64-lane group through the out-of-line albedo
-constexpr int kR1Lo0 = -50, kR1Lo1 = -29, kR1Lo2 = -46;
-constexpr int kR1N0 = 91, kR1N1 = 56, kR1N2 = 86;
+// random1(cell) over [-80, 80) x [-48, 48) x [-80, 80) voxel ids (9.8 MB): the cave's bake box (-42..32, -21..18, -38..31) and
+// the rock around it as far as BASELINE's largest grid reaches (C5: 128 x 64 x 128 probes, spacing 1).  A probe grid that
+// reaches past the box hits wall voxels out there — 0.7 % of C3's wall hits, 3 % of C5's — and ONE such lane sends its
+// whole 64-lane group through the out-of-line albedo.
+constexpr int kR1Lo0 = -80, kR1Lo1 = -48, kR1Lo2 = -80;
+constexpr int kR1N0 = 160, kR1N1 = 96, kR1N2 = 160;
 }  // namespace lut
 
 struct NoiseLut
@@ -125,11 +126,6 @@ struct NoiseLut
     // wall[o*ny + (iy-y0)] for octave o = 0..7 (freq 2..256) holds that value
     const float* wall = nullptr;
     const float* r1 = nullptr;    // random1(cell), x fastest
-    // Device hot paths only: where to note that a lattice point fell outside the tables INSTEAD of evaluating the hash in
-    // place (the value returned is then meaningless and the caller redoes the whole albedo out of line, ddgi_trace_wf.hip:
-    // block_albedo_computed).  A binary64 sine is an out-of-line call; inlined into every table miss of every block type
-    // it put 161 call sites into the trace kernel, and every one of them constrains the kernel's register allocation.
-    bool* miss = nullptr;
 };
 constexpr float kWallFbmX = 0.05f;
 DDGI_HD float random1_at(f3 cell, const NoiseLut& L)  // random1 of a voxel id (integer-valued floats)
@@ -138,11 +134,6 @@ DDGI_HD float random1_at(f3 cell, const NoiseLut& L)  // random1 of a voxel id (
                    uz = static_cast<unsigned>(gl_int(cell.z) - lut::kR1Lo2);
     if (L.r1 && ux < static_cast<unsigned>(lut::kR1N0) && uy < static_cast<unsigned>(lut::kR1N1) && uz < static_cast<unsigned>(lut::kR1N2))
         return L.r1[(uz * static_cast<unsigned>(lut::kR1N1) + uy) * static_cast<unsigned>(lut::kR1N0) + ux];
-    if (L.miss)
-    {
-        *L.miss = true;
-        return 0.0f;
-    }
     return random1(cell);
 }
 
@@ -157,11 +148,6 @@ DDGI_HD float interp_noise2D(float x, float y, const NoiseLut& L = NoiseLut())  
     {
         const float* q = L.n2 + static_cast<size_t>(ux) * lut::kN2NY + uy;
         a = q[0], c = q[1], b = q[lut::kN2NY], d = q[lut::kN2NY + 1];
-    }
-    else if (L.miss)
-    {
-        *L.miss = true;
-        a = b = c = d = 0.0f;
     }
     else
     {
@@ -211,11 +197,6 @@ DDGI_HD float noise1_at(float i, const NoiseLut& L)
 {
     const unsigned u = static_cast<unsigned>(gl_int(i) - lut::kN1I0);
     if (L.n1 && u < static_cast<unsigned>(lut::kN1N)) return L.n1[u];
-    if (L.miss)
-    {
-        *L.miss = true;
-        return 0.0f;
-    }
     return noise1(i);
 }
 DDGI_HD float interp_noise1D(float x, const NoiseLut& L = NoiseLut())  // :441-448
@@ -248,11 +229,6 @@ DDGI_HD f2 worley_point(f2 cell, const NoiseLut& L)
     {
         const float* q = L.wp + (static_cast<size_t>(ux) * lut::kWpN + uy) * 2;
         return f2{q[0], q[1]};
-    }
-    if (L.miss)
-    {
-        *L.miss = true;
-        return f2{0.0f, 0.0f};
     }
     return worley_point_eval(cell);
 }

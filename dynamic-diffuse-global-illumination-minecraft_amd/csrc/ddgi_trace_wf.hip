@@ -516,10 +516,6 @@ DDGI_D void feeler_outcome(const LightK& L, f3 hpos, f3 nh, f3 hcol, bool any_hi
     }
 }
 
-// block_albedo with every lattice hash evaluated (binary64 sines) instead of read from the tables: the cold path of a hit whose
-// lattice points the tables do not cover.  A table entry IS the hash's value, so both give the same bits.  ONE call site.
-__device__ __attribute__((noinline, cold)) inline f3 block_albedo_computed(f3 p, int type, f3 n) { return block_albedo(p, type, n, NoiseLut()); }
-
 // One event of pool slot `slot` in bucket b (ddgi_trace_wf.hip: shade_bucket): shades a finished march /
 // starts local ray r in an empty slot (b == kBucketRefill).  Returns true when the slot has a new march
 // posted that goes on (return 1: its state is in the pool arrays, its shading record stored), when the new
@@ -667,20 +663,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     const bool ordinary = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))) < 0x1.0p20f;
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary)) DDGI_PROBE(lp, 1);  // section 1: albedo
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary))
-                    {
-                        // the albedo from the memoised lattice tables; a hit whose lattice points fall outside them (user scenes,
-                        // far-out probes) is redone as a whole, out of line, with every hash computed — the same value
-                        NoiseLut lut = A.noise;
-                        bool lut_miss = false;
-                        lut.miss = &lut_miss;
-                        hcol = (Cfg::ablate(A) & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, lut);
-                        if (lut_miss) hcol = block_albedo_computed(p, type, nn);
-                        if ((Cfg::ablate(A) & 16) && A.stats)  // profiling build: albedo evaluations by block type, table misses
-                        {
-                            if (lut_miss) atomicAdd(&A.stats[16 + (type & 15)], 1ull);
-                            if (lut_miss) atomicAdd(&A.stats[type == 9 ? 31 : 30], 1ull);
-                        }
-                    }
+                        hcol = (Cfg::ablate(A) & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
 #ifdef DDGI_LAP
                     DDGI_PROBE(lp, 7);  // after the albedo: visibility class, feeler decision
 #endif

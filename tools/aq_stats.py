@@ -28,6 +28,3 @@ print("feelers per ray (profiling build, ablate 16):", {k: round(v / rays, 3) fo
 for nm, (visits, lanes) in st["sections"].items():
     if visits:
         print("  section %-34s visits %8d  lanes/visit %5.1f  lane-visits/ray %6.2f" % (nm, visits, lanes / visits, lanes / rays))
-if os.environ.get("DDGI_LIB", "").endswith("_prof.so"):
-    print("albedo evaluations per ray by block type (profiling build):", {t: round(v / rays, 4) for t, v in enumerate(st["bucket_cycles"] + st["bucket_groups"][:6]) if v},
-          " lattice-table misses per ray: stem %.4f, others %.4f" % (st["bucket_groups"][7] / rays, st["bucket_groups"][6] / rays))
