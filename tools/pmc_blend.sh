@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD S
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES -d $OUT -o mfma --output-format csv -- $BENCH > $OUT/mfma.log 2>&1
 python3 - <<PY
 import csv, collections
-print("# rocprofv3 --pmc passes on `bench.py --mode ddgi --steps 3 --warmup 1`: per-launch means of the DDGI blend kernels (C3: 16 384 probes x 256 rays)")
+print("# rocprofv3 --pmc passes on bench.py --mode ddgi --steps 3 --warmup 1: per-launch means of the DDGI blend kernels (C3: 16 384 probes x 256 rays)")
 for f in ["sq1","sq2","mfma","mem","memw"]:
     agg=collections.defaultdict(list)
     try:
