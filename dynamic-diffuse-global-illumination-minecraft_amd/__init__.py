@@ -32,6 +32,7 @@ from .probe_engine import (  # noqa: F401
     probe_tile_origin,
     read_scene_file,
     scene_block_at,
+    scene_skip_field,
     scene_save,
     texture_size,
 )

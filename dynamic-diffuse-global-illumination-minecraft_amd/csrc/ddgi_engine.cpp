@@ -1635,6 +1635,19 @@ int ddgi_scene_block_at(int scene, int x, int y, int z)
     return baked_scene(scene).block_at(x, y, z);
 }
 
+int ddgi_scene_skip_field(int scene, int32_t lo[3], int32_t dim[3], uint8_t* codes, size_t capacity)
+{
+    if (scene < 0 || scene > 2 || !lo || !dim) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2} / null output", scene);
+    const SceneBake& b = baked_scene(scene);
+    for (int a = 0; a < 3; ++a) lo[a] = b.lo[a], dim[a] = b.dim[a];
+    if (!codes) return DDGI_OK;  // (size query)
+    if (capacity < b.types.size()) return fail(DDGI_ERR_INVALID_ARGUMENT, "capacity %zu < %zu voxels", capacity, b.types.size());
+    std::vector<uint32_t> words;
+    build_skip_field(b, 0, words);
+    for (size_t i = 0; i < b.types.size(); ++i) codes[i] = static_cast<uint8_t>((words[i >> 4] >> ((i & 15) * 2)) & 3u);
+    return DDGI_OK;
+}
+
 float ddgi_pinned_sinf(float x) { return pm::sinf_pinned(x); }
 float ddgi_pinned_cosf(float x) { return pm::cosf_pinned(x); }
 float ddgi_pinned_acosf(float x) { return pm::acosf_pinned(x); }

@@ -168,6 +168,7 @@ _SIGNATURES = {
     "ddgi_scene_load": (C.c_int, [_VP, C.c_char_p]),
     "ddgi_scene_set_grid": (C.c_int, [_VP, _VP, _VP, _VP]),
     "ddgi_scene_block_at": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ddgi_scene_skip_field": (C.c_int, [C.c_int, _VP, _VP, _VP, C.c_size_t]),
     "ddgi_pinned_sinf": (C.c_float, [C.c_float]),
     "ddgi_pinned_cosf": (C.c_float, [C.c_float]),
     "ddgi_pinned_acosf": (C.c_float, [C.c_float]),
@@ -276,6 +277,15 @@ def read_scene_file(path):
     lo, dim = tuple(int(v) for v in hdr[2:5]), tuple(int(v) for v in hdr[5:8])
     types = np.frombuffer(raw, dtype=np.uint8, count=dim[0] * dim[1] * dim[2], offset=8 + 32 + 4)
     return lo, dim, types.reshape(dim[2], dim[1], dim[0]).copy()
+
+
+def scene_skip_field(scene):
+    """(lo, codes[z, y, x]) — the fast march's skip field of a built-in scene, one byte per voxel of the bake box (host only)."""
+    lo, dim = (C.c_int32 * 3)(), (C.c_int32 * 3)()
+    _check(load_library().ddgi_scene_skip_field(scene, lo, dim, None, 0))
+    codes = np.empty((dim[2], dim[1], dim[0]), dtype=np.uint8)
+    _check(load_library().ddgi_scene_skip_field(scene, lo, dim, _ptr(codes), codes.size))
+    return tuple(lo), codes
 
 
 def scene_block_at(scene, x, y, z):

@@ -418,6 +418,12 @@ int ddgi_scene_set_grid(ddgi_handle h, const int32_t lo[3], const int32_t dim[3]
  * oracle. */
 int ddgi_scene_block_at(int scene, int x, int y, int z);
 
+/* The fast march's skip field of a built-in scene (tuning "fast_march"; csrc/ddgi_device.h: fast_march_step), unpacked to one byte
+ * per voxel of the bake box (x fastest): 0 = occupied, else 1 + min(r, 2) with r the voxel's free Chebyshev radius — every voxel
+ * within r of it, in the world the kernels see (outside the box the border layer repeats), is empty.  lo / dim receive the box;
+ * codes == NULL only queries them.  Usable without a GPU; exists so the field's guarantee can be checked by brute force. */
+int ddgi_scene_skip_field(int scene, int32_t lo[3], int32_t dim[3], uint8_t* codes, size_t capacity);
+
 /* The pinned elementary functions the engine uses on host and device ("Arithmetic
  * pinning"); exported so tests can compare them with libm and with the oracle's restatement. */
 float ddgi_pinned_sinf(float x);

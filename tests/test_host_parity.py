@@ -124,3 +124,25 @@ def test_repeated_generate_calls_continue_the_rand_sequence(ddgi, oracle):
     assert first.tobytes() != second.tobytes()
     mine2 = ddgi.generate_probe_rays_host(ddgi.make_field(counts, side, s, origin), seed=1, skip_calls=1)
     assert mine2.tobytes() == second.tobytes()
+
+
+@pytest.mark.parametrize("scene", [0, 1, 2])
+def test_skip_field_is_a_lower_bound_of_the_free_radius(ddgi, scene):
+    """The fast march (tolerance mode) skips `code - 1` voxels beyond grid_march's own step on the strength of the scene's skip
+    field: code 0 = occupied, else every voxel within Chebyshev distance code - 1 — in the world the kernels see, i.e. with clamped
+    lookups outside the bake box — must be empty, and the code must be the largest (up to 3) for which that holds.  Brute force."""
+    from scipy import ndimage
+
+    lo, codes = ddgi.scene_skip_field(scene)
+    nz, ny, nx = codes.shape
+    occ = np.zeros(codes.shape, dtype=bool)
+    for iz in range(nz):   # the bake, voxel by voxel, through the same clamped lookup the kernels' world is defined by
+        for iy in range(ny):
+            for ix in range(0, nx, max(1, nx // 8)):   # (a spread of columns suffices to tie `codes == 0` to the bake ...)
+                assert (ddgi.scene_block_at(scene, lo[0] + ix, lo[1] + iy, lo[2] + iz) > 0) == (codes[iz, iy, ix] == 0)
+    occ = codes == 0                                   # (... the rest of the check uses the field's own occupancy)
+    pad = np.pad(occ, 3, mode="edge")                  # outside the box the border layer repeats
+    dist = ndimage.distance_transform_cdt(~pad, metric="chessboard")[3:-3, 3:-3, 3:-3]   # Chebyshev distance to the nearest occupied voxel
+    want = np.where(occ, 0, np.minimum(dist, 3)).astype(np.uint8)   # free radius r = dist - 1; code = 1 + min(r, 2) = min(dist, 3)
+    assert np.array_equal(codes, want)
+    assert (codes == 3).any() and (codes == 1).any()
