@@ -83,7 +83,6 @@ static const TuningKey kTuningKeys[] = {
     {"wf_drain", &Tuning::wf_drain, "DDGI_WF_DRAIN"},
     {"wait_threshold", &Tuning::wait_threshold, "DDGI_WAIT_THRESHOLD"},
     {"fast_march", &Tuning::fast_march, "DDGI_FAST_MARCH"},
-    {"probe_order", &Tuning::probe_order, "DDGI_PROBE_ORDER"},
     {"light_vis", &Tuning::light_vis, "DDGI_LIGHT_VIS"},
     {"sample_group", &Tuning::sample_group, "DDGI_SAMPLE_GROUP"},
     {"sample_box", &Tuning::sample_box, "DDGI_SAMPLE_BOX"},
@@ -403,7 +402,6 @@ int ddgi_destroy(ddgi_handle e)
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->d_sample_scratch) (void)hipFree(e->d_sample_scratch);
     if (e->d_box) (void)hipFree(e->d_box);
-    if (e->d_probe_order) (void)hipFree(e->d_probe_order);
     if (e->d_blend_w) (void)hipFree(e->d_blend_w);
     if (e->d_work) (void)hipFree(e->d_work);
     if (e->d_wf_cold) (void)hipFree(e->d_wf_cold);
@@ -666,53 +664,6 @@ static unsigned long long aq_config_key(const ddgi_engine* e, const TraceArgs& a
     return h | 1ull;
 }
 
-// The order in which a launch hands out its probes (TraceArgs::probe_order).  The launch's rays are claimed 64 at a time from one
-// counter; its last claims decide how long the pool takes to drain, because a ray's life is a chain of up to 8 x (march + event)
-// that nothing shortens.  A probe that stands in rock sends rays that end with their first step at every bounce — a tenth of the
-// life of a ray that crosses the cave.  So the probes in open space go first and the launch ends on short-lived rays: the tail
-// that used to be the long rays' lives is filled with work.  Openness = the Chebyshev distance from the probe's voxel to the
-// nearest occupied one (capped at 8).  A schedule only — any order writes the same texels.
-static int ensure_probe_order(ddgi_engine* e, const GridK& g, int scene, unsigned long long key)
-{
-    if (e->d_probe_order && e->probe_order_key == key) return DDGI_OK;
-    const SceneBake& b = scene == 3 ? e->user_scene : baked_scene(scene);
-    constexpr int kCap = 8;
-    std::vector<uint8_t> open;
-    scene_openness(b, kCap, open);
-    const size_t n_local = static_cast<size_t>(g.cx) * g.cy * g.czl;
-    std::vector<uint8_t> cls(n_local);
-    size_t count[kCap + 1] = {};
-    for (int y = 0; y < g.cy; ++y)
-        for (int zl = 0; zl < g.czl; ++zl)
-            for (int x = 0; x < g.cx; ++x)
-            {
-                const float pos[3] = {probe_axis_position(x, g.cx, g.side, g.origin[0]), probe_axis_position(y, g.cy, g.side, g.origin[1]),
-                                      probe_axis_position(g.z0 + zl, g.cz, g.side, g.origin[2])};
-                int v[3] = {static_cast<int>(std::ceil(pos[0])), static_cast<int>(std::ceil(pos[1])), static_cast<int>(std::ceil(pos[2]))};
-                for (int a = 0; a < 3; ++a) v[a] = std::min(std::max(v[a], b.lo[a]), b.hi[a]);
-                const uint8_t c = open[(static_cast<size_t>(v[2] - b.lo[2]) * b.dim[1] + (v[1] - b.lo[1])) * b.dim[0] + (v[0] - b.lo[0])];
-                cls[(static_cast<size_t>(y) * g.czl + zl) * g.cx + x] = c;
-                count[c] += 1;
-            }
-    size_t at[kCap + 1];
-    size_t run = 0;
-    for (int c = kCap; c >= 0; --c) at[c] = run, run += count[c];  // most open first
-    std::vector<uint32_t> order(n_local);
-    for (size_t pl = 0; pl < n_local; ++pl) order[at[cls[pl]]++] = static_cast<uint32_t>(pl);
-    if (n_local > e->probe_order_capacity)
-    {
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        if (e->d_probe_order) (void)hipFree(e->d_probe_order);
-        e->d_probe_order = nullptr, e->probe_order_capacity = 0, e->probe_order_key = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_probe_order), n_local * sizeof(uint32_t)));
-        e->probe_order_capacity = n_local;
-    }
-    HIP_TRY(hipStreamSynchronize(e->stream));  // (an update in flight may still be reading the previous order)
-    HIP_TRY(hipMemcpy(e->d_probe_order, order.data(), n_local * sizeof(uint32_t), hipMemcpyHostToDevice));
-    e->probe_order_key = key;
-    return DDGI_OK;
-}
-
 // One probe update's trace launch, fully decided: arguments, kernel, pool, grid.  Built by plan_trace (which
 // also makes sure every buffer the launch needs exists), used by ddgi_probe_update and ddgi_tune.
 struct TracePlan
@@ -916,23 +867,6 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
         if (p.grid > chunks) p.grid = chunks;
     }
     p.key = aq_config_key(e, a, p.ddgi_mode);
-    if (tn.probe_order && p.pool > 0)
-    {
-        // (the order depends on the grid, the shard and the scene — all part of the configuration key; not on mode, lights or march)
-        unsigned long long okey = 1469598103934665603ull;
-        auto mix = [&](unsigned long long v) { okey = (okey ^ v) * 1099511628211ull; };
-        for (int i = 0; i < 3; ++i) mix(static_cast<unsigned>(e->field.probe_count[i]));
-        mix(static_cast<unsigned>(e->field.side_length));
-        for (int i = 0; i < 3; ++i)
-        {
-            unsigned u;
-            std::memcpy(&u, &e->field.field_origin[i], 4);
-            mix(u);
-        }
-        mix(static_cast<unsigned>(scene)), mix(static_cast<unsigned>(e->rank)), mix(static_cast<unsigned>(e->world)), mix(e->scene_epoch);
-        if (int rc = ensure_probe_order(e, a.grid, scene, okey | 1ull)) return rc;
-        a.probe_order = e->d_probe_order;
-    }
     return DDGI_OK;
 }
 
@@ -1295,7 +1229,6 @@ static int ensure_sample_box(ddgi_engine* e, const GridK& grid)
     {
         HIP_TRY(hipStreamSynchronize(e->stream));
         if (e->d_box) (void)hipFree(e->d_box);
-    if (e->d_probe_order) (void)hipFree(e->d_probe_order);
         e->d_box = nullptr, e->box_texels = 0, e->box_of = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_box), texels * sizeof(float4)));
         e->box_texels = texels;

@@ -25,7 +25,6 @@ struct Tuning
     int blend_kernel = 0;   // DDGI blend: 0 auto, 1 one probe per workgroup (cross-check)
     int aq_pool = 0, wf_pool = 0, wf_maxpool = 0, wf_threads = 1024;
     int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
-    int probe_order = 1;    // trace the probes that stand in open space first (their rays live longest): a schedule, results do not depend on it
     int fast_march = 0;     // tolerance mode: marches skip empty space (NOT bit-exact; tests/test_gpu_fast_march.py states the tolerance)
     int light_vis = 1;      // per-voxel light-feeler classes (k_light_visibility): 0 = march every feeler
     int sample_box = 1;     // REF ddgi_sample*: large batches go through the per-texel table of sample_probe (0: every point evaluates its 8 x 26 texels)
@@ -141,9 +140,6 @@ struct ddgi_engine
         int cur = 0;               // pair written by the most recent update
         unsigned long long k = 0;  // updates issued since the exchange was set up
     } xch;
-    uint32_t* d_probe_order = nullptr;      // trace schedule: local probes, the ones in open space first (ddgi_engine.cpp: ensure_probe_order)
-    size_t probe_order_capacity = 0;
-    unsigned long long probe_order_key = 0; // the configuration it was built for (0: none)
     float4* d_box = nullptr;                // REF mode: sample_probe per texel of the current textures (k_sample_box_filter), built on demand
     size_t box_texels = 0;
     const void* box_of = nullptr;           // ... the texture it was built from (null: stale — any update, exchange or rebind resets it)

@@ -137,41 +137,6 @@ void build_skip_field(const SceneBake& b, int shift, std::vector<uint32_t>& word
     }
 }
 
-void scene_openness(const SceneBake& b, int cap, std::vector<uint8_t>& dist)
-{
-    const int nx = b.dim[0], ny = b.dim[1], nz = b.dim[2];
-    const size_t n = b.types.size();
-    std::vector<uint8_t> cur(n), nxt(n), tmp(n);
-    for (size_t i = 0; i < n; ++i) cur[i] = b.types[i] ? 1 : 0;
-    dist.assign(n, static_cast<uint8_t>(cap));
-    for (size_t i = 0; i < n; ++i)
-        if (cur[i]) dist[i] = 0;
-    auto dilate_axis = [&](const std::vector<uint8_t>& src, std::vector<uint8_t>& dst, int axis) {
-        const int dim[3] = {nx, ny, nz};
-        const size_t stride[3] = {1, static_cast<size_t>(nx), static_cast<size_t>(nx) * ny};
-        for (int z = 0; z < nz; ++z)
-            for (int y = 0; y < ny; ++y)
-                for (int x = 0; x < nx; ++x)
-                {
-                    const int c[3] = {x, y, z};
-                    const size_t i = (static_cast<size_t>(z) * ny + y) * nx + x;
-                    uint8_t v = src[i];
-                    if (c[axis] > 0) v |= src[i - stride[axis]];
-                    if (c[axis] + 1 < dim[axis]) v |= src[i + stride[axis]];
-                    dst[i] = v;
-                }
-    };
-    for (int r = 1; r < cap; ++r)
-    {
-        dilate_axis(cur, nxt, 0);
-        dilate_axis(nxt, tmp, 1);
-        dilate_axis(tmp, nxt, 2);
-        for (size_t i = 0; i < n; ++i)
-            if (nxt[i] && !cur[i]) dist[i] = static_cast<uint8_t>(r);
-        cur.swap(nxt);
-    }
-}
-
 const SceneBake& baked_scene(int scene)
 {
     static std::array<SceneBake, 3> cache;

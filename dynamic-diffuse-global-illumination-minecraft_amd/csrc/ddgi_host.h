@@ -29,10 +29,6 @@ const SceneBake& baked_scene(int scene);  // cached, thread-safe; scene in {0,1,
 // occupancy bitmap (ddgi_engine.cpp: ensure_scene), 16 entries per word.
 void build_skip_field(const SceneBake& b, int shift, std::vector<uint32_t>& words);
 
-// Chebyshev distance of every voxel of the bake box to the nearest occupied voxel (0 = occupied), capped at `cap`, in the world the
-// kernels see (edges replicated).  A scheduling aid: how long the marches of a probe that stands there tend to be.
-void scene_openness(const SceneBake& b, int cap, std::vector<uint8_t>& dist);
-
 // glibc rand() (random_r TYPE_3) restated: the reference draws its ray jitter from the unseeded C
 // library generator (src/rvpt/rvpt.cpp:1161-1162).
 struct GlibcRand

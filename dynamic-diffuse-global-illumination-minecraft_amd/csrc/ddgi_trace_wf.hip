@@ -534,13 +534,9 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
     {
         if (r_valid)
         {
-            // the r-th ray of the launch: ray i of the local probe that the schedule puts in place r / n (A.probe_order: probes whose rays
-            // live long first, so that the launch's tail is made of short-lived ones; any order gives the same texels)
-            const int pl_seq = static_cast<int>(r / static_cast<uint32_t>(rays_per_probe));
-            const int i = static_cast<int>(r) - pl_seq * rays_per_probe;
-            const int pl = A.probe_order ? static_cast<int>(A.probe_order[pl_seq]) : pl_seq;
-            r = static_cast<uint32_t>(pl * rays_per_probe + i);
             // local (y, zl, x) probe enumeration -> reference probe index p -> global ray index
+            const int pl = static_cast<int>(r / static_cast<uint32_t>(rays_per_probe));
+            const int i = static_cast<int>(r) - pl * rays_per_probe;
             const int slab_row = G.czl * G.cx;
             const int y = pl / slab_row;
             const int rem = pl - y * slab_row;

@@ -104,7 +104,6 @@ struct TraceArgs
     float rot[9];
     float* rad_rgb;  // ray records, see RayRecords
     float* rad_dd;
-    const uint32_t* probe_order;  // local probe handled r-th (a schedule, not a result: probes in open space first, see ddgi_engine.cpp), or null: in order
     int fast_march;      // tolerance mode (ddgi_set_tuning "fast_march"): marches skip empty space (ddgi_device.h: fast_march_step)
     const uint8_t* vis;  // single light: feeler classes per (voxel of the baked box, face): [voxel * 8 + face] (k_light_visibility), or null
     const uint32_t* vis_occ;  // ... and for class kVisListed the occupied voxels of the bundle: [(voxel * 8 + face) * kVisListMax + k]
