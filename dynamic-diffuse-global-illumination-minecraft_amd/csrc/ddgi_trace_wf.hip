@@ -241,6 +241,17 @@ struct CfgRuntimeT
     static DDGI_D bool ddgi(const TraceArgs& A) { return A.ddgi != 0; }
 };
 using CfgRuntime = CfgRuntimeT<false>;
+// CfgMulti<kMode>: any number of lights (read from the arguments), everything else as CfgPlain — BASELINE's S-Dyn configuration
+// (4 animated lights) would otherwise run the fully generic instantiation with its run-time pool and mode.
+template <int kMode, bool kFastT = false>
+struct CfgMulti
+{
+    static constexpr int kNl = 0;
+    static constexpr bool kFast = kFastT;
+    static DDGI_D int nl(const TraceArgs& A) { return A.nl; }
+    static DDGI_D int ablate(const TraceArgs&) { return 0; }
+    static DDGI_D bool ddgi(const TraceArgs&) { return kMode != 0; }
+};
 template <int kMode, bool kFastT = false>
 struct CfgPlain
 {
@@ -1643,6 +1654,9 @@ hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_block
     if (pool == kAqPool && args.nl == 1 && args.ablate == 0)
         return args.ddgi ? launch_aq<false, kAqPool, CfgPlain<1>>(args, pool, grid_blocks, march_waves, work_counter, status, stream)
                          : launch_aq<false, kAqPool, CfgPlain<0>>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+    if (pool == kAqPool && args.nl > 1 && args.ablate == 0)
+        return args.ddgi ? launch_aq<false, kAqPool, CfgMulti<1>>(args, pool, grid_blocks, march_waves, work_counter, status, stream)
+                         : launch_aq<false, kAqPool, CfgMulti<0>>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
     return launch_aq<false, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
 }
 
