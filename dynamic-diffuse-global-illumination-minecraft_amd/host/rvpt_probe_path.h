@@ -31,6 +31,12 @@ public:
     // ncclComm_t of that size/rank (ddgi_comm_create / ddgi_comm_create_all, or the host's own RCCL); draw() then
     // also issues the in-place all-gather of the probe textures, pipelined behind the next frame's update.
     RVPTProbePath(int device, int rank, int world, void* nccl_comm) : device_(device), rank_(rank), world_(world), comm_(nccl_comm) {}
+    // The same slab with the peer-to-peer exchange instead of RCCL (one process per rank; ddgi_exchange_p2p_*): every rank pushes
+    // its slab into its peers' IPC-mapped textures.  `gather(mine, all, bytes, user)` is the host's all-gather of `bytes` per rank
+    // in rank order (MPI_Allgather, a socket, pipes through a parent ...) — the only thing the library cannot do by itself; it
+    // returns false on failure.  Called by initialize() and again whenever the textures are recreated.
+    using AddressGather = bool (*)(const uint8_t* mine, uint8_t* all, size_t bytes, void* user);
+    RVPTProbePath(int device, int rank, int world, AddressGather gather, void* user) : device_(device), rank_(rank), world_(world), gather_(gather), gather_user_(user) {}
     ~RVPTProbePath() { shutdown(); }
     RVPTProbePath(const RVPTProbePath&) = delete;
     RVPTProbePath& operator=(const RVPTProbePath&) = delete;
@@ -48,7 +54,7 @@ public:
     {
         if (handle_) return true;
         if (!ok(ddgi_create_sharded(&ir, &render_settings, device_, rank_, world_, &handle_), "ddgi_create_sharded")) return false;
-        if (comm_ && !ok(ddgi_exchange_init(handle_, comm_, 1), "ddgi_exchange_init")) return false;
+        if (!attach_exchange()) return false;
         return flush_rays();
     }
 
@@ -66,7 +72,7 @@ public:
     bool draw()
     {
         if (!handle_ || !ok(ddgi_probe_update(handle_, &render_settings), "ddgi_probe_update")) return false;
-        return !comm_ || ok(ddgi_exchange(handle_), "ddgi_exchange");
+        return !(comm_ || gather_) || ok(ddgi_exchange(handle_), "ddgi_exchange");
     }
 
     // rvpt.cpp:661-755; keep_surviving_probes: probes that stand where an old probe stood keep their tiles
@@ -76,7 +82,7 @@ public:
         need_change_probe_texture_ = false;
         if (!handle_) return initialize();
         if (!ok(ddgi_reconfigure(handle_, &ir, &render_settings, keep_surviving_probes ? 1 : 0), "ddgi_reconfigure")) return false;
-        if (comm_ && !ok(ddgi_exchange_init(handle_, comm_, 1), "ddgi_exchange_init")) return false;  // reconfiguring detaches the exchange
+        if (!attach_exchange()) return false;  // reconfiguring detaches the exchange
         need_generate_probe_rays_ = true;
         return flush_rays();
     }
@@ -109,6 +115,21 @@ public:
     ddgi_handle native_handle() const { return handle_; }
 
 private:
+    // pipelined in both transports: two texture pairs, the exchange of frame k behind the update of frame k + 1
+    bool attach_exchange()
+    {
+        if (comm_) return ok(ddgi_exchange_init(handle_, comm_, 1), "ddgi_exchange_init");
+        if (!gather_) return true;
+        uint8_t mine[DDGI_P2P_ADDRESS_BYTES];
+        if (!ok(ddgi_exchange_p2p_export(handle_, 1, mine), "ddgi_exchange_p2p_export")) return false;
+        std::vector<uint8_t> all(static_cast<size_t>(world_) * DDGI_P2P_ADDRESS_BYTES);
+        if (!gather_(mine, all.data(), DDGI_P2P_ADDRESS_BYTES, gather_user_))
+        {
+            std::fprintf(stderr, "the host's address all-gather failed\n");
+            return false;
+        }
+        return ok(ddgi_exchange_p2p_init(handle_, all.data(), world_), "ddgi_exchange_p2p_init");
+    }
     bool flush_rays()
     {
         if (!need_generate_probe_rays_) return true;
@@ -123,6 +144,8 @@ private:
 
     int device_ = 0, rank_ = 0, world_ = 1;
     void* comm_ = nullptr;  // ncclComm_t, caller-owned
+    AddressGather gather_ = nullptr;  // peer-to-peer exchange: the host's all-gather of the 512-byte addresses
+    void* gather_user_ = nullptr;
     ddgi_handle handle_ = nullptr;
     bool need_generate_probe_rays_ = true;    // rvpt.h:96
     bool need_change_probe_texture_ = false;  // rvpt.h:95

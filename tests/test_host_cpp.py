@@ -59,3 +59,30 @@ def test_sharded_cpp_loop_every_rank_holds_the_unsharded_field(tmp_path, ddgi, o
     want, _ = oracle.probe_update(f, oracle.make_settings(1, 8), rays)
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("rank ")]
     assert lines and all(f"checksum {int(want.astype(np.uint64).sum())}" in ln for ln in lines), res.stdout
+
+
+P2P_SRC = os.path.join(PKG, "host", "example_p2p_loop.cpp")
+
+
+def test_p2p_cpp_host_compiles(tmp_path, ddgi):
+    _build(tmp_path, ddgi, P2P_SRC, extra=("-lamdhip64",))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_cpp_loop_every_rank_holds_the_unsharded_field(tmp_path, ddgi, oracle, world):
+    """A C++ host, one process per rank, no RCCL and no Python: 2 / 4 ranks on the test box's one GPU exchange their slabs through
+    the peer-to-peer transport (IPC-mapped textures, flags waited for by the command processor), new ray jitter every frame, the
+    exchange pipelined behind the next frame.  Every rank must print the checksum of the unsharded field after the last frame."""
+    frames = 4
+    exe = _build(tmp_path, ddgi, P2P_SRC, extra=("-lamdhip64",))
+    res = subprocess.run([str(exe), str(frames), str(world)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    f = oracle.make_field((2, 2, 8), 3, 8, (0.0, 0.0, 15.0))
+    st = oracle.new_rand_state(1)
+    for _ in range(frames):
+        rays = oracle.generate_probe_rays(f, st)      # (the host generator's sequence goes on from frame to frame, Q1)
+    want, _ = oracle.probe_update(f, oracle.make_settings(1, 8), rays)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("rank ")]
+    assert len(lines) == world and all(f"checksum {int(want.astype(np.uint64).sum())}" in ln for ln in lines), res.stdout
+    assert len({ln.split("pid ")[1].split(",")[0] for ln in lines}) == world   # really one process per rank
