@@ -1572,6 +1572,7 @@ static int fill_user_scene(ddgi_engine* e, const int lo[3], const int dim[3], co
     ddgi_engine::DevScene& d = e->dev_scene[3];
     if (d.bits) (void)hipFree(d.bits);
     if (d.types) (void)hipFree(d.types);
+    if (d.skip) (void)hipFree(d.skip);
     if (d.vis) (void)hipFree(d.vis);
     if (d.vis_occ) (void)hipFree(d.vis_occ);
     if (d.vis_list) (void)hipFree(d.vis_list);

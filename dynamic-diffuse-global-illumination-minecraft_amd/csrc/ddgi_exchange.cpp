@@ -141,7 +141,7 @@ struct ddgi_engine::P2P
     };
     uint32_t* flags = nullptr;   // own: [q] = ready, written by rank q; [kP2PMaxWorld + r] = arrived, written by rank r
     std::vector<Peer> peers;     // [world]; the own rank's entry is unused
-    uint32_t seq = 0;            // exchanges issued
+    uint32_t seq = 0;            // exchanges issued (the flags carry it and are compared with >=: good for 2^32 exchanges per attachment — 50 days at 1000 per second)
     uint32_t pair_seq[2] = {0, 0};  // exchange number that last filled pair i
     bool exported_pipelined = false;
     bool connected = false;

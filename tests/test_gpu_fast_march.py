@@ -150,3 +150,28 @@ def test_fast_march_falls_back_where_the_skip_field_does_not_fit(ddgi, oracle):
             got[fast] = eng.read_textures()[0]
             assert eng.get_tuning("fast_march_active") == 0
     assert np.array_equal(got[False], got[True]) and got[True][..., :3].any()
+
+
+def test_fast_march_on_a_user_scene(ddgi):
+    """A caller's voxel grid (scene 3) gets its own skip field when it is installed — and a second grid replaces it."""
+    rng = np.random.default_rng(8)
+    counts, side, s, origin = (4, 3, 4), 3, 8, (0.0, 6.0, 0.0)
+    lights = np.zeros(1, dtype=ddgi.LIGHT_DTYPE)
+    lights["intensity"], lights["col"], lights["pos"] = 30, [[1, 1, 1]], [[0.5, 12.5, 0.5]]
+    with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(3, 6)) as eng:
+        for density in (0.03, 0.12):
+            types = np.zeros((24, 20, 24), dtype=np.uint8)
+            types[:, :2, :] = 5
+            sprinkle = rng.random(types.shape) < density
+            types[sprinkle] = rng.integers(1, 14, size=int(sprinkle.sum()), dtype=np.uint8)
+            eng.set_scene_grid((-12, 0, -12), types)
+            eng.set_lights(3, lights)
+            eng.generate_probe_rays(seed=1, reseed=True)
+            got = {}
+            for fast in (1, 0):
+                eng.set_tuning("fast_march", fast)
+                eng.probe_update()
+                got[fast] = eng.read_textures()[0]
+                assert eng.get_tuning("fast_march_active") == fast
+            within, mean, _ = texel_tolerance_stats(got[1], got[0])
+            assert within >= 0.999 and mean < 0.05 and got[0][..., :3].any(), (density, within, mean)
