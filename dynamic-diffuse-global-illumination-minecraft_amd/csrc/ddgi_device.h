@@ -167,6 +167,26 @@ DDGI_D bool march_step_burst(March& m, const SceneK& S, const uint32_t* __restri
     return __builtin_amdgcn_ubfe(base[idx >> 5], static_cast<uint32_t>(idx), 1u) != 0u;
 }
 
+// march_step_burst for a burst WITHOUT exec-mask predication: a lane whose march has ended (`frozen`) takes a step of length 0 —
+// t, hence the position and the voxel looked up, stay what they were, bit for bit — instead of being masked out of the step.  One
+// v_cndmask per step in place of the s_and_saveexec / s_or pair and its bookkeeping around every step of the unrolled burst.
+DDGI_D bool march_step_frozen(March& m, const SceneK& S, const uint32_t* __restrict__ s_bits, f3 hi, bool frozen)
+{
+    const float fx = gl_fract(m.p.x), fy = gl_fract(m.p.y), fz = gl_fract(m.p.z);
+    const float tx = (m.cc.x - fx) * m.inv.x;
+    const f2v tyz = (f2v{m.cc.y, m.cc.z} - f2v{fy, fz}) * f2v{m.inv.y, m.inv.z};
+    const float step = fminf(fminf(tx, tyz.x), tyz.y) + 0.0001f;
+    m.t += frozen ? 0.0f : step;
+    m.p = ray_at(m.ro, m.dn, m.t);
+    const float kx = __builtin_amdgcn_fmed3f(ceilf(m.p.x), S.lo_f[0], hi.x);
+    const float ky = __builtin_amdgcn_fmed3f(ceilf(m.p.y), S.lo_f[1], hi.y);
+    const float kz = __builtin_amdgcn_fmed3f(ceilf(m.p.z), S.lo_f[2], hi.z);
+    const int idx = static_cast<int>(fmaf(kz, S.nxy_f, fmaf(ky, S.nx_f, kx)));
+    m.cell = idx;
+    const uint32_t* __restrict__ base = s_bits - (S.bias32 >> 5);
+    return __builtin_amdgcn_ubfe(base[idx >> 5], static_cast<uint32_t>(idx), 1u) != 0u;
+}
+
 // ---- the fast march (tolerance mode, opt-in: ddgi_set_tuning "fast_march") -----------------------------------------
 // grid_march (intersection.glsl:1051-1100) re-derives every step from the position it has reached — t += (distance to
 // the next voxel boundary) + 1e-4 — so the position after crossing a given plane is that plane's t + 1e-4 whatever came
