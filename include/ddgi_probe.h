@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DDGI_ABI_VERSION 2
+#define DDGI_ABI_VERSION 3 /* 3: ddgi_exchange_p2p_*, ddgi_exchange_transport, ddgi_scene_skip_field; tuning "fast_march", "sample_box"; "autotune" off by default */
 
 /* ---- wire formats: byte-identical to the reference's UBO/SSBO records ------------------------ */
 
