@@ -1124,6 +1124,10 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
 #define DDGI_AQ_THIN 0
 #endif
 constexpr int kAqThinTrip = DDGI_AQ_THIN;    // a march wave with fewer lanes in flight (and nothing queued) yields for a moment
+#ifndef DDGI_AQ_PARTIAL_BELOW
+#define DDGI_AQ_PARTIAL_BELOW 64
+#endif
+constexpr uint32_t kAqPartialBelow = DDGI_AQ_PARTIAL_BELOW;  // an event wave takes a partial group only while fewer marches than this are queued
 constexpr int kAqEventQueues = 7;  // buckets 0..6 (kBucketRefill is served from FQ)
 
 struct AqShared  // control block at the start of dynamic LDS (32 dwords)
@@ -1490,7 +1494,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 k = __shfl(k, 0);
                 // 3) the fullest partial group — unless the march side still has work queued: then a full
                 //    group is worth waiting for
-                if (k == 0u && (no_more || aq_load(&sh->mq_tail) - aq_load(&sh->mq_head) < 64u))
+                if (k == 0u && (no_more || aq_load(&sh->mq_tail) - aq_load(&sh->mq_head) < kAqPartialBelow))
                 {
                     uint32_t best = 0, best_n = 0;
 #pragma unroll
