@@ -10,6 +10,7 @@
 #include "ddgi_sampler.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace ddgi {
 
@@ -444,15 +445,23 @@ DDGI_D void blend_depth_resident(const BlendArgs& A, const float* __restrict__ r
                 if (idx < kResGroupF4) sh.b_all[buf][idx] = r[k];
             }
         };
-        // texel waves (the first four): lane's output texel e = 64 sw_id + lane of a 16x16 tile, the staging offset of the interior
-        // texel it takes its sums from, and that texel's weight sum
+        // texel waves (the first four), a quarter of the 16x16 tile each: lane's output texel e, the staging offset of the interior
+        // texel it takes its sums from, and that texel's weight sum.  (Two quarters each on the two service waves that share their
+        // SIMD with ONE contraction wave: slower, 54 -> 60 us.)
+        constexpr int kQuarters = 1;
         const bool texel_wave = sw_id < 4;
-        const int e = 64 * (sw_id & 3) + lane, tx = e & (kDepTile - 1), ty = e / kDepTile;
-        int sx = tx, sy = ty;
-        if (tx == 0 || ty == 0 || tx == kDepTile - 1 || ty == kDepTile - 1) border_source(tx, ty, kDepTile, sx, sy);
-        const int c = (sy - 1) * (kDepTile - 2) + (sx - 1);
-        const int stage_off = (c >> 5) * (32 * kStageStride) + (c & 31) * kStageStride;
-        const float sw = w_sum[c];
+        const int first_quarter = sw_id & 3;
+        int e_q[kQuarters], stage_off_q[kQuarters];
+        float sw_q[kQuarters];
+#pragma unroll
+        for (int q = 0; q < kQuarters; ++q)
+        {
+            const int e = 64 * (first_quarter + q) + lane, tx = e & (kDepTile - 1), ty = e / kDepTile;
+            int sx = tx, sy = ty;
+            if (tx == 0 || ty == 0 || tx == kDepTile - 1 || ty == kDepTile - 1) border_source(tx, ty, kDepTile, sx, sy);
+            const int c = (sy - 1) * (kDepTile - 2) + (sx - 1);
+            e_q[q] = e, stage_off_q[q] = (c >> 5) * (32 * kStageStride) + (c & 31) * kStageStride, sw_q[q] = w_sum[c];
+        }
         const float hyst = G.hysteresis;
         {
             float4 r[kResLoads];
@@ -474,23 +483,41 @@ DDGI_D void blend_depth_resident(const BlendArgs& A, const float* __restrict__ r
                 const float* __restrict__ st = &sh.stage_all[(it - 1u) & 1u][0][0];
                 const uint32_t np = min(16u, A.n_local_probes - task * 16u);
                 const uint32_t my_slot = static_cast<uint32_t>(blend_tile_slot(G, min(task * 16u + static_cast<uint32_t>(lane & 15), A.n_local_probes - 1u)));
-                float2 old[16];
+                // A full group (all but possibly the last) runs as straight-line code: with a branch per probe the compiler no longer
+                // knows how many memory operations are in flight and waits for ALL of them — each probe's store included — before
+                // the next probe's texel; and a VALU instruction issued beside two contraction waves costs 22 cycles instead of 6
+                // (tools/microbench/mfma_valu_coissue.hip), so every instruction saved here counts four times.
+                auto texels = [&](auto full, int q) {
+                    constexpr bool kFull = decltype(full)::value;
+                    const int e = e_q[q], stage_off = stage_off_q[q];
+                    const float sw = sw_q[q];
+                    const bool divide = sw > 1e-6f;
+                    float2 old[16];
 #pragma unroll
-                for (uint32_t p = 0; p < 16u; ++p)
-                {
-                    const size_t tile_off = static_cast<size_t>(__builtin_amdgcn_readlane(my_slot, p)) * (kDepTile * kDepTile * 2);
-                    old[p] = p < np ? *reinterpret_cast<const float2*>(A.depth_old + tile_off + e * 2) : float2{0.0f, 0.0f};
-                }
-#pragma unroll
-                for (uint32_t p = 0; p < 16u; ++p)
-                    if (p < np)  // (wave-uniform)
+                    for (uint32_t p = 0; p < 16u; ++p)
                     {
                         const size_t tile_off = static_cast<size_t>(__builtin_amdgcn_readlane(my_slot, p)) * (kDepTile * kDepTile * 2);
-                        const float s0 = st[stage_off + static_cast<int>(p)], s1 = st[stage_off + 16 + static_cast<int>(p)];
-                        float r0 = 0.0f, r1 = 0.0f;
-                        if (sw > 1e-6f) r0 = s0 / sw, r1 = s1 / sw;
-                        *reinterpret_cast<float2*>(A.depth + tile_off + e * 2) = float2{gl_mix(old[p].x, r0, hyst), gl_mix(old[p].y, r1, hyst)};
+                        old[p] = (kFull || p < np) ? *reinterpret_cast<const float2*>(A.depth_old + tile_off + e * 2) : float2{0.0f, 0.0f};
                     }
+#pragma unroll
+                    for (uint32_t p = 0; p < 16u; ++p)
+                        if (kFull || p < np)  // (wave-uniform)
+                        {
+                            const size_t tile_off = static_cast<size_t>(__builtin_amdgcn_readlane(my_slot, p)) * (kDepTile * kDepTile * 2);
+                            const float s0 = st[stage_off + static_cast<int>(p)], s1 = st[stage_off + 16 + static_cast<int>(p)];
+                            const float q0 = s0 / sw, q1 = s1 / sw;  // (a lane whose weight sum is ~0 divides too and drops the quotient)
+                            const float r0 = divide ? q0 : 0.0f, r1 = divide ? q1 : 0.0f;
+                            *reinterpret_cast<float2*>(A.depth + tile_off + e * 2) = float2{gl_mix(old[p].x, r0, hyst), gl_mix(old[p].y, r1, hyst)};
+                        }
+                };
+#pragma unroll
+                for (int q = 0; q < kQuarters; ++q)
+                {
+                    if (np == 16u)
+                        texels(std::true_type{}, q);
+                    else
+                        texels(std::false_type{}, q);
+                }
             }
             if (more) park_records(static_cast<int>((it + 1u) & 1u), r);  // (that buffer was read last in the previous iteration)
             __syncthreads();
@@ -536,30 +563,42 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
         __syncthreads();
         const uint32_t np = min(32u, A.n_local_probes - task * 32u);
         constexpr uint32_t kBatch = 8;  // old tiles in flight per wave
-        for (uint32_t p0 = static_cast<uint32_t>(mi); p0 < np; p0 += 2u * kBatch)
-        {
-            float4 old[kBatch];
-#pragma unroll
-            for (uint32_t b = 0; b < kBatch; ++b)
+        const bool divide = sw > 1e-6f;
+        // (full groups as straight-line code: see blend_depth_resident)
+        auto tiles = [&](auto full) {
+            constexpr bool kFull = decltype(full)::value;
+            for (uint32_t p0 = static_cast<uint32_t>(mi); p0 < np; p0 += 2u * kBatch)
             {
-                const uint32_t p = min(p0 + 2u * b, 31u);
-                old[b] = *reinterpret_cast<const float4*>(A.irradiance_old + static_cast<size_t>(slot_sh[p]) * (kIrrTile * kIrrTile * 4) + e * 4);
-            }
+                float4 old[kBatch];
 #pragma unroll
-            for (uint32_t b = 0; b < kBatch; ++b)
-            {
-                const uint32_t p = p0 + 2u * b;
-                if (p < np)  // (wave-uniform)
+                for (uint32_t b = 0; b < kBatch; ++b)
                 {
-                    float res[3] = {0.0f, 0.0f, 0.0f};
-                    if (sw > 1e-6f)
+                    const uint32_t p = min(p0 + 2u * b, 31u);
+                    old[b] = *reinterpret_cast<const float4*>(A.irradiance_old + static_cast<size_t>(slot_sh[p]) * (kIrrTile * kIrrTile * 4) + e * 4);
+                }
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) res[k] = stage_src[k * (32 * kStageStride) + static_cast<int>(p)] / sw;
-                    *reinterpret_cast<float4*>(A.irradiance + static_cast<size_t>(slot_sh[p]) * (kIrrTile * kIrrTile * 4) + e * 4) =
-                        float4{gl_mix(old[b].x, res[0], hyst), gl_mix(old[b].y, res[1], hyst), gl_mix(old[b].z, res[2], hyst), 1.0f};
+                for (uint32_t b = 0; b < kBatch; ++b)
+                {
+                    const uint32_t p = p0 + 2u * b;
+                    if (kFull || p < np)  // (wave-uniform)
+                    {
+                        float res[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                        {
+                            const float q = stage_src[k * (32 * kStageStride) + static_cast<int>(p)] / sw;  // (dropped where the weight sum is ~0)
+                            res[k] = divide ? q : 0.0f;
+                        }
+                        *reinterpret_cast<float4*>(A.irradiance + static_cast<size_t>(slot_sh[p]) * (kIrrTile * kIrrTile * 4) + e * 4) =
+                            float4{gl_mix(old[b].x, res[0], hyst), gl_mix(old[b].y, res[1], hyst), gl_mix(old[b].z, res[2], hyst), 1.0f};
+                    }
                 }
             }
-        }
+        };
+        if (np == 32u)
+            tiles(std::true_type{});
+        else
+            tiles(std::false_type{});
     }
 }
 

@@ -1,5 +1,7 @@
 #!/bin/bash
+# blend kernels' times per build on the same GPU box:  tools/ab_blend.sh [alt names...]   (libddgi_probe_<name>.so from `make alt`)
 D=$PWD/dynamic-diffuse-global-illumination-minecraft_amd
-for lib in libddgi_probe.so $(cd $D; ls libddgi_probe_ng*.so); do
-  echo -n "$lib : "; DDGI_LIB=$D/$lib python tools/ddgi_timing.py 2>/dev/null | grep "trace ms" | sed 's/.*blend ms//'
+for rep in 1 2; do
+echo "== main"; bash tools/ddgi_kernel_times.sh X=0 | grep -i "blend"
+for n in "$@"; do echo "== $n"; bash tools/ddgi_kernel_times.sh DDGI_LIB=$D/libddgi_probe_$n.so | grep -i "blend"; done
 done
