@@ -245,10 +245,26 @@ DDGI_D void blend_contract3(const float* __restrict__ wa, const float* __restric
 // for a fixed column) and then walks it with lanes = texels, so that a probe's texels are written as runs of
 // consecutive addresses and everything that depends on the texel only (wrap destinations, weight sum) is set up once.
 constexpr int kStageStride = 33;
+template <int kStride = kStageStride>
 DDGI_D void stage_tile(float* stage, const f16v& acc, int col, int half)
 {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * half) * kStageStride + col] = acc[r];  // C/D map of the 32x32 MFMA
+    for (int r = 0; r < 16; ++r) stage[((r & 3) + 8 * (r >> 2) + 4 * half) * kStride + col] = acc[r];  // C/D map of the 32x32 MFMA
+}
+
+// Does any of the wave's sums lie outside pm::div_prepared's numerator domain (zero, or 2^-100 .. 2^60)?  Sums are >= +0 (weights
+// and records are), so their bit patterns order like the values; `u - 1` sends zero past every threshold.  (A negative, infinite or
+// NaN sum — records the engine did not write — counts as outside.)  Wave-uniform result.
+DDGI_D bool sums_outside_div_domain(const f16v& acc)
+{
+    uint32_t hi = 0u, lo = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+    {
+        const uint32_t u = __float_as_uint(acc[r]);
+        hi = max(hi, u), lo = min(lo, u - 1u);
+    }
+    return __builtin_amdgcn_ballot_w64(hi > pm::kDivPreparedHi || lo < pm::kDivPreparedLo - 1u) != 0ull;
 }
 
 // depth: workgroup = 7 waves, wave m = depth tile m of the 16 probes of a group; B columns = moment * 16 + probe
@@ -259,10 +275,12 @@ struct DepthShared
     float stage_all[kBlendWaves][32 * kStageStride];
     uint32_t slot_sh[16];  // tile slots of the group's probes (through LDS, not readlane: the epilogue runs under a partial exec mask)
 };
+constexpr int kIrrStageStride = 97;  // [texel row][3 probe + channel]: a texel's r, g, b side by side; odd: conflict-free for a fixed column
 struct IrrShared
 {
-    float stage_all[kIrrMTiles][3][32 * kStageStride];
-    uint32_t slot_sh[32];
+    float stage_all[kIrrMTiles][32 * kIrrStageStride];
+    uint32_t slot_sh[2][32];  // by task parity: written before the contraction, while the other wave may still read the previous task's
+    uint32_t unsafe[2];       // per wave: a sum of the group lies outside pm::div_prepared's domain
 };
 union BlendShared
 {
@@ -372,15 +390,52 @@ DDGI_D void blend_depth_role(const BlendArgs& A, const float* __restrict__ rad_d
 // A texel is mixed with the old value AT ITS OWN PLACE (the update may run in place, and a border's source is another lane's
 // output): for a border texel that is its source's old value because every tile this engine writes has its borders equal
 // to their sources, and fresh tiles are zero — tiles brought in through ddgi_bind_textures must keep that (ddgi_probe.h).
+// One step of a wave's MFMA chain, followed by wait states.  A wave whose next instruction is an MFMA that waits — for the
+// previous link of its chain, or for the matrix pipe while the SIMD's other chain has it — holds the SIMD's vector issue port while
+// it waits: a third wave on that SIMD gets to issue next to nothing, whatever its priority (tools/blend_laps.py: texel waves that
+// had nothing to do in a stage still reached its barrier 16 000 cycles late; tools/microbench/mfma_valu_coissue.hip: a chain written
+// as a loop, whose branch opens a gap after every MFMA, lets a third wave issue every 22 cycles).  So the chain steps aside by
+// itself: after an MFMA the wave idles in s_nop — which holds nothing — for most of the 128 clocks until its next MFMA can go
+// (two chains share a SIMD's pipe, 64 clocks each; a wait state is 4 clocks).  The MFMA is inline assembly so that the wait states stay behind it; the last
+// ones also cover the 18 wait states the hardware wants between a 16-pass MFMA and a read of its result by another unit.
+#ifndef DDGI_BLEND_PACE
+#define DDGI_BLEND_PACE 18  // wait states (4 clocks each) behind an MFMA of a paced chain; 0: no chain is paced
+#endif
+#define DDGI_STR2(x) #x
+#define DDGI_STR(x) DDGI_STR2(x)
+template <bool kPaced>
+DDGI_D f16v mfma_step(float a, float b, f16v acc)
+{
+#if DDGI_BLEND_PACE == 0
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#else
+    if (!kPaced) return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    static_assert(DDGI_BLEND_PACE >= 18 && DDGI_BLEND_PACE <= 32, "at least the 18 wait states between a 16-pass MFMA and a read of its result; two s_nop");
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n"
+                 "s_nop 15\n"
+                 "s_nop " DDGI_STR(DDGI_BLEND_PACE - 17)
+                 : "+v"(acc)
+                 : "v"(a), "v"(b));
+    return acc;
+#endif
+}
+
+#ifdef DDGI_BLEND_LAPS  // timing build (tools/blend_laps.py): workgroup 0's waves stamp s_memtime at the start, and before / after every stage's barrier
+__device__ unsigned long long g_blend_laps[14][24];  // rows 0-11: k_probe_blend_depth_res' waves; 12, 13: k_probe_blend_irr's
+#define BLEND_LAP(i) do { if (blockIdx.x == 0 && lane == 0 && (i) < 24) g_blend_laps[wave][(i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BLEND_LAP(i) do { } while (0)
+#endif
 constexpr int kResN4 = 32;                          // float4 per lane of a resident tile: 128 ray pairs
 constexpr int kResGroupF4 = kResN4 * 64;            // float4 of one group's records (16 probes x 2 moments x 256 rays)
 constexpr int kResServiceWaves = 5;
 constexpr int kResWaves = kBlendWaves + kResServiceWaves;
-constexpr int kResLoads = (kResGroupF4 + kResServiceWaves * 64 - 1) / (kResServiceWaves * 64);  // per service thread: 7
 struct DepthResShared
 {
     float4 b_all[2][kResGroupF4];
     float stage_all[2][kBlendWaves][32 * kStageStride];
+    uint32_t slots[2][16];    // tile slots of a group's probes (two integer divisions each: computed once, by the service wave with time to spare)
+    uint32_t unsafe[2][8];    // per contraction wave: a sum of the group lies outside pm::div_prepared's domain
 };
 DDGI_D void blend_depth_resident(const BlendArgs& A, const float* __restrict__ rad_dd, const float* __restrict__ w_tiles, const float* __restrict__ w_sum, DepthResShared& sh,
                                  uint32_t first_task, uint32_t task_stride)
@@ -390,6 +445,7 @@ DDGI_D void blend_depth_resident(const BlendArgs& A, const float* __restrict__ r
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t n_tasks = (A.n_local_probes + 15u) / 16u;
     const uint32_t my_tasks = first_task < n_tasks ? (n_tasks - first_task + task_stride - 1u) / task_stride : 0u;
+    BLEND_LAP(22);  // (entry)
     if (wave < kBlendWaves)
     {
         // ================= contraction waves: wave = depth tile =================
@@ -399,128 +455,175 @@ DDGI_D void blend_depth_resident(const BlendArgs& A, const float* __restrict__ r
 #pragma unroll
             for (int k = 0; k < kResN4; ++k) a_res[k] = pa[static_cast<size_t>(k) * 64];
         }
+        BLEND_LAP(0);
         __syncthreads();
+        BLEND_LAP(1);
         for (uint32_t it = 0; it <= my_tasks; ++it)
         {
             if (it < my_tasks)
             {
                 const int cur = static_cast<int>(it & 1u);
                 f16v acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                auto contract = [&](auto paced) {
 #pragma unroll
-                for (int k = 0; k < kResN4; ++k)
-                {
-                    const float4 bv = sh.b_all[cur][k * 64 + lane];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_res[k].x, bv.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_res[k].y, bv.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_res[k].z, bv.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_res[k].w, bv.w, acc, 0, 0, 0);
-                }
-                stage_tile(sh.stage_all[cur][wave], acc, lane & 31, lane >> 5);
+                    for (int k = 0; k < kResN4; ++k)
+                    {
+                        const float4 bv = sh.b_all[cur][k * 64 + lane];
+                        acc = mfma_step<decltype(paced)::value>(a_res[k].x, bv.x, acc);
+                        acc = mfma_step<decltype(paced)::value>(a_res[k].y, bv.y, acc);
+                        acc = mfma_step<decltype(paced)::value>(a_res[k].z, bv.z, acc);
+                        acc = mfma_step<decltype(paced)::value>(a_res[k].w, bv.w, acc);
+                    }
+                };
+#ifndef DDGI_BLEND_PACE_ALL
+#define DDGI_BLEND_PACE_ALL 0
+#endif
+                if (DDGI_BLEND_PACE_ALL || wave == 3)  // the one contraction wave of the texel waves' SIMD
+                    contract(std::true_type{});
+                else
+                    contract(std::false_type{});
+                stage_tile(sh.stage_all[cur][wave], acc, ((lane & 15) << 1) | ((lane >> 4) & 1), lane >> 5);  // column = 2 probe + moment: a texel's pair is adjacent
+                const bool outside = sums_outside_div_domain(acc);
+                if (lane == 0) sh.unsafe[cur][wave] = outside ? 1u : 0u;
             }
+            BLEND_LAP(2 + 2 * it);
             __syncthreads();
+            BLEND_LAP(3 + 2 * it);
         }
     }
     else
     {
         // ================= service waves =================
-        // (In-kernel clocks: a texel wave that shares its SIMD with two contraction waves needs 27 000 cycles per group for work
-        // that takes 5 000 alone — while an f32 MFMA of another wave runs, this wave's VALU instructions mostly wait — and is the
-        // critical path, not the 16 400 cycles of the two contractions.  Priority over the contraction waves buys 1 us of 55.)
-        __builtin_amdgcn_s_setprio(2);
-        const int sw_id = wave - kBlendWaves, st_tid = static_cast<int>(threadIdx.x) - kBlendWaves * 64;
-        auto fetch_records = [&](uint32_t it, float4 (&r)[kResLoads]) {
-            const float4* __restrict__ gb = reinterpret_cast<const float4*>(rad_dd + static_cast<size_t>(first_task + it * task_stride) * n_pad * 32);
-#pragma unroll
-            for (int k = 0; k < kResLoads; ++k)
-            {
-                const int idx = st_tid + k * kResServiceWaves * 64;
-                r[k] = idx < kResGroupF4 ? gb[idx] : float4{0.0f, 0.0f, 0.0f, 0.0f};
-            }
-        };
-        auto park_records = [&](int buf, const float4 (&r)[kResLoads]) {
-#pragma unroll
-            for (int k = 0; k < kResLoads; ++k)
-            {
-                const int idx = st_tid + k * kResServiceWaves * 64;
-                if (idx < kResGroupF4) sh.b_all[buf][idx] = r[k];
-            }
-        };
-        // texel waves (the first four), a quarter of the 16x16 tile each: lane's output texel e, the staging offset of the interior
-        // texel it takes its sums from, and that texel's weight sum.  (Two quarters each on the two service waves that share their
-        // SIMD with ONE contraction wave: slower, 54 -> 60 us.)
-        constexpr int kQuarters = 1;
-        const bool texel_wave = sw_id < 4;
-        const int first_quarter = sw_id & 3;
-        int e_q[kQuarters], stage_off_q[kQuarters];
-        float sw_q[kQuarters];
-#pragma unroll
-        for (int q = 0; q < kQuarters; ++q)
+        // What shapes this (tools/blend_laps.py, tools/microbench/mfma_valu_coissue.hip): a wave whose next instruction is an MFMA
+        // that waits — for the previous link of its chain, or for the matrix pipe — holds its SIMD's vector issue port while it
+        // waits.  Beside the TWO contraction waves of SIMDs 0-2 a third wave issues next to nothing until they are done, whatever
+        // its priority (a wave with nothing to do in a stage reached the barrier 16 000 cycles late); beside the ONE contraction
+        // wave of SIMD 3 (waves go round the SIMDs: tile 3, service waves 0 and 4) it runs at half speed, and that SIMD's matrix
+        // pipe is idle for half of every stage anyway.  So:
+        //   service waves 0, 4   (SIMD 3) do everything: they turn the previous group's sums into texels, two quarters of the 16x16
+        //                        tile each; compute tile slots (integer divisions); and fetch records TWO groups ahead — at the top
+        //                        of a stage they park the group they hold in registers (requested at the end of the previous
+        //                        stage), at its end they request the one after it, so no stage waits for HBM.  Their SIMD's contraction wave (tile 3) runs
+        //                        its chain with wait states behind every MFMA (mfma_step) so that they get to issue all along.
+        //   service waves 1-3    (SIMDs 0-2) idle; in the last stage, with no contraction running, 1 and 2 take a quarter each.
+        const int sw_id = wave - kBlendWaves;
+        const float hyst = G.hysteresis;
+        // a quarter of the 16x16 tile: lane's output texel e, the staging offset of the interior texel it takes its sums from, and
+        // that texel's weight sum (or +inf where that is ~0: quotient +0, the sums are >= +0)
+        struct Quarter
         {
-            const int e = 64 * (first_quarter + q) + lane, tx = e & (kDepTile - 1), ty = e / kDepTile;
+            int e2, stage_off;
+            pm::DivBy by;
+        };
+        auto quarter_of = [&](int q) {
+            const int e = 64 * q + lane, tx = e & (kDepTile - 1), ty = e / kDepTile;
             int sx = tx, sy = ty;
             if (tx == 0 || ty == 0 || tx == kDepTile - 1 || ty == kDepTile - 1) border_source(tx, ty, kDepTile, sx, sy);
             const int c = (sy - 1) * (kDepTile - 2) + (sx - 1);
-            e_q[q] = e, stage_off_q[q] = (c >> 5) * (32 * kStageStride) + (c & 31) * kStageStride, sw_q[q] = w_sum[c];
-        }
-        const float hyst = G.hysteresis;
+            const float sw = w_sum[c];
+            return Quarter{e * 2, (c >> 5) * (32 * kStageStride) + (c & 31) * kStageStride, pm::div_by(sw > 1e-6f ? sw : __builtin_inff())};
+        };
+        // the texels of group (stage - 1), quarter Q
+        auto texels_of = [&](uint32_t it, const Quarter& Q) {
+            const uint32_t prev = (it - 1u) & 1u;
+            const uint32_t task = first_task + (it - 1u) * task_stride;
+            const float* __restrict__ st = &sh.stage_all[prev][0][0];
+            const uint32_t np = min(16u, A.n_local_probes - task * 16u);
+            const uint32_t my_slot = sh.slots[prev][lane & 15];
+            uint32_t outside = 0u;
+#pragma unroll
+            for (int w = 0; w < kBlendWaves; ++w) outside |= sh.unsafe[prev][w];
+            // A full group (all but possibly the last) runs as straight-line code: with a branch per probe the compiler no longer
+            // knows how many memory operations are in flight and waits for ALL of them — each probe's store included — before the
+            // next probe's texel.  Few instructions: the tile slots come from a fetch wave, a texel's two sums sit side by side in
+            // the staging, the quotients are pm::div_prepared2's (the contraction waves checked the group's sums against its domain).
+            auto texels = [&](auto full, auto prepared) {
+                constexpr bool kFull = decltype(full)::value, kPrepared = decltype(prepared)::value;
+                pm::f2v old[16];
+#pragma unroll
+                for (uint32_t p = 0; p < 16u; ++p)
+                {
+                    const float* tile = A.depth_old + static_cast<size_t>(__builtin_amdgcn_readlane(my_slot, p)) * (kDepTile * kDepTile * 2);
+                    old[p] = (kFull || p < np) ? *reinterpret_cast<const pm::f2v*>(tile + Q.e2) : pm::f2v{0.0f, 0.0f};
+                }
+#pragma unroll
+                for (uint32_t p = 0; p < 16u; ++p)
+                    if (kFull || p < np)  // (wave-uniform)
+                    {
+                        float* tile = A.depth + static_cast<size_t>(__builtin_amdgcn_readlane(my_slot, p)) * (kDepTile * kDepTile * 2);
+                        const pm::f2v s2 = {st[Q.stage_off + 2 * static_cast<int>(p)], st[Q.stage_off + 2 * static_cast<int>(p) + 1]};
+                        const pm::f2v r = kPrepared ? pm::div_prepared2(s2, Q.by) : pm::f2v{s2.x / Q.by.d, s2.y / Q.by.d};
+                        *reinterpret_cast<pm::f2v*>(tile + Q.e2) = pm::f2v{gl_mix(old[p].x, r.x, hyst), gl_mix(old[p].y, r.y, hyst)};
+                    }
+            };
+            if (np == 16u && __builtin_amdgcn_readfirstlane(outside) == 0u)
+                texels(std::true_type{}, std::true_type{});
+            else if (np == 16u)
+                texels(std::true_type{}, std::false_type{});
+            else
+                texels(std::false_type{}, std::false_type{});
+        };
+        if (sw_id == 0 || sw_id == 4)
         {
-            float4 r[kResLoads];
+            // ---- texel waves: 128 threads, 16 float4 of a group's records each (2048 per group) ----
+            __builtin_amdgcn_s_setprio(2);
+            const Quarter Qa = quarter_of(sw_id == 0 ? 0 : 2), Qb = quarter_of(sw_id == 0 ? 1 : 3);
+            constexpr int kFetchLoads = kResGroupF4 / 128;
+            const int ft = (sw_id >> 2) * 64 + lane;
+            typedef float f4v __attribute__((ext_vector_type(4)));  // (a plain vector type, initialised: as an array of float4 the registers-across-stages end up in scratch)
+            f4v r[kFetchLoads];
+#pragma unroll
+            for (int k = 0; k < kFetchLoads; ++k) r[k] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+            auto group_records = [&](uint32_t g) { return reinterpret_cast<const f4v*>(rad_dd + static_cast<size_t>(first_task + g * task_stride) * n_pad * 32) + ft; };
+#define DDGI_FETCH(g)                                                                       \
+    do {                                                                                    \
+        const f4v* __restrict__ gb_ = group_records(g);                                     \
+        _Pragma("unroll") for (int k = 0; k < kFetchLoads; ++k) r[k] = gb_[k * 128];         \
+    } while (0)
+#define DDGI_PARK(buf)                                                                      \
+    do {                                                                                    \
+        f4v* park_ = reinterpret_cast<f4v*>(&sh.b_all[buf][0]) + ft;                        \
+        _Pragma("unroll") for (int k = 0; k < kFetchLoads; ++k) park_[k * 128] = r[k];       \
+    } while (0)
             if (my_tasks > 0u)
             {
-                fetch_records(0u, r);
-                park_records(0, r);
+                DDGI_FETCH(0u);
+                DDGI_PARK(0);
             }
+            if (my_tasks > 1u) DDGI_FETCH(1u);
+            BLEND_LAP(0);
+            __syncthreads();
+            BLEND_LAP(1);
+            for (uint32_t it = 0; it <= my_tasks; ++it)
+            {
+                if (it + 1u < my_tasks) DDGI_PARK((it + 1u) & 1u);  // group it + 1, requested in the previous stage; its buffer was read last in stage it - 1
+                if (sw_id == 0 && it < my_tasks && lane < 16)  // the group being contracted now: its texels are written in the next stage
+                    sh.slots[it & 1u][lane] = static_cast<uint32_t>(blend_tile_slot(G, min((first_task + it * task_stride) * 16u + static_cast<uint32_t>(lane), A.n_local_probes - 1u)));
+                if (it >= 1u)
+                {
+                    texels_of(it, Qa);
+                    if (it < my_tasks) texels_of(it, Qb);  // (in the last stage: an idle wave's)
+                }
+                if (it + 2u < my_tasks) DDGI_FETCH(it + 2u);  // (after the texels: the registers are free again; it travels while the stage ends and the next begins)
+                BLEND_LAP(2 + 2 * it);
+                __syncthreads();
+                BLEND_LAP(3 + 2 * it);
+            }
+#undef DDGI_FETCH
+#undef DDGI_PARK
+            return;
         }
+        // ---- service waves 1-3: nothing to do beside two contraction waves; in the last stage 1 and 2 take a quarter each ----
+        const Quarter Ql = quarter_of(sw_id == 1 ? 1 : 3);
+        BLEND_LAP(0);
         __syncthreads();
+        BLEND_LAP(1);
         for (uint32_t it = 0; it <= my_tasks; ++it)
         {
-            const bool more = it + 1u < my_tasks;
-            float4 r[kResLoads];
-            if (more) fetch_records(it + 1u, r);
-            if (it >= 1u && texel_wave)
-            {
-                const uint32_t task = first_task + (it - 1u) * task_stride;
-                const float* __restrict__ st = &sh.stage_all[(it - 1u) & 1u][0][0];
-                const uint32_t np = min(16u, A.n_local_probes - task * 16u);
-                const uint32_t my_slot = static_cast<uint32_t>(blend_tile_slot(G, min(task * 16u + static_cast<uint32_t>(lane & 15), A.n_local_probes - 1u)));
-                // A full group (all but possibly the last) runs as straight-line code: with a branch per probe the compiler no longer
-                // knows how many memory operations are in flight and waits for ALL of them — each probe's store included — before
-                // the next probe's texel; and a VALU instruction issued beside two contraction waves costs 22 cycles instead of 6
-                // (tools/microbench/mfma_valu_coissue.hip), so every instruction saved here counts four times.
-                auto texels = [&](auto full, int q) {
-                    constexpr bool kFull = decltype(full)::value;
-                    const int e = e_q[q], stage_off = stage_off_q[q];
-                    const float sw = sw_q[q];
-                    const bool divide = sw > 1e-6f;
-                    float2 old[16];
-#pragma unroll
-                    for (uint32_t p = 0; p < 16u; ++p)
-                    {
-                        const size_t tile_off = static_cast<size_t>(__builtin_amdgcn_readlane(my_slot, p)) * (kDepTile * kDepTile * 2);
-                        old[p] = (kFull || p < np) ? *reinterpret_cast<const float2*>(A.depth_old + tile_off + e * 2) : float2{0.0f, 0.0f};
-                    }
-#pragma unroll
-                    for (uint32_t p = 0; p < 16u; ++p)
-                        if (kFull || p < np)  // (wave-uniform)
-                        {
-                            const size_t tile_off = static_cast<size_t>(__builtin_amdgcn_readlane(my_slot, p)) * (kDepTile * kDepTile * 2);
-                            const float s0 = st[stage_off + static_cast<int>(p)], s1 = st[stage_off + 16 + static_cast<int>(p)];
-                            const float q0 = s0 / sw, q1 = s1 / sw;  // (a lane whose weight sum is ~0 divides too and drops the quotient)
-                            const float r0 = divide ? q0 : 0.0f, r1 = divide ? q1 : 0.0f;
-                            *reinterpret_cast<float2*>(A.depth + tile_off + e * 2) = float2{gl_mix(old[p].x, r0, hyst), gl_mix(old[p].y, r1, hyst)};
-                        }
-                };
-#pragma unroll
-                for (int q = 0; q < kQuarters; ++q)
-                {
-                    if (np == 16u)
-                        texels(std::true_type{}, q);
-                    else
-                        texels(std::false_type{}, q);
-                }
-            }
-            if (more) park_records(static_cast<int>((it + 1u) & 1u), r);  // (that buffer was read last in the previous iteration)
+            if (it == my_tasks && it >= 1u && sw_id <= 2) texels_of(it, Ql);
+            BLEND_LAP(2 + 2 * it);
             __syncthreads();
+            BLEND_LAP(3 + 2 * it);
         }
     }
 }
@@ -541,6 +644,10 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
     const int mi = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float hyst = G.hysteresis;
     const uint32_t n_tasks = (A.n_local_probes + 31u) / 32u;
+#ifdef DDGI_BLEND_LAPS
+    const int wave = 12 + mi;
+#endif
+    BLEND_LAP(22);
     // epilogue role: lane = output texel e of the 8x8 tile (borders included: computed from their octahedral-wrap source's
     // sums — the same arithmetic on the same values), wave mi takes the group's probes of parity mi: a probe's tile is one
     // 1 KB load and one 1 KB store.  (Old value at the texel's own place: see blend_depth_resident.)
@@ -549,56 +656,72 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
     if (tx == 0 || ty == 0 || tx == kIrrTile - 1 || ty == kIrrTile - 1) border_source(tx, ty, kIrrTile, sx, sy);
     const int c = (sy - 1) * (kIrrTile - 2) + (sx - 1);
     const float sw = w_sum[kDepInterior + c];
-    const float* stage_src = &stage_all[c >> 5][0][(c & 31) * kStageStride];
-    for (uint32_t task = first_task; task < n_tasks; task += task_stride)
+    const pm::DivBy by = pm::div_by(sw > 1e-6f ? sw : __builtin_inff());  // (+inf: quotient +0 where the weight sum is ~0; the sums are >= +0)
+    const float* stage_src = &stage_all[c >> 5][(c & 31) * kIrrStageStride];
+    constexpr uint32_t kBatch = 8;        // old tiles in flight per wave
+    constexpr bool kEarly = kDepth >= 8;  // the stand-alone kernel has the registers to fetch a task's first old tiles BEFORE its contraction.  (All
+                                          // sixteen: the epilogue shrinks from 6 500 to 4 000 cycles and the contraction grows from 36 000 to 43 000 —
+                                          // it is bound by what the memory system delivers, and the old tiles queue up in front of its operands.)
+    uint32_t par = 0u;
+    for (uint32_t task = first_task; task < n_tasks; task += task_stride, par ^= 1u)
     {
         const float* wa = w_tiles + static_cast<size_t>(kDepMTiles + mi) * n_pad * 32 + lane * 4;
         const float* vb = rad_rgb + static_cast<size_t>(task) * 3 * n_pad * 32 + lane * 4;
+        const uint32_t* slots = slot_sh[par];
+        if (threadIdx.x < 32) slot_sh[par][threadIdx.x] = static_cast<uint32_t>(blend_tile_slot(G, min(task * 32u + threadIdx.x, A.n_local_probes - 1u)));
+        BLEND_LAP(0);
+        __syncthreads();  // (and: the previous task's staging has been read)
+        BLEND_LAP(1);
+        auto load_old = [&](uint32_t p0, float4 (&old)[kBatch]) {
+#pragma unroll
+            for (uint32_t b = 0; b < kBatch; ++b)
+                old[b] = *reinterpret_cast<const float4*>(A.irradiance_old + static_cast<size_t>(slots[min(p0 + 2u * b, 31u)]) * (kIrrTile * kIrrTile * 4) + e * 4);
+        };
+        float4 old[kBatch];
+        if (kEarly) load_old(static_cast<uint32_t>(mi), old);
         f16v acc[3];
         blend_contract3<kDepth>(wa, vb, static_cast<size_t>(n_pad) * 32, q_pairs, acc);
-        __syncthreads();  // (the previous task's staging has been read)
+        BLEND_LAP(2);
+        bool outside = false;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) stage_tile(stage_all[mi][k], acc[k], lane & 31, lane >> 5);
-        if (threadIdx.x < 32) slot_sh[threadIdx.x] = static_cast<uint32_t>(blend_tile_slot(G, min(task * 32u + threadIdx.x, A.n_local_probes - 1u)));
+        for (int k = 0; k < 3; ++k)
+        {
+            stage_tile<kIrrStageStride>(stage_all[mi], acc[k], (lane & 31) * 3 + k, lane >> 5);
+            outside |= sums_outside_div_domain(acc[k]);
+        }
+        if (lane == 0) sh.unsafe[mi] = outside ? 1u : 0u;
         __syncthreads();
+        BLEND_LAP(3);
         const uint32_t np = min(32u, A.n_local_probes - task * 32u);
-        constexpr uint32_t kBatch = 8;  // old tiles in flight per wave
-        const bool divide = sw > 1e-6f;
-        // (full groups as straight-line code: see blend_depth_resident)
-        auto tiles = [&](auto full) {
-            constexpr bool kFull = decltype(full)::value;
+        const bool prepared = __builtin_amdgcn_readfirstlane(sh.unsafe[0] | sh.unsafe[1]) == 0u;
+        // (full groups as straight-line code, pm::div_prepared quotients: see blend_depth_resident)
+        auto tiles = [&](auto full, auto prep) {
+            constexpr bool kFull = decltype(full)::value, kPrepared = decltype(prep)::value;
             for (uint32_t p0 = static_cast<uint32_t>(mi); p0 < np; p0 += 2u * kBatch)
             {
-                float4 old[kBatch];
-#pragma unroll
-                for (uint32_t b = 0; b < kBatch; ++b)
-                {
-                    const uint32_t p = min(p0 + 2u * b, 31u);
-                    old[b] = *reinterpret_cast<const float4*>(A.irradiance_old + static_cast<size_t>(slot_sh[p]) * (kIrrTile * kIrrTile * 4) + e * 4);
-                }
+                if (!kEarly || p0 != static_cast<uint32_t>(mi)) load_old(p0, old);
 #pragma unroll
                 for (uint32_t b = 0; b < kBatch; ++b)
                 {
                     const uint32_t p = p0 + 2u * b;
                     if (kFull || p < np)  // (wave-uniform)
                     {
-                        float res[3];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                        {
-                            const float q = stage_src[k * (32 * kStageStride) + static_cast<int>(p)] / sw;  // (dropped where the weight sum is ~0)
-                            res[k] = divide ? q : 0.0f;
-                        }
-                        *reinterpret_cast<float4*>(A.irradiance + static_cast<size_t>(slot_sh[p]) * (kIrrTile * kIrrTile * 4) + e * 4) =
-                            float4{gl_mix(old[b].x, res[0], hyst), gl_mix(old[b].y, res[1], hyst), gl_mix(old[b].z, res[2], hyst), 1.0f};
+                        const float* sp = stage_src + 3 * static_cast<int>(p);
+                        const pm::f2v rg = kPrepared ? pm::div_prepared2(pm::f2v{sp[0], sp[1]}, by) : pm::f2v{sp[0] / by.d, sp[1] / by.d};
+                        const float bl = kPrepared ? pm::div_prepared(sp[2], by) : sp[2] / by.d;
+                        *reinterpret_cast<float4*>(A.irradiance + static_cast<size_t>(slots[p]) * (kIrrTile * kIrrTile * 4) + e * 4) =
+                            float4{gl_mix(old[b].x, rg.x, hyst), gl_mix(old[b].y, rg.y, hyst), gl_mix(old[b].z, bl, hyst), 1.0f};
                     }
                 }
             }
         };
-        if (np == 32u)
-            tiles(std::true_type{});
+        if (np == 32u && prepared)
+            tiles(std::true_type{}, std::true_type{});
+        else if (np == 32u)
+            tiles(std::true_type{}, std::false_type{});
         else
-            tiles(std::false_type{});
+            tiles(std::false_type{}, std::false_type{});
+        BLEND_LAP(4);
     }
 }
 
@@ -619,7 +742,10 @@ __global__ __launch_bounds__(kIrrWaves * 64) void k_probe_blend_irr(const BlendA
                                                                     const float* __restrict__ w_sum)
 {
     __shared__ IrrShared sh;
-    blend_irr_role<8>(A, rad_rgb, w_tiles, w_sum, sh, blockIdx.x, gridDim.x);
+#ifndef DDGI_IRR_DEPTH
+#define DDGI_IRR_DEPTH 8
+#endif
+    blend_irr_role<DDGI_IRR_DEPTH>(A, rad_rgb, w_tiles, w_sum, sh, blockIdx.x, gridDim.x);
 }
 
 // Few probes (one rank's slab of a sharded grid: fewer groups than the chip has room for): one launch for both — blocks
@@ -800,6 +926,10 @@ hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t st
     hipLaunchKernelGGL(k_probe_blend, dim3(blocks), dim3(kBlendBlock), lds, stream, args);
     return hipGetLastError();
 }
+
+#ifdef DDGI_BLEND_LAPS
+extern "C" int ddgi_debug_blend_laps(unsigned long long* out) { return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blend_laps), sizeof(g_blend_laps))); }
+#endif
 
 hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream)
 {

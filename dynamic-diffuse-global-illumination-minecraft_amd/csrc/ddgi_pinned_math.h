@@ -165,5 +165,45 @@ __device__ __forceinline__ float rcp_upto_2p94(float x)
     return rcp_fixed(x * 0x1.0p32f) * 0x1.0p32f;
 }
 
+
+// n / d for many numerators against one denominator, 6 instructions per quotient instead of 11: the compiler's correctly rounded
+// division is v_div_scale (x 2), v_rcp_f32 + one Newton step on the scaled denominator, q = n r and two residual corrections (the
+// second one in v_div_fmas), v_div_fixup.  Wherever v_div_scale leaves BOTH operands alone (ISA, V_DIV_SCALE_F32: d normal with
+// 1/d normal, n / d normal, exponent(n) - exponent(d) < 96, |n| >= 2^-103; there v_div_fmas is a plain fma) the quotient is a
+// function of n, d and the refined reciprocal only — and the reciprocal depends on d alone.  Domain used here, with margins:
+//   2^-24 <= |d| < 2^25, or +-inf (quotient 0: v_div_fixup);   n = +-0, or 2^-100 <= |n| <= 2^60 (kDivPreparedLo/Hi)
+// (exponent differences within (-126, 96); the residuals n - d q are exact even where they are subnormal)
+// Same bits as `n / d` there (tests/exact_rcp_sqrt_check.hip: every mantissa of d against numerators across the domain and at
+// its edges).  A caller with numerators outside the domain uses `/`.
+struct DivBy
+{
+    float d, r;
+};
+constexpr uint32_t kDivPreparedLo = 0x0d800000u, kDivPreparedHi = 0x5d800000u;  // 2^-100, 2^60 as bits
+__device__ __forceinline__ DivBy div_by(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    return DivBy{d, fmaf(fmaf(-d, r0, 1.0f), r0, r0)};
+}
+__device__ __forceinline__ float div_prepared(float n, const DivBy& by)
+{
+    float q = n * by.r;
+    q = fmaf(fmaf(-by.d, q, n), by.r, q);
+    q = fmaf(fmaf(-by.d, q, n), by.r, q);
+    return __builtin_amdgcn_div_fixupf(q, by.d, n);
+}
+// two numerators against the same denominator: the same operations as v_pk_mul_f32 / v_pk_fma_f32 — half the instructions to
+// issue (not half the time in the ALU: the packed forms run at the scalar forms' lane rate; it is the issue slots that are
+// scarce where this is used, beside waves that run MFMA chains)
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v div_prepared2(f2v n, const DivBy& by)
+{
+    const f2v nd = {-by.d, -by.d}, r = {by.r, by.r};
+    f2v q = n * r;
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q, n), r, q);
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(nd, q, n), r, q);
+    return f2v{__builtin_amdgcn_div_fixupf(q.x, by.d, n.x), __builtin_amdgcn_div_fixupf(q.y, by.d, n.y)};
+}
+
 }  // namespace pm
 }  // namespace ddgi

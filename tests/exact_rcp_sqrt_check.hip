@@ -1,5 +1,5 @@
 // Exhaustive check, on the GPU, of the short branch-free 1/x and sqrt(x) sequences the kernels use on arguments of known
-// range (csrc/ddgi_pinned_math.h: pm::sqrt_core, rcp_sqrt_core, rcp_fixed, rcp_upto_2p94) against the compiler's correctly
+// range (csrc/ddgi_pinned_math.h: pm::sqrt_core, rcp_sqrt_core, rcp_fixed, rcp_upto_2p94; div_prepared) against the compiler's correctly
 // rounded `/` and sqrtf: every one of the 2^32 binary32 arguments that lies in a function's stated domain, bit for bit.
 // Prints OK or the mismatch counts.  Run by tests/test_gpu_device_math.py.
 #include <hip/hip_runtime.h>
@@ -53,8 +53,57 @@ __global__ void k_check(unsigned long long* bad, unsigned long long* checked)
     }
 }
 
+// pm::div_prepared against `/`: every mantissa of the denominator at a spread of its exponents (and +inf), against numerators
+// spread over the domain (pseudo-random mantissas at every exponent of [2^-100, 2^60], the domain's two ends, zero)
+__device__ __attribute__((noinline)) float ref_div(float n, float d) { return n / d; }
+__global__ void k_check_div(unsigned long long* bad, unsigned long long* checked)
+{
+    const uint64_t tid = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x, stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    unsigned long long b = 0, n_checked = 0;
+    const int d_exps[7] = {-24, -20, -1, 0, 1, 8, 24};
+    for (uint64_t m = tid; m < (1ull << 23); m += stride)
+        for (int de = 0; de < 8; ++de)
+        {
+            const float d = de < 7 ? __uint_as_float((static_cast<uint32_t>(127 + d_exps[de]) << 23) | static_cast<uint32_t>(m)) : __builtin_inff();
+            const pm::DivBy by = pm::div_by(d);
+            uint32_t h = static_cast<uint32_t>(m) * 2654435761u + static_cast<uint32_t>(de);
+            for (int k = 0; k < 24; ++k)
+            {
+                h = h * 1664525u + 1013904223u;
+                float n;
+                if (k == 0) n = 0.0f;
+                else if (k == 1) n = __uint_as_float(pm::kDivPreparedLo);
+                else if (k == 2) n = __uint_as_float(pm::kDivPreparedHi);
+                else
+                {
+                    const uint32_t e = 27u + (h >> 9) % 160u;                     // biased exponents 27 .. 186 = 2^-100 .. 2^59
+                    n = __uint_as_float((e << 23) | (h & 0x7fffffu));
+                }
+                if (!same(pm::div_prepared(n, by), ref_div(n, d))) b++;
+                const pm::f2v two = pm::div_prepared2(pm::f2v{n, -n}, by);  // the packed form, and negative numerators
+                if (!same(two.x, ref_div(n, d)) || !same(two.y, ref_div(-n, d))) b++;
+                n_checked += 3;
+            }
+        }
+    if (b) atomicAdd(&bad[0], b);
+    atomicAdd(&checked[0], n_checked);
+}
+
 int main()
 {
+    {
+        unsigned long long* dd = nullptr;
+        if (hipMalloc(&dd, 2 * sizeof(unsigned long long)) != hipSuccess || hipMemset(dd, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return 2;
+        hipLaunchKernelGGL(k_check_div, dim3(4096), dim3(256), 0, 0, dd, dd + 1);
+        unsigned long long hd[2] = {1, 0};
+        if (hipMemcpy(hd, dd, sizeof(hd), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+        std::printf("%-14s %llu mismatches in %llu quotients\n", "div_prepared", hd[0], hd[1]);
+        if (hd[0] || hd[1] < (1ull << 30))
+        {
+            std::printf("FAILED\n");
+            return 1;
+        }
+    }
     unsigned long long* d = nullptr;
     if (hipMalloc(&d, 8 * sizeof(unsigned long long)) != hipSuccess || hipMemset(d, 0, 8 * sizeof(unsigned long long)) != hipSuccess) return 2;
     hipLaunchKernelGGL(k_check, dim3(4096), dim3(256), 0, 0, d, d + 4);

@@ -7,6 +7,9 @@ import numpy as np
 import ddgi_amd
 from bench import WORKLOAD as w
 
+if os.environ.get("DDGI_TIMING_COUNTS"):   # another grid size for the same scene, e.g. 32,32,32
+    w = dict(w, counts=tuple(int(v) for v in os.environ["DDGI_TIMING_COUNTS"].split(",")))
+
 eng = ddgi_amd.ProbeEngine(ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"]),
                            ddgi_amd.make_settings(w["scene"], w["max_bounces"]))
 eng.set_mode(ddgi_amd.MODE_DDGI)

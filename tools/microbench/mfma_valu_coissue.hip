@@ -105,6 +105,42 @@ void run(const char* name, uint32_t mm, uint32_t vm, int per_iter, const char* u
     printf("\n");
 }
 
+// The whole chip running f32 MFMA chains: 2 waves per SIMD on every CU.  Reports the time per MFMA per SIMD from HIP events (what a
+// kernel pays), and the shader clock it implies if an MFMA is 64 cycles; s_memtime against the 100 MHz s_memrealtime gives
+// the frequency of the counter the single-workgroup cases above are quoted in.
+__global__ __launch_bounds__(512) void k_chip(int mfma_n, float* io, unsigned long long* stamps)
+{
+    const int lane = threadIdx.x & 63;
+    float a = io[lane], b = io[lane + 64];
+    f16v acc;
+    for (int r = 0; r < 16; ++r) acc[r] = io[lane + r];
+    const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int i = 0; i < mfma_n; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    const unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    float s = 0;
+    for (int r = 0; r < 16; ++r) s += acc[r];
+    io[4096 + (threadIdx.x & 1023)] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) stamps[0] = t1 - t0, stamps[1] = w1 - w0;
+}
+static void run_chip(int blocks, const char* name)
+{
+    const int N = 1 << 16;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_chip, dim3(blocks), dim3(512), 0, 0, N, io, cyc);
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k_chip, dim3(blocks), dim3(512), 0, 0, N, io, cyc);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long st[2];
+    (void)hipMemcpy(st, cyc, sizeof st, hipMemcpyDeviceToHost);
+    const double ns_per_mfma = ms * 1e6 / (2.0 * N);  // two waves share a SIMD's matrix pipe
+    printf("%-28s %.3f ms: %.1f ns per MFMA per SIMD = %.2f GHz if an MFMA is 64 cycles;  s_memtime: %.1f ticks per MFMA pair, %.0f MHz\n", name, ms, ns_per_mfma,
+           64.0 / ns_per_mfma, double(st[0]) / N, double(st[0]) / (double(st[1]) / 100.0));
+}
+
 int main()
 {
     (void)hipMalloc(&io, 65536), (void)hipMalloc(&cyc, 12 * 8), (void)hipMalloc(&hw, 12 * 4);
@@ -134,5 +170,9 @@ int main()
     run<1, 0, 0>("16x16x4: mfma w0,w4", 0x011, 0, 1, "");
     run<1, 0, 0>("16x16x4: fma-indep w8 + mfma w0,w4", 0x011, 0x100, 32, "cyc/fma");
     run<1, 3, 0>("16x16x4: div w8 + mfma w0,w4", 0x011, 0x100, 8, "cyc/div");
+    run_chip(1, "one workgroup (one CU)");
+    run_chip(32, "32 workgroups");
+    run_chip(256, "256 workgroups (every CU)");
+    run_chip(256, "256 workgroups again");
     return 0;
 }
