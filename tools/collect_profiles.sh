@@ -32,3 +32,8 @@ timeout 300 python bench.py --workload c4 --steps 5 --warmup 2 > $OUT/${R}_${T}_
 timeout 300 python bench.py --workload c4 --mode ddgi --steps 5 --warmup 2 > $OUT/${R}_${T}_c4_ddgi_bench.json 2> /dev/null
 timeout 400 python bench.py --workload c5 --mode ddgi --steps 12 > $OUT/${R}_${T}_c5_sdyn_ddgi_bench.json 2> /dev/null
 ls -la $OUT
+# round 3, blend: the MFMA / VALU issue microbenchmark, the depth kernel's lap timers (library built with -DDDGI_BLEND_LAPS), blend against the number of probes
+timeout 120 tools/microbench/mfma_valu_coissue.bin > $OUT/${R}_mfma_valu_coissue.txt 2>&1
+[ -f dynamic-diffuse-global-illumination-minecraft_amd/libddgi_probe_laps.so ] && timeout 200 python tools/blend_laps.py 2>/dev/null | grep -v amdgpu > $OUT/${R}_${T}_blend_laps.txt
+timeout 400 bash tools/blend_sizes.sh > $OUT/${R}_${T}_blend_sizes.txt 2>&1
+ls -la $OUT
