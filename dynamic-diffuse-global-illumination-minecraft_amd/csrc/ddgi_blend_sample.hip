@@ -189,9 +189,61 @@ DDGI_D f16v blend_contract(const float* __restrict__ wa, const float* __restrict
 
 // The same for three B streams (the colour channels, `b_stride` floats apart) against ONE pass over the A stream: three
 // independent chains, each in ray order; the weights are read once instead of three times.
+// The same for 256 rays (32 float4 per lane and stream), written out: with the loop above the compiler rotates the prefetch ring
+// through ~190 register moves at the end of every trip — and waits for EVERY outstanding load first (in-kernel clocks: 36 000
+// cycles for 384 MFMAs that take 24 576).  Unrolled, ring slot u simply is a set of registers, and each wait names the load it needs.
+template <int kDepth>
+DDGI_D void blend_contract3_256(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, f16v (&acc)[3])
+{
+    constexpr int n4 = 32;
+    static_assert(n4 % kDepth == 0, "the ring goes round a whole number of times");
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] = f16v{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const float4* __restrict__ pa = reinterpret_cast<const float4*>(wa);
+    const float4* __restrict__ pb[3] = {reinterpret_cast<const float4*>(vb), reinterpret_cast<const float4*>(vb + b_stride), reinterpret_cast<const float4*>(vb + 2 * b_stride)};
+    float4 ab[kDepth], bb[3][kDepth];
+#pragma unroll
+    for (int u = 0; u < kDepth; ++u)
+    {
+        ab[u] = pa[static_cast<size_t>(u) * 64];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) bb[c][u] = pb[c][static_cast<size_t>(u) * 64];
+    }
+#pragma unroll
+    for (int k = 0; k < n4; ++k)
+    {
+        const int u = k % kDepth;
+        const float4 a = ab[u];
+        float4 b[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) b[c] = bb[c][u];
+        if (k + kDepth < n4)
+        {
+            ab[u] = pa[static_cast<size_t>(k + kDepth) * 64];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bb[c][u] = pb[c][static_cast<size_t>(k + kDepth) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (the requests stay kDepth steps ahead of their use: the scheduler would sink them to save registers)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[c].x, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[c].y, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[c].z, acc[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[c].w, acc[c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int kDepth>
 DDGI_D void blend_contract3(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, int q_pairs, f16v (&acc)[3])
 {
+    if (q_pairs == 128)  // (wave-uniform: 256 rays per probe, the common case)
+    {
+        blend_contract3_256<kDepth>(wa, vb, b_stride, acc);
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[c] = f16v{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const float4* __restrict__ pa = reinterpret_cast<const float4*>(wa);
@@ -253,18 +305,13 @@ DDGI_D void stage_tile(float* stage, const f16v& acc, int col, int half)
 }
 
 // Does any of the wave's sums lie outside pm::div_prepared's numerator domain (zero, or 2^-100 .. 2^60)?  Sums are >= +0 (weights
-// and records are), so their bit patterns order like the values; `u - 1` sends zero past every threshold.  (A negative, infinite or
-// NaN sum — records the engine did not write — counts as outside.)  Wave-uniform result.
+// and records are); anything else — records the engine did not write — counts as outside.  Wave-uniform result.
 DDGI_D bool sums_outside_div_domain(const f16v& acc)
 {
-    uint32_t hi = 0u, lo = 0xffffffffu;
+    pm::DivDomainCheck c;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-    {
-        const uint32_t u = __float_as_uint(acc[r]);
-        hi = max(hi, u), lo = min(lo, u - 1u);
-    }
-    return __builtin_amdgcn_ballot_w64(hi > pm::kDivPreparedHi || lo < pm::kDivPreparedLo - 1u) != 0ull;
+    for (int r = 0; r < 16; ++r) c.add(acc[r]);
+    return __builtin_amdgcn_ballot_w64(c.outside()) != 0ull;
 }
 
 // depth: workgroup = 7 waves, wave m = depth tile m of the 16 probes of a group; B columns = moment * 16 + probe
@@ -530,7 +577,7 @@ DDGI_D void blend_depth_resident(const BlendArgs& A, const float* __restrict__ r
             const float* __restrict__ st = &sh.stage_all[prev][0][0];
             const uint32_t np = min(16u, A.n_local_probes - task * 16u);
             const uint32_t my_slot = sh.slots[prev][lane & 15];
-            uint32_t outside = 0u;
+            uint32_t outside = A.force_division;
 #pragma unroll
             for (int w = 0; w < kBlendWaves; ++w) outside |= sh.unsafe[prev][w];
             // A full group (all but possibly the last) runs as straight-line code: with a branch per probe the compiler no longer
@@ -666,7 +713,11 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
     for (uint32_t task = first_task; task < n_tasks; task += task_stride, par ^= 1u)
     {
         const float* wa = w_tiles + static_cast<size_t>(kDepMTiles + mi) * n_pad * 32 + lane * 4;
+#ifdef DDGI_IRR_ALIAS  // timing experiment (wrong tiles): every group reads the first 8 groups' records — they stay in L2
+        const float* vb = rad_rgb + static_cast<size_t>(task & 7u) * 3 * n_pad * 32 + lane * 4;
+#else
         const float* vb = rad_rgb + static_cast<size_t>(task) * 3 * n_pad * 32 + lane * 4;
+#endif
         const uint32_t* slots = slot_sh[par];
         if (threadIdx.x < 32) slot_sh[par][threadIdx.x] = static_cast<uint32_t>(blend_tile_slot(G, min(task * 32u + threadIdx.x, A.n_local_probes - 1u)));
         BLEND_LAP(0);
@@ -693,7 +744,7 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
         __syncthreads();
         BLEND_LAP(3);
         const uint32_t np = min(32u, A.n_local_probes - task * 32u);
-        const bool prepared = __builtin_amdgcn_readfirstlane(sh.unsafe[0] | sh.unsafe[1]) == 0u;
+        const bool prepared = __builtin_amdgcn_readfirstlane(sh.unsafe[0] | sh.unsafe[1] | A.force_division) == 0u;
         // (full groups as straight-line code, pm::div_prepared quotients: see blend_depth_resident)
         auto tiles = [&](auto full, auto prep) {
             constexpr bool kFull = decltype(full)::value, kPrepared = decltype(prep)::value;

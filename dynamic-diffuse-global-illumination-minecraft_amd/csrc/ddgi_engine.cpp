@@ -102,7 +102,7 @@ static Tuning read_env_tuning()
             if (const char* v = std::getenv(k.env)) t.*(k.field) = std::atoi(v);
     if (const char* v = std::getenv("DDGI_TRACE_KERNEL"))
         t.trace_kernel = !std::strcmp(v, "rounds") ? 1 : !std::strcmp(v, "lane") ? 2 : !std::strcmp(v, "queues") ? 3 : 0;
-    if (std::getenv("DDGI_BLEND_KERNEL")) t.blend_kernel = 1;
+    if (const char* v = std::getenv("DDGI_BLEND_KERNEL")) t.blend_kernel = std::strcmp(v, "division") == 0 ? 2 : 1;
     if (std::getenv("DDGI_NO_NOISE_LUT")) t.noise_lut = 0;
     return t;
 }
@@ -1010,6 +1010,7 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         b.w_sum = e->d_blend_w;
         b.w = e->d_blend_w + 256;
         if (e->tuning.blend_kernel == 1) b.w = b.w_sum = nullptr;  // one probe per workgroup, weights in place
+        b.force_division = e->tuning.blend_kernel == 2 ? 1u : 0u;
         // the blend's weight tiles depend on the frame's ray directions only: made before the trace, off the critical path
         // between the last ray and the first tile
         HIP_TRY(launch_blend_weights(b, e->stream));

@@ -22,7 +22,7 @@ struct Tuning
     int march_waves = 0;    // queue kernel: waves that march; 0 = per configuration (measured, see "autotune")
     int autotune = 0;       // 1: measure the march/event split on the first update of a configuration (that update BLOCKS the host
                             // once); default off — ddgi_probe_update never blocks, ddgi_tune() measures on request
-    int blend_kernel = 0;   // DDGI blend: 0 auto, 1 one probe per workgroup (cross-check)
+    int blend_kernel = 0;   // DDGI blend: 0 auto, 1 one probe per workgroup (cross-check), 2 auto with the compiler's division (cross-check)
     int aq_pool = 0, wf_pool = 0, wf_maxpool = 0, wf_threads = 1024;
     int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
     int fast_march = 0;     // tolerance mode: marches skip empty space (NOT bit-exact; tests/test_gpu_fast_march.py states the tolerance)

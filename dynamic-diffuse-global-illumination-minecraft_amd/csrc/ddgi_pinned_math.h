@@ -192,6 +192,20 @@ __device__ __forceinline__ float div_prepared(float n, const DivBy& by)
     q = fmaf(fmaf(-by.d, q, n), by.r, q);
     return __builtin_amdgcn_div_fixupf(q, by.d, n);
 }
+// Are all of a set of numerators in div_prepared's domain?  Two integer instructions per value: for values >= +0 the bit patterns
+// order like the values, and `u - 1` sends zero past every threshold.  A negative, infinite or NaN value counts as outside
+// (-0 too: conservative).  tests/exact_rcp_sqrt_check.hip walks all 2^32 bit patterns: whatever passes here divides like `/`.
+struct DivDomainCheck
+{
+    uint32_t hi = 0u, lo = 0xffffffffu;
+    __device__ __forceinline__ void add(float v)
+    {
+        const uint32_t u = __float_as_uint(v);
+        hi = hi > u ? hi : u, lo = lo < u - 1u ? lo : u - 1u;
+    }
+    __device__ __forceinline__ bool outside() const { return hi > kDivPreparedHi || lo < kDivPreparedLo - 1u; }
+};
+
 // two numerators against the same denominator: the same operations as v_pk_mul_f32 / v_pk_fma_f32 — half the instructions to
 // issue (not half the time in the ALU: the packed forms run at the scalar forms' lane rate; it is the issue slots that are
 // scarce where this is used, beside waves that run MFMA chains)

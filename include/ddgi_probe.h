@@ -204,7 +204,9 @@ int ddgi_tune(ddgi_handle h);
  *                   runs the exact march; ddgi_get_tuning "fast_march_active" tells.  0 (default) = the exact march [DDGI_FAST_MARCH]
  *   "march_waves"   n > 0 pins the split (waves that march, of 16); 0 = per configuration            [DDGI_AQ_MARCH]
  *   "trace_kernel"  0 auto, 1 round-based, 2 ray per lane, 3 queues (cross-checks)   [DDGI_TRACE_KERNEL=rounds|lane|queues]
- *   "blend_kernel"  0 auto, 1 one probe per workgroup (cross-check)                                  [DDGI_BLEND_KERNEL]
+ *   "blend_kernel"  0 auto, 1 one probe per workgroup (cross-check), 2 auto but every quotient by the compiler's
+ *                   division — the path a probe group takes whose sums lie outside the short division's domain
+ *                   (cross-check)                                                   [DDGI_BLEND_KERNEL=probe|division]
  *   "verbose", "noise_lut", "aq_pool", "wf_pool", ... (profiling; see ddgi_engine.cpp: kTuningKeys)
  * ddgi_get_tuning also answers "march_waves_measured": the split most recently measured (0 = none yet), so a
  * host can persist it and pin it next time. */

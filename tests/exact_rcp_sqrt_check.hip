@@ -89,8 +89,49 @@ __global__ void k_check_div(unsigned long long* bad, unsigned long long* checked
     atomicAdd(&checked[0], n_checked);
 }
 
+// The guard and the division together: every binary32 bit pattern as a numerator.  What pm::DivDomainCheck lets through must be
+// zero or lie in [2^-100, 2^60], and must divide like `/` (here: by six divisors of the range the blend kernels use, and +inf);
+// what it holds back must be outside.
+__global__ void k_check_guard(unsigned long long* bad, unsigned long long* passed)
+{
+    const uint64_t tid = blockIdx.x * static_cast<uint64_t>(blockDim.x) + threadIdx.x, stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const float ds[7] = {1.0e-6f, 0.37f, 1.0f, 3.7f, 99.99f, 255.9f, __builtin_inff()};
+    pm::DivBy by[7];
+    for (int i = 0; i < 7; ++i) by[i] = pm::div_by(ds[i]);
+    unsigned long long b = 0, n = 0;
+    for (uint64_t u = tid; u < (1ull << 32); u += stride)
+    {
+        const float v = __uint_as_float(static_cast<uint32_t>(u));
+        pm::DivDomainCheck c;
+        c.add(v);
+        const bool in_domain = (u == 0u) || (v >= 0x1.0p-100f && v <= 0x1.0p60f);
+        if (c.outside() == in_domain) b++;
+        if (!c.outside())
+        {
+            n++;
+            for (int i = 0; i < 7; ++i)
+                if (!same(pm::div_prepared(v, by[i]), ref_div(v, ds[i]))) b++;
+        }
+    }
+    if (b) atomicAdd(&bad[0], b);
+    atomicAdd(&passed[0], n);
+}
+
 int main()
 {
+    {
+        unsigned long long* dg = nullptr;
+        if (hipMalloc(&dg, 2 * sizeof(unsigned long long)) != hipSuccess || hipMemset(dg, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return 2;
+        hipLaunchKernelGGL(k_check_guard, dim3(4096), dim3(256), 0, 0, dg, dg + 1);
+        unsigned long long hg[2] = {1, 0};
+        if (hipMemcpy(hg, dg, sizeof(hg), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+        std::printf("%-14s %llu mismatches; %llu of 2^32 numerators pass the guard, each divided by 7 divisors\n", "DivDomainCheck", hg[0], hg[1]);
+        if (hg[0] || hg[1] != 160ull * (1ull << 23) + 2ull)   // biased exponents 27 .. 186, every mantissa; +0; 2^60 itself
+        {
+            std::printf("FAILED\n");
+            return 1;
+        }
+    }
     {
         unsigned long long* dd = nullptr;
         if (hipMalloc(&dd, 2 * sizeof(unsigned long long)) != hipSuccess || hipMemset(dd, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return 2;

@@ -103,9 +103,9 @@ def test_blend_kernels_agree_on_ragged_shapes(ddgi, oracle, counts, s):
     o_irr = np.zeros((n_probes, 8, 8, 4), dtype=np.float32)
     o_dep = np.zeros((n_probes, 16, 16, 2), dtype=np.float32)
     results = {}
-    for kernel in ("scalar", "probe"):
-        if kernel == "probe":
-            os.environ["DDGI_BLEND_KERNEL"] = "probe"
+    for kernel in ("scalar", "probe", "division"):
+        if kernel != "scalar":
+            os.environ["DDGI_BLEND_KERNEL"] = kernel
         try:
             with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin, hysteresis=0.7), ddgi.make_settings(scene, 4)) as eng:
                 eng.set_mode(ddgi.MODE_DDGI)
@@ -130,9 +130,11 @@ def test_persistent_depth_blend_agrees_with_the_per_probe_kernel_on_a_large_grid
     import os
     counts, side, s, origin, scene = (24, 16, 24), 2, 16, (0.0, 0.0, 0.0), 0
     results = {}
-    for kernel in ("mfma", "probe"):
-        if kernel == "probe":
-            os.environ["DDGI_BLEND_KERNEL"] = "probe"
+    # "division": the MFMA kernels with the compiler's `/` for every quotient — the path a group takes whose sums lie outside the
+    # short division's domain (pm::div_prepared; tests/exact_rcp_sqrt_check.hip), which no scene here reaches by itself
+    for kernel in ("mfma", "probe", "division"):
+        if kernel != "mfma":
+            os.environ["DDGI_BLEND_KERNEL"] = kernel
         try:
             with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin, hysteresis=0.7), ddgi.make_settings(scene, 3)) as eng:
                 eng.set_mode(ddgi.MODE_DDGI)
@@ -142,5 +144,6 @@ def test_persistent_depth_blend_agrees_with_the_per_probe_kernel_on_a_large_grid
         finally:
             os.environ.pop("DDGI_BLEND_KERNEL", None)
     assert results["mfma"][1].any() and results["mfma"][0].any()
-    assert np.array_equal(_bits(results["mfma"][0]), _bits(results["probe"][0]))
-    assert np.array_equal(_bits(results["mfma"][1]), _bits(results["probe"][1]))
+    for other in ("probe", "division"):
+        assert np.array_equal(_bits(results["mfma"][0]), _bits(results[other][0])), other
+        assert np.array_equal(_bits(results["mfma"][1]), _bits(results[other][1])), other

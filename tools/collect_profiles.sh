@@ -15,8 +15,10 @@ timeout 200 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$T -o ddgi
 python $ROOT/tools/profile_summary.py $ROOT/gpurun_out/prof_$T/ddgi "bench.py --mode ddgi --steps 20 --warmup 5" > $OUT/${R}_${T}_ddgi_kernel_stats.txt
 # counters (separate passes, kernel trace only)
 cd $ROOT
+export DDGI_AQ_MARCH=$MW   # (the counter passes pin the split too: to what the bench line's first update measured)
 timeout 300 bash tools/pmc_icache.sh $T > /dev/null 2>&1; python tools/pmc_issue.py $T $OUT/${R}_pmc_${T}_issue.txt > /dev/null
 timeout 400 bash tools/pmc_run.sh $T > /dev/null 2>&1; python tools/pmc_traffic.py $T $R > /dev/null
+unset DDGI_AQ_MARCH
 # slab scaling, sampler throughput, lane statistics
 timeout 200 python tools/slab_timing.py > $OUT/${R}_${T}_slab_scaling.txt 2>/dev/null
 timeout 200 python tools/sample_bench.py 2>/dev/null | grep mode > $OUT/${R}_${T}_sample_bench.txt
