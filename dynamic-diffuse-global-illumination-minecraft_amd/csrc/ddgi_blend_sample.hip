@@ -189,11 +189,23 @@ DDGI_D f16v blend_contract(const float* __restrict__ wa, const float* __restrict
 
 // The same for three B streams (the colour channels, `b_stride` floats apart) against ONE pass over the A stream: three
 // independent chains, each in ray order; the weights are read once instead of three times.
+#ifdef DDGI_BLEND_LAPS  // timing build (tools/blend_laps.py): workgroup 0's waves stamp s_memtime at the start, and before / after every stage's barrier
+__device__ unsigned long long g_blend_laps[14][24];  // rows 0-11: k_probe_blend_depth_res' waves; 12, 13: k_probe_blend_irr's
+#define BLEND_LAP(i) do { if (blockIdx.x == 0 && lane == 0 && (i) < 24) g_blend_laps[wave][(i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define BLEND_LAP(i) do { } while (0)
+#endif
+#ifndef DDGI_IRR_EXP
+#define DDGI_IRR_EXP 0
+#endif
+#ifndef DDGI_IRR_ORDER
+#define DDGI_IRR_ORDER 1
+#endif
 // The same for 256 rays (32 float4 per lane and stream), written out: with the loop above the compiler rotates the prefetch ring
 // through ~190 register moves at the end of every trip — and waits for EVERY outstanding load first (in-kernel clocks: 36 000
 // cycles for 384 MFMAs that take 24 576).  Unrolled, ring slot u simply is a set of registers, and each wait names the load it needs.
-template <int kDepth>
-DDGI_D void blend_contract3_256(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, f16v (&acc)[3])
+template <int kDepth, class AfterFill>
+DDGI_D void blend_contract3_256(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, f16v (&acc)[3], AfterFill&& after_fill)
 {
     constexpr int n4 = 32;
     static_assert(n4 % kDepth == 0, "the ring goes round a whole number of times");
@@ -209,21 +221,30 @@ DDGI_D void blend_contract3_256(const float* __restrict__ wa, const float* __res
 #pragma unroll
         for (int c = 0; c < 3; ++c) bb[c][u] = pb[c][static_cast<size_t>(u) * 64];
     }
+#ifdef DDGI_BLEND_LAPS
+    const int lane = threadIdx.x & 63, wave = 12 + (threadIdx.x >> 6);
+#endif
+    after_fill();  // (the caller's own requests: behind the first operands — loads return in order —, with kDepth steps to arrive)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < n4; ++k)
     {
         const int u = k % kDepth;
+        if (k % 8 == 1) BLEND_LAP(5 + k / 8);  // (timing build: the second step of every eight — the first one's operands have arrived)
         const float4 a = ab[u];
         float4 b[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) b[c] = bb[c][u];
         if (k + kDepth < n4)
         {
+#if DDGI_IRR_EXP != 2  // (timing experiments, wrong tiles: 1 = one colour channel's records for all three chains, 2 = the weights of the first steps for all)
             ab[u] = pa[static_cast<size_t>(k + kDepth) * 64];
+#endif
 #pragma unroll
-            for (int c = 0; c < 3; ++c) bb[c][u] = pb[c][static_cast<size_t>(k + kDepth) * 64];
+            for (int c = 0; c < (DDGI_IRR_EXP == 1 ? 1 : 3); ++c) bb[c][u] = pb[c][static_cast<size_t>(k + kDepth) * 64];
         }
         __builtin_amdgcn_sched_barrier(0);  // (the requests stay kDepth steps ahead of their use: the scheduler would sink them to save registers)
+#if DDGI_IRR_ORDER == 0
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[c].x, acc[c], 0, 0, 0);
 #pragma unroll
@@ -232,18 +253,32 @@ DDGI_D void blend_contract3_256(const float* __restrict__ wa, const float* __res
         for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[c].z, acc[c], 0, 0, 0);
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[c].w, acc[c], 0, 0, 0);
+#else
+        // a chain's four links of this step back to back: a dependent MFMA takes its accumulator from the one before it; three
+        // chains taking turns read theirs from the register file every time
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+        {
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[c].x, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[c].y, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[c].z, acc[c], 0, 0, 0);
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[c].w, acc[c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);  // (the scheduler would interleave the chains again)
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <int kDepth>
-DDGI_D void blend_contract3(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, int q_pairs, f16v (&acc)[3])
+template <int kDepth, class AfterFill>
+DDGI_D void blend_contract3(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, int q_pairs, f16v (&acc)[3], AfterFill&& after_fill)
 {
     if (q_pairs == 128)  // (wave-uniform: 256 rays per probe, the common case)
     {
-        blend_contract3_256<kDepth>(wa, vb, b_stride, acc);
+        blend_contract3_256<kDepth>(wa, vb, b_stride, acc, after_fill);
         return;
     }
+    after_fill();
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[c] = f16v{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const float4* __restrict__ pa = reinterpret_cast<const float4*>(wa);
@@ -458,7 +493,10 @@ DDGI_D f16v mfma_step(float a, float b, f16v acc)
 #else
     if (!kPaced) return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     static_assert(DDGI_BLEND_PACE >= 18 && DDGI_BLEND_PACE <= 32, "at least the 18 wait states between a 16-pass MFMA and a read of its result; two s_nop");
-    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n"
+    // (the compiler does not know that this is an MFMA: the two wait states in front are the ones it would put between a VALU write
+    // of an operand — the accumulator's zeroes — and the MFMA that reads it)
+    asm volatile("s_nop 1\n"
+                 "v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n"
                  "s_nop 15\n"
                  "s_nop " DDGI_STR(DDGI_BLEND_PACE - 17)
                  : "+v"(acc)
@@ -467,12 +505,6 @@ DDGI_D f16v mfma_step(float a, float b, f16v acc)
 #endif
 }
 
-#ifdef DDGI_BLEND_LAPS  // timing build (tools/blend_laps.py): workgroup 0's waves stamp s_memtime at the start, and before / after every stage's barrier
-__device__ unsigned long long g_blend_laps[14][24];  // rows 0-11: k_probe_blend_depth_res' waves; 12, 13: k_probe_blend_irr's
-#define BLEND_LAP(i) do { if (blockIdx.x == 0 && lane == 0 && (i) < 24) g_blend_laps[wave][(i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define BLEND_LAP(i) do { } while (0)
-#endif
 constexpr int kResN4 = 32;                          // float4 per lane of a resident tile: 128 ray pairs
 constexpr int kResGroupF4 = kResN4 * 64;            // float4 of one group's records (16 probes x 2 moments x 256 rays)
 constexpr int kResServiceWaves = 5;
@@ -729,9 +761,10 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
                 old[b] = *reinterpret_cast<const float4*>(A.irradiance_old + static_cast<size_t>(slots[min(p0 + 2u * b, 31u)]) * (kIrrTile * kIrrTile * 4) + e * 4);
         };
         float4 old[kBatch];
-        if (kEarly) load_old(static_cast<uint32_t>(mi), old);
         f16v acc[3];
-        blend_contract3<kDepth>(wa, vb, static_cast<size_t>(n_pad) * 32, q_pairs, acc);
+        blend_contract3<kDepth>(wa, vb, static_cast<size_t>(n_pad) * 32, q_pairs, acc, [&] {
+            if (kEarly) load_old(static_cast<uint32_t>(mi), old);
+        });
         BLEND_LAP(2);
         bool outside = false;
 #pragma unroll

@@ -34,4 +34,4 @@ for wv in range(12):
 print("k_probe_blend_irr, workgroup 0 (cycles since entry): slots written | barrier | contraction done | staged + barrier | texels stored")
 for wv in (12, 13):
     row = laps[wv].astype(np.int64)
-    print("wave %d: " % (wv - 12), "  ".join("%6d" % (row[i] - row[22]) for i in range(5)))
+    print("wave %d: " % (wv - 12), "  ".join("%6d" % (row[i] - row[22]) for i in range(5)), "  | second step of every eight of the contraction:", "  ".join("%6d" % (row[i] - row[22]) for i in range(5, 9)))
