@@ -31,7 +31,7 @@ hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, i
 hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t stream);
 int aq_pool_size(int nwords, size_t lds_limit);
 int aq_pool_size_fast(int nwords_skip, size_t lds_limit, bool plain);
-hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream);
+hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, uint32_t* next_work_counter, hipStream_t stream);
 size_t blend_weights_floats(int n);
 hipError_t launch_blend_weights(const BlendArgs& args, hipStream_t stream);
 hipError_t launch_carry_tiles(void* dst, const void* src, const int32_t* map, uint32_t n_probes, uint32_t words_per_tile, hipStream_t stream);
@@ -88,6 +88,7 @@ static const TuningKey kTuningKeys[] = {
     {"sample_box", &Tuning::sample_box, "DDGI_SAMPLE_BOX"},
     {"noise_lut", &Tuning::noise_lut, nullptr},
     {"lut_off", &Tuning::lut_off, "DDGI_LUT_OFF"},
+    {"timing", &Tuning::timing, "DDGI_TIMING"},
     {"verbose", &Tuning::verbose, "DDGI_VERBOSE"},
 #ifdef DDGI_PROFILING
     {"ablate", &Tuning::ablate, "DDGI_ABLATE"},
@@ -828,8 +829,10 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     {
         if (!e->d_work)
         {
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_work), 2 * sizeof(uint32_t)));  // [0] ray counter, [1] kernel status
-            HIP_TRY(hipMemsetAsync(e->d_work, 0, 2 * sizeof(uint32_t), e->stream));
+            // [0], [2] the queue kernel's ray counters (they take turns: a launch zeroes the next one's), [1] kernel status, [3] the round kernel's counter
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_work), 4 * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(e->d_work, 0, 4 * sizeof(uint32_t), e->stream));
+            e->work_turn = 0;
         }
         // one persistent workgroup per CU unless the launch is tiny (the launcher sizes the ray claims
         // so that every workgroup gets several: launch_probe_trace_wf)
@@ -884,7 +887,8 @@ static int measure_march_waves(ddgi_engine* e, const TracePlan& p, int start, in
         {
             float t = 0.0f;
             HIP_TRY(hipEventRecord(ev[0], e->stream));
-            HIP_TRY(launch_probe_trace_aq(p.a, p.pool, static_cast<int>(p.grid), mw, e->d_work, e->d_work + 1, e->stream));
+            HIP_TRY(launch_probe_trace_aq(p.a, p.pool, static_cast<int>(p.grid), mw, e->d_work + 2 * e->work_turn, e->d_work + 1, e->d_work + 2 * (1 - e->work_turn), e->stream));
+            e->work_turn ^= 1;
             HIP_TRY(hipEventRecord(ev[1], e->stream));
             HIP_TRY(hipEventSynchronize(ev[1]));
             HIP_TRY(hipEventElapsedTime(&t, ev[0], ev[1]));
@@ -986,7 +990,8 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     int march_waves = 5;
     if (p.pool > 0 && p.use_async)
         if (int rc = choose_march_waves(e, p, true, false, &march_waves)) return rc;
-    HIP_TRY(hipEventRecord(ev[0], e->stream));  // (DDGI mode: the trace time includes the blend's two small weight kernels)
+    const bool timing = e->tuning.timing != 0;  // (two or three events per update: ~3 us of the stream's time each)
+    if (timing) HIP_TRY(hipEventRecord(ev[0], e->stream));  // (DDGI mode: the trace time includes the blend's two small weight kernels)
     BlendArgs b{};
     if (p.ddgi_mode)
     {
@@ -1018,13 +1023,16 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     if (p.pool > 0)
     {
         if (p.use_async)
-            HIP_TRY(launch_probe_trace_aq(a, p.pool, static_cast<int>(p.grid), march_waves, e->d_work, e->d_work + 1, e->stream));
+        {
+            HIP_TRY(launch_probe_trace_aq(a, p.pool, static_cast<int>(p.grid), march_waves, e->d_work + 2 * e->work_turn, e->d_work + 1, e->d_work + 2 * (1 - e->work_turn), e->stream));
+            e->work_turn ^= 1;
+        }
         else
-            HIP_TRY(launch_probe_trace_wf(a, p.wf_threads, p.pool, static_cast<int>(p.grid), e->d_work, e->stream));
+            HIP_TRY(launch_probe_trace_wf(a, p.wf_threads, p.pool, static_cast<int>(p.grid), e->d_work + 3, e->stream));
     }
     else
         HIP_TRY(launch_probe_trace_ref(a, static_cast<int>(p.grid), e->stream));
-    HIP_TRY(hipEventRecord(ev[1], e->stream));
+    if (timing) HIP_TRY(hipEventRecord(ev[1], e->stream));
     if (p.ddgi_mode)
     {
         HIP_TRY(launch_probe_blend(b, e->num_cus, e->stream));
@@ -1032,7 +1040,10 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     }
     pair_switch.launched = true;
     e->box_of = nullptr;  // the textures change: the sampler's per-texel table is stale
-    HIP_TRY(hipEventRecord(ev[2], e->stream));
+    // (REF mode: nothing follows the trace kernel, its end event is the update's end — an event costs the stream microseconds)
+    e->ev_has_blend[e->updates % ddgi_engine::kRing] = p.ddgi_mode;
+    e->ev_valid[e->updates % ddgi_engine::kRing] = timing;
+    if (timing && p.ddgi_mode) HIP_TRY(hipEventRecord(ev[2], e->stream));
     e->updates += 1;
     return DDGI_OK;
 }
@@ -1066,14 +1077,17 @@ int ddgi_last_update_ms(ddgi_handle e, float* trace_ms, float* blend_ms, float* 
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     if (e->updates == 0) return fail(DDGI_ERR_NOT_READY, "no probe update has been issued yet");
     HIP_TRY(hipSetDevice(e->device));
-    hipEvent_t* ev = e->ev[(e->updates - 1) % ddgi_engine::kRing];
-    HIP_TRY(hipEventSynchronize(ev[2]));
+    const size_t slot = (e->updates - 1) % ddgi_engine::kRing;
+    if (!e->ev_valid[slot]) return fail(DDGI_ERR_NOT_READY, "the last update was not timed (tuning \"timing\" is 0)");
+    hipEvent_t* ev = e->ev[slot];
+    const bool blend = e->ev_has_blend[slot];
+    HIP_TRY(hipEventSynchronize(ev[blend ? 2 : 1]));
     float t01 = 0.f, t12 = 0.f, t02 = 0.f;
     HIP_TRY(hipEventElapsedTime(&t01, ev[0], ev[1]));
-    HIP_TRY(hipEventElapsedTime(&t12, ev[1], ev[2]));
-    HIP_TRY(hipEventElapsedTime(&t02, ev[0], ev[2]));
+    if (blend) HIP_TRY(hipEventElapsedTime(&t12, ev[1], ev[2]));
+    HIP_TRY(hipEventElapsedTime(&t02, ev[0], ev[blend ? 2 : 1]));
     if (trace_ms) *trace_ms = t01;
-    if (blend_ms) *blend_ms = e->mode == DDGI_MODE_REF ? 0.f : t12;
+    if (blend_ms) *blend_ms = t12;
     if (total_ms) *total_ms = t02;
     return DDGI_OK;
 }
@@ -1086,13 +1100,16 @@ int ddgi_update_history_ms(ddgi_handle e, float* trace_ms, float* blend_ms, int 
     unsigned long long have = e->updates < static_cast<unsigned long long>(ddgi_engine::kRing) ? e->updates : ddgi_engine::kRing;
     if (have > static_cast<unsigned long long>(capacity)) have = capacity;
     for (unsigned long long i = 0; i < have; ++i)
+        if (!e->ev_valid[(e->updates - have + i) % ddgi_engine::kRing]) return fail(DDGI_ERR_NOT_READY, "an update of the history was not timed (tuning \"timing\" was 0)");
+    for (unsigned long long i = 0; i < have; ++i)
     {
-        hipEvent_t* ev = e->ev[(e->updates - have + i) % ddgi_engine::kRing];
+        const size_t slot = (e->updates - have + i) % ddgi_engine::kRing;
+        hipEvent_t* ev = e->ev[slot];
         float t01 = 0.f, t12 = 0.f;
         HIP_TRY(hipEventElapsedTime(&t01, ev[0], ev[1]));
-        HIP_TRY(hipEventElapsedTime(&t12, ev[1], ev[2]));
+        if (e->ev_has_blend[slot]) HIP_TRY(hipEventElapsedTime(&t12, ev[1], ev[2]));
         if (trace_ms) trace_ms[i] = t01;
-        if (blend_ms) blend_ms[i] = e->mode == DDGI_MODE_REF ? 0.f : t12;
+        if (blend_ms) blend_ms[i] = t12;
     }
     *n_out = static_cast<int>(have);
     return DDGI_OK;

@@ -25,6 +25,7 @@ struct Tuning
     int blend_kernel = 0;   // DDGI blend: 0 auto, 1 one probe per workgroup (cross-check), 2 auto with the compiler's division (cross-check)
     int aq_pool = 0, wf_pool = 0, wf_maxpool = 0, wf_threads = 1024;
     int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
+    int timing = 1;         // per-update events for ddgi_last_update_ms / ddgi_update_history_ms (0: none — saves the stream ~6 us per update)
     int fast_march = 0;     // tolerance mode: marches skip empty space (NOT bit-exact; tests/test_gpu_fast_march.py states the tolerance)
     int light_vis = 1;      // per-voxel light-feeler classes (k_light_visibility): 0 = march every feeler
     int sample_box = 1;     // REF ddgi_sample*: large batches go through the per-texel table of sample_probe (0: every point evaluates its 8 x 26 texels)
@@ -107,9 +108,12 @@ struct ddgi_engine
 
     static constexpr int kRing = 64;  // timing history: one event triple per recent update
     hipEvent_t ev[kRing][3] = {};
+    bool ev_has_blend[kRing] = {};    // the update recorded ev[2] (DDGI mode: after the blend); otherwise ev[1] is its end
+    bool ev_valid[kRing] = {};        // the update recorded its events at all (tuning "timing")
     unsigned long long updates = 0;
     int wait_threshold = 64;
-    uint32_t* d_work = nullptr;             // chunk counter of the wavefront trace kernel
+    uint32_t* d_work = nullptr;             // ray counters and status word of the wavefront trace kernels (ddgi_engine.cpp: plan_trace)
+    int work_turn = 0;                      // which of the queue kernel's two ray counters the next launch uses
     void* d_wf_cold = nullptr;              // wavefront kernel scratch: per-slot shading state
     float4* d_wf_dir = nullptr;
     size_t wf_cold_slots = 0, wf_dir_slots = 0;

@@ -1191,11 +1191,14 @@ DDGI_D void aq_push(uint16_t* ring, uint32_t* tail, bool pred, uint32_t value, i
 // offset (folded into the ds instructions: no address arithmetic, one SGPR instead of eleven).
 template <bool kStats, int kPool, class Cfg>
 __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, const int pool_size, const int march_waves, uint32_t* __restrict__ work_counter,
-                                                            uint32_t* __restrict__ status)
+                                                            uint32_t* __restrict__ status, uint32_t* __restrict__ next_work_counter)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t wf_lds[];
     constexpr int T = 1024;
     const int tid = threadIdx.x;
+    // The ray counter of the NEXT launch on this handle (the two take turns): zeroed here instead of by a fill kernel in front of
+    // every launch — 5 us of kernel and a dependency of its own per update.  (The launch before this one zeroed this launch's.)
+    if (blockIdx.x == 0 && tid == 0) *next_work_counter = 0u;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const uint32_t PS = kPool > 0 ? static_cast<uint32_t>(kPool) : static_cast<uint32_t>(pool_size);
@@ -1644,35 +1647,34 @@ int aq_pool_size_fast(int nwords_skip, size_t lds_limit, bool plain)
 }
 
 template <bool kStats, int kPool, class Cfg>
-static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
+static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, uint32_t* next_work_counter, hipStream_t stream)
 {
     const size_t lds = Cfg::kFast ? aq_lds_bytes(args.scene.nwords_skip, pool, true, kPool > 0 ? kAqCapFast : kAqCap) : aq_lds_bytes(args.scene.nwords, pool);
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_probe_trace_aq<kStats, kPool, Cfg>), 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_probe_trace_aq<kStats, kPool, Cfg>), dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter, status);
+    hipLaunchKernelGGL((k_probe_trace_aq<kStats, kPool, Cfg>), dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter, status, next_work_counter);
     return hipGetLastError();
 }
 
-hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, hipStream_t stream)
+// work_counter must be zero: the handle's two counters take turns, each launch zeroes the other one (next_work_counter)
+hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, uint32_t* next_work_counter, hipStream_t stream)
 {
     if (args.fast_march)
     {
         // (the tolerance-mode build: no counters kernel, no ablation switches)
         if (pool == kAqPoolFast && args.nl == 1)
-            return args.ddgi ? launch_aq<false, kAqPoolFast, CfgPlain<1, true>>(args, pool, grid_blocks, march_waves, work_counter, status, stream)
-                             : launch_aq<false, kAqPoolFast, CfgPlain<0, true>>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
-        return launch_aq<false, 0, CfgRuntimeT<true>>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+            return args.ddgi ? launch_aq<false, kAqPoolFast, CfgPlain<1, true>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream)
+                             : launch_aq<false, kAqPoolFast, CfgPlain<0, true>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
+        return launch_aq<false, 0, CfgRuntimeT<true>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
     }
-    if (args.stats) return launch_aq<true, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+    if (args.stats) return launch_aq<true, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
     if (pool == kAqPool && args.nl == 1 && args.ablate == 0)
-        return args.ddgi ? launch_aq<false, kAqPool, CfgPlain<1>>(args, pool, grid_blocks, march_waves, work_counter, status, stream)
-                         : launch_aq<false, kAqPool, CfgPlain<0>>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+        return args.ddgi ? launch_aq<false, kAqPool, CfgPlain<1>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream)
+                         : launch_aq<false, kAqPool, CfgPlain<0>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
     if (pool == kAqPool && args.nl > 1 && args.ablate == 0)
-        return args.ddgi ? launch_aq<false, kAqPool, CfgMulti<1>>(args, pool, grid_blocks, march_waves, work_counter, status, stream)
-                         : launch_aq<false, kAqPool, CfgMulti<0>>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
-    return launch_aq<false, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, work_counter, status, stream);
+        return args.ddgi ? launch_aq<false, kAqPool, CfgMulti<1>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream)
+                         : launch_aq<false, kAqPool, CfgMulti<0>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
+    return launch_aq<false, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
 }
 
 // LDS bytes of k_probe_trace_wf for a pool of `pool` rays

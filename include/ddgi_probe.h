@@ -204,6 +204,9 @@ int ddgi_tune(ddgi_handle h);
  *                   runs the exact march; ddgi_get_tuning "fast_march_active" tells.  0 (default) = the exact march [DDGI_FAST_MARCH]
  *   "march_waves"   n > 0 pins the split (waves that march, of 16); 0 = per configuration            [DDGI_AQ_MARCH]
  *   "trace_kernel"  0 auto, 1 round-based, 2 ray per lane, 3 queues (cross-checks)   [DDGI_TRACE_KERNEL=rounds|lane|queues]
+ *   "timing"        1 (default): every update records two (REF) or three (DDGI) events on its stream for ddgi_last_update_ms /
+ *                   ddgi_update_history_ms; 0: none — the queries then fail with DDGI_ERR_NOT_READY, and a stream of
+ *                   back-to-back updates loses ~6 us per update less to the command processor                [DDGI_TIMING]
  *   "blend_kernel"  0 auto, 1 one probe per workgroup (cross-check), 2 auto but every quotient by the compiler's
  *                   division — the path a probe group takes whose sums lie outside the short division's domain
  *                   (cross-check)                                                   [DDGI_BLEND_KERNEL=probe|division]
