@@ -213,3 +213,34 @@ def test_queue_kernel_safety_net_reports_instead_of_hanging(ddgi):
     res = subprocess.run([sys.executable, "-c", _SAFETY_NET_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "ABORT-REPORTED" in res.stdout and "RECOVERED" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.gpu
+def test_update_timing_can_be_switched_off(ddgi):
+    """Tuning "timing": an update records its events (two in REF mode, three in DDGI mode) unless told not to; the timing queries
+    then say DDGI_ERR_NOT_READY instead of returning stale numbers, and the textures are the same either way."""
+    counts, side, s, origin, _ = CONFIGS["c2_cornell"]
+    with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(1, 4)) as eng:
+        eng.generate_probe_rays(seed=1)
+        eng.probe_update()
+        timed = eng.read_textures()
+        ms = eng.last_update_ms()
+        assert ms["trace_ms"] > 0 and ms["blend_ms"] == 0 and abs(ms["total_ms"] - ms["trace_ms"]) < 1e-6   # REF mode: one kernel
+        eng.set_tuning("timing", 0)
+        eng.probe_update()
+        untimed = eng.read_textures()
+        with pytest.raises(ddgi.DDGIError) as err:
+            eng.last_update_ms()
+        assert "not timed" in str(err.value)
+        with pytest.raises(ddgi.DDGIError):
+            eng.update_history_ms(4)
+        eng.set_tuning("timing", 1)
+        eng.probe_update()
+        assert eng.last_update_ms()["trace_ms"] > 0
+        tr, bl = eng.update_history_ms(1)
+        assert len(tr) == 1 and tr[0] > 0 and bl[0] == 0
+        assert all(np.array_equal(a, b) for a, b in zip(timed, untimed))
+        eng.set_mode(ddgi.MODE_DDGI)
+        eng.probe_update()
+        ms = eng.last_update_ms()
+        assert ms["blend_ms"] > 0 and ms["total_ms"] >= ms["trace_ms"] + ms["blend_ms"] - 1e-3
