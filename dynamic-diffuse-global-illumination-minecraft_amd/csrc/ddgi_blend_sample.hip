@@ -832,10 +832,11 @@ __global__ __launch_bounds__(kIrrWaves * 64) void k_probe_blend_irr(const BlendA
     blend_irr_role<DDGI_IRR_DEPTH>(A, rad_rgb, w_tiles, w_sum, sh, blockIdx.x, gridDim.x);
 }
 
-// Few probes (one rank's slab of a sharded grid: fewer groups than the chip has room for): one launch for both — blocks
+// Few probes (one rank's slab of a sharded grid: fewer depth groups than half the CUs): one launch for both — blocks
 // [0, irr_blocks) take irradiance groups with their first two waves (the other five leave at once), the rest take depth
-// groups: the two contractions are bound by their own latency there and overlap instead of running one after the other
-// (2 048 probes: 51 -> 28 us; with 16 384 probes the half-empty irradiance workgroups cost more than the overlap gains).
+// groups: the two contractions are bound by their own latency there and overlap instead of running one after the other.
+// Measured on slabs of C3 (tools/blend_merge_sweep.sh; one launch / two launches): 2 048 probes 27 / 35 us, 4 096 probes 43 / 36 us,
+// 8 192 probes 65 / 46 us — since round 3's persistent depth kernel the two launches win from one group per CU on.
 __global__ __launch_bounds__(kBlendWaves * 64) void k_probe_blend_mfma(const BlendArgs A, const float* __restrict__ rad_rgb, const float* __restrict__ rad_dd,
                                                                        const float* __restrict__ w_tiles, const float* __restrict__ w_sum, const uint32_t irr_blocks)
 {
@@ -985,7 +986,7 @@ hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t st
     {
         const uint32_t dep_tasks = (args.n_local_probes + 15u) / 16u, irr_tasks = (args.n_local_probes + 31u) / 32u;
         const uint32_t dep_blocks = std::min<uint32_t>(dep_tasks, static_cast<uint32_t>(num_cus) * 8u), irr_blocks = std::min<uint32_t>(irr_tasks, static_cast<uint32_t>(num_cus) * 16u);
-        if (dep_tasks <= static_cast<uint32_t>(num_cus) * 2u)
+        if (dep_tasks * 2u <= static_cast<uint32_t>(num_cus) * args.merge_below)  // (default: fewer depth groups than half the CUs)
             hipLaunchKernelGGL(k_probe_blend_mfma, dim3(irr_blocks + dep_blocks), dim3(kBlendWaves * 64), 0, stream, args, args.rad_rgb, args.rad_dd, static_cast<const float*>(args.w),
                                static_cast<const float*>(args.w_sum), irr_blocks);
         else

@@ -73,6 +73,7 @@ static const TuningKey kTuningKeys[] = {
     {"march_waves", &Tuning::march_waves, "DDGI_AQ_MARCH"},
     {"autotune", &Tuning::autotune, "DDGI_AUTOTUNE"},
     {"blend_kernel", &Tuning::blend_kernel, nullptr},
+    {"blend_merge", &Tuning::blend_merge, "DDGI_BLEND_MERGE"},
     {"aq_pool", &Tuning::aq_pool, "DDGI_AQ_POOL"},
     {"wf_pool", &Tuning::wf_pool, "DDGI_WF_POOL"},
     {"wf_maxpool", &Tuning::wf_maxpool, "DDGI_WF_MAXPOOL"},
@@ -1016,6 +1017,7 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         b.w = e->d_blend_w + 256;
         if (e->tuning.blend_kernel == 1) b.w = b.w_sum = nullptr;  // one probe per workgroup, weights in place
         b.force_division = e->tuning.blend_kernel == 2 ? 1u : 0u;
+        b.merge_below = static_cast<uint32_t>(e->tuning.blend_merge < 0 ? 0 : e->tuning.blend_merge);
         // the blend's weight tiles depend on the frame's ray directions only: made before the trace, off the critical path
         // between the last ray and the first tile
         HIP_TRY(launch_blend_weights(b, e->stream));

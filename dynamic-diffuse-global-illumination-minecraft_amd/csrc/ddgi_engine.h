@@ -25,6 +25,7 @@ struct Tuning
     int blend_kernel = 0;   // DDGI blend: 0 auto, 1 one probe per workgroup (cross-check), 2 auto with the compiler's division (cross-check)
     int aq_pool = 0, wf_pool = 0, wf_maxpool = 0, wf_threads = 1024;
     int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
+    int blend_merge = 1;    // DDGI blend: up to this many HALF depth groups (of 16 probes) per CU, depth and irradiance run as one launch
     int timing = 1;         // per-update events for ddgi_last_update_ms / ddgi_update_history_ms (0: none — saves the stream ~6 us per update)
     int fast_march = 0;     // tolerance mode: marches skip empty space (NOT bit-exact; tests/test_gpu_fast_march.py states the tolerance)
     int light_vis = 1;      // per-voxel light-feeler classes (k_light_visibility): 0 = march every feeler

@@ -148,6 +148,7 @@ struct BlendArgs
     uint32_t n_local_probes;
     float* w;      // per-update texel weights as MFMA A tiles (k_blend_weights; ddgi_blend_sample.hip: weight_index), or null
     float* w_sum;  // [256] weight sum per texel column: [0,196) depth texels, [196,232) irradiance texels
+    uint32_t merge_below;     // HALF depth groups per CU up to which depth and irradiance run as ONE launch (k_probe_blend_mfma); tuning "blend_merge"
     uint32_t force_division;  // 1: the MFMA kernels divide with the compiler's `/` everywhere (what they do for a group whose sums lie
                               // outside pm::div_prepared's domain) — tuning "blend_kernel" 2, the cross-check of that path
 };

@@ -207,6 +207,8 @@ int ddgi_tune(ddgi_handle h);
  *   "timing"        1 (default): every update records two (REF) or three (DDGI) events on its stream for ddgi_last_update_ms /
  *                   ddgi_update_history_ms; 0: none — the queries then fail with DDGI_ERR_NOT_READY, and a stream of
  *                   back-to-back updates loses ~6 us per update less to the command processor                [DDGI_TIMING]
+ *   "blend_merge"   DDGI blend: depth and irradiance tiles in ONE launch up to this many half probe groups (8 probes) per CU
+ *                   (default 1: grids / slabs of up to 8 probes per CU), in two launches above                  [DDGI_BLEND_MERGE]
  *   "blend_kernel"  0 auto, 1 one probe per workgroup (cross-check), 2 auto but every quotient by the compiler's
  *                   division — the path a probe group takes whose sums lie outside the short division's domain
  *                   (cross-check)                                                   [DDGI_BLEND_KERNEL=probe|division]
