@@ -201,13 +201,12 @@ __device__ unsigned long long g_blend_laps[14][24];  // rows 0-11: k_probe_blend
 #ifndef DDGI_IRR_ORDER
 #define DDGI_IRR_ORDER 1
 #endif
-// The same for 256 rays (32 float4 per lane and stream), written out: with the loop above the compiler rotates the prefetch ring
+// The same for 256 or 512 rays (n4 = 32 or 64 float4 per lane and stream), written out: with the loop above the compiler rotates the prefetch ring
 // through ~190 register moves at the end of every trip — and waits for EVERY outstanding load first (in-kernel clocks: 36 000
 // cycles for 384 MFMAs that take 24 576).  Unrolled, ring slot u simply is a set of registers, and each wait names the load it needs.
-template <int kDepth, class AfterFill>
-DDGI_D void blend_contract3_256(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, f16v (&acc)[3], AfterFill&& after_fill)
+template <int kDepth, int n4, class AfterFill>
+DDGI_D void blend_contract3_unrolled(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, f16v (&acc)[3], AfterFill&& after_fill)
 {
-    constexpr int n4 = 32;
     static_assert(n4 % kDepth == 0, "the ring goes round a whole number of times");
 #pragma unroll
     for (int c = 0; c < 3; ++c) acc[c] = f16v{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -273,9 +272,16 @@ DDGI_D void blend_contract3_256(const float* __restrict__ wa, const float* __res
 template <int kDepth, class AfterFill>
 DDGI_D void blend_contract3(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, int q_pairs, f16v (&acc)[3], AfterFill&& after_fill)
 {
-    if (q_pairs == 128)  // (wave-uniform: 256 rays per probe, the common case)
+    // (the stand-alone irradiance kernel only: the merged small-grid kernel shares its CUs with depth workgroups and keeps the loop's
+    // smaller register footprint)
+    if (kDepth >= 8 && q_pairs == 128)  // (wave-uniform: 256 rays per probe, the common case)
     {
-        blend_contract3_256<kDepth>(wa, vb, b_stride, acc, after_fill);
+        blend_contract3_unrolled<kDepth, 32>(wa, vb, b_stride, acc, after_fill);
+        return;
+    }
+    if (kDepth >= 8 && q_pairs == 256)  // (512 rays: BASELINE's C4)
+    {
+        blend_contract3_unrolled<kDepth, 64>(wa, vb, b_stride, acc, after_fill);
         return;
     }
     after_fill();
