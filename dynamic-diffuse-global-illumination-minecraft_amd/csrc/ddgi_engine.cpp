@@ -431,6 +431,7 @@ int ddgi_destroy(ddgi_handle e)
 int ddgi_configure(ddgi_handle e, const ddgi_irradiance_field* field, const ddgi_render_settings* settings)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if (int rc = validate_config(field, settings, e->world)) return rc;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -452,6 +453,7 @@ static float probe_axis_position(int idx, int count, int side, float origin)
 int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const ddgi_render_settings* settings, int carry_over)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if (!carry_over) return ddgi_configure(e, field, settings);
     if (int rc = validate_config(field, settings, e->world)) return rc;
     HIP_TRY(hipSetDevice(e->device));
@@ -538,6 +540,7 @@ int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const dd
 int ddgi_set_mode(ddgi_handle e, int mode)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if (mode != DDGI_MODE_REF && mode != DDGI_MODE_DDGI) return fail(DDGI_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
     if (mode == e->mode) return DDGI_OK;
     HIP_TRY(hipSetDevice(e->device));
@@ -954,6 +957,7 @@ static int choose_march_waves(ddgi_engine* e, const TracePlan& p, bool may_block
 int ddgi_tune(ddgi_handle e)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     HIP_TRY(hipSetDevice(e->device));
     TracePlan p;
     if (int rc = plan_trace(e, p)) return rc;
@@ -1047,6 +1051,7 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     e->ev_valid[e->updates % ddgi_engine::kRing] = timing;
     if (timing && p.ddgi_mode) HIP_TRY(hipEventRecord(ev[2], e->stream));
     e->updates += 1;
+    e->tex_ops_since_update = false;
     return DDGI_OK;
 }
 
@@ -1140,6 +1145,7 @@ int ddgi_trace_stats(ddgi_handle e, int enable, unsigned long long* out64)
 int ddgi_read_textures(ddgi_handle e, uint8_t* albedo, uint8_t* distance)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if (e->mode != DDGI_MODE_REF) return fail(DDGI_ERR_UNSUPPORTED, "ddgi_read_textures is REF-mode only; use ddgi_read_tiles");
     HIP_TRY(hipSetDevice(e->device));
     const GridK g = make_grid(e);
@@ -1173,6 +1179,7 @@ int ddgi_read_textures(ddgi_handle e, uint8_t* albedo, uint8_t* distance)
 int ddgi_read_tiles(ddgi_handle e, float* irradiance, float* depth)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if (e->mode != DDGI_MODE_DDGI) return fail(DDGI_ERR_UNSUPPORTED, "ddgi_read_tiles is DDGI-mode only; use ddgi_read_textures");
     HIP_TRY(hipSetDevice(e->device));
     const GridK g = make_grid(e);
@@ -1269,6 +1276,7 @@ static void release_sample_box_if_borrowed(ddgi_engine* e)
 int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, size_t n, float* d_rgb, int32_t* d_cage)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if (n == 0) return DDGI_OK;
     if (!d_pos || !d_nrm || !d_rgb) return fail(DDGI_ERR_INVALID_ARGUMENT, "null device pointer");
     if (n > 0xffffffffull) return fail(DDGI_ERR_INVALID_ARGUMENT, "too many points");
@@ -1321,6 +1329,7 @@ int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, si
 int ddgi_sample(ddgi_handle e, const float* pos, const float* nrm, size_t n, float* rgb, int32_t* cage)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if (n == 0) return DDGI_OK;
     if (!pos || !nrm || !rgb) return fail(DDGI_ERR_INVALID_ARGUMENT, "null pointer");
     HIP_TRY(hipSetDevice(e->device));
@@ -1367,6 +1376,7 @@ int ddgi_sample(ddgi_handle e, const float* pos, const float* nrm, size_t n, flo
 int ddgi_render_device(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_settings* st, uint32_t* d_rgba8, float* d_rgb_f32)
 {
     if (!e || !cam || !st || !d_rgba8) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/camera/settings/output");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if (st->scene < 0 || st->scene > 3) return fail(DDGI_ERR_INVALID_ARGUMENT, "scene %d not in {0,1,2,3}", st->scene);
     if (st->screen_width < 1 || st->screen_height < 1 || 1ll * st->screen_width * st->screen_height > 0x7fffffffll)
         return fail(DDGI_ERR_INVALID_ARGUMENT, "bad image size %d x %d", st->screen_width, st->screen_height);
@@ -1423,6 +1433,7 @@ int ddgi_render_device(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_
 int ddgi_render(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_settings* st, uint8_t* rgba8, float* rgb_f32)
 {
     if (!e || !cam || !st || !rgba8) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/camera/settings/output");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     HIP_TRY(hipSetDevice(e->device));
     const size_t n = static_cast<size_t>(st->screen_width > 0 ? st->screen_width : 0) * (st->screen_height > 0 ? st->screen_height : 0);
     uint32_t* d_img = nullptr;
@@ -1449,6 +1460,7 @@ int ddgi_render(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_setting
 int ddgi_set_stream(ddgi_handle e, void* hip_stream)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -1461,6 +1473,7 @@ int ddgi_device_textures(ddgi_handle e, void** tex0, size_t* tex0_bytes, void** 
                          size_t* slab_offset0, size_t* slab_bytes0, size_t* slab_offset1, size_t* slab_bytes1)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if (tex0) *tex0 = e->tex[0];
     if (tex1) *tex1 = e->tex[1];
     if (tex0_bytes) *tex0_bytes = e->tex_bytes[0];
@@ -1476,6 +1489,7 @@ int ddgi_device_textures(ddgi_handle e, void** tex0, size_t* tex0_bytes, void** 
 int ddgi_bind_textures(ddgi_handle e, void* tex0, void* tex1)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if ((tex0 == nullptr) != (tex1 == nullptr)) return fail(DDGI_ERR_INVALID_ARGUMENT, "bind both textures or neither");
     if (e->xch.pipelined || e->xch.p2p) return fail(DDGI_ERR_INVALID_ARGUMENT, "the pipelined / peer-to-peer exchange owns the texture pairs: ddgi_exchange_init(h, NULL, 0) first");
     HIP_TRY(hipSetDevice(e->device));

@@ -110,6 +110,7 @@ struct ddgi_engine
     static constexpr int kRing = 64;  // timing history: one event triple per recent update
     hipEvent_t ev[kRing][3] = {};
     bool ev_has_blend[kRing] = {};    // the update recorded ev[2] (DDGI mode: after the blend); otherwise ev[1] is its end
+    bool tex_ops_since_update = true;  // an API call other than ddgi_probe_update / ddgi_exchange* may have put work that touches the textures on the stream
     bool ev_valid[kRing] = {};        // the update recorded its events at all (tuning "timing")
     unsigned long long updates = 0;
     int wait_threshold = 64;

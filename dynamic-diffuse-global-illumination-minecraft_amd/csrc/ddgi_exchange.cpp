@@ -202,6 +202,26 @@ int p2p_wait_arrived(ddgi_engine* e, uint32_t seq)
     return DDGI_OK;
 }
 
+// The event the exchange's streams wait for: "this rank's slab is written".  Normally the last update's own end event — recorded
+// for ddgi_last_update_ms anyway (an event costs the stream microseconds, and a slab's update is short) —, a fresh one if the
+// update was not timed or if another call may have put work that touches the textures on the stream since.
+static int update_written_event(ddgi_engine* e, hipEvent_t* out)
+{
+    ddgi_engine::Exchange& x = e->xch;
+    if (!e->tex_ops_since_update && e->updates > 0)
+    {
+        const size_t slot = (e->updates - 1) % ddgi_engine::kRing;
+        if (e->ev_valid[slot])
+        {
+            *out = e->ev[slot][e->ev_has_blend[slot] ? 2 : 1];
+            return DDGI_OK;
+        }
+    }
+    HIP_TRY(hipEventRecord(x.written, e->stream));
+    *out = x.written;
+    return DDGI_OK;
+}
+
 int p2p_exchange(ddgi_engine* e)
 {
     ddgi_engine::Exchange& x = e->xch;
@@ -209,7 +229,8 @@ int p2p_exchange(ddgi_engine* e)
     const uint32_t seq = ++p.seq;
     const int cur = x.pipelined ? x.cur : 0;
     p.pair_seq[cur] = seq;
-    HIP_TRY(hipEventRecord(x.written, e->stream));
+    hipEvent_t written = nullptr;
+    if (int rc = update_written_event(e, &written)) return rc;
     // REF mode: the reference never assigns its `distances` image — every rank's copy is all zeros already
     const int n_tex = e->mode == DDGI_MODE_DDGI ? 2 : 1;
     // Phase 1, receiver -> every sender: everything this rank enqueued that reads the pair is done (`written` follows it in
@@ -220,7 +241,7 @@ int p2p_exchange(ddgi_engine* e)
     {
         const int q = (e->rank + step) % e->world;  // every rank starts with a different peer
         ddgi_engine::P2P::Peer& peer = p.peers[static_cast<size_t>(q)];
-        HIP_TRY(hipStreamWaitEvent(peer.stream, x.written, 0));
+        HIP_TRY(hipStreamWaitEvent(peer.stream, written, 0));
         if (int rc = p2p_write_flag(p, peer.stream, peer.flags + e->rank, seq)) return rc;
     }
     // Phase 2, sender: once q is ready, push the slab and tell q that it has landed
@@ -581,8 +602,9 @@ int ddgi_exchange(ddgi_handle e)
     hipStream_t s = e->stream;
     if (x.pipelined)
     {
-        HIP_TRY(hipEventRecord(x.written, e->stream));
-        HIP_TRY(hipStreamWaitEvent(x.comm_stream, x.written, 0));
+        hipEvent_t written = nullptr;
+        if (int rc = update_written_event(e, &written)) return rc;
+        HIP_TRY(hipStreamWaitEvent(x.comm_stream, written, 0));
         s = x.comm_stream;
     }
     // REF mode: the reference never assigns its `distances` image (probe_pass.comp:276,302) — every rank's copy is
