@@ -652,7 +652,6 @@ DDGI_D void blend_depth_resident(const BlendArgs& A, const float* __restrict__ r
         {
             // ---- texel waves: 128 threads, 16 float4 of a group's records each (2048 per group) ----
             __builtin_amdgcn_s_setprio(2);
-            const Quarter Qa = quarter_of(sw_id == 0 ? 0 : 2), Qb = quarter_of(sw_id == 0 ? 1 : 3);
             constexpr int kFetchLoads = kResGroupF4 / 128;
             const int ft = (sw_id >> 2) * 64 + lane;
             typedef float f4v __attribute__((ext_vector_type(4)));  // (a plain vector type, initialised: as an array of float4 the registers-across-stages end up in scratch)
@@ -670,11 +669,9 @@ DDGI_D void blend_depth_resident(const BlendArgs& A, const float* __restrict__ r
         f4v* park_ = reinterpret_cast<f4v*>(&sh.b_all[buf][0]) + ft;                        \
         _Pragma("unroll") for (int k = 0; k < kFetchLoads; ++k) park_[k * 128] = r[k];       \
     } while (0)
-            if (my_tasks > 0u)
-            {
-                DDGI_FETCH(0u);
-                DDGI_PARK(0);
-            }
+            if (my_tasks > 0u) DDGI_FETCH(0u);  // (first of all: the quarters' set-up below waits for a load of its own)
+            const Quarter Qa = quarter_of(sw_id == 0 ? 0 : 2), Qb = quarter_of(sw_id == 0 ? 1 : 3);
+            if (my_tasks > 0u) DDGI_PARK(0);
             if (my_tasks > 1u) DDGI_FETCH(1u);
             BLEND_LAP(0);
             __syncthreads();
@@ -740,8 +737,7 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
     int sx = tx, sy = ty;
     if (tx == 0 || ty == 0 || tx == kIrrTile - 1 || ty == kIrrTile - 1) border_source(tx, ty, kIrrTile, sx, sy);
     const int c = (sy - 1) * (kIrrTile - 2) + (sx - 1);
-    const float sw = w_sum[kDepInterior + c];
-    const pm::DivBy by = pm::div_by(sw > 1e-6f ? sw : __builtin_inff());  // (+inf: quotient +0 where the weight sum is ~0; the sums are >= +0)
+    const float sw = w_sum[kDepInterior + c];  // (requested here, used in the epilogue: nothing before the first operands waits for it)
     const float* stage_src = &stage_all[c >> 5][(c & 31) * kIrrStageStride];
     constexpr uint32_t kBatch = 8;        // old tiles in flight per wave
     constexpr bool kEarly = kDepth >= 8;  // the stand-alone kernel has the registers to fetch a task's first old tiles BEFORE its contraction.  (All
@@ -784,6 +780,7 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
         BLEND_LAP(3);
         const uint32_t np = min(32u, A.n_local_probes - task * 32u);
         const bool prepared = __builtin_amdgcn_readfirstlane(sh.unsafe[0] | sh.unsafe[1] | A.force_division) == 0u;
+        const pm::DivBy by = pm::div_by(sw > 1e-6f ? sw : __builtin_inff());  // (+inf: quotient +0 where the weight sum is ~0; the sums are >= +0)
         // (full groups as straight-line code, pm::div_prepared quotients: see blend_depth_resident)
         auto tiles = [&](auto full, auto prep) {
             constexpr bool kFull = decltype(full)::value, kPrepared = decltype(prep)::value;
