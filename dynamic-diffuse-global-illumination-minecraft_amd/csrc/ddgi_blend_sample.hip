@@ -204,8 +204,8 @@ __device__ unsigned long long g_blend_laps[14][24];  // rows 0-11: k_probe_blend
 // The same for 256 or 512 rays (n4 = 32 or 64 float4 per lane and stream), written out: with the loop above the compiler rotates the prefetch ring
 // through ~190 register moves at the end of every trip — and waits for EVERY outstanding load first (in-kernel clocks: 36 000
 // cycles for 384 MFMAs that take 24 576).  Unrolled, ring slot u simply is a set of registers, and each wait names the load it needs.
-template <int kDepth, int n4, class AfterFill>
-DDGI_D void blend_contract3_unrolled(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, f16v (&acc)[3], AfterFill&& after_fill)
+template <int kDepth, int n4, class AfterFill, class AtTail>
+DDGI_D void blend_contract3_unrolled(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, f16v (&acc)[3], AfterFill&& after_fill, AtTail&& at_tail)
 {
     static_assert(n4 % kDepth == 0, "the ring goes round a whole number of times");
 #pragma unroll
@@ -266,22 +266,27 @@ DDGI_D void blend_contract3_unrolled(const float* __restrict__ wa, const float* 
         }
 #endif
         __builtin_amdgcn_sched_barrier(0);
+        if (k == n4 - kDepth)  // the last operands have been requested: the ring's registers come free from here on
+        {
+            at_tail();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 }
 
-template <int kDepth, class AfterFill>
-DDGI_D void blend_contract3(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, int q_pairs, f16v (&acc)[3], AfterFill&& after_fill)
+template <int kDepth, class AfterFill, class AtTail>
+DDGI_D void blend_contract3(const float* __restrict__ wa, const float* __restrict__ vb, size_t b_stride, int q_pairs, f16v (&acc)[3], AfterFill&& after_fill, AtTail&& at_tail)
 {
     // (the stand-alone irradiance kernel only: the merged small-grid kernel shares its CUs with depth workgroups and keeps the loop's
     // smaller register footprint)
     if (kDepth >= 8 && q_pairs == 128)  // (wave-uniform: 256 rays per probe, the common case)
     {
-        blend_contract3_unrolled<kDepth, 32>(wa, vb, b_stride, acc, after_fill);
+        blend_contract3_unrolled<kDepth, 32>(wa, vb, b_stride, acc, after_fill, at_tail);
         return;
     }
     if (kDepth >= 8 && q_pairs == 256)  // (512 rays: BASELINE's C4)
     {
-        blend_contract3_unrolled<kDepth, 64>(wa, vb, b_stride, acc, after_fill);
+        blend_contract3_unrolled<kDepth, 64>(wa, vb, b_stride, acc, after_fill, at_tail);
         return;
     }
     after_fill();
@@ -332,6 +337,7 @@ DDGI_D void blend_contract3(const float* __restrict__ wa, const float* __restric
             }
         }
     }
+    at_tail();
 }
 
 // Epilogue staging: a wave parks its accumulator tile in LDS as [texel row][column] (row stride 33 words: conflict-free
@@ -762,11 +768,11 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
             for (uint32_t b = 0; b < kBatch; ++b)
                 old[b] = *reinterpret_cast<const float4*>(A.irradiance_old + static_cast<size_t>(slots[min(p0 + 2u * b, 31u)]) * (kIrrTile * kIrrTile * 4) + e * 4);
         };
-        float4 old[kBatch];
+        float4 old[kBatch], old_late[kBatch];  // the wave's first and second eight probes
         f16v acc[3];
-        blend_contract3<kDepth>(wa, vb, static_cast<size_t>(n_pad) * 32, q_pairs, acc, [&] {
-            if (kEarly) load_old(static_cast<uint32_t>(mi), old);
-        });
+        blend_contract3<kDepth>(
+            wa, vb, static_cast<size_t>(n_pad) * 32, q_pairs, acc, [&] { if (kEarly) load_old(static_cast<uint32_t>(mi), old); },
+            [&] { if (kEarly) load_old(static_cast<uint32_t>(mi) + 2u * kBatch, old_late); });  // (while the last steps' MFMAs run)
         BLEND_LAP(2);
         bool outside = false;
 #pragma unroll
@@ -784,9 +790,13 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
         // (full groups as straight-line code, pm::div_prepared quotients: see blend_depth_resident)
         auto tiles = [&](auto full, auto prep) {
             constexpr bool kFull = decltype(full)::value, kPrepared = decltype(prep)::value;
-            for (uint32_t p0 = static_cast<uint32_t>(mi); p0 < np; p0 += 2u * kBatch)
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
             {
-                if (!kEarly || p0 != static_cast<uint32_t>(mi)) load_old(p0, old);
+                const uint32_t p0 = static_cast<uint32_t>(mi) + static_cast<uint32_t>(half) * 2u * kBatch;
+                if (!kFull && p0 >= np) break;
+                float4 (&o)[kBatch] = (kEarly && half == 1) ? old_late : old;  // (not early: one set of registers, loaded twice)
+                if (!kEarly) load_old(p0, o);
 #pragma unroll
                 for (uint32_t b = 0; b < kBatch; ++b)
                 {
@@ -797,7 +807,7 @@ DDGI_D void blend_irr_role(const BlendArgs& A, const float* __restrict__ rad_rgb
                         const pm::f2v rg = kPrepared ? pm::div_prepared2(pm::f2v{sp[0], sp[1]}, by) : pm::f2v{sp[0] / by.d, sp[1] / by.d};
                         const float bl = kPrepared ? pm::div_prepared(sp[2], by) : sp[2] / by.d;
                         *reinterpret_cast<float4*>(A.irradiance + static_cast<size_t>(slots[p]) * (kIrrTile * kIrrTile * 4) + e * 4) =
-                            float4{gl_mix(old[b].x, rg.x, hyst), gl_mix(old[b].y, rg.y, hyst), gl_mix(old[b].z, bl, hyst), 1.0f};
+                            float4{gl_mix(o[b].x, rg.x, hyst), gl_mix(o[b].y, rg.y, hyst), gl_mix(o[b].z, bl, hyst), 1.0f};
                     }
                 }
             }
