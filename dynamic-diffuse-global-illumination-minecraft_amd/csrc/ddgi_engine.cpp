@@ -419,6 +419,8 @@ int ddgi_destroy(ddgi_handle e)
         if (d.vis) (void)hipFree(d.vis);
         if (d.vis_occ) (void)hipFree(d.vis_occ);
         if (d.vis_list) (void)hipFree(d.vis_list);
+        for (auto& v : d.vis_more)
+            if (v) (void)hipFree(v);
     }
     for (auto& triple : e->ev)
         for (auto& ev : triple)
@@ -732,8 +734,8 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
         a.rays = nullptr;
         a.n_rays = static_cast<uint32_t>(local_rays);
     }
-    // single light: which feelers need no march (ddgi_visibility.hip); recomputed when the light has moved
-    if (a.nl == 1 && tn.light_vis && tn.trace_kernel != 2)
+    // which feelers need no march (ddgi_visibility.hip): one table per light (the first kVisLights), recomputed when the light has moved
+    if (a.nl >= 1 && tn.light_vis && tn.trace_kernel != 2)
     {
         ddgi_engine::DevScene& d = e->dev_scene[scene];
         const int n_vox = (a.scene.hi[0] - a.scene.lo[0] + 1) * (a.scene.hi[1] - a.scene.lo[1] + 1) * (a.scene.hi[2] - a.scene.lo[2] + 1);
@@ -787,6 +789,30 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
         }
         a.vis = d.vis;
         a.vis_occ = d.vis_occ;
+        // lights 1 ..: classes only (no lists of occupied voxels: the event of a hit under several lights does not use them)
+        for (int li = 1; li < a.nl && li < kVisLights; ++li)
+        {
+            uint8_t*& v = d.vis_more[li - 1];
+            if (!v)
+            {
+                hipError_t he = hipMalloc(reinterpret_cast<void**>(&v), static_cast<size_t>(n_vox) * 8);
+                if (he == hipSuccess) he = hipMemsetAsync(v, 0, static_cast<size_t>(n_vox) * 8, e->stream);
+                if (he != hipSuccess)
+                {
+                    if (v) (void)hipFree(v);
+                    v = nullptr;
+                    return fail(he == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY : DDGI_ERR_HIP, "allocating the light-feeler classes failed: %s", hipGetErrorString(he));
+                }
+                d.vis_more_valid[li - 1] = false;
+            }
+            if (!d.vis_more_valid[li - 1] || std::memcmp(d.vis_more_light[li - 1], a.lights[li].pos, sizeof(d.vis_more_light[li - 1])) != 0)
+            {
+                HIP_TRY(launch_light_visibility(a.scene, a.lights[li].pos, d.vis_list, d.n_vis_list, v, nullptr, e->stream));
+                std::memcpy(d.vis_more_light[li - 1], a.lights[li].pos, sizeof(d.vis_more_light[li - 1]));
+                d.vis_more_valid[li - 1] = true;
+            }
+            a.vis_more[li - 1] = v;
+        }
     }
     a.albedo = static_cast<uint32_t*>(e->tex[0]);
     a.distance = static_cast<uint32_t*>(e->tex[1]);
@@ -1610,6 +1636,8 @@ static int fill_user_scene(ddgi_engine* e, const int lo[3], const int dim[3], co
     if (d.vis) (void)hipFree(d.vis);
     if (d.vis_occ) (void)hipFree(d.vis_occ);
     if (d.vis_list) (void)hipFree(d.vis_list);
+    for (auto& v : d.vis_more)
+        if (v) (void)hipFree(v);
     d = ddgi_engine::DevScene{};
     e->user_scene = std::move(b);
     return DDGI_OK;

@@ -87,6 +87,9 @@ struct ddgi_engine
         int n_vis_list = 0;
         float vis_light[3] = {0, 0, 0};     // ... computed for this light position
         bool vis_valid = false;
+        uint8_t* vis_more[3] = {nullptr, nullptr, nullptr};  // the same table for lights 1..3 of a scene with several lights (no lists)
+        float vis_more_light[3][3] = {};
+        bool vis_more_valid[3] = {false, false, false};
     } dev_scene[4];
 
     // memoised lattice hashes on device

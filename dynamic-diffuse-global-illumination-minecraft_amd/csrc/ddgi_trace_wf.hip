@@ -446,10 +446,9 @@ DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contr
 // when there is no table, the origin is outside the baked box, or it is not where the table's guarantee holds: 5e-4 ..
 // 1.5e-3 off the face that was hit (it is put 1e-3 off it) and at least 5e-4 inside the voxel on the two other axes.
 // n: the hit's axis normal (points from the block that was hit into the voxel the feeler starts in).
-DDGI_D uint32_t light_vis_class(const TraceArgs& A, f3 o, f3 n, int& entry)
+// (light_vis_entry: the table index of that (voxel, face), or -1)
+DDGI_D int light_vis_entry(const TraceArgs& A, f3 o, f3 n)
 {
-    entry = 0;
-    if (!A.vis) return kVisUnknown;
     const SceneK& S = A.scene;
     const f3 cell = cell_id(o);
     const float ux = cell.x - o.x, uy = cell.y - o.y, uz = cell.z - o.z;  // in [0, 1): distance to the voxel's upper faces
@@ -460,12 +459,21 @@ DDGI_D uint32_t light_vis_class(const TraceArgs& A, f3 o, f3 n, int& entry)
     const float l1 = ax ? uy : ux, l2 = (ax || ay) ? uz : uy;
     const bool inside = off >= 5.0e-4f && off <= 1.5e-3f && fminf(l1, l2) >= 5.0e-4f && fmaxf(l1, l2) <= 1.0f - 5.0e-4f && cell.x >= S.lo_f[0] && cell.x <= S.hi_f[0] &&
                         cell.y >= S.lo_f[1] && cell.y <= S.hi_f[1] && cell.z >= S.lo_f[2] && cell.z <= S.hi_f[2];  // (false for NaN)
-    if (!inside) return kVisUnknown;
+    if (!inside) return -1;
     const int idx = static_cast<int>(fmaf(cell.z, S.nxy_f, fmaf(cell.y, S.nx_f, cell.x))) - S.bias;
     const int face = (ax ? 0 : (ay ? 2 : 4)) + ((n.x + n.y + n.z) < 0.0f ? 1 : 0);  // 2 axis + (the block that was hit is on the + side)
-    entry = idx * 8 + face;
-    return A.vis[entry];
+    return idx * 8 + face;
 }
+DDGI_D uint32_t light_vis_class(const TraceArgs& A, f3 o, f3 n, int& entry)
+{
+    entry = 0;
+    if (!A.vis) return kVisUnknown;
+    const int en = light_vis_entry(A, o, n);
+    if (en < 0) return kVisUnknown;
+    entry = en;
+    return A.vis[en];
+}
+
 
 // A feeler that starts in a patch of class kVisListed (ddgi_visibility.hip) and did not end within its first step: its own ray
 // (o, unit direction dn, light sphere at t_light) against the patch's list of occupied voxels — everything else its march can look
@@ -525,6 +533,49 @@ DDGI_D void feeler_outcome(const LightK& L, f3 hpos, f3 nh, f3 hcol, bool any_hi
         contribution = (hcol * 0.2f) * lambert;  // Q10 early return
         early = true;
     }
+}
+
+// Several lights (get_direct_lighting's loop, probe_pass.comp:186-207): the lights from `li` on whose feeler from hpos is decided
+// by their table (k_light_visibility, one table per light for the first kVisLights) are dealt with right here — no march, no
+// queue trip, no event.  Returns the first light whose feeler has to be marched, or the number of lights when the loop is over
+// (all decided, or the early return of a blocked feeler: `early`).
+//   kVisLit     no occupied voxel between the hit and light li's layer: the feeler ends on the nearest light sphere its ray meets
+//               (its own at the latest — the ray points at its centre), as for a single light.
+//   kVisShadow  the feeler lands in an occupied voxel before light li's sphere — unless ANOTHER light's sphere lies on the ray in
+//               front of it: then the reference's closest hit may be that sphere.  Used only when the nearest sphere on the ray is
+//               li's own (or none); otherwise the feeler is marched.
+//   kVisListed (light 0's table has them) counts as unknown here.
+// The table's guarantee is about the start patch (voxel, face) only, which all of a hit's feelers share: one entry for all lights.
+template <class Cfg>
+DDGI_D int decided_feelers(const TraceArgs& A, int li, bool on_axis_face, f3 hpos, f3 hnrm, f3 nh, f3 hcol, f3& direct, int& nvis, f3& contribution, bool& early)
+{
+    const int nl = Cfg::nl(A);
+    if (!on_axis_face || !A.vis) return li;
+    const int en = light_vis_entry(A, hpos, hnrm);
+    if (en < 0) return li;
+    while (li < nl && li < kVisLights)
+    {
+        const uint8_t* table = li == 0 ? A.vis : A.vis_more[li - 1];
+        const uint32_t cls = table ? table[en] : kVisUnknown;
+        if (cls != kVisLit && cls != kVisShadow) break;
+        const LightK& L = A.lights[li];
+        const f3 to_light = normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos);
+        float ftl = __builtin_inff();
+        int flid = -1;
+        light_spheres<0>(hpos, to_light, A, ftl, flid);
+        bool any, block;
+        if (cls == kVisLit)
+            block = false, any = ftl < __builtin_inff();
+        else
+        {
+            if (flid >= 0 && flid != li) break;  // another light's sphere in front: march it
+            block = any = true;
+        }
+        feeler_outcome(L, hpos, nh, hcol, any, block, direct, nvis, contribution, early);
+        if (early) return nl;
+        ++li;
+    }
+    return li;
 }
 
 // One event of pool slot `slot` in bucket b (ddgi_trace_wf.hip: shade_bucket): shades a finished march /
@@ -733,10 +784,25 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     }
                     else
                     {
-                        c.cnt = cnt;
-                        if (multi_light) P.dirbuf[slot] = float4{0.0f, 0.0f, 0.0f, 0.0f};
-                        mo = hpos, md = to_light;
-                        as_feeler = posted = true;
+                        // several lights: those whose feeler is decided by their table are dealt with here, the first that is not
+                        // is marched (its index and what the loop has gathered so far travel in cnt and dirbuf)
+                        f3 direct = mk3(0, 0, 0), contribution = mk3(0, 0, 0);
+                        int nvis = 0;
+                        bool early = false;
+                        const int li = decided_feelers<Cfg>(A, 0, block_wins && axis_normal, hpos, hnrm, nh, hcol, direct, nvis, contribution, early);
+                        if (!early && li < Cfg::nl(A))
+                        {
+                            c.cnt = cnt | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
+                            if (multi_light) P.dirbuf[slot] = float4{direct.x, direct.y, direct.z, 0.0f};
+                            const LightK& Ln = A.lights[li];
+                            mo = hpos, md = li == 0 ? to_light : normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos);
+                            as_feeler = posted = true;
+                        }
+                        else
+                        {
+                            if (!early && nvis != 0) contribution = nvis == 1 ? hcol * direct : div3(hcol * direct, static_cast<float>(nvis));  // x / 1.0f == x
+                            ld_contribution = contribution, lit_done = true;
+                        }
                     }
                 }
                 else
@@ -769,6 +835,13 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 feeler_outcome(A.lights[li], hpos, nh, hcol, any_hit, block_wins, direct, nvis, contribution, early);
             }
             li += 1;
+            if (!early && li < Cfg::nl(A) && multi_light)
+            {
+                const bool is_axis = (fabsf(hnrm.x) + fabsf(hnrm.y) + fabsf(hnrm.z) == 1.0f) &&
+                                     (fabsf(hnrm.x) == 1.0f || fabsf(hnrm.y) == 1.0f || fabsf(hnrm.z) == 1.0f);
+                const f3 nh = is_axis ? hnrm : normalize3(hnrm);
+                li = decided_feelers<Cfg>(A, li, is_axis, hpos, hnrm, nh, hcol, direct, nvis, contribution, early);
+            }
             if (!early && li < Cfg::nl(A))
             {
                 c.cnt = (cnt & 255u) | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);

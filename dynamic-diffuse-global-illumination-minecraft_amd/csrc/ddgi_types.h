@@ -70,6 +70,7 @@ enum : uint8_t
                       // and the event tests the feeler's own ray against them (wf_event: listed_feeler_outcome)
 };
 constexpr int kVisListMax = 4;
+constexpr int kVisLights = 4;  // lights that get a table (the commented 4-light cave table of the reference, structs.glsl:65-68); further lights' feelers are marched
 constexpr uint32_t kVisListEnd = 0xffffffffu;
 // a listed voxel: its id minus the start voxel's, per axis, biased by 512 into 10 bits (the table's range is 400 voxels)
 inline __host__ __device__ uint32_t vis_pack_offset(int dx, int dy, int dz) { return static_cast<uint32_t>(dx + 512) | (static_cast<uint32_t>(dy + 512) << 10) | (static_cast<uint32_t>(dz + 512) << 20); }
@@ -107,6 +108,7 @@ struct TraceArgs
     int fast_march;      // tolerance mode (ddgi_set_tuning "fast_march"): marches skip empty space (ddgi_device.h: fast_march_step)
     const uint8_t* vis;  // single light: feeler classes per (voxel of the baked box, face): [voxel * 8 + face] (k_light_visibility), or null
     const uint32_t* vis_occ;  // ... and for class kVisListed the occupied voxels of the bundle: [(voxel * 8 + face) * kVisListMax + k]
+    const uint8_t* vis_more[kVisLights - 1];  // several lights: the same table for lights 1 .. kVisLights - 1 (classes kVisLit / kVisShadow only), or null
 };
 
 // DDGI-mode ray records, laid out as the B operand of the blend's MFMA contraction (ddgi_blend_sample.hip): for local
