@@ -243,12 +243,13 @@ struct CfgRuntimeT
 using CfgRuntime = CfgRuntimeT<false>;
 // CfgMulti<kMode>: any number of lights (read from the arguments), everything else as CfgPlain — BASELINE's S-Dyn configuration
 // (4 animated lights) would otherwise run the fully generic instantiation with its run-time pool and mode.
-template <int kMode, bool kFastT = false>
+// kNlT > 0: that many lights, known at compile time (4: the reference's commented cave table, S-Dyn's) — the light loops unroll.
+template <int kMode, bool kFastT = false, int kNlT = 0>
 struct CfgMulti
 {
-    static constexpr int kNl = 0;
+    static constexpr int kNl = kNlT;
     static constexpr bool kFast = kFastT;
-    static DDGI_D int nl(const TraceArgs& A) { return A.nl; }
+    static DDGI_D int nl(const TraceArgs& A) { return kNlT > 0 ? kNlT : A.nl; }
     static DDGI_D int ablate(const TraceArgs&) { return 0; }
     static DDGI_D bool ddgi(const TraceArgs&) { return kMode != 0; }
 };
@@ -562,7 +563,7 @@ DDGI_D int decided_feelers(const TraceArgs& A, int li, bool on_axis_face, f3 hpo
         const f3 to_light = normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos);
         float ftl = __builtin_inff();
         int flid = -1;
-        light_spheres<0>(hpos, to_light, A, ftl, flid);
+        light_spheres<Cfg::kNl>(hpos, to_light, A, ftl, flid);
         bool any, block;
         if (cls == kVisLit)
             block = false, any = ftl < __builtin_inff();
@@ -637,6 +638,41 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
     {
         WfCold c = load_cold<Cfg::kFast>(P, slot, b == kBucketFeeler);
         f3 mo = mk3(0, 0, 0), md = mk3(0, 0, 0);  // the march this event posts, if any
+        // Several lights: get_direct_lighting's loop (probe_pass.comp:186-207) from light li on, as far as it gets without a march —
+        // a light whose feeler is decided by its table (decided_feelers) costs nothing more; the others' feelers are set up right
+        // here, and most end within their first step (wf_post_march: on the surface's own relief): the loop goes on.  The first
+        // feeler that has to be marched takes the slot to the march queue with the loop's state (light index and visible lights in
+        // cnt, the sum in dirbuf): returns true, and the loop resumes in that feeler's event.  False: the loop is over, the hit's
+        // direct light is in `contribution`.
+        auto lights_from = [&](int li, f3 hpos, f3 hnrm, f3 nh, bool on_axis_face, f3 hcol, uint32_t cnt_low, f3 direct, int nvis, f3& contribution) -> bool {
+            bool early = false;
+            contribution = mk3(0, 0, 0);
+            for (;;)
+            {
+                li = decided_feelers<Cfg>(A, li, on_axis_face, hpos, hnrm, nh, hcol, direct, nvis, contribution, early);
+                if (early || li >= Cfg::nl(A)) break;
+                const LightK& L = A.lights[li];
+                const f3 to_light = normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos);
+                c.cnt = cnt_low | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
+                float ftl = inf;
+                int flid = -1;
+                light_spheres<Cfg::kNl>(hpos, to_light, A, ftl, flid);
+                InlineEnd fe;
+                const bool inline_end = wf_post_march<Cfg, true>(P, slot, c, hpos, to_light, true, A, s_bits, &fe, true, ftl, flid, lp) >= 0;
+                if (!inline_end)
+                {
+                    if (multi_light) P.dirbuf[slot] = float4{direct.x, direct.y, direct.z, 0.0f};
+                    store_cold<Cfg::kFast>(P, slot, c, true);  // (hn and the albedo travel with the marched feeler)
+                    return true;
+                }
+                const bool block = fe.occ && (fe.t < fe.tl), any = block || (fe.tl < inf);
+                feeler_outcome(L, hpos, nh, hcol, any, block, direct, nvis, contribution, early);
+                if (early) break;
+                ++li;
+            }
+            if (!early && nvis != 0) contribution = nvis == 1 ? hcol * direct : div3(hcol * direct, static_cast<float>(nvis));  // x / 1.0f == x
+            return false;
+        };
         bool as_feeler = false;
         // Every path on which get_direct_lighting has come to its end for this hit sets these and meets at ONE
         // wf_lighting_done below (the bounce set-up — hemisphere sample, new march — is the longest stretch of an event:
@@ -784,25 +820,11 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     }
                     else
                     {
-                        // several lights: those whose feeler is decided by their table are dealt with here, the first that is not
-                        // is marched (its index and what the loop has gathered so far travel in cnt and dirbuf)
-                        f3 direct = mk3(0, 0, 0), contribution = mk3(0, 0, 0);
-                        int nvis = 0;
-                        bool early = false;
-                        const int li = decided_feelers<Cfg>(A, 0, block_wins && axis_normal, hpos, hnrm, nh, hcol, direct, nvis, contribution, early);
-                        if (!early && li < Cfg::nl(A))
-                        {
-                            c.cnt = cnt | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
-                            if (multi_light) P.dirbuf[slot] = float4{direct.x, direct.y, direct.z, 0.0f};
-                            const LightK& Ln = A.lights[li];
-                            mo = hpos, md = li == 0 ? to_light : normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos);
-                            as_feeler = posted = true;
-                        }
-                        else
-                        {
-                            if (!early && nvis != 0) contribution = nvis == 1 ? hcol * direct : div3(hcol * direct, static_cast<float>(nvis));  // x / 1.0f == x
-                            ld_contribution = contribution, lit_done = true;
-                        }
+                        // several lights: the loop over the lights runs right here as far as it can (lights_from)
+                        f3 contribution = mk3(0, 0, 0);
+                        c.cnt = cnt;
+                        if (lights_from(0, hpos, hnrm, nh, block_wins && axis_normal, hcol, cnt, mk3(0, 0, 0), 0, contribution)) return 1;
+                        ld_contribution = contribution, lit_done = true;
                     }
                 }
                 else
@@ -835,26 +857,16 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 feeler_outcome(A.lights[li], hpos, nh, hcol, any_hit, block_wins, direct, nvis, contribution, early);
             }
             li += 1;
-            if (!early && li < Cfg::nl(A) && multi_light)
+            if (!early && li < Cfg::nl(A))
             {
                 const bool is_axis = (fabsf(hnrm.x) + fabsf(hnrm.y) + fabsf(hnrm.z) == 1.0f) &&
                                      (fabsf(hnrm.x) == 1.0f || fabsf(hnrm.y) == 1.0f || fabsf(hnrm.z) == 1.0f);
                 const f3 nh = is_axis ? hnrm : normalize3(hnrm);
-                li = decided_feelers<Cfg>(A, li, is_axis, hpos, hnrm, nh, hcol, direct, nvis, contribution, early);
+                if (lights_from(li, hpos, hnrm, nh, is_axis, hcol, cnt & 255u, direct, nvis, contribution)) return 1;
             }
-            if (!early && li < Cfg::nl(A))
-            {
-                c.cnt = (cnt & 255u) | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
-                if (multi_light) P.dirbuf[slot] = float4{direct.x, direct.y, direct.z, 0.0f};
-                const LightK& Ln = A.lights[li];
-                mo = hpos, md = normalize3(f3{Ln.pos[0], Ln.pos[1], Ln.pos[2]} - hpos);
-                as_feeler = posted = true;
-            }
-            else
-            {
-                if (!early && nvis != 0) contribution = nvis == 1 ? hcol * direct : div3(hcol * direct, static_cast<float>(nvis));  // x / 1.0f == x
-                ld_contribution = contribution, ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt, lit_done = true;
-            }
+            else if (!early && nvis != 0)
+                contribution = nvis == 1 ? hcol * direct : div3(hcol * direct, static_cast<float>(nvis));  // x / 1.0f == x
+            ld_contribution = contribution, ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt, lit_done = true;
         }
         if (lit_done) posted = wf_lighting_done<Cfg>(P, slot, c, ld_contribution, ld_hpos, ld_hnrm, ld_cnt, A, mo, md, lp);
         if (posted)
@@ -1745,8 +1757,13 @@ hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_block
         return args.ddgi ? launch_aq<false, kAqPool, CfgPlain<1>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream)
                          : launch_aq<false, kAqPool, CfgPlain<0>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
     if (pool == kAqPool && args.nl > 1 && args.ablate == 0)
+    {
+        if (args.nl == 4)
+            return args.ddgi ? launch_aq<false, kAqPool, CfgMulti<1, false, 4>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream)
+                             : launch_aq<false, kAqPool, CfgMulti<0, false, 4>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
         return args.ddgi ? launch_aq<false, kAqPool, CfgMulti<1>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream)
                          : launch_aq<false, kAqPool, CfgMulti<0>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
+    }
     return launch_aq<false, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
 }
 
