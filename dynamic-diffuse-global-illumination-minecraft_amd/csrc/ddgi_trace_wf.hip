@@ -163,6 +163,11 @@ DDGI_D void store_cold(const WfPool& P, uint32_t slot, const WfCold& c, bool wit
     P.rng[slot] = c.rng, P.cnt[slot] = c.cnt, P.dst[slot] = c.dst;
 }
 
+// A value of lane `src` (wave-uniform: a constant, or derived from a ballot) for every lane: v_readlane_b32 into a scalar register.
+// (__shfl(v, src) is a ds_bpermute_b32 — a trip through the LDS crossbar and a wait for it, on the queue kernel's serial path
+// between two events four times per group.)
+DDGI_D uint32_t lane_bcast(uint32_t v, int src) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), src)); }
+
 // Appends one entry per lane with pred to a list whose fill count is *counter; returns the lane's
 // index (valid only where pred).  One LDS atomic per wave.
 DDGI_D uint32_t wave_append(bool pred, uint32_t* counter, int lane)
@@ -173,7 +178,7 @@ DDGI_D uint32_t wave_append(bool pred, uint32_t* counter, int lane)
     uint32_t base = 0;
     const int leader = __ffsll(static_cast<long long>(mask)) - 1;
     if (lane == leader) base = atomicAdd(counter, cnt);
-    base = __shfl(base, leader);
+    base = lane_bcast(base, leader);
     return base + static_cast<uint32_t>(__popcll(mask & ((1ull << lane) - 1ull)));
 }
 
@@ -1202,6 +1207,9 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
 #ifndef DDGI_AQ_SLEEP
 #define DDGI_AQ_SLEEP 2  // an idle wave's nap between two looks at the queues, in units of 64 cycles
 #endif
+#ifndef DDGI_AQ_QUICK
+#define DDGI_AQ_QUICK 1
+#endif
 #ifndef DDGI_EVENT_PRIO
 #define DDGI_EVENT_PRIO 1
 #endif
@@ -1362,7 +1370,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             {
                 uint32_t base = 0, k = 0;
                 if (lane == 0) k = aq_claim(&sh->mq_head, &sh->mq_tail, static_cast<uint32_t>(n_idle), base);
-                k = __shfl(k, 0), base = __shfl(base, 0);
+                k = lane_bcast(k, 0), base = lane_bcast(base, 0);
                 const uint32_t rank = static_cast<uint32_t>(__popcll(idle_mask & ((1ull << lane) - 1ull)));
                 if (!have && rank < k)
                 {
@@ -1448,7 +1456,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             {
                 uint32_t base = 0, k = 0;
                 if (lane == 0) k = aq_claim(&sh->mq_head, &sh->mq_tail, static_cast<uint32_t>(n_idle), base);
-                k = __shfl(k, 0), base = __shfl(base, 0);
+                k = lane_bcast(k, 0), base = lane_bcast(base, 0);
                 if (kStats && static_cast<int>(k) < n_idle) st_q[6] += 1;
                 const uint32_t rank = static_cast<uint32_t>(__popcll(idle_mask & ((1ull << lane) - 1ull)));
                 if (!have && rank < k)
@@ -1560,7 +1568,8 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             // the marching waves of the same SIMD want, so it is kept to a handful of instructions).
             uint32_t b = 0, base = 0, k = 0;
             uint32_t avail = 0;
-            if (lane < kAqEventQueues) avail = aq_load(&sh->eq_tail[lane]) - aq_load(&sh->eq_head[lane]);
+            uint32_t head_seen = 0;
+            if (lane < kAqEventQueues) head_seen = aq_load(&sh->eq_head[lane]), avail = aq_load(&sh->eq_tail[lane]) - head_seen;
             if (avail > kCap) avail = 0;  // a claim in flight can make tail - head wrap for an instant
             const unsigned long long full = __ballot(avail >= 64u);
             const bool no_more = aq_load(&sh->no_more) != 0u;
@@ -1569,7 +1578,18 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             {
                 // 1) a full group, dearest bucket first
                 b = static_cast<uint32_t>(__ffsll(static_cast<long long>(full)) - 1);
+#if DDGI_AQ_QUICK
+                // the queue held 64 entries above the head this wave has just read: claim them with that value (one trip to the LDS
+                // instead of aq_claim's two); only if another wave got there first is the queue looked at again
+                const uint32_t h0 = lane_bcast(head_seen, static_cast<int>(b));
+                if (lane == 0)
+                {
+                    if (atomicCAS(&sh->eq_head[b], h0, h0 + 64u) == h0) k = 64u, base = h0;
+                    else k = aq_claim(&sh->eq_head[b], &sh->eq_tail[b], 64u, base);
+                }
+#else
                 if (lane == 0) k = aq_claim(&sh->eq_head[b], &sh->eq_tail[b], 64u, base);
+#endif
             }
             else
             {
@@ -1579,7 +1599,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                     b = kBucketRefill;
                     if (lane == 0) k = aq_claim(&sh->fq_head, &sh->fq_tail, 64u, base);
                 }
-                k = __shfl(k, 0);
+                k = lane_bcast(k, 0);
                 // 3) the fullest partial group — unless the march side still has work queued: then a full
                 //    group is worth waiting for
                 if (k == 0u && (no_more || aq_load(&sh->mq_tail) - aq_load(&sh->mq_head) < kAqPartialBelow))
@@ -1588,7 +1608,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
 #pragma unroll
                     for (int bb = 0; bb < kAqEventQueues; ++bb)
                     {
-                        const uint32_t n = __shfl(avail, bb);
+                        const uint32_t n = lane_bcast(avail, bb);
                         if (n > best_n) best = static_cast<uint32_t>(bb), best_n = n;
                     }
                     if (best_n > 0u)
@@ -1598,7 +1618,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                     }
                 }
             }
-            k = __shfl(k, 0), base = __shfl(base, 0);
+            k = lane_bcast(k, 0), base = lane_bcast(base, 0);
             if (k == 0u)
             {
                 if ((no_more && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
@@ -1628,7 +1648,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                     atomicAdd(&sh->live, k);  // counted before they exist, so that `live` never reads 0 early
                     rbase = atomicAdd(work_counter, k);
                 }
-                rbase = __shfl(rbase, 0);
+                rbase = lane_bcast(rbase, 0);
                 const uint32_t r = rbase + static_cast<uint32_t>(lane);
                 const bool r_valid = valid && r < A.n_rays;
                 if (valid) slot = aq_take<kCap>(ring_fq, base + lane, &sh->abort);
@@ -1663,6 +1683,23 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             if (kStats) probe.at(15);  // outside the event code: queue traffic, polling
 #endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#if DDGI_AQ_QUICK
+            {
+                // the three kinds of pushes of a group — marches that go on, freed slots, slots whose new march ended at once — reserve
+                // their ring indices together (the atomics are issued back to back, ONE wait for all of them) and then write
+                const bool to_mq = posted && !(Cfg::ablate(A) & 8);  // DDGI_ABLATE=8: fault injection for the safety-net test
+                const unsigned long long m_mq = __ballot(to_mq), m_fq = __ballot(freed);
+                const int l_mq = m_mq ? __ffsll(static_cast<long long>(m_mq)) - 1 : 0, l_fq = m_fq ? __ffsll(static_cast<long long>(m_fq)) - 1 : 0;
+                uint32_t b_mq = 0, b_fq = 0, at_eq = 0;
+                if (m_mq != 0ull && lane == l_mq) b_mq = atomicAdd(&sh->mq_tail, static_cast<uint32_t>(__popcll(m_mq)));
+                if (m_fq != 0ull && lane == l_fq) b_fq = atomicAdd(&sh->fq_tail, static_cast<uint32_t>(__popcll(m_fq)));
+                if (ev_bucket >= 0) at_eq = atomicAdd(&sh->eq_tail[ev_bucket], 1u);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (to_mq) ring_mq[(lane_bcast(b_mq, l_mq) + static_cast<uint32_t>(__popcll(m_mq & below))) % kCap] = static_cast<uint16_t>(slot);
+                if (freed) ring_fq[(lane_bcast(b_fq, l_fq) + static_cast<uint32_t>(__popcll(m_fq & below))) % kCap] = static_cast<uint16_t>(slot);
+                if (ev_bucket >= 0) (ring_eq + ev_bucket * kCap)[at_eq % kCap] = static_cast<uint16_t>(slot);
+            }
+#else
             aq_push<kCap>(ring_mq, &sh->mq_tail, posted && !(Cfg::ablate(A) & 8), slot, lane);  // DDGI_ABLATE=8: fault injection for the safety-net test
             aq_push<kCap>(ring_fq, &sh->fq_tail, freed, slot, lane);
             if (ev_bucket >= 0)
@@ -1670,6 +1707,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 const uint32_t at = atomicAdd(&sh->eq_tail[ev_bucket], 1u);
                 (ring_eq + ev_bucket * kCap)[at % kCap] = static_cast<uint16_t>(slot);
             }
+#endif
             if (b != kBucketRefill)
             {
                 const uint32_t n_done = static_cast<uint32_t>(__popcll(__ballot(freed)));
