@@ -131,6 +131,13 @@ DDGI_D WfCold load_cold(const WfPool& P, uint32_t slot, bool with_hn)
 {
     WfCold c;
     c.hn[0] = c.hn[1] = c.hn[2] = 0.0f;
+    // (the LDS words are read whatever with_hn says and the record's loads stand in a branch of their own: written as an
+    // if / else the two sides became ONE flat load through a selected pointer — generic addressing for every event's LDS reads)
+    if (kFast)
+        c.hc[0] = P.rd[0][slot], c.hc[1] = c.hc[2] = 0.0f;
+    else
+        c.hc[0] = P.rd[0][slot], c.hc[1] = P.rd[1][slot], c.hc[2] = P.rd[2][slot];
+    asm volatile("" : "+v"(c.hc[0]), "+v"(c.hc[1]), "+v"(c.hc[2]));  // (pins the three ds_reads here: the optimizer would sink them into the select again)
     if (with_hn)
     {
         const uint4* q = reinterpret_cast<const uint4*>(P.cold + slot);
@@ -138,10 +145,6 @@ DDGI_D WfCold load_cold(const WfPool& P, uint32_t slot, bool with_hn)
         c.hc[0] = __uint_as_float(a.x), c.hc[1] = __uint_as_float(a.y), c.hc[2] = __uint_as_float(a.z);
         c.hn[0] = __uint_as_float(b.x), c.hn[1] = __uint_as_float(b.y), c.hn[2] = __uint_as_float(b.z);
     }
-    else if (kFast)
-        c.hc[0] = P.rd[0][slot], c.hc[1] = c.hc[2] = 0.0f;
-    else
-        c.hc[0] = P.rd[0][slot], c.hc[1] = P.rd[1][slot], c.hc[2] = P.rd[2][slot];
     c.col[0] = P.col[0][slot], c.col[1] = P.col[1][slot], c.col[2] = P.col[2][slot];
     c.rng = P.rng[slot], c.cnt = P.cnt[slot], c.dst = P.dst[slot];
     return c;
@@ -1257,8 +1260,10 @@ DDGI_D uint32_t aq_claim(uint32_t* head, const uint32_t* tail, uint32_t want, ui
 template <uint32_t kCap>
 DDGI_D uint32_t aq_take(uint16_t* ring, uint32_t idx, uint32_t* abort)
 {
-    volatile uint16_t* p = ring + (idx % kCap);
-    uint32_t v = *p;
+    // (relaxed atomics, not `volatile`: address-space inference leaves volatile accesses generic — flat_load / flat_store with
+    // system scope and a wait for EVERY outstanding global store of the wave in front of each ring entry; these are ds_read_u16 / ds_write_b16)
+    uint16_t* p = ring + (idx % kCap);
+    uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (int spins = 0; v == 0xffffu; ++spins)
     {
         if (spins > (1 << 22))
@@ -1266,9 +1271,9 @@ DDGI_D uint32_t aq_take(uint16_t* ring, uint32_t idx, uint32_t* abort)
             *abort = 1u;
             return 0u;
         }
-        v = *p;
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    *p = 0xffffu;
+    __hip_atomic_store(p, static_cast<uint16_t>(0xffffu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return v;
 }
 
