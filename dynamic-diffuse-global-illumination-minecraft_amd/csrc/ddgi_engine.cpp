@@ -31,7 +31,7 @@ hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, i
 hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t stream);
 int aq_pool_size(int nwords, size_t lds_limit);
 int aq_pool_size_fast(int nwords_skip, size_t lds_limit, bool plain);
-hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, uint32_t* next_work_counter, hipStream_t stream);
+hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, const AqChain& chain, uint32_t* status, hipStream_t stream);
 size_t blend_weights_floats(int n);
 hipError_t launch_blend_weights(const BlendArgs& args, hipStream_t stream);
 hipError_t launch_carry_tiles(void* dst, const void* src, const int32_t* map, uint32_t n_probes, uint32_t words_per_tile, hipStream_t stream);
@@ -90,6 +90,7 @@ static const TuningKey kTuningKeys[] = {
     {"noise_lut", &Tuning::noise_lut, nullptr},
     {"lut_off", &Tuning::lut_off, "DDGI_LUT_OFF"},
     {"timing", &Tuning::timing, "DDGI_TIMING"},
+    {"frames_in_flight", &Tuning::frames_in_flight, "DDGI_FRAMES_IN_FLIGHT"},
     {"verbose", &Tuning::verbose, "DDGI_VERBOSE"},
 #ifdef DDGI_PROFILING
     {"ablate", &Tuning::ablate, "DDGI_ABLATE"},
@@ -189,15 +190,35 @@ void ddgi_texture_bytes(int mode, const ddgi_irradiance_field& f, int rays_per_p
         bytes[0] = bytes[1] = probes * static_cast<size_t>(rays_per_probe) * 4;
 }
 
-// Allocates and zero-fills a texture pair; on failure nothing is left allocated.
+// Updates one launch of the queue kernel may work on (tuning "frames_in_flight"): REF mode on the handle's own textures only —
+// DDGI mode's updates differ from frame to frame (ray rotation, RNG keys, animated lights), and a host that holds pointers to a
+// pair (ddgi_bind_textures, ddgi_device_textures) expects the handle to stay on it.  The pair a ray writes travels in the top
+// two bits of its texel index (ddgi_trace_wf.hip: kDstPairShift).
+static int chain_len_for(const ddgi_engine* e, size_t albedo_bytes)
+{
+    if (e->mode != DDGI_MODE_REF || e->pin_pair || e->caller_tex) return 1;
+    if (albedo_bytes / 4 >= (static_cast<size_t>(1) << 30)) return 1;
+    return std::min(kAqChainMax, std::max(1, e->tuning.frames_in_flight));
+}
+int ddgi_chain_len(const ddgi_engine* e) { return chain_len_for(e, e->tex_bytes[0]); }
+
+// Pairs the handle's ring should hold: one per update a launch may work on; twice that (at least two) when the multi-GPU
+// exchange is pipelined — the all-gathers of one group's pairs run while the next group's are written.
+int ddgi_pairs_wanted(const ddgi_engine* e, bool pipelined)
+{
+    const int len = ddgi_chain_len(e);
+    return pipelined ? std::max(2, 2 * len) : len;
+}
+
+// Allocates and zero-fills a ring of np texture pairs (one allocation per texture); on failure nothing is left allocated.
 // (the reference leaves the images undefined until the first probe pass, rvpt.cpp:873-890; here they start zeroed)
-int ddgi_alloc_texture_pair(ddgi_engine* e, const size_t bytes[2], void* out[2])
+int ddgi_alloc_texture_pair(ddgi_engine* e, const size_t bytes[2], int np, void* out[2])
 {
     out[0] = out[1] = nullptr;
     for (int i = 0; i < 2; ++i)
     {
-        hipError_t he = hipMalloc(&out[i], bytes[i]);
-        if (he == hipSuccess) he = hipMemsetAsync(out[i], 0, bytes[i], e->stream);
+        hipError_t he = hipMalloc(&out[i], bytes[i] * static_cast<size_t>(np));
+        if (he == hipSuccess) he = hipMemsetAsync(out[i], 0, bytes[i] * static_cast<size_t>(np), e->stream);
         if (he != hipSuccess)
         {
             for (int k = 0; k < 2; ++k)
@@ -217,15 +238,49 @@ static int alloc_textures(ddgi_engine* e)
     ddgi_exchange_release(e);  // a new configuration: the exchange is set up again by ddgi_exchange_init
     size_t bytes[2];
     texture_bytes(e->mode, e->field, make_grid(e).n, bytes);
+    e->caller_tex = false;
+    const int np = chain_len_for(e, bytes[0]);  // (the ring's length follows the NEW configuration)
     void* fresh[2];
-    if (int rc = alloc_texture_pair(e, bytes, fresh)) return rc;
+    if (int rc = alloc_texture_pair(e, bytes, np, fresh)) return rc;
     for (int i = 0; i < 2; ++i)
     {
         if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
         e->own_tex[i] = e->tex[i] = fresh[i];
+        e->tex_prev[i] = nullptr;
         e->tex_bytes[i] = bytes[i];
     }
+    e->np = np, e->pair_cur = 0, e->ring_k = 0, e->chain_break = true;
     e->frame = 0;
+    return DDGI_OK;
+}
+
+// A ring of another length (tuning "frames_in_flight" changed, the pipelined exchange was switched on or off).  Blocks.  The
+// current pair's contents become pair 0 of the new ring — what consumers read and what a DDGI blend mixes with next —,
+// the other pairs start zeroed.  Only for the handle's own textures.
+int ddgi_resize_ring(ddgi_engine* e, int np)
+{
+    if (e->caller_tex) return fail(DDGI_ERR_INVALID_ARGUMENT, "the handle is on caller-bound textures: unbind them first");
+    if (np == e->np) return DDGI_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    void* fresh[2];
+    if (int rc = alloc_texture_pair(e, e->tex_bytes, np, fresh)) return rc;
+    hipError_t he = hipSuccess;
+    for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipMemcpyAsync(fresh[i], e->tex[i], e->tex_bytes[i], hipMemcpyDeviceToDevice, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (he != hipSuccess)
+    {
+        (void)hipFree(fresh[0]);
+        (void)hipFree(fresh[1]);
+        return fail(DDGI_ERR_HIP, "moving the probe textures to a ring of %d pairs failed: %s", np, hipGetErrorString(he));
+    }
+    for (int i = 0; i < 2; ++i)
+    {
+        (void)hipFree(e->own_tex[i]);
+        e->own_tex[i] = e->tex[i] = fresh[i];
+        e->tex_prev[i] = nullptr;
+    }
+    e->np = np, e->pair_cur = 0, e->ring_k = 0, e->chain_break = true;
+    e->box_of = nullptr;
     return DDGI_OK;
 }
 
@@ -300,6 +355,7 @@ static int ensure_noise(ddgi_engine* e)
 
 static int upload_local_rays(ddgi_engine* e)
 {
+    e->chain_break = true;  // new rays: the next update is not a continuation of the last (frames in flight)
     const GridK g = make_grid(e);
     const size_t n = static_cast<size_t>(g.n);
     const size_t local_probes = static_cast<size_t>(g.cx) * g.cy * g.czl;
@@ -406,6 +462,9 @@ int ddgi_destroy(ddgi_handle e)
     if (e->d_box) (void)hipFree(e->d_box);
     if (e->d_blend_w) (void)hipFree(e->d_blend_w);
     if (e->d_work) (void)hipFree(e->d_work);
+    if (e->pub) (void)hipHostFree(e->pub);
+    for (auto& m : e->milestone)
+        if (m) (void)hipEventDestroy(m);
     if (e->d_wf_cold) (void)hipFree(e->d_wf_cold);
     if (e->d_wf_dir) (void)hipFree(e->d_wf_dir);
     if (e->d_radiance) (void)hipFree(e->d_radiance);
@@ -496,7 +555,8 @@ int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const dd
     size_t bytes[2];
     texture_bytes(e->mode, *field, field->sqrt_rays_per_probe * field->sqrt_rays_per_probe, bytes);
     void* fresh[2];
-    if (int rc = alloc_texture_pair(e, bytes, fresh)) return rc;
+    const int np = chain_len_for(e, bytes[0]);  // (the exchange, if any, is set up again afterwards: ddgi_exchange_release below)
+    if (int rc = alloc_texture_pair(e, bytes, np, fresh)) return rc;
     if (carried > 0)
     {
         // (a pipelined exchange may still be writing the other ranks' slabs into the pair the carry reads)
@@ -528,8 +588,11 @@ int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const dd
     {
         if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
         e->own_tex[i] = e->tex[i] = fresh[i];
+        e->tex_prev[i] = nullptr;
         e->tex_bytes[i] = bytes[i];
     }
+    e->caller_tex = false;
+    e->np = np, e->pair_cur = 0, e->ring_k = 0, e->chain_break = true;
     e->field = *field;
     e->tile[0] = e->tile[1] = 0;
     e->settings = *settings;
@@ -547,7 +610,7 @@ int ddgi_set_mode(ddgi_handle e, int mode)
     if (mode == e->mode) return DDGI_OK;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->tex[0] != e->own_tex[0]) return fail(DDGI_ERR_INVALID_ARGUMENT, "unbind caller textures before changing the mode");
+    if (e->caller_tex) return fail(DDGI_ERR_INVALID_ARGUMENT, "unbind caller textures before changing the mode");
     e->mode = mode;
     e->updates = 0;
     return alloc_textures(e);  // the two modes keep differently shaped textures; both start zeroed
@@ -563,7 +626,7 @@ int ddgi_set_ray_tile(ddgi_handle e, int tile_x, int tile_y)
     if (g.sx == tile_x && g.sy == tile_y) return DDGI_OK;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->tex[0] != e->own_tex[0]) return fail(DDGI_ERR_INVALID_ARGUMENT, "unbind caller textures before changing the ray tile");
+    if (e->caller_tex) return fail(DDGI_ERR_INVALID_ARGUMENT, "unbind caller textures before changing the ray tile");
     e->tile[0] = tile_x, e->tile[1] = tile_y;
     e->host_rays.clear();
     e->n_local_rays = 0;
@@ -696,7 +759,7 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     if (int rc = ensure_noise(e)) return rc;
 
     TraceArgs& a = p.a;
-    a = TraceArgs{};
+    std::memset(&a, 0, sizeof a);  // (padding too: plan_hash compares launches byte by byte)
     a.grid = make_grid(e);
     a.scene = e->dev_scene[scene].k;
     a.scene_id = scene;
@@ -859,10 +922,18 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     {
         if (!e->d_work)
         {
-            // [0], [2] the queue kernel's ray counters (they take turns: a launch zeroes the next one's), [1] kernel status, [3] the round kernel's counter
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_work), 4 * sizeof(uint32_t)));
-            HIP_TRY(hipMemsetAsync(e->d_work, 0, 4 * sizeof(uint32_t), e->stream));
-            e->work_turn = 0;
+            // [1] kernel status, [3] the round kernel's counter, [8 .. 15] the queue kernel's ray counters: launch s uses [8 + s % 8] and zeroes
+            // the one of launch s + 4 (ddgi_types.h: AqChain).  `pub`: the host's ring of published continuations, read by running launches.
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_work), 16 * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(e->d_work, 0, 16 * sizeof(uint32_t), e->stream));
+            e->launch_seq = 0;
+        }
+        if (!e->pub)
+        {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->pub), kAqPubRing * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(e->pub, 0, kAqPubRing * sizeof(uint32_t));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->pub_dev), e->pub, 0));
+            for (auto& m : e->milestone) HIP_TRY(hipEventCreateWithFlags(&m, hipEventDisableTiming));
         }
         // one persistent workgroup per CU unless the launch is tiny (the launcher sizes the ray claims
         // so that every workgroup gets several: launch_probe_trace_wf)
@@ -903,6 +974,61 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     return DDGI_OK;
 }
 
+// What a launch is, for "is the next update the same work": every argument of the kernel but the textures it writes, and the
+// kernel's shape.  (What the arguments POINT at — rays, scene, tables — is covered by ddgi_engine::chain_break: every entry point
+// that can change any of it sets it.)
+static unsigned long long plan_hash(const TracePlan& p, int march_waves)
+{
+    TraceArgs a = p.a;
+    a.albedo = a.distance = nullptr;
+    unsigned long long h = 1469598103934665603ull;
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(&a);
+    for (size_t i = 0; i < sizeof a; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    const unsigned extra[6] = {static_cast<unsigned>(p.pool), p.grid, static_cast<unsigned>(march_waves), p.use_async ? 1u : 0u, p.fast ? 1u : 0u, static_cast<unsigned>(p.wf_threads)};
+    for (unsigned v : extra) h = (h ^ v) * 1099511628211ull;
+    return h | 1ull;
+}
+
+// One launch of the queue kernel with the handle's next sequence number.  chain_max: updates after its own the launch may go
+// on with; publish: this launch's update continues its predecessor's (ddgi_probe_update) — said so in the host ring BEFORE the
+// launch, so that a predecessor still running can pick the rays up.
+static int launch_aq_numbered(ddgi_engine* e, const TracePlan& p, int march_waves, int chain_max, bool publish)
+{
+    if (e->counters_dirty)
+    {
+        // a launch failed after its number was handed out: the counter it was to zero may be stale.  Start over on a clean ring.
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipMemsetAsync(e->d_work + 8, 0, 8 * sizeof(uint32_t), e->stream));
+        e->launch_seq = (e->launch_seq + 15u) & ~7u;
+        e->counters_dirty = false;
+        publish = false, chain_max = 0;
+    }
+    const uint32_t seq = e->launch_seq;
+    // the host ring is reused every kAqPubRing launches: never run further ahead of the device than 48 launches
+    if ((seq & 15u) == 0u)
+    {
+        const int m = static_cast<int>((seq >> 4) & 1u);
+        if (seq >= 32u) HIP_TRY(hipEventSynchronize(e->milestone[m]));  // (recorded 32 launches ago)
+        HIP_TRY(hipEventRecord(e->milestone[m], e->stream));
+    }
+    // (a slot still holds what launch seq - 64 left there, which is never seq + 1)
+    __atomic_store_n(&e->pub[seq & (kAqPubRing - 1u)], publish ? seq + 1u : 0u, __ATOMIC_RELEASE);
+    AqChain c;
+    c.counters = e->d_work + 8;
+    c.continued = e->d_work + 4;
+    c.pub = e->pub_dev;
+    c.seq = seq;
+    c.chain_max = static_cast<uint32_t>(chain_max);
+    e->launch_seq = seq + 1u;
+    const hipError_t he = launch_probe_trace_aq(p.a, p.pool, static_cast<int>(p.grid), march_waves, c, e->d_work + 1, e->stream);
+    if (he != hipSuccess)
+    {
+        e->counters_dirty = true;
+        return fail(DDGI_ERR_HIP, "launching the trace kernel failed: %s", hipGetErrorString(he));
+    }
+    return DDGI_OK;
+}
+
 // How many of the queue kernel's 16 waves march (the rest run events) is the one knob the balance of a scene
 // moves: C3 is fastest at 5 (4: 3.44 ms, 5: 2.96, 6: 3.14, 8: 3.7), Cornell and the house at 6, a sparser cave
 // grid at 3.  Measured per configuration: a few extra launches of the same (idempotent) trace, hill-climbing
@@ -917,8 +1043,7 @@ static int measure_march_waves(ddgi_engine* e, const TracePlan& p, int start, in
         {
             float t = 0.0f;
             HIP_TRY(hipEventRecord(ev[0], e->stream));
-            HIP_TRY(launch_probe_trace_aq(p.a, p.pool, static_cast<int>(p.grid), mw, e->d_work + 2 * e->work_turn, e->d_work + 1, e->d_work + 2 * (1 - e->work_turn), e->stream));
-            e->work_turn ^= 1;
+            if (int rc = launch_aq_numbered(e, p, mw, 0, false)) return rc;
             HIP_TRY(hipEventRecord(ev[1], e->stream));
             HIP_TRY(hipEventSynchronize(ev[1]));
             HIP_TRY(hipEventElapsedTime(&t, ev[0], ev[1]));
@@ -984,6 +1109,7 @@ int ddgi_tune(ddgi_handle e)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
+    e->chain_break = true;
     HIP_TRY(hipSetDevice(e->device));
     TracePlan p;
     if (int rc = plan_trace(e, p)) return rc;
@@ -1001,26 +1127,71 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         e->settings = *settings;
     }
     HIP_TRY(hipSetDevice(e->device));
-    if (int rc = ddgi_exchange_before_update(e)) return rc;  // pipelined exchange: which texture pair this update writes
-    // ... committed only once the update's kernels are on the stream: a plan or launch that fails (NOT_READY, out of memory,
-    // unsupported) leaves the handle on the pair it had — consumers keep reading the latest finished update
-    struct PairSwitch
-    {
-        ddgi_engine* e;
-        bool launched = false;
-        ~PairSwitch()
-        {
-            if (!launched) ddgi_exchange_update_failed(e);
-        }
-    } pair_switch{e};
     TracePlan p;
     if (int rc = plan_trace(e, p)) return rc;
-    const TraceArgs& a = p.a;
+    TraceArgs& a = p.a;
+    // (the queue kernel's wave split: pinned, measured earlier for this configuration, or — tuning "autotune" — measured below, by
+    // launches into the pair this update writes)
+    int march_waves = 5;
+    const bool measure_split = p.pool > 0 && p.use_async && e->tuning.autotune && e->tuning.ablate == 0 && e->tuning.march_waves <= 0 && e->aq_split.find(p.key) == e->aq_split.end();
+    if (p.pool > 0 && p.use_async && !measure_split)
+        if (int rc = choose_march_waves(e, p, false, false, &march_waves)) return rc;
+
+    // ---- which texture pair of the ring this update writes -------------------------------------------------------------
+    // Frames in flight (REF mode, the queue kernel): updates come in groups of up to `len`.  The first of a group takes the next
+    // aligned run of `len` pairs; an update that is THE SAME WORK as its predecessor (same launch, byte for byte, and nothing but
+    // probe updates, exchanges and consumers on the handle in between) continues the group into the next pair — and is published,
+    // so that the predecessor's launch, if it is still running when its own rays are used up, goes on with this update's rays
+    // instead of draining (k_probe_trace_aq).  Each update still has its own launch, in stream order behind its predecessor's:
+    // whatever that one left is traced there, and everything stream-ordered behind an update's launch sees the update complete.
+    // Which pair an update writes and where it stands in its group depend on the NUMBER of the update only (ring_k: updates since
+    // the ring was made) — every rank of a sharded grid must pick the same pair whatever it decides locally about continuing.
+    const int group = (e->caller_tex || (e->pin_pair && !e->xch.pipelined)) ? 1 : std::max(1, std::min(ddgi_chain_len(e), e->np));
+    const int pos = e->np % group == 0 ? static_cast<int>(e->ring_k % static_cast<unsigned long long>(group)) : 0;
+    const bool can_chain = group > 1 && e->np % group == 0 && p.pool > 0 && p.use_async && !p.ddgi_mode && a.stats == nullptr && !measure_split;
+    const unsigned long long hash = plan_hash(p, march_waves);
+    const bool follows = can_chain && pos > 0 && !e->chain_break && hash == e->chain_hash;
+    // (what the handle goes back to when the update cannot be launched: consumers keep reading the latest finished update)
+    struct Saved
+    {
+        ddgi_engine* e;
+        void *tex[2], *prev[2];
+        int pair_cur;
+        bool launched = false;
+        ~Saved()
+        {
+            if (launched) return;
+            for (int i = 0; i < 2; ++i) e->tex[i] = tex[i], e->tex_prev[i] = prev[i];
+            e->pair_cur = pair_cur;
+            e->chain_break = true;
+        }
+    } saved{e, {e->tex[0], e->tex[1]}, {e->tex_prev[0], e->tex_prev[1]}, e->pair_cur};
+    if (!e->caller_tex)
+    {
+        const bool stay = e->pin_pair && !e->xch.pipelined;  // (the host holds pointers to this pair: ddgi_device_textures)
+        const int pair = stay ? e->pair_cur : static_cast<int>(e->ring_k % static_cast<unsigned long long>(e->np));
+        // pipelined exchange: the pairs this launch may write — its own and the ones it may continue into — must have left for the
+        // other ranks (the launch that may continue waits for the rest of its group's pairs as well: a continued update has no
+        // wait of its own that the predecessor's launch would see)
+        if (!follows)
+            if (int rc = ddgi_exchange_before_update(e, pair, can_chain ? group - pos : 1)) return rc;
+        for (int i = 0; i < 2; ++i)
+        {
+            e->tex_prev[i] = pair != e->pair_cur ? e->tex[i] : nullptr;  // DDGI blend: where the previous update's tiles are, when not in place
+            e->tex[i] = ddgi_pair_ptr(e, pair, i);
+        }
+        e->pair_cur = pair;
+    }
+    else
+        e->tex_prev[0] = e->tex_prev[1] = nullptr;
+    a.albedo = static_cast<uint32_t*>(e->tex[0]);
+    a.distance = static_cast<uint32_t*>(e->tex[1]);
+    const int chain_max = can_chain ? group - 1 - pos : 0;
+    a.pair_words = can_chain ? static_cast<uint32_t>(e->tex_bytes[0] / 4) : 0u;
+    if (measure_split)
+        if (int rc = choose_march_waves(e, p, true, false, &march_waves)) return rc;
 
     hipEvent_t* ev = e->ev[e->updates % ddgi_engine::kRing];
-    int march_waves = 5;
-    if (p.pool > 0 && p.use_async)
-        if (int rc = choose_march_waves(e, p, true, false, &march_waves)) return rc;
     const bool timing = e->tuning.timing != 0;  // (two or three events per update: ~3 us of the stream's time each)
     if (timing) HIP_TRY(hipEventRecord(ev[0], e->stream));  // (DDGI mode: the trace time includes the blend's two small weight kernels)
     BlendArgs b{};
@@ -1056,8 +1227,7 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     {
         if (p.use_async)
         {
-            HIP_TRY(launch_probe_trace_aq(a, p.pool, static_cast<int>(p.grid), march_waves, e->d_work + 2 * e->work_turn, e->d_work + 1, e->d_work + 2 * (1 - e->work_turn), e->stream));
-            e->work_turn ^= 1;
+            if (int rc = launch_aq_numbered(e, p, march_waves, chain_max, follows)) return rc;
         }
         else
             HIP_TRY(launch_probe_trace_wf(a, p.wf_threads, p.pool, static_cast<int>(p.grid), e->d_work + 3, e->stream));
@@ -1070,7 +1240,9 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         HIP_TRY(launch_probe_blend(b, e->num_cus, e->stream));
         e->frame += 1;
     }
-    pair_switch.launched = true;
+    saved.launched = true;
+    e->chain_hash = hash, e->chain_break = measure_split || !can_chain;
+    e->ring_k += 1;
     e->box_of = nullptr;  // the textures change: the sampler's per-texel table is stale
     // (REF mode: nothing follows the trace kernel, its end event is the update's end — an event costs the stream microseconds)
     e->ev_has_blend[e->updates % ddgi_engine::kRing] = p.ddgi_mode;
@@ -1102,6 +1274,13 @@ int ddgi_synchronize(ddgi_handle e)
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    e->chain_break = true;  // nothing is in flight: the next update starts a group of its own —
+    {
+        // — of its own in the ring as well: the next update's number moves up to the next group's first (every rank of a sharded
+        // grid synchronises at the same points of its frame loop, so the ranks' pair indices stay in step)
+        const unsigned long long g = static_cast<unsigned long long>(std::max(1, std::min(ddgi_chain_len(e), e->np)));
+        if (e->np % static_cast<int>(g) == 0) e->ring_k = (e->ring_k + g - 1) / g * g;
+    }
     return check_kernel_status(e);
 }
 
@@ -1238,6 +1417,26 @@ int ddgi_set_tuning(ddgi_handle e, const char* name, int value)
     for (const TuningKey& k : kTuningKeys)
         if (!std::strcmp(k.name, name))
         {
+            e->chain_break = true;
+            if (k.field == &Tuning::frames_in_flight)
+            {
+                // the ring of texture pairs follows (blocks; the current textures carry over).  The multi-GPU exchange has the
+                // ring's addresses (RCCL calls in flight, IPC mappings on the peers): detach it first.
+                if (value < 1 || value > kAqChainMax) return fail(DDGI_ERR_INVALID_ARGUMENT, "frames_in_flight %d not in [1,%d]", value, kAqChainMax);
+                if (e->xch.transport || e->xch.p2p) return fail(DDGI_ERR_INVALID_ARGUMENT, "set frames_in_flight before the exchange is set up (ddgi_exchange_init(h, NULL, 0) detaches it)");
+                const int before = e->tuning.frames_in_flight;
+                e->tuning.frames_in_flight = value;
+                if (!e->caller_tex)
+                {
+                    HIP_TRY(hipSetDevice(e->device));
+                    if (int rc = ddgi_resize_ring(e, ddgi_pairs_wanted(e, false)))
+                    {
+                        e->tuning.frames_in_flight = before;
+                        return rc;
+                    }
+                }
+                return DDGI_OK;
+            }
             e->tuning.*(k.field) = value;
             return DDGI_OK;
         }
@@ -1250,6 +1449,23 @@ int ddgi_get_tuning(ddgi_handle e, const char* name, int* value)
     if (!std::strcmp(name, "march_waves_measured"))  // the split in use for the last planned configuration (0: none yet)
     {
         *value = e->aq_last;
+        return DDGI_OK;
+    }
+    if (!std::strcmp(name, "continued_workgroups"))  // frames in flight: workgroups that went on with a later update's rays, so far (synchronises)
+    {
+        uint32_t v = 0;
+        if (e->d_work)
+        {
+            HIP_TRY(hipSetDevice(e->device));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            HIP_TRY(hipMemcpy(&v, e->d_work + 4, sizeof v, hipMemcpyDeviceToHost));
+        }
+        *value = static_cast<int>(v);
+        return DDGI_OK;
+    }
+    if (!std::strcmp(name, "texture_pairs"))  // pairs in the handle's ring
+    {
+        *value = e->np;
         return DDGI_OK;
     }
     if (!std::strcmp(name, "fast_march_active"))  // did the most recent update run the fast march ("fast_march" is a request)
@@ -1275,15 +1491,31 @@ int ddgi_set_frame(ddgi_handle e, uint32_t frame)
 
 // REF mode: the per-texel table of sample_probe for the handle's current textures (k_sample_box_filter), rebuilt when they have
 // changed since it was last built — one pass over the texels, about what sampling 100 000 points directly costs.
-static int ensure_sample_box(ddgi_engine* e, const GridK& grid)
+// The table costs 16 B per texel (4 x the albedo texture) and a pass over every texel; it pays when the batch would otherwise
+// read more texels than that pass does: a point evaluates 8 x 26 texels directly, the pass about 26 per texel — so from
+// texels / 8 points on (C3: 0.5 M points; never below 65 536).  *usable = false (and DDGI_OK): no table for this batch — too few
+// points for this grid, or the table could not be allocated (a C5-sized grid's is 4.3 GB): the caller evaluates sample_probe per
+// point, as it would for a small batch.
+static bool sample_box_pays(const ddgi_engine* e, size_t n_points)
 {
+    const size_t texels = e->tex_bytes[0] / 4;
+    return n_points >= std::max<size_t>(65536, texels / 8);
+}
+static int ensure_sample_box(ddgi_engine* e, const GridK& grid, bool* usable)
+{
+    *usable = false;
     const size_t texels = e->tex_bytes[0] / 4;
     if (texels > e->box_texels)
     {
         HIP_TRY(hipStreamSynchronize(e->stream));
         if (e->d_box) (void)hipFree(e->d_box);
         e->d_box = nullptr, e->box_texels = 0, e->box_of = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_box), texels * sizeof(float4)));
+        if (hipMalloc(reinterpret_cast<void**>(&e->d_box), texels * sizeof(float4)) != hipSuccess)
+        {
+            (void)hipGetLastError();  // not an error of the call: the direct path needs no table
+            e->d_box = nullptr;
+            return DDGI_OK;
+        }
         e->box_texels = texels;
     }
     if (e->box_of != e->tex[0])
@@ -1291,12 +1523,14 @@ static int ensure_sample_box(ddgi_engine* e, const GridK& grid)
         HIP_TRY(launch_sample_box_filter(grid, static_cast<const uint32_t*>(e->tex[0]), e->d_box, e->num_cus, e->stream));
         e->box_of = e->tex[0];
     }
+    *usable = true;
     return DDGI_OK;
 }
-// caller-owned textures (ddgi_bind_textures) may change behind the handle's back: their table is never reused
+// textures the host can write behind the handle's back — its own (ddgi_bind_textures), or the handle's through the pointers
+// ddgi_device_textures gave out (an all-gather in place): their table is never reused
 static void release_sample_box_if_borrowed(ddgi_engine* e)
 {
-    if (e->tex[0] != e->own_tex[0] && !e->xch.pipelined) e->box_of = nullptr;
+    if (e->caller_tex || e->pin_pair) e->box_of = nullptr;
 }
 
 int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, size_t n, float* d_rgb, int32_t* d_cage)
@@ -1319,14 +1553,17 @@ int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, si
     a.n = static_cast<uint32_t>(n);
     // REF mode, a large batch (or the table is there already): sample_probe comes from its per-texel table — built now if the
     // textures have changed since it was last built (one pass over the texels, ~ the cost of sampling 100 000 points directly)
-    constexpr size_t kBoxMinPoints = 65536;
-    if (e->mode == DDGI_MODE_REF && e->tuning.sample_box && (n >= kBoxMinPoints || e->box_of == e->tex[0]))
+    if (e->mode == DDGI_MODE_REF && e->tuning.sample_box && (sample_box_pays(e, n) || e->box_of == e->tex[0]))
     {
-        if (int rc = ensure_sample_box(e, a.grid)) return rc;
-        a.box = e->d_box;
-        HIP_TRY(launch_probe_sample_ref(a, e->stream));  // 8 table entries per point: nothing to gain from grouping
-        release_sample_box_if_borrowed(e);
-        return DDGI_OK;
+        bool usable = false;
+        if (int rc = ensure_sample_box(e, a.grid, &usable)) return rc;
+        if (usable)
+        {
+            a.box = e->d_box;
+            HIP_TRY(launch_probe_sample_ref(a, e->stream));  // 8 table entries per point: nothing to gain from grouping
+            release_sample_box_if_borrowed(e);
+            return DDGI_OK;
+        }
     }
     if (e->tuning.sample_group && n >= 4096)  // a batch worth grouping by cage (small ones are launch-latency bound anyway)
     {
@@ -1441,12 +1678,14 @@ int ddgi_render_device(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_
     else
     {
         r.albedo = static_cast<const uint32_t*>(e->tex[0]);
-        // only for the views that read the probe field (integrator_DDGI, integrator_indirect, the cage colours): a frame's pixels are
-        // always worth the table
-        if (e->tuning.sample_box && !(st->render_mode == 1 || (st->render_mode >= 3 && st->render_mode <= 6)))
+        // only for the views that read the probe field (integrator_DDGI, integrator_indirect, the cage colours), and when the frame's
+        // pixels are worth a pass over the grid's texels (sample_box_pays) or the table is there already
+        const size_t pixels = static_cast<size_t>(st->screen_width > 0 ? st->screen_width : 0) * (st->screen_height > 0 ? st->screen_height : 0);
+        if (e->tuning.sample_box && !(st->render_mode == 1 || (st->render_mode >= 3 && st->render_mode <= 6)) && (sample_box_pays(e, pixels) || e->box_of == e->tex[0]))
         {
-            if (int rc = ensure_sample_box(e, r.trace.grid)) return rc;
-            r.box = e->d_box;
+            bool usable = false;
+            if (int rc = ensure_sample_box(e, r.trace.grid, &usable)) return rc;
+            if (usable) r.box = e->d_box;
         }
     }
     r.rgba8 = d_rgba8;
@@ -1492,6 +1731,7 @@ int ddgi_set_stream(ddgi_handle e, void* hip_stream)
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     e->own_stream = false;
     e->stream = static_cast<hipStream_t>(hip_stream);
+    e->chain_break = true;
     return DDGI_OK;
 }
 
@@ -1500,6 +1740,12 @@ int ddgi_device_textures(ddgi_handle e, void** tex0, size_t* tex0_bytes, void** 
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
+    // The host may keep these pointers (an all-gather of its own in place, Vulkan interop): from here on the handle stays on
+    // this pair — no frames in flight — unless the pipelined exchange alternates pairs by contract (include/ddgi_probe.h); and
+    // what the host writes through them is invisible to the sampler's per-texel table, which is therefore not reused.
+    if (!e->xch.pipelined) e->pin_pair = true;
+    e->chain_break = true;
+    e->box_of = nullptr;
     if (tex0) *tex0 = e->tex[0];
     if (tex1) *tex1 = e->tex[1];
     if (tex0_bytes) *tex0_bytes = e->tex_bytes[0];
@@ -1520,8 +1766,11 @@ int ddgi_bind_textures(ddgi_handle e, void* tex0, void* tex1)
     if (e->xch.pipelined || e->xch.p2p) return fail(DDGI_ERR_INVALID_ARGUMENT, "the pipelined / peer-to-peer exchange owns the texture pairs: ddgi_exchange_init(h, NULL, 0) first");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    e->tex[0] = tex0 ? tex0 : e->own_tex[0];
-    e->tex[1] = tex1 ? tex1 : e->own_tex[1];
+    e->caller_tex = tex0 != nullptr;
+    e->tex[0] = tex0 ? tex0 : ddgi_pair_ptr(e, e->pair_cur, 0);
+    e->tex[1] = tex1 ? tex1 : ddgi_pair_ptr(e, e->pair_cur, 1);
+    e->tex_prev[0] = e->tex_prev[1] = nullptr;
+    e->chain_break = true;
     e->box_of = nullptr;
     return DDGI_OK;
 }
@@ -1587,6 +1836,7 @@ static uint32_t noise_id()
 static int fill_user_scene(ddgi_engine* e, const int lo[3], const int dim[3], const uint8_t* types)
 {
     e->scene_epoch += 1;  // the trace kernel's wave split is measured again for the new scene
+    e->chain_break = true;
     for (int a = 0; a < 3; ++a)
         if (dim[a] < 1 || dim[a] > 4096 || lo[a] < -(1 << 20) || lo[a] > (1 << 20)) return fail(DDGI_ERR_INVALID_ARGUMENT, "bad scene box");
     const size_t n = static_cast<size_t>(dim[0]) * dim[1] * dim[2];

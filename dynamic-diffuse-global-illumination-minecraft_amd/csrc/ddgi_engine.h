@@ -26,6 +26,9 @@ struct Tuning
     int aq_pool = 0, wf_pool = 0, wf_maxpool = 0, wf_threads = 1024;
     int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
     int blend_merge = 1;    // DDGI blend: up to this many HALF depth groups (of 16 probes) per CU, depth and irradiance run as one launch
+    int frames_in_flight = 2;  // REF mode: probe updates a launch may work on at once (the reference's MAX_FRAMES_IN_FLIGHT, src/rvpt/rvpt.h:23): an update
+                               // submitted while its predecessor runs, with the same inputs, is continued by the predecessor's workgroups instead of
+                               // waiting for their drain (ddgi_engine.cpp: ddgi_probe_update; k_probe_trace_aq); 1: every launch traces its own update only
     int timing = 1;         // per-update events for ddgi_last_update_ms / ddgi_update_history_ms (0: none — saves the stream ~6 us per update)
     int fast_march = 0;     // tolerance mode: marches skip empty space (NOT bit-exact; tests/test_gpu_fast_march.py states the tolerance)
     int light_vis = 1;      // per-voxel light-feeler classes (k_light_visibility): 0 = march every feeler
@@ -104,12 +107,19 @@ struct ddgi_engine
     size_t d_rays_capacity = 0;             // in rays
     uint32_t n_local_rays = 0;
 
-    // textures (REF: rgba8 texels, slab-major)
+    // textures (REF: rgba8 texels, slab-major).  The handle owns a RING of `np` texture pairs, one allocation per texture
+    // (pair k of texture i starts at own_tex[i] + k * tex_bytes[i]): np = 1 unless updates are in flight together — REF mode's
+    // frames in flight (a launch continues the next update into the next pair) and/or the pipelined multi-GPU exchange (the
+    // all-gather of one pair runs while the next update writes another).
     void* own_tex[2] = {nullptr, nullptr};
-    void* tex[2] = {nullptr, nullptr};       // the textures the next update writes and consumers read
+    int np = 1;
+    int pair_cur = 0;                        // ring index of the pair in `tex` (while tex is the handle's own)
+    void* tex[2] = {nullptr, nullptr};       // the textures the latest update wrote and consumers read
+    bool caller_tex = false;                 // ... are the caller's (ddgi_bind_textures), not a pair of the ring
     void* tex_prev[2] = {nullptr, nullptr};  // DDGI blend: where the previous update's tiles are, when not in tex (pipelined exchange)
     size_t tex_bytes[2] = {0, 0};
 
+    static constexpr int kMaxPairs = 8;  // 2 x the most updates one launch works on (ddgi_types.h: kAqChainMax)
     static constexpr int kRing = 64;  // timing history: one event triple per recent update
     hipEvent_t ev[kRing][3] = {};
     bool ev_has_blend[kRing] = {};    // the update recorded ev[2] (DDGI mode: after the blend); otherwise ev[1] is its end
@@ -118,7 +128,16 @@ struct ddgi_engine
     unsigned long long updates = 0;
     int wait_threshold = 64;
     uint32_t* d_work = nullptr;             // ray counters and status word of the wavefront trace kernels (ddgi_engine.cpp: plan_trace)
-    int work_turn = 0;                      // which of the queue kernel's two ray counters the next launch uses
+    // frames in flight (ddgi_types.h: AqChain): the queue kernel's launches are numbered; an update that continues its predecessor is published in `pub`
+    uint32_t launch_seq = 0;                // sequence number of the next k_probe_trace_aq launch
+    uint32_t* pub = nullptr;                // pinned host memory, kAqPubRing words (the kernel reads it through pub_dev)
+    uint32_t* pub_dev = nullptr;
+    hipEvent_t milestone[2] = {nullptr, nullptr};  // recorded every 16 launches: bounds how far the host runs ahead of the ring
+    unsigned long long ring_k = 0;          // updates since the ring of texture pairs was made: update k writes pair k % np
+    bool chain_break = true;                // something other than a probe update has touched the handle since: the next update starts a group
+    unsigned long long chain_hash = 0;      // what the latest update's launch was (ddgi_engine.cpp: plan_hash)
+    bool counters_dirty = false;            // a launch failed after its sequence number was handed out: re-zero before the next
+    bool pin_pair = false;                  // the host holds pointers to the current pair (ddgi_device_textures): the handle stays on it
     void* d_wf_cold = nullptr;              // wavefront kernel scratch: per-slot shading state
     float4* d_wf_dir = nullptr;
     size_t wf_cold_slots = 0, wf_dir_slots = 0;
@@ -140,14 +159,11 @@ struct ddgi_engine
         int transport = 0;      // 0 none, 1 RCCL all-gather, 2 peer-to-peer pushes (DDGI_EXCHANGE_*)
         void* comm = nullptr;   // RCCL: ncclComm_t; caller-owned unless made by ddgi_comm_create
         P2P* p2p = nullptr;     // peer-to-peer: mapped peer buffers, flags, per-peer streams
-        bool pipelined = false;
-        void* pair[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // pipelined: two engine-owned texture pairs, used alternately
+        bool pipelined = false;                 // the exchange of a pair runs on comm_stream while later updates write other pairs of the ring
         hipStream_t comm_stream = nullptr;
         hipEvent_t written = nullptr;           // handle's stream: the update's kernels have finished
-        hipEvent_t sent[2] = {nullptr, nullptr};  // comm stream: pair i's last exchange is over (RCCL) / this rank's slab has left (p2p)
-        bool sent_valid[2] = {false, false};
-        int cur = 0;               // pair written by the most recent update
-        unsigned long long k = 0;  // updates issued since the exchange was set up
+        hipEvent_t sent[kMaxPairs] = {};        // comm stream: pair i's last exchange is over (RCCL) / this rank's slab has left (p2p)
+        bool sent_valid[kMaxPairs] = {};
     } xch;
     float4* d_box = nullptr;                // REF mode: sample_probe per texel of the current textures (k_sample_box_filter), built on demand
     size_t box_texels = 0;
@@ -160,9 +176,12 @@ struct ddgi_engine
 // shared by ddgi_engine.cpp and ddgi_exchange.cpp
 GridK ddgi_make_grid(const ddgi_engine* e);
 void ddgi_texture_bytes(int mode, const ddgi_irradiance_field& f, int rays_per_probe, size_t bytes[2]);
-int ddgi_alloc_texture_pair(ddgi_engine* e, const size_t bytes[2], void* out[2]);
+int ddgi_alloc_texture_pair(ddgi_engine* e, const size_t bytes[2], int np, void* out[2]);  // a ring of np pairs, zeroed
+inline void* ddgi_pair_ptr(const ddgi_engine* e, int pair, int i) { return static_cast<uint8_t*>(e->own_tex[i]) + static_cast<size_t>(pair) * e->tex_bytes[i]; }
+int ddgi_chain_len(const ddgi_engine* e);           // updates one launch may work on (1: no continuation)
+int ddgi_pairs_wanted(const ddgi_engine* e, bool pipelined);
+int ddgi_resize_ring(ddgi_engine* e, int np);       // blocks; the current pair's contents move to pair 0 of the new ring
 // exchange hooks called by the engine (no-ops without an initialised exchange)
-int ddgi_exchange_before_update(ddgi_engine* e);   // pipelined: pick + bind the pair the update writes, wait for its last exchange
-void ddgi_exchange_update_failed(ddgi_engine* e);  // ... and take that back: the update was not launched (the handle keeps the pair it had)
+int ddgi_exchange_before_update(ddgi_engine* e, int first_pair, int n_pairs);  // pipelined: the stream waits for the last exchanges of the pairs a launch may write
 int ddgi_exchange_wait_latest(ddgi_engine* e);     // consumers: the handle's stream waits until the latest pair is complete
 void ddgi_exchange_release(ddgi_engine* e);        // configuration changed / handle destroyed: drop pairs, stream, events

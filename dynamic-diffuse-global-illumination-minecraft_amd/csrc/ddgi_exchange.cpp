@@ -31,8 +31,10 @@
 #include <dlfcn.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cstring>
 #include <mutex>
+#include <random>
 #include <vector>
 
 #include "ddgi_engine.h"
@@ -122,10 +124,24 @@ struct P2PAddress
     uint32_t magic, rank, world, pipelined;
     int32_t pid, device;
     uint64_t tex_bytes[2];
-    hipIpcMemHandle_t pair[2][2];
+    uint32_t np, pad;            // texture pairs in the rank's ring
+    uint64_t process;            // a random number drawn once per process: two ranks with the same one share a process (a pid would
+                                 // not do: one container per rank with a shared IPC namespace makes every rank pid 1)
+    hipIpcMemHandle_t ring[2];   // the two textures' rings (pair k of texture i at k * tex_bytes[i])
     hipIpcMemHandle_t flags;
 };
 static_assert(sizeof(P2PAddress) <= DDGI_P2P_ADDRESS_BYTES, "the published address must fit the ABI's blob");
+
+uint64_t process_nonce()
+{
+    static const uint64_t nonce = [] {
+        std::random_device rd;
+        uint64_t v = (static_cast<uint64_t>(rd()) << 32) ^ rd();
+        v ^= static_cast<uint64_t>(std::chrono::steady_clock::now().time_since_epoch().count()) * 0x9e3779b97f4a7c15ull;
+        return v ? v : 1ull;
+    }();
+    return nonce;
+}
 
 }  // namespace
 
@@ -133,7 +149,7 @@ struct ddgi_engine::P2P
 {
     struct Peer
     {
-        void* pair[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+        void* ring[2] = {nullptr, nullptr};  // the peer's texture rings, mapped
         uint32_t* flags = nullptr;
         bool ipc = false;  // mapped with hipIpcOpenMemHandle (to be closed)
         hipStream_t stream = nullptr;
@@ -142,7 +158,7 @@ struct ddgi_engine::P2P
     uint32_t* flags = nullptr;   // own: [q] = ready, written by rank q; [kP2PMaxWorld + r] = arrived, written by rank r
     std::vector<Peer> peers;     // [world]; the own rank's entry is unused
     uint32_t seq = 0;            // exchanges issued (the flags carry it and are compared with >=: good for 2^32 exchanges per attachment — 50 days at 1000 per second)
-    uint32_t pair_seq[2] = {0, 0};  // exchange number that last filled pair i
+    uint32_t pair_seq[ddgi_engine::kMaxPairs] = {};  // exchange number that last filled pair i
     bool exported_pipelined = false;
     bool connected = false;
     bool write_value_ok = true;  // hipStreamWriteValue32 accepts peer memory (else a one-word fill)
@@ -178,9 +194,8 @@ void p2p_release(ddgi_engine* e)
         if (peer.stream) (void)hipStreamSynchronize(peer.stream);
         if (peer.ipc)
         {
-            for (auto& pr : peer.pair)
-                for (void* q : pr)
-                    if (q) (void)hipIpcCloseMemHandle(q);
+            for (void* q : peer.ring)
+                if (q) (void)hipIpcCloseMemHandle(q);
             if (peer.flags) (void)hipIpcCloseMemHandle(peer.flags);
         }
         if (peer.done) (void)hipEventDestroy(peer.done);
@@ -227,7 +242,7 @@ int p2p_exchange(ddgi_engine* e)
     ddgi_engine::Exchange& x = e->xch;
     ddgi_engine::P2P& p = *x.p2p;
     const uint32_t seq = ++p.seq;
-    const int cur = x.pipelined ? x.cur : 0;
+    const int cur = e->pair_cur;
     p.pair_seq[cur] = seq;
     hipEvent_t written = nullptr;
     if (int rc = update_written_event(e, &written)) return rc;
@@ -254,7 +269,7 @@ int p2p_exchange(ddgi_engine* e)
         {
             const size_t slab = e->tex_bytes[i] / static_cast<size_t>(e->world);
             const size_t off = slab * static_cast<size_t>(e->rank);
-            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(peer.pair[cur][i]) + off, static_cast<const uint8_t*>(e->tex[i]) + off, slab, hipMemcpyDeviceToDevice, peer.stream));
+            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(peer.ring[i]) + static_cast<size_t>(cur) * e->tex_bytes[i] + off, static_cast<const uint8_t*>(e->tex[i]) + off, slab, hipMemcpyDeviceToDevice, peer.stream));
         }
         if (int rc = p2p_write_flag(p, peer.stream, peer.flags + kP2PMaxWorld + e->rank, seq)) return rc;
         HIP_TRY(hipEventRecord(peer.done, peer.stream));
@@ -286,53 +301,29 @@ struct PendingSent
     int pair;
 };
 thread_local int g_group_depth = 0;
-thread_local std::vector<PendingSent> g_group_pending;
+// (one list for the process, under a lock: a handle destroyed from another thread than the one that exchanged must still be
+// purged from it — ddgi_exchange_release)
+std::mutex g_group_mu;
+std::vector<PendingSent> g_group_pending;
 }  // namespace
 
-int ddgi_exchange_before_update(ddgi_engine* e)
+// Pipelined exchange: pairs [first, first + n) of the ring are about to be written (an update's launch, and the updates it may
+// continue into): the stream waits until their previous exchanges have left the buffers.
+int ddgi_exchange_before_update(ddgi_engine* e, int first_pair, int n_pairs)
 {
     ddgi_engine::Exchange& x = e->xch;
-    if (!x.transport || !x.pipelined)
-    {
-        e->tex_prev[0] = e->tex_prev[1] = nullptr;
-        return DDGI_OK;
-    }
-    const int cur = static_cast<int>(x.k & 1ull);
-    if (x.sent_valid[cur]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[cur], 0));  // its previous exchange has left the buffers
-    x.k += 1;
-    for (int i = 0; i < 2; ++i)
-    {
-        e->tex[i] = x.pair[cur][i];
-        e->tex_prev[i] = x.pair[cur ^ 1][i];
-    }
-    x.cur = cur;
+    if (!x.transport || !x.pipelined) return DDGI_OK;
+    for (int k = first_pair; k < first_pair + n_pairs && k < e->np; ++k)
+        if (x.sent_valid[k]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[k], 0));
     return DDGI_OK;
-}
-
-// The update that ddgi_exchange_before_update prepared was not launched (planning or a launch failed): the handle
-// goes back to the pair it had, so that consumers keep reading the latest finished update and the next update
-// mixes with the right tiles.
-void ddgi_exchange_update_failed(ddgi_engine* e)
-{
-    ddgi_engine::Exchange& x = e->xch;
-    if (!x.transport || !x.pipelined || x.k == 0) return;
-    x.k -= 1;
-    const int prev = static_cast<int>((x.k & 1ull) ^ 1ull);  // the pair the update before wrote (pair 0 before the first)
-    const int cur = x.k == 0 ? 0 : prev;
-    for (int i = 0; i < 2; ++i)
-    {
-        e->tex[i] = x.pair[cur][i];
-        e->tex_prev[i] = x.pair[cur ^ 1][i];
-    }
-    x.cur = cur;
 }
 
 int ddgi_exchange_wait_latest(ddgi_engine* e)
 {
     ddgi_engine::Exchange& x = e->xch;
     if (!x.transport || !x.pipelined) return DDGI_OK;  // in-order exchange: stream order already covers it
-    if (x.transport == DDGI_EXCHANGE_P2P) return p2p_wait_arrived(e, x.p2p->pair_seq[x.cur]);
-    if (x.sent_valid[x.cur]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[x.cur], 0));
+    if (x.transport == DDGI_EXCHANGE_P2P) return p2p_wait_arrived(e, x.p2p->pair_seq[e->pair_cur]);
+    if (x.sent_valid[e->pair_cur]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[e->pair_cur], 0));
     return DDGI_OK;
 }
 
@@ -340,20 +331,16 @@ void ddgi_exchange_release(ddgi_engine* e)
 {
     ddgi_engine::Exchange& x = e->xch;
     e->box_of = nullptr;
-    for (auto it = g_group_pending.begin(); it != g_group_pending.end();)
-        it = it->e == e ? g_group_pending.erase(it) : it + 1;
+    {
+        std::lock_guard<std::mutex> lock(g_group_mu);
+        for (auto it = g_group_pending.begin(); it != g_group_pending.end();)
+            it = it->e == e ? g_group_pending.erase(it) : it + 1;
+    }
+    e->chain_break = true;
     if (x.comm_stream) (void)hipStreamSynchronize(x.comm_stream);
     p2p_release(e);
-    if (x.pipelined)
-    {
-        // pair[0] is the handle's own pair; pair[1] was allocated by ddgi_exchange_init
-        for (int i = 0; i < 2; ++i)
-        {
-            if (x.pair[1][i] && x.pair[1][i] != e->own_tex[i]) (void)hipFree(x.pair[1][i]);
-            e->tex[i] = e->own_tex[i];
-            e->tex_prev[i] = nullptr;
-        }
-    }
+    // (the ring keeps the pairs the pipelined exchange asked for: the handle goes on alternating them, which costs memory only;
+    // the next configuration or "frames_in_flight" change sizes it anew)
     if (x.comm_stream) (void)hipStreamDestroy(x.comm_stream);
     if (x.written) (void)hipEventDestroy(x.written);
     for (auto& ev : x.sent)
@@ -368,21 +355,18 @@ int exchange_common_setup(ddgi_engine* e, bool pipelined, bool always_streams)
     ddgi_engine::Exchange& x = e->xch;
     if (pipelined)
     {
-        if (e->tex[0] != e->own_tex[0]) return fail(DDGI_ERR_INVALID_ARGUMENT, "the pipelined exchange alternates the handle's own texture pairs: unbind caller textures first");
-        void* second[2];
-        if (int rc = ddgi_alloc_texture_pair(e, e->tex_bytes, second)) return rc;
-        for (int i = 0; i < 2; ++i)
-        {
-            x.pair[0][i] = e->own_tex[i];
-            x.pair[1][i] = second[i];
-        }
+        if (e->caller_tex) return fail(DDGI_ERR_INVALID_ARGUMENT, "the pipelined exchange alternates the handle's own texture pairs: unbind caller textures first");
+        // twice the pairs one launch may write (at least two): the exchanges of one group of updates run while the next group's
+        // pairs are written.  The tiles so far move to pair 0 — what the next update's blend mixes with, what consumers read.
+        e->pin_pair = false;
+        if (int rc = ddgi_resize_ring(e, ddgi_pairs_wanted(e, true))) return rc;
         x.pipelined = true;
     }
     if (pipelined || always_streams)
     {
         hipError_t he = hipStreamCreateWithFlags(&x.comm_stream, hipStreamNonBlocking);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&x.written, hipEventDisableTiming);
-        for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&x.sent[i], hipEventDisableTiming);
+        for (int i = 0; i < ddgi_engine::kMaxPairs && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&x.sent[i], hipEventDisableTiming);
         if (he != hipSuccess)
         {
             const int rc = fail(DDGI_ERR_HIP, "exchange stream/event creation failed: %s", hipGetErrorString(he));
@@ -390,10 +374,6 @@ int exchange_common_setup(ddgi_engine* e, bool pipelined, bool always_streams)
             return rc;
         }
     }
-    if (pipelined)
-        // the first update writes pair 0 (the tiles so far), mixing with pair 1: start pair 1 as a copy, so that a
-        // DDGI field that has already converged carries on
-        for (int i = 0; i < 2; ++i) HIP_TRY(hipMemcpyAsync(x.pair[1][i], x.pair[0][i], e->tex_bytes[i], hipMemcpyDeviceToDevice, e->stream));
     return DDGI_OK;
 }
 }  // namespace
@@ -455,16 +435,24 @@ int ddgi_exchange_group_end(void)
     if (g_group_depth == 0)
     {
         // the collectives recorded inside the bracket are on their streams NOW: this is where "exchange over" is in stream order
+        // (every pending handle gets its event, whatever happens to another one's: a pair left without it would be overwritten by
+        // the update after next while its all-gather may still be reading it; the first error is what the call returns)
         std::vector<PendingSent> pending;
-        pending.swap(g_group_pending);
+        {
+            std::lock_guard<std::mutex> lock(g_group_mu);
+            pending.swap(g_group_pending);
+        }
+        int first_rc = DDGI_OK;
         for (const PendingSent& ps : pending)
         {
             ddgi_engine::Exchange& x = ps.e->xch;
             if (x.transport != DDGI_EXCHANGE_RCCL || !x.pipelined) continue;
-            HIP_TRY(hipSetDevice(ps.e->device));
-            HIP_TRY(hipEventRecord(x.sent[ps.pair], x.comm_stream));
-            x.sent_valid[ps.pair] = true;
+            hipError_t he = hipSetDevice(ps.e->device);
+            if (he == hipSuccess) he = hipEventRecord(x.sent[ps.pair], x.comm_stream);
+            if (he == hipSuccess) x.sent_valid[ps.pair] = true;
+            else if (first_rc == DDGI_OK) first_rc = fail(DDGI_ERR_HIP, "recording the end of an exchange failed: %s", hipGetErrorString(he));
         }
+        return first_rc;
     }
     return DDGI_OK;
 }
@@ -495,11 +483,10 @@ int ddgi_exchange_p2p_export(ddgi_handle e, int pipelined, uint8_t address[DDGI_
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     ddgi_exchange_release(e);
-    if (e->tex[0] != e->own_tex[0]) return fail(DDGI_ERR_INVALID_ARGUMENT, "the peer-to-peer exchange publishes the handle's own textures: unbind caller textures first");
+    if (e->caller_tex) return fail(DDGI_ERR_INVALID_ARGUMENT, "the peer-to-peer exchange publishes the handle's own textures: unbind caller textures first");
     if (int rc = exchange_common_setup(e, pipelined != 0, true)) return rc;
     ddgi_engine::Exchange& x = e->xch;
-    if (!x.pipelined)
-        for (int i = 0; i < 2; ++i) x.pair[0][i] = e->own_tex[i];
+    e->pin_pair = false;  // (the peers write into whichever pair of the ring an update has just written)
     x.p2p = new (std::nothrow) ddgi_engine::P2P();
     if (!x.p2p)
     {
@@ -512,13 +499,13 @@ int ddgi_exchange_p2p_export(ddgi_handle e, int pipelined, uint8_t address[DDGI_
     std::memset(&a, 0, sizeof a);
     a.magic = kP2PMagic, a.rank = static_cast<uint32_t>(e->rank), a.world = static_cast<uint32_t>(e->world), a.pipelined = x.pipelined ? 1u : 0u;
     a.pid = static_cast<int32_t>(getpid()), a.device = e->device;
+    a.process = process_nonce();
+    a.np = static_cast<uint32_t>(e->np);
     hipError_t he = hipMalloc(reinterpret_cast<void**>(&p.flags), 2 * kP2PMaxWorld * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(p.flags, 0, 2 * kP2PMaxWorld * sizeof(uint32_t));
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);  // (the second pair's first contents)
     if (he == hipSuccess) he = hipIpcGetMemHandle(&a.flags, p.flags);
-    for (int pr = 0; pr < (x.pipelined ? 2 : 1) && he == hipSuccess; ++pr)
-        for (int i = 0; i < 2 && he == hipSuccess; ++i)
-            he = hipIpcGetMemHandle(&a.pair[pr][i], x.pair[pr][i]);
+    for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipIpcGetMemHandle(&a.ring[i], e->own_tex[i]);
     for (int i = 0; i < 2; ++i) a.tex_bytes[i] = e->tex_bytes[i];
     if (he != hipSuccess)
     {
@@ -540,22 +527,21 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
     HIP_TRY(hipSetDevice(e->device));
     ddgi_engine::P2P& p = *x.p2p;
     p.peers.assign(static_cast<size_t>(world), ddgi_engine::P2P::Peer{});
-    const int n_pairs = x.pipelined ? 2 : 1;
     int rc = DDGI_OK;
     for (int q = 0; q < world && rc == DDGI_OK; ++q)
     {
         P2PAddress a;
         std::memcpy(&a, addresses + static_cast<size_t>(q) * DDGI_P2P_ADDRESS_BYTES, sizeof a);
         if (a.magic != kP2PMagic || static_cast<int>(a.rank) != q || static_cast<int>(a.world) != world || (a.pipelined != 0) != x.pipelined || a.tex_bytes[0] != e->tex_bytes[0] ||
-            a.tex_bytes[1] != e->tex_bytes[1])
+            a.tex_bytes[1] != e->tex_bytes[1] || static_cast<int>(a.np) != e->np)
         {
-            rc = fail(DDGI_ERR_INVALID_ARGUMENT, "address %d does not describe rank %d of %d with this handle's textures and pipelining", q, q, world);
+            rc = fail(DDGI_ERR_INVALID_ARGUMENT, "address %d does not describe rank %d of %d with this handle's textures, pipelining and frames in flight", q, q, world);
             break;
         }
         if (q == e->rank) continue;
         ddgi_engine::P2P::Peer& peer = p.peers[static_cast<size_t>(q)];
         hipError_t he = hipSuccess;
-        if (a.pid == static_cast<int32_t>(getpid()))
+        if (a.process == process_nonce())
         {
             // The rendezvous is a flag another rank writes LATER, waited for by the command processor.  Between processes each
             // rank's queues make progress on their own; inside one process the host enqueues rank after rank, and two handles'
@@ -567,8 +553,7 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
         void* fl = nullptr;
         he = hipIpcOpenMemHandle(&fl, a.flags, hipIpcMemLazyEnablePeerAccess);
         peer.flags = static_cast<uint32_t*>(fl);
-        for (int pr = 0; pr < n_pairs && he == hipSuccess; ++pr)
-            for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipIpcOpenMemHandle(&peer.pair[pr][i], a.pair[pr][i], hipIpcMemLazyEnablePeerAccess);
+        for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipIpcOpenMemHandle(&peer.ring[i], a.ring[i], hipIpcMemLazyEnablePeerAccess);
         if (he == hipSuccess) he = hipStreamCreateWithFlags(&peer.stream, hipStreamNonBlocking);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&peer.done, hipEventDisableTiming);
         if (he != hipSuccess && rc == DDGI_OK) rc = fail(DDGI_ERR_HIP, "mapping rank %d's probe textures failed: %s", q, hipGetErrorString(he));
@@ -625,13 +610,14 @@ int ddgi_exchange(ddgi_handle e)
             // inside ddgi_exchange_group_begin/end the all-gather is not on comm_stream yet: an event recorded now would fire
             // before it.  Until the bracket closes the pair counts as "exchange not over" for nobody — consumers and the next
             // update only come after ddgi_exchange_group_end, which records it.
-            x.sent_valid[x.cur] = false;
-            g_group_pending.push_back(PendingSent{e, x.cur});
+            x.sent_valid[e->pair_cur] = false;
+            std::lock_guard<std::mutex> lock(g_group_mu);
+            g_group_pending.push_back(PendingSent{e, e->pair_cur});
         }
         else
         {
-            HIP_TRY(hipEventRecord(x.sent[x.cur], x.comm_stream));
-            x.sent_valid[x.cur] = true;
+            HIP_TRY(hipEventRecord(x.sent[e->pair_cur], x.comm_stream));
+            x.sent_valid[e->pair_cur] = true;
         }
     }
     return DDGI_OK;
@@ -645,12 +631,12 @@ int ddgi_exchange_finish(ddgi_handle e)
     HIP_TRY(hipSetDevice(e->device));
     if (x.transport == DDGI_EXCHANGE_P2P)
     {
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < ddgi_engine::kMaxPairs; ++i)
             if (x.sent_valid[i]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[i], 0));
         return p2p_wait_arrived(e, x.p2p->seq);
     }
     if (!x.pipelined) return DDGI_OK;
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < ddgi_engine::kMaxPairs; ++i)
         if (x.sent_valid[i]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[i], 0));
     return DDGI_OK;
 }

@@ -58,6 +58,10 @@ enum : uint32_t
     kFlagDeadHint = 1u << 20,
 };
 
+// REF mode, frames in flight (k_probe_trace_aq): WfCold::dst = texel index | (update's distance from the launch's own) << 30
+constexpr uint32_t kDstPairShift = 30;
+constexpr uint32_t kDstTexelMask = (1u << kDstPairShift) - 1u;
+
 struct WfShared  // control block at the start of dynamic LDS (32 dwords)
 {
     uint32_t n_march[2];  // fill counts of the two march lists (this round's / next round's)
@@ -424,8 +428,11 @@ DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst
     }
     else
     {
-        A.albedo[dst] = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
-        A.distance[dst] = 0u;  // `distances` is never assigned (probe_pass.comp:276,302)
+        // (a ray of a CHAINED update — k_probe_trace_aq, frames in flight — carries in dst[31:30] how many texture pairs after the
+        // launch's own its update writes; the pairs of a handle lie pair_words apart)
+        const uint32_t at = A.pair_words ? (dst & kDstTexelMask) + (dst >> kDstPairShift) * A.pair_words : dst;
+        A.albedo[at] = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
+        A.distance[at] = 0u;  // `distances` is never assigned (probe_pass.comp:276,302)
     }
     P.flags[slot] = kSlotEmpty;
 }
@@ -593,7 +600,7 @@ DDGI_D int decided_feelers(const TraceArgs& A, int li, bool on_axis_face, f3 hpo
 // march already ended within its first steps (return 2 + the event bucket it now waits in), or 0 when the ray
 // is finished (it has written its output and left the slot empty).
 template <class Cfg>
-DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits, uint32_t b, uint32_t slot, uint32_t r, bool r_valid, LaneProbe* lp = nullptr)
+DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits, uint32_t b, uint32_t slot, uint32_t r, bool r_valid, LaneProbe* lp = nullptr, uint32_t dst_tag = 0u)
 {
     DDGI_PROBE(lp, 0);  // section 0: the event (all lanes of the group)
     const GridK& G = A.grid;
@@ -631,7 +638,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 ray_o = mk3(ra.x, ra.y, ra.z);
                 ray_d = mk3(rb.x, rb.y, rb.z);
                 const int dst_probe = static_cast<int>(rc.x);  // int(probe_info.x), probe_pass.comp:269
-                c.dst = static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.sx + static_cast<int>(rc.y);
+                c.dst = (static_cast<uint32_t>(slab_slot(G, dst_probe)) * rays_per_probe + static_cast<int>(rc.z) * G.sx + static_cast<int>(rc.y)) | dst_tag;
                 c.rng = wang_hash(global_ray);  // p_idx == buffer index (probe_pass.comp:55-57)
             }
             c.cnt = 0u;
@@ -1234,7 +1241,8 @@ struct AqShared  // control block at the start of dynamic LDS (32 dwords)
     uint32_t live;     // rays in flight (claimed and not yet finished)
     uint32_t no_more;  // the launch's ray counter is used up
     uint32_t abort;    // safety net tripped: every wave leaves
-    uint32_t pad[32 - 4 - 2 * kAqEventQueues - 3];
+    uint32_t cur_seq;  // the update whose rays the workgroup claims (frames in flight: the launch's own, then the ones chained to it)
+    uint32_t pad[32 - 4 - 2 * kAqEventQueues - 4];
 };
 static_assert(sizeof(AqShared) == 32 * 4, "control block is 32 dwords");
 
@@ -1288,15 +1296,24 @@ DDGI_D void aq_push(uint16_t* ring, uint32_t* tail, bool pred, uint32_t value, i
 // kPool > 0: the pool size is a compile-time constant, so every pool array is the LDS base plus a constant
 // offset (folded into the ds instructions: no address arithmetic, one SGPR instead of eleven).
 template <bool kStats, int kPool, class Cfg>
-__global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, const int pool_size, const int march_waves, uint32_t* __restrict__ work_counter,
-                                                            uint32_t* __restrict__ status, uint32_t* __restrict__ next_work_counter)
+__global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, const int pool_size, const int march_waves, const AqChain C, uint32_t* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t wf_lds[];
     constexpr int T = 1024;
     const int tid = threadIdx.x;
-    // The ray counter of the NEXT launch on this handle (the two take turns): zeroed here instead of by a fill kernel in front of
-    // every launch — 5 us of kernel and a dependency of its own per update.  (The launch before this one zeroed this launch's.)
-    if (blockIdx.x == 0 && tid == 0) *next_work_counter = 0u;
+    // Every launch on a handle has a sequence number; launch s claims its rays from counters[s % 8].  The counter launch s + 4 will
+    // use is zeroed here instead of by a fill kernel in front of every launch (5 us of kernel and a dependency of its own per
+    // update): its last user, launch s - 4, ended before this one started (stream order), and its next user starts after this
+    // one has ended — a launch claims rays of at most kAqChainMax - 1 = 3 launches after itself (below).
+    if (blockIdx.x == 0 && tid == 0) C.counters[(C.seq + 4u) & 7u] = 0u;
+    // FRAMES IN FLIGHT.  When the rays of this launch's update are used up, the workgroups would drain — all of them at once, for
+    // the life of their last rays (a ray's 8 bounces are a dependent chain: 0.25 ms of thinning pool per launch).  If the host has
+    // already submitted the NEXT update, and that update is the same work into the next texture pair (C.pub, written by
+    // ddgi_probe_update before it launches that update's own kernel), the workgroups go on with ITS rays instead, up to
+    // C.chain_max updates ahead.  That update's own launch then finds its counter used up and leaves at once (here).
+    if (tid == 0) wf_lds[0] = __hip_atomic_load(C.counters + (C.seq & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (wf_lds[0] >= A.n_rays) return;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const uint32_t PS = kPool > 0 ? static_cast<uint32_t>(kPool) : static_cast<uint32_t>(pool_size);
@@ -1336,7 +1353,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     for (uint32_t i = tid; i < PS; i += T) ring_fq[i] = static_cast<uint16_t>(i);  // every slot starts free
     if (tid < 32) wf_lds[tid] = 0u;
     __syncthreads();
-    if (tid == 0) sh->fq_tail = PS;
+    if (tid == 0) sh->fq_tail = PS, sh->cur_seq = C.seq;
     __syncthreads();
 
     const float inf = __builtin_inff();
@@ -1646,21 +1663,24 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
             int ev_bucket = -1;
             if (b == kBucketRefill)
             {
-                // k free slots: claim k rays of the launch for them
-                uint32_t rbase = 0;
+                // k free slots: claim k rays of the update the workgroup is at for them
+                uint32_t rbase = 0, cs = 0;
                 if (lane == 0)
                 {
                     atomicAdd(&sh->live, k);  // counted before they exist, so that `live` never reads 0 early
-                    rbase = atomicAdd(work_counter, k);
+                    cs = aq_load(&sh->cur_seq);
+                    rbase = atomicAdd(C.counters + (cs & 7u), k);
                 }
                 rbase = lane_bcast(rbase, 0);
+                if (C.chain_max) cs = lane_bcast(cs, 0);
                 const uint32_t r = rbase + static_cast<uint32_t>(lane);
                 const bool r_valid = valid && r < A.n_rays;
                 if (valid) slot = aq_take<kCap>(ring_fq, base + lane, &sh->abort);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if (r_valid)
                 {
-                    const int rc = wf_event<Cfg>(A, P, s_bits, kBucketRefill, slot, r, true, kStats ? &probe : nullptr);
+                    const uint32_t dst_tag = C.chain_max ? (cs - C.seq) << kDstPairShift : 0u;  // which texture pair after the launch's own
+                    const int rc = wf_event<Cfg>(A, P, s_bits, kBucketRefill, slot, r, true, kStats ? &probe : nullptr, dst_tag);
                     posted = rc == 1;
                     if (rc >= 2) ev_bucket = rc - 2;
                 }
@@ -1669,7 +1689,15 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
                 if (lane == 0)
                 {
                     if (n_back) atomicSub(&sh->live, n_back);
-                    if (rbase + k >= A.n_rays) __hip_atomic_store(&sh->no_more, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (rbase + k >= A.n_rays)
+                    {
+                        // this update's rays are used up.  Has the host submitted the next one as a continuation of this one (its
+                        // sequence number + 1 in its slot of the pinned host ring)?  Then go on with its rays; else the launch ends.
+                        bool go_on = false;
+                        if (cs - C.seq < C.chain_max) go_on = __hip_atomic_load(C.pub + ((cs + 1u) & (kAqPubRing - 1u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == cs + 2u;
+                        if (go_on && atomicCAS(&sh->cur_seq, cs, cs + 1u) == cs) atomicAdd(C.continued, 1u);  // (another wave may have got there first)
+                        else if (aq_load(&sh->cur_seq) == cs) __hip_atomic_store(&sh->no_more, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
             else
@@ -1775,39 +1803,39 @@ int aq_pool_size_fast(int nwords_skip, size_t lds_limit, bool plain)
 }
 
 template <bool kStats, int kPool, class Cfg>
-static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, uint32_t* next_work_counter, hipStream_t stream)
+static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, const AqChain& chain, uint32_t* status, hipStream_t stream)
 {
     const size_t lds = Cfg::kFast ? aq_lds_bytes(args.scene.nwords_skip, pool, true, kPool > 0 ? kAqCapFast : kAqCap) : aq_lds_bytes(args.scene.nwords, pool);
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_probe_trace_aq<kStats, kPool, Cfg>), 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_probe_trace_aq<kStats, kPool, Cfg>), dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, work_counter, status, next_work_counter);
+    hipLaunchKernelGGL((k_probe_trace_aq<kStats, kPool, Cfg>), dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, chain, status);
     return hipGetLastError();
 }
 
-// work_counter must be zero: the handle's two counters take turns, each launch zeroes the other one (next_work_counter)
-hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, uint32_t* work_counter, uint32_t* status, uint32_t* next_work_counter, hipStream_t stream)
+// chain.counters[chain.seq % 8] must be zero: every launch zeroes the counter of the launch four after it (k_probe_trace_aq)
+hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, const AqChain& chain, uint32_t* status, hipStream_t stream)
 {
     if (args.fast_march)
     {
         // (the tolerance-mode build: no counters kernel, no ablation switches)
         if (pool == kAqPoolFast && args.nl == 1)
-            return args.ddgi ? launch_aq<false, kAqPoolFast, CfgPlain<1, true>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream)
-                             : launch_aq<false, kAqPoolFast, CfgPlain<0, true>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
-        return launch_aq<false, 0, CfgRuntimeT<true>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
+            return args.ddgi ? launch_aq<false, kAqPoolFast, CfgPlain<1, true>>(args, pool, grid_blocks, march_waves, chain, status, stream)
+                             : launch_aq<false, kAqPoolFast, CfgPlain<0, true>>(args, pool, grid_blocks, march_waves, chain, status, stream);
+        return launch_aq<false, 0, CfgRuntimeT<true>>(args, pool, grid_blocks, march_waves, chain, status, stream);
     }
-    if (args.stats) return launch_aq<true, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
+    if (args.stats) return launch_aq<true, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, chain, status, stream);
     if (pool == kAqPool && args.nl == 1 && args.ablate == 0)
-        return args.ddgi ? launch_aq<false, kAqPool, CfgPlain<1>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream)
-                         : launch_aq<false, kAqPool, CfgPlain<0>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
+        return args.ddgi ? launch_aq<false, kAqPool, CfgPlain<1>>(args, pool, grid_blocks, march_waves, chain, status, stream)
+                         : launch_aq<false, kAqPool, CfgPlain<0>>(args, pool, grid_blocks, march_waves, chain, status, stream);
     if (pool == kAqPool && args.nl > 1 && args.ablate == 0)
     {
         if (args.nl == 4)
-            return args.ddgi ? launch_aq<false, kAqPool, CfgMulti<1, false, 4>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream)
-                             : launch_aq<false, kAqPool, CfgMulti<0, false, 4>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
-        return args.ddgi ? launch_aq<false, kAqPool, CfgMulti<1>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream)
-                         : launch_aq<false, kAqPool, CfgMulti<0>>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
+            return args.ddgi ? launch_aq<false, kAqPool, CfgMulti<1, false, 4>>(args, pool, grid_blocks, march_waves, chain, status, stream)
+                             : launch_aq<false, kAqPool, CfgMulti<0, false, 4>>(args, pool, grid_blocks, march_waves, chain, status, stream);
+        return args.ddgi ? launch_aq<false, kAqPool, CfgMulti<1>>(args, pool, grid_blocks, march_waves, chain, status, stream)
+                         : launch_aq<false, kAqPool, CfgMulti<0>>(args, pool, grid_blocks, march_waves, chain, status, stream);
     }
-    return launch_aq<false, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, work_counter, status, next_work_counter, stream);
+    return launch_aq<false, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, chain, status, stream);
 }
 
 // LDS bytes of k_probe_trace_wf for a pool of `pool` rays

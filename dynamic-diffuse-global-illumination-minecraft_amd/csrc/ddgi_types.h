@@ -109,6 +109,23 @@ struct TraceArgs
     const uint8_t* vis;  // single light: feeler classes per (voxel of the baked box, face): [voxel * 8 + face] (k_light_visibility), or null
     const uint32_t* vis_occ;  // ... and for class kVisListed the occupied voxels of the bundle: [(voxel * 8 + face) * kVisListMax + k]
     const uint8_t* vis_more[kVisLights - 1];  // several lights: the same table for lights 1 .. kVisLights - 1 (classes kVisLit / kVisShadow only), or null
+    uint32_t pair_words;  // REF mode, frames in flight: 32-bit words between two consecutive texture pairs of the handle's ring (albedo + k * pair_words
+                          // is the pair k updates after this launch's own); 0: the launch writes its own pair only (ddgi_trace_wf.hip: wf_finish_ray)
+};
+
+// k_probe_trace_aq's place in the handle's sequence of launches (ddgi_engine.cpp: "frames in flight").  Launch `seq` claims its
+// rays from counters[seq % 8]; when they are used up and the host has published launch seq + 1 as a CONTINUATION (the same
+// work into the next texture pair: pub[(seq + 1) % kAqPubRing] == seq + 2), the launch's workgroups go on with that update's
+// rays instead of draining — up to chain_max updates ahead.
+constexpr uint32_t kAqPubRing = 64;  // entries of the host's ring of published continuations (pinned host memory)
+constexpr int kAqChainMax = 4;       // updates one launch can work on (its own + 3): the counters ring holds 2 x that
+struct AqChain
+{
+    uint32_t* counters;   // device: 8 ray counters
+    uint32_t* continued;  // device: counts the workgroups that went on with a later update (ddgi_get_tuning "continued_workgroups")
+    const uint32_t* pub;  // pinned host memory, device-visible: kAqPubRing words
+    uint32_t seq;
+    uint32_t chain_max;   // 0: this launch works on its own update only
 };
 
 // DDGI-mode ray records, laid out as the B operand of the blend's MFMA contraction (ddgi_blend_sample.hip): for local

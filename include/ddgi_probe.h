@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define DDGI_ABI_VERSION 3 /* 3: ddgi_exchange_p2p_*, ddgi_exchange_transport, ddgi_scene_skip_field; tuning "fast_march", "sample_box"; "autotune" off by default */
+#define DDGI_ABI_VERSION 4 /* 4: tuning "frames_in_flight" (default 2): the handle owns a ring of texture pairs, ddgi_device_textures pins the current one;
+                              3: ddgi_exchange_p2p_*, ddgi_exchange_transport, ddgi_scene_skip_field; tuning "fast_march", "sample_box"; "autotune" off by default */
 
 /* ---- wire formats: byte-identical to the reference's UBO/SSBO records ------------------------ */
 
@@ -204,6 +205,18 @@ int ddgi_tune(ddgi_handle h);
  *                   runs the exact march; ddgi_get_tuning "fast_march_active" tells.  0 (default) = the exact march [DDGI_FAST_MARCH]
  *   "march_waves"   n > 0 pins the split (waves that march, of 16); 0 = per configuration            [DDGI_AQ_MARCH]
  *   "trace_kernel"  0 auto, 1 round-based, 2 ray per lane, 3 queues (cross-checks)   [DDGI_TRACE_KERNEL=rounds|lane|queues]
+ *   "frames_in_flight"  REF mode.  The reference's host contract is MAX_FRAMES_IN_FLIGHT = 2 with a fence per frame (src/rvpt/rvpt.h:23,
+ *                   rvpt.cpp:277-278): frame k + 1 is submitted while frame k runs.  n (default 2, at most 4): the handle keeps n texture
+ *                   pairs (2 n under the pipelined exchange) and updates come in groups of n; an update submitted as the SAME WORK as
+ *                   its predecessor (same configuration, rays, lights, tuning — nothing but probe updates, exchanges, samples, renders and
+ *                   reads on the handle in between) while the predecessor's launch still runs is continued by that launch's resident
+ *                   workgroups instead of waiting for their drain (one ray's 8 bounces are a dependent chain: 0.25 ms of thinning
+ *                   occupancy per launch).  Results are unchanged bit for bit; every update still has its own launch in stream order, so
+ *                   everything enqueued behind an update sees it complete — but an update's end event can fire up to n - 1 updates
+ *                   late (its launch went on with its successors' rays): a host that consumes every update at once loses nothing
+ *                   and gains nothing, a host that runs frames ahead gains the drain.  1 = every launch traces its own update only, one
+ *                   pair, in place.  Changing it blocks and re-makes the ring (the textures carry over); set it before the exchange
+ *                   is attached.                                                                            [DDGI_FRAMES_IN_FLIGHT]
  *   "timing"        1 (default): every update records two (REF) or three (DDGI) events on its stream for ddgi_last_update_ms /
  *                   ddgi_update_history_ms; 0: none — the queries then fail with DDGI_ERR_NOT_READY, and a stream of
  *                   back-to-back updates loses ~6 us per update less to the command processor                [DDGI_TIMING]
@@ -304,7 +317,10 @@ int ddgi_set_stream(ddgi_handle h, void* hip_stream);
  *   REF : tex0 = albedo   [cz][cy][cx][s][s] rgba8,  tex1 = distance, same shape
  *   DDGI: tex0 = irradiance [cz][cy][cx][8][8] 4xf32, tex1 = depth [cz][cy][cx][16][16] 2xf32
  * and of this rank's contiguous slab inside each (offset/bytes), which is what an all-gather
- * exchanges. */
+ * exchanges.  The handle owns a ring of texture pairs (tuning "frames_in_flight") and moves on to the next
+ * one with every update; a host that asks for the addresses may keep them: from this call on the handle STAYS on the pair it
+ * returns (no frames in flight; the sampler's per-texel table is no longer cached, since the host may write through the
+ * pointers) — except under the pipelined exchange, which alternates pairs by contract (call this after every update there). */
 int ddgi_device_textures(ddgi_handle h, void** tex0, size_t* tex0_bytes, void** tex1,
                          size_t* tex1_bytes, size_t* slab_offset0, size_t* slab_bytes0,
                          size_t* slab_offset1, size_t* slab_bytes1);
@@ -336,10 +352,11 @@ int ddgi_sample_device(ddgi_handle h, const float* d_pos_xyz, const float* d_nrm
 /* Attaches a communicator (an ncclComm_t whose size/rank equal the handle's world/rank; the caller keeps
  * ownership) and sets the exchange up; nccl_comm == NULL detaches.
  *   pipelined == 0  the all-gather runs on the handle's stream, in order after the update.
- *   pipelined != 0  two texture pairs are used alternately and the all-gather of update k runs on a
- *                   communication stream while update k+1 already traces into the other pair (the DDGI
- *                   blend reads its own slab's previous tiles from the pair it wrote last).  Every
- *                   consumer call on the handle (sample / render / read) waits for the latest exchange.
+ *   pipelined != 0  the handle's ring of texture pairs is doubled (two pairs; 2 x "frames_in_flight" in REF mode) and the
+ *                   all-gather of update k runs on a communication stream while later updates already trace into
+ *                   other pairs (the DDGI blend reads its own slab's previous tiles from the pair it wrote last).
+ *                   Every consumer call on the handle (sample / render / read) waits for the latest exchange.
+ *                   Blocks (the ring is re-made; the textures so far carry over).
  * ddgi_configure / ddgi_reconfigure / ddgi_set_mode / ddgi_set_ray_tile detach: call this again after them. */
 int ddgi_exchange_init(ddgi_handle h, void* nccl_comm, int pipelined);
 /* Issues the all-gather of the most recent ddgi_probe_update (asynchronous). */

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Steady-state time per probe update of ONE rank's slab of the bench workload (C3, REF) at world = 1, 2, 4, 8 and
+frames_in_flight = 1, 2, 4 (GPU box, one GPU): wall clock over a run of back-to-back updates, no per-update events
+(a continued update has no kernel time of its own).  What strong scaling can reach before any exchange cost."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ddgi_amd
+from bench import WORKLOAD as w
+
+N = int(os.environ.get("FIF_UPDATES", "48"))
+fast = os.environ.get("FIF_FAST", "0") == "1"
+base = {}
+for world in (1, 2, 4, 8):
+    for fif in (1, 2, 4):
+        eng = ddgi_amd.ProbeEngine(ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"]),
+                                   ddgi_amd.make_settings(w["scene"], w["max_bounces"]), rank=world // 2, world=world)
+        eng.set_tuning("frames_in_flight", fif)
+        eng.set_tuning("fast_march", 1 if fast else 0)
+        eng.generate_probe_rays(seed=1)
+        eng.tune()
+        eng.set_tuning("timing", 0)
+        best = None
+        for rep in range(3):
+            for _ in range(8):
+                eng.probe_update()
+            eng.synchronize()
+            before = eng.get_tuning("continued_workgroups")
+            t0 = time.perf_counter()
+            for _ in range(N):
+                eng.probe_update()
+            eng.synchronize()
+            dt = (time.perf_counter() - t0) / N * 1e3
+            cont = eng.get_tuning("continued_workgroups") - before
+            best = dt if best is None else min(best, dt)
+        if world == 1:
+            base[fif] = best
+        print("world %d frames_in_flight %d%s: %.4f ms per update (march waves %d, %d workgroup continuations in %d updates)  -> %.2fx of one GPU's %.3f ms (fif 1)" % (
+            world, fif, " fast-march" if fast else "", best, eng.get_tuning("march_waves_measured"), cont, N, base[1] / best, base[1]), flush=True)
+        eng.close()
