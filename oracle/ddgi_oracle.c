@@ -1346,6 +1346,18 @@ int oracle_intersect_scene(const o_settings* st, const float* o, const float* d,
     return info.type;
 }
 
+/* KAT helper: intersect_sphere; out = {t, px, py, pz}; returns hit */
+int oracle_intersect_sphere(const float* o, const float* d, float mint, float maxt, float* out)
+{
+    Ray r;
+    r.o = V3(o[0], o[1], o[2]);
+    r.d = V3(d[0], d[1], d[2]);
+    Isect info;
+    const int hit = intersect_sphere(r, mint, maxt, &info);
+    out[0] = info.t, out[1] = info.pos.x, out[2] = info.pos.y, out[3] = info.pos.z;
+    return hit;
+}
+
 float oracle_sinf(float x) { return o_sin(x); }
 void oracle_sincos_small(float x, float* s, float* c) { opm_sincos_small(x, s, c); }
 float oracle_cosf(float x) { return o_cos(x); }

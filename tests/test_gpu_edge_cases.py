@@ -3,7 +3,7 @@ several lights, zero bounces, empty batches, reconfiguration, and BASELINE's lar
 import numpy as np
 import pytest
 
-from tests.common import CONFIGS, shading_points
+from tests.common import CONFIGS, c3_oracle_albedo, shading_points
 
 pytestmark = pytest.mark.gpu
 
@@ -248,24 +248,28 @@ def test_update_timing_can_be_switched_off(ddgi):
 
 @pytest.mark.parametrize("time", [0.0, 46.0])
 def test_full_size_c3_four_lights_every_texel(ddgi, oracle, time):
-    """The headline grid under the reference's 4-light cave table (S-Dyn's lights), REF mode, every one of the 4 194 304 texels
-    against the oracle, at two moments of the lights' animation.  With several lights the event deals with the feelers that the
-    per-light tables of k_light_visibility decide without marching them (wf_event: decided_feelers) — a LIT patch ends on the nearest
-    light sphere on its ray, a SHADOW patch counts only when no OTHER light's sphere lies on the ray; a hole in either argument shows
-    as a handful of texels here."""
+    """The headline grid under the reference's 4-light cave table (S-Dyn's lights), REF mode, against the oracle: EVERY one of the
+    4 194 304 texels with the table as written, and an eighth of the probes (spread over the grid) with the table as
+    update_lights(time = 46) moves it (probe_pass.comp:217-251; REF mode itself does not animate — the moved table is handed to
+    both sides).  With several lights the event deals with the feelers that the per-light tables of k_light_visibility decide without
+    marching them (wf_event: decided_feelers) — a LIT patch ends on the nearest light sphere on its ray, a SHADOW patch counts only
+    when no OTHER light's sphere lies on the ray; a hole in either argument shows as a handful of texels here."""
     counts, side, s, origin, scene = CONFIGS["c3_cave"]
-    lights = np.array(FOUR_LIGHTS_CAVE, dtype=ddgi.LIGHT_DTYPE)
-    with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8, time=time)) as eng:
+    base = np.array(FOUR_LIGHTS_CAVE, dtype=oracle.LIGHT_DTYPE)
+    table = base if time == 0.0 else oracle.update_lights(scene, time, base)
+    assert time == 0.0 or not np.array_equal(table["pos"], base["pos"])
+    lights = np.array([(float(l["intensity"]), tuple(l["col"]), tuple(l["pos"])) for l in table], dtype=ddgi.LIGHT_DTYPE)
+    with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8)) as eng:
         eng.set_lights(scene, lights)
         eng.generate_probe_rays(seed=1)
-        eng.probe_update(ddgi.make_settings(scene, 8, time=time))
+        eng.probe_update()
         got, _ = eng.read_textures()
         eng.set_tuning("light_vis", 0)          # the same without the tables: every feeler marched
-        eng.probe_update(ddgi.make_settings(scene, 8, time=time))
+        eng.probe_update()
         marched, _ = eng.read_textures()
-    f = oracle.make_field(counts, side, s, origin)
-    rays = oracle.generate_probe_rays(f, oracle.new_rand_state(1))
-    want, _ = oracle.probe_update(f, oracle.make_settings(scene, 8, time=time), rays, lights=np.array(FOUR_LIGHTS_CAVE, dtype=oracle.LIGHT_DTYPE))
-    assert np.array_equal(marched, want), "marched feelers differ from the oracle"
-    nbad = int((got != want).any(axis=-1).sum())
-    assert nbad == 0, f"time {time}: {nbad} of {got.shape[0] * got.shape[1]} texels differ from the oracle"
+    want = c3_oracle_albedo(oracle, "pinned", seed=1, lights=table, fraction=1 if time == 0.0 else 8)
+    mask = want[..., 3] == 255
+    assert mask.all() if time == 0.0 else mask.sum() >= got.shape[0] * got.shape[1] // 10
+    assert np.array_equal(marched[mask], want[mask]), "marched feelers differ from the oracle"
+    nbad = int((got[mask] != want[mask]).any(axis=-1).sum())
+    assert nbad == 0, f"time {time}: {nbad} of {int(mask.sum())} compared texels differ from the oracle"

@@ -222,16 +222,17 @@ def test_full_size_c3_full_grid_other_ray_sets(ddgi, oracle, seed):
     (feelers decided by k_light_visibility's classes and lists, dead feelers) rests on arguments about the reference's float
     march; a hole in one shows as a handful of texels in 4 million (a SHADOW rule that overlooked grid_march stepping over a
     voxel whose entry plane it lands on exactly differed in ONE texel), so more than one ray set is compared."""
-    counts, side, s, origin, scene = CONFIGS["c3_cave"]
     with _engine(ddgi, "c3_cave") as eng:
         eng.generate_probe_rays(seed=seed)
         eng.probe_update()
         a1, _ = eng.read_textures()
-    f = oracle.make_field(counts, side, s, origin)
-    rays = oracle.generate_probe_rays(f, oracle.new_rand_state(seed))
-    want, _ = oracle.probe_update(f, oracle.make_settings(scene, 8), rays)
-    nbad = int((a1 != want).any(axis=-1).sum())
-    assert nbad == 0, f"seed {seed}: {nbad} of {a1.shape[0] * a1.shape[1]} texels of the full C3 grid differ from the oracle"
+    # (every texel of the grid is compared for seed 1 — test_full_size_c3_full_grid_vs_oracle; of these ray sets a quarter of the
+    # probes, spread over the grid: the oracle's raster is what the GPU suite's time goes into)
+    want = c3_oracle_albedo(oracle, "pinned", seed=seed, fraction=4)
+    mask = want[..., 3] == 255
+    assert mask.sum() >= a1.shape[0] * a1.shape[1] // 5
+    nbad = int((a1[mask] != want[mask]).any(axis=-1).sum())
+    assert nbad == 0, f"seed {seed}: {nbad} of {int(mask.sum())} compared texels of the C3 grid differ from the oracle"
 
 
 def test_torch_owned_textures_and_stream(ddgi, oracle):
