@@ -223,7 +223,10 @@ def _call_bounded(fn, seconds):
     return True, box.get("r")
 
 
-VALU_LANE_PEAK = 256 * 4 * 16 * 2.4e9   # CUs x SIMDs x lanes per SIMD-cycle x clock (MI355X_MICROARCH.md): 3.93e13 lane-ops/s
+# CUs x SIMDs x lanes per SIMD-cycle x clock: CDNA4's SIMDs are 32 lanes wide — a wave64 VALU instruction issues over 2 cycles
+# (MI355X_MICROARCH.md "Wave scheduling"; tools/microbench/valu_latency.hip measures 2.5 cycles per v_fma_f32 at 8 waves per SIMD,
+# 3.1 at the trace kernel's 4 waves of dependent code) — 7.86e13 lane-ops/s.  (Rounds 1-3 priced the kernel against a 16-lane SIMD.)
+VALU_LANE_PEAK = 256 * 4 * 32 * 2.4e9
 
 
 def main():
@@ -443,8 +446,11 @@ def main():
         lane_ops = issue["valu_wave_instructions_per_launch"] * 64.0 * issue["valu_lane_use"]
         valu = {"useful_lane_ops_per_s": lane_ops / (kernel_ms * 1e-3), "lane_peak_per_s": VALU_LANE_PEAK,
                 "frac_of_lane_peak": lane_ops / (kernel_ms * 1e-3) / VALU_LANE_PEAK, "lane_use": issue["valu_lane_use"], "valu_busy": issue["valu_busy"],
+                "valu_issue_cycles_frac": issue["valu_wave_instructions_per_launch"] * 2.0 / (1024 * 2.4e9 * kernel_ms * 1e-3),
                 "note": "instruction count and lane use REPLAYED from " + issue["replayed_from"] + " (the build those counters were taken on), time measured by this run; "
-                        "lane peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz"}
+                        "lane peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (a wave64 VALU instruction issues over 2 cycles on CDNA4); valu_issue_cycles_frac = the share of "
+                        "the SIMDs' cycles in which a VALU instruction issues: the kernel is bound by the LATENCY of its 16 waves' dependent instruction streams "
+                        "(4 per SIMD at 128 VGPRs), not by the issue rate"}
     out = {
         "metric": "probe_rays_per_sec",
         "value": total_rays / (elapsed / args.steps),
@@ -485,7 +491,7 @@ def main():
             "issue": issue,
             "note": "achieved / peak / frac are the HBM figures the task defines (algorithmic bytes per update / mean launch duration of the timed updates, HIP events on the launch "
                     "stream; with frames in flight a launch traces up to `frames_in_flight` updates and the continued updates' own launches are empty — the mean is per update); "
-                    "`bound` says what the kernel really sits at: VALU issue (dependent voxel steps + hit shading, DESIGN.md section 4), `valu` prices it against the lane peak. "
+                    "`bound` says what the kernel really sits at: its waves' dependent VALU instruction streams (voxel steps + hit shading, DESIGN.md section 4), `valu` prices it against the lane peak. "
                     "`traffic`, `issue` and the instruction count inside `valu` are REPLAYED from the committed rocprofv3 --pmc passes named beside them (counters need their own passes)",
         },
     }

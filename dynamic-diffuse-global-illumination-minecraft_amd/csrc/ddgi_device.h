@@ -275,6 +275,54 @@ DDGI_D int hit_block_type(const SceneK& S, int scene_id, f3 cell, int raw)
     return S.types[raw - S.bias];
 }
 
+// march_step_frozen for TWO marches of a lane at once, statement by statement: the two dependent chains alternate in the
+// instruction stream, so that one's next instruction is ready when the other's has just issued (a wave issues in order).
+DDGI_D void march_step_frozen2(March (&m)[2], const SceneK& S, const uint32_t* __restrict__ s_bits, f3 hi, const bool (&frozen)[2], bool (&occ)[2])
+{
+    float fx[2], fy[2], fz[2], tx[2], step[2], kx[2], ky[2], kz[2];
+    f2v tyz[2];
+    int idx[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) fx[q] = gl_fract(m[q].p.x);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) fy[q] = gl_fract(m[q].p.y);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) fz[q] = gl_fract(m[q].p.z);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) tx[q] = (m[q].cc.x - fx[q]) * m[q].inv.x;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) tyz[q] = (f2v{m[q].cc.y, m[q].cc.z} - f2v{fy[q], fz[q]}) * f2v{m[q].inv.y, m[q].inv.z};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) step[q] = fminf(fminf(tx[q], tyz[q].x), tyz[q].y) + 0.0001f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) m[q].t += frozen[q] ? 0.0f : step[q];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) m[q].p.x = fmaf(m[q].dn.x, m[q].t, m[q].ro.x);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) m[q].p.y = fmaf(m[q].dn.y, m[q].t, m[q].ro.y);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) m[q].p.z = fmaf(m[q].dn.z, m[q].t, m[q].ro.z);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) kx[q] = __builtin_amdgcn_fmed3f(ceilf(m[q].p.x), S.lo_f[0], hi.x);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) ky[q] = __builtin_amdgcn_fmed3f(ceilf(m[q].p.y), S.lo_f[1], hi.y);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) kz[q] = __builtin_amdgcn_fmed3f(ceilf(m[q].p.z), S.lo_f[2], hi.z);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) idx[q] = static_cast<int>(fmaf(kz[q], S.nxy_f, fmaf(ky[q], S.nx_f, kx[q])));
+    const uint32_t* __restrict__ base = s_bits - (S.bias32 >> 5);
+    uint32_t word[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) m[q].cell = idx[q], word[q] = base[idx[q] >> 5];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) occ[q] = __builtin_amdgcn_ubfe(word[q], static_cast<uint32_t>(idx[q]), 1u) != 0u;
+}
+
+DDGI_D void march_step_frozen2(March (&m)[1], const SceneK& S, const uint32_t* __restrict__ s_bits, f3 hi, const bool (&frozen)[1], bool (&occ)[2])
+{
+    occ[0] = march_step_frozen(m[0], S, s_bits, hi, frozen[0]), occ[1] = false;  // (one march per lane: never called, only compiled)
+}
+
 // True when the march can no longer hit a block: the position is outside the baked box on some
 // axis, moving away from it, and the border layer it left through is entirely empty (so the whole
 // half space beyond is empty).  Skipping the remaining iterations does not change any result.

@@ -33,9 +33,16 @@ DDGI_HD float gl_mix(float a, float b, float t) { return a * (1.0f - t) + b * t;
 DDGI_HD f3 gl_mix3(f3 a, f3 b, float t) { return f3{gl_mix(a.x, b.x, t), gl_mix(a.y, b.y, t), gl_mix(a.z, b.z, t)}; }
 DDGI_HD float gl_mod(float x, float y) { return x - y * floorf(x / y); }
 
-// int(x): truncation, NaN -> 0, saturating (what v_cvt_i32_f32 does)
+// int(x): truncation, NaN -> 0, saturating — exactly what v_cvt_i32_f32 does, so the device takes the instruction itself: written
+// out (C++'s conversion is undefined outside int's range) the compiler makes three nested exec-mask branches of it, ~16
+// instructions apiece, and the noise functions convert a lattice coordinate 94 times over the event code (11 per cave-wall hit)
 DDGI_HD int gl_int(float x)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#endif
     if (x != x) return 0;
     if (x >= 2147483648.0f) return 2147483647;
     if (x <= -2147483648.0f) return -2147483647 - 1;

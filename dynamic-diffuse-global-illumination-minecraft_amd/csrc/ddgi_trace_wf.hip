@@ -39,6 +39,10 @@ constexpr int kWfStepsPerTrip = 16;  // voxel steps per march-loop trip (burst)
 #define DDGI_AQ_STEPS 24
 #endif
 constexpr int kAqStepsPerTrip = DDGI_AQ_STEPS;  // the same for k_probe_trace_aq
+#ifndef DDGI_LANE_MARCHES
+#define DDGI_LANE_MARCHES 1
+#endif
+constexpr int kLaneMarches = DDGI_LANE_MARCHES;  // marches a lane of k_probe_trace_aq's march waves steps in turn (independent chains interleaved)
 constexpr int kWfTailSteps = 1;          // straggler trips (bursts) after the march list is drained
 constexpr int kWfDrainTail = 8;      // straggler trips once no new ray can be claimed (8 x 16 steps >= kMarchIters)
 constexpr int kWfFetchLanes = 8;     // pull new march tasks once this many lanes are idle
@@ -1461,118 +1465,166 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     else if (wave < march_waves)
     {
         // ================= march waves =================
-        March m;
-        m.ro = m.rd = m.dn = m.inv = m.cc = m.p = mk3(0, 0, 0);
-        m.t = 0.0f, m.tl = inf, m.it = 0, m.lid = -1, m.cell = 0;
-        uint32_t slot = 0, fl = 0;
+        // A lane holds kLaneMarches marches at a time and steps them in turn inside one burst.  CDNA4's SIMDs are 32 lanes wide:
+        // a wave64 VALU instruction issues over 2 cycles, a wave can issue one every 4, and a DEPENDENT one only every ~7.6
+        // (tools/microbench/valu_latency.hip) — and a voxel step is a dependent chain from end to end, with a trip to LDS in it.
+        // A march wave is therefore bound by its own latency, not by the SIMD's issue rate (the kernel keeps the VALU busy about
+        // half the cycles): two independent chains interleaved in one wave march nearly twice as many rays per wave, so that
+        // fewer of the workgroup's 16 waves have to march and more of them run events — which is what limits the kernel.
+        constexpr int kM = kLaneMarches;
+        March m[kM];
+        uint32_t slot[kM], fl[kM];
+        bool have[kM];
+#pragma unroll
+        for (int q = 0; q < kM; ++q)
+        {
+            // (a lane without a march takes zero-length steps from this state: every index it computes is inside the bitmap)
+            m[q].ro = m[q].rd = m[q].dn = m[q].inv = m[q].cc = m[q].p = mk3(0, 0, 0);
+            m[q].t = 0.0f, m[q].tl = inf, m[q].it = 0, m[q].lid = -1, m[q].cell = 0;
+            slot[q] = 0, fl[q] = 0, have[q] = false;
+        }
         f3 hi_v = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
         asm volatile("" : "+v"(hi_v.x), "+v"(hi_v.y), "+v"(hi_v.z));
-        bool have = false;
-        int trips = 0, thin_waits = 0;
+        int trips = 0;
         for (;;)
         {
             if (++guard > (1u << 23)) sh->abort = 1u;
-            const unsigned long long idle_mask = __ballot(!have);
-            const int n_idle = __popcll(idle_mask);
+            unsigned long long idle_mask[kM];
+            int n_idle = 0;
+#pragma unroll
+            for (int q = 0; q < kM; ++q) idle_mask[q] = __ballot(!have[q]), n_idle += __popcll(idle_mask[q]);
             if (n_idle >= fetch_lanes)
             {
                 uint32_t base = 0, k = 0;
                 if (lane == 0) k = aq_claim(&sh->mq_head, &sh->mq_tail, static_cast<uint32_t>(n_idle), base);
                 k = lane_bcast(k, 0), base = lane_bcast(base, 0);
                 if (kStats && static_cast<int>(k) < n_idle) st_q[6] += 1;
-                const uint32_t rank = static_cast<uint32_t>(__popcll(idle_mask & ((1ull << lane) - 1ull)));
-                if (!have && rank < k)
+                uint32_t before = 0;  // idle places of the marches in front of march q
+#pragma unroll
+                for (int q = 0; q < kM; ++q)
                 {
-                    slot = aq_take<kCap>(ring_mq, base + rank, &sh->abort);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    fl = P.flags[slot];
-                    m.ro = ld3(P.ro, slot);
-                    m.dn = ld3(P.dn, slot);
-                    m.inv = f3{axis_inv(m.dn.x), axis_inv(m.dn.y), axis_inv(m.dn.z)};  // P5; recomputed, not stored
-                    m.t = P.t[slot];
-                    m.tl = P.tl[slot];
-                    m.it = static_cast<int>((fl >> 4) & 255u);
-                    m.cc = f3{m.dn.x >= 0.0f ? 1.0f : 0.0f, m.dn.y >= 0.0f ? 1.0f : 0.0f, m.dn.z >= 0.0f ? 1.0f : 0.0f};
-                    m.p = ray_at(m.ro, m.dn, m.t);
-                    have = true;
+                    const uint32_t rank = before + static_cast<uint32_t>(__popcll(idle_mask[q] & ((1ull << lane) - 1ull)));
+                    before += static_cast<uint32_t>(__popcll(idle_mask[q]));
+                    if (!have[q] && rank < k)
+                    {
+                        slot[q] = aq_take<kCap>(ring_mq, base + rank, &sh->abort);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        fl[q] = P.flags[slot[q]];
+                        m[q].ro = ld3(P.ro, slot[q]);
+                        m[q].dn = ld3(P.dn, slot[q]);
+                        m[q].inv = f3{axis_inv(m[q].dn.x), axis_inv(m[q].dn.y), axis_inv(m[q].dn.z)};  // P5; recomputed, not stored
+                        m[q].t = P.t[slot[q]];
+                        m[q].tl = P.tl[slot[q]];
+                        m[q].it = static_cast<int>((fl[q] >> 4) & 255u);
+                        m[q].cc = f3{m[q].dn.x >= 0.0f ? 1.0f : 0.0f, m[q].dn.y >= 0.0f ? 1.0f : 0.0f, m[q].dn.z >= 0.0f ? 1.0f : 0.0f};
+                        m[q].p = ray_at(m[q].ro, m[q].dn, m[q].t);
+                        have[q] = true;
+                    }
                 }
             }
-            if (__ballot(have) == 0ull)
+            bool any = false;
+#pragma unroll
+            for (int q = 0; q < kM; ++q) any = any || have[q];
+            if (__ballot(any) == 0ull)
             {
                 if ((aq_load(&sh->no_more) != 0u && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
                 __builtin_amdgcn_s_sleep(DDGI_AQ_SLEEP);
                 continue;
             }
-            // a thin trip costs the SIMD as many issue slots as a full one: with few marches in flight and none queued, give the
-            // slots to the event waves for a moment and look again (bounded) — but only while new rays still come in.  Once the
-            // launch's rays are used up (most of a rank's slab of a sharded grid: 2 048 rays per workgroup for a pool of 1 344),
-            // every ray's next event is on the critical path and waiting costs 5-14 % of the launch.  (On the full grid the
-            // yield does not change the time — 2.113 against 2.112 ms — but it saves 2 % of the VALU instructions.)
-            if (__popcll(__ballot(have)) < kAqThinTrip && thin_waits < 4 && aq_load(&sh->no_more) == 0u)
-            {
-                ++thin_waits;
-                __builtin_amdgcn_s_sleep(4);
-                continue;
-            }
-            thin_waits = 0;
             guard = 0;
-            bool finished = false;
-            uint32_t bucket = 0;
-            if (kStats) st_a += 1, st_b += static_cast<unsigned long long>(__popcll(__ballot(have)));
-            if (kStats) st_q[5] += 1, st_q[7] += static_cast<unsigned long long>(__popcll(__ballot(have)));
+            if (kStats)
+            {
+                unsigned long long busy = 0;
+#pragma unroll
+                for (int q = 0; q < kM; ++q) busy += static_cast<unsigned long long>(__popcll(__ballot(have[q])));
+                st_a += 1, st_b += busy, st_q[5] += 1, st_q[7] += busy;
+            }
             // The burst.  Per step the wave pays 26 VALU and a dozen scalar instructions of lane-mask bookkeeping, and the kernel's
             // time follows the total: (1) whether the cell reached is occupied is NOT carried from step to step as a lane mask
             // — it is the bit of the last cell reached (m.cell), read once after the burst; (2) the test against grid_march's
             // iteration limit is dropped from the steps when no lane of the wave can reach the limit within this burst (all but
-            // the last burst of the few marches longer than 101 steps).  C3: 2.052 -> 2.016 ms.  (The steps as NESTED ifs — a lane
-            // that ends drops out of exec, nothing restored until all levels close: 4 scalar instructions per step instead of 8 —
-            // were slower, 2.028 ms: 24 live exec copies.)
-            const bool near_limit = __ballot(have && kMarchIters - m.it < kAqStepsPerTrip) != 0ull;
-            if (have)
+            // the last burst of the few marches longer than 101 steps); (3) no exec-mask predication inside the burst: a march that
+            // has ended — or a place without a march — takes steps of length 0 (march_step_frozen).
+            bool near = false;
+#pragma unroll
+            for (int q = 0; q < kM; ++q) near = near || (have[q] && kMarchIters - m[q].it < kAqStepsPerTrip);
+            const bool near_limit = __ballot(near) != 0ull;
+            bool finished[kM];
+            uint32_t bucket[kM];
+#pragma unroll
+            for (int q = 0; q < kM; ++q) finished[q] = false, bucket[q] = 0;
+            if (any)
             {
-                const int left = kMarchIters - m.it;
-                bool fin;
+                bool fin[kM];
                 if (near_limit)
                 {
-                    fin = march_step_burst(m, A.scene, s_bits, hi_v) | (m.t >= m.tl) | (left <= 1);
 #pragma unroll
-                    for (int sub = 1; sub < kAqStepsPerTrip; ++sub)
-                        if (!fin) fin = march_step_burst(m, A.scene, s_bits, hi_v) | (m.t >= m.tl) | (left <= sub + 1);
+                    for (int q = 0; q < kM; ++q) fin[q] = !have[q] || (kMarchIters - m[q].it <= 0);
+#pragma unroll
+                    for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
+#pragma unroll
+                        for (int q = 0; q < kM; ++q) fin[q] = fin[q] | march_step_frozen(m[q], A.scene, s_bits, hi_v, fin[q]) | (m[q].t >= m[q].tl) | (kMarchIters - m[q].it <= sub + 1);
                 }
                 else
                 {
-                    // (no exec-mask predication inside the burst: a lane whose march has ended takes steps of length 0, march_step_frozen —
-                    // 28 instructions per step instead of 34; C3 1.923 -> 1.911 ms: the march waves are not what limits the kernel)
-                    fin = march_step_burst(m, A.scene, s_bits, hi_v) | (m.t >= m.tl);
 #pragma unroll
-                    for (int sub = 1; sub < kAqStepsPerTrip; ++sub) fin = fin | march_step_frozen(m, A.scene, s_bits, hi_v, fin) | (m.t >= m.tl);
+                    for (int q = 0; q < kM; ++q) fin[q] = !have[q];
+                    if constexpr (kM == 2)
+                    {
+#pragma unroll
+                        for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
+                        {
+                            bool occ2[2];
+                            march_step_frozen2(m, A.scene, s_bits, hi_v, fin, occ2);
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) fin[q] = fin[q] | occ2[q] | (m[q].t >= m[q].tl);
+                        }
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
+#pragma unroll
+                            for (int q = 0; q < kM; ++q) fin[q] = fin[q] | march_step_frozen(m[q], A.scene, s_bits, hi_v, fin[q]) | (m[q].t >= m[q].tl);
+                    }
                 }
                 const uint32_t* __restrict__ bits_base = s_bits - (A.scene.bias32 >> 5);
-                const bool occ = __builtin_amdgcn_ubfe(bits_base[m.cell >> 5], static_cast<uint32_t>(m.cell), 1u) != 0u;  // (march_step_burst's own test)
-                m.it += kAqStepsPerTrip;
-                if (!fin && ((trips & 3) == 3)) fin = march_escaped(m, A.scene);
-                if (fin)
+#pragma unroll
+                for (int q = 0; q < kM; ++q)
                 {
-                    const uint32_t hf = !occ ? 0u : ((fl & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
-                    P.t[slot] = m.t;
-                    P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | hf;
-                    const bool block_wins = occ && (m.t < m.tl);
-                    bucket = (fl & kFlagFeeler) ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock);
-                    have = false;
-                    finished = true;
+                    if (!have[q]) continue;
+                    const bool occ = __builtin_amdgcn_ubfe(bits_base[m[q].cell >> 5], static_cast<uint32_t>(m[q].cell), 1u) != 0u;  // (march_step_frozen's own test)
+                    m[q].it += kAqStepsPerTrip;
+                    bool f = fin[q];
+                    if (!f && ((trips & 3) == 3)) f = march_escaped(m[q], A.scene);
+                    if (f)
+                    {
+                        const uint32_t hf = !occ ? 0u : ((fl[q] & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m[q].p), m[q].cell)), m[q].p, false));
+                        P.t[slot[q]] = m[q].t;
+                        P.flags[slot[q]] = (fl[q] & 0xf000u) | ((fl[q] & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl[q] & kFlagFeeler) | hf;
+                        const bool block_wins = occ && (m[q].t < m[q].tl);
+                        bucket[q] = (fl[q] & kFlagFeeler) ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock);
+                        have[q] = false;
+                        finished[q] = true;
+                    }
                 }
             }
             ++trips;
-            if (__ballot(finished) != 0ull)
+            bool any_finished = false;
+#pragma unroll
+            for (int q = 0; q < kM; ++q) any_finished = any_finished || finished[q];
+            if (__ballot(any_finished) != 0ull)
             {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 // a handful of lanes finish per trip, spread over six queues: one LDS atomic per lane is
                 // cheaper than six wave-aggregated appends
-                if (finished)
-                {
-                    const uint32_t at = atomicAdd(&sh->eq_tail[bucket], 1u);
-                    (ring_eq + bucket * kCap)[at % kCap] = static_cast<uint16_t>(slot);
-                }
+#pragma unroll
+                for (int q = 0; q < kM; ++q)
+                    if (finished[q])
+                    {
+                        const uint32_t at = atomicAdd(&sh->eq_tail[bucket[q]], 1u);
+                        (ring_eq + bucket[q] * kCap)[at % kCap] = static_cast<uint16_t>(slot[q]);
+                    }
             }
         }
     }
