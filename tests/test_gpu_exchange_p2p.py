@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import pytest
 
-from tests.common import CONFIGS
+from tests.common import CONFIGS, c3_oracle_albedo
 
 pytestmark = pytest.mark.gpu
 
@@ -37,6 +37,8 @@ def _run_frames(ddgi, eng, mode, scene, frames, read_at):
     """Drives `frames` updates (+ exchanges when the handle has one) and returns {frame: digest of the full field}."""
     out = {}
     has_exchange = eng.exchange_transport()[0] != "none"
+    if mode == "ref_static":
+        eng.generate_probe_rays(seed=1)   # one ray set, updates back to back: consecutive updates are CONTINUED (frames in flight) across the exchanges
     for frame in range(frames):
         if mode == "ref":
             eng.generate_probe_rays(seed=frame + 1, reseed=True)   # new jitter: every frame's texels differ
@@ -44,12 +46,20 @@ def _run_frames(ddgi, eng, mode, scene, frames, read_at):
         if has_exchange:
             eng.exchange()
         if frame in read_at:
-            out[frame] = _digest(*(eng.read_textures() if mode == "ref" else eng.read_tiles()))
+            out[frame] = _digest(*(eng.read_tiles() if mode == "ddgi" else eng.read_textures()))
     return out
 
 
-def _expected(ddgi, name, mode, frames, read_at):
+def _expected(ddgi, name, mode, frames, read_at, oracle=None):
     counts, side, s, origin, scene = CONFIGS[name]
+    if mode == "ref_static":
+        # the oracle's raster (every frame writes the same texels: Q18); `distances` is never assigned
+        if name == "c3_cave":
+            want = c3_oracle_albedo(oracle, "pinned", seed=1)
+        else:
+            f = oracle.make_field(counts, side, s, origin)
+            want = oracle.probe_update(f, oracle.make_settings(scene, 8), oracle.generate_probe_rays(f, oracle.new_rand_state(1)))[0]
+        return {frame: _digest(want, np.zeros_like(want)) for frame in read_at}
     with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8)) as eng:
         if mode == "ddgi":
             eng.set_mode(ddgi.MODE_DDGI)
@@ -62,6 +72,10 @@ SCENARIOS = [
     ("cave_small", "ref", True, 5, (1, 3, 4)),      # updates 1, 3 are issued while the exchange before them is in flight
     ("cave_small", "ddgi", False, 3, (0, 1, 2)),
     ("cave_small", "ddgi", True, 5, (0, 2, 3, 4)),  # the temporal blend reads the previous tiles from the OTHER pair
+    # BASELINE's C2 and C3 with the pipelined exchange, updates back to back (frames in flight: a launch goes on with the next update's
+    # rays into the next pair of the ring while the previous pairs' slabs are still leaving) — expected = the ORACLE's raster
+    ("c2_cornell", "ref_static", True, 6, (2, 5)),
+    ("c3_cave", "ref_static", True, 7, (3, 6)),
 ]
 
 
@@ -92,10 +106,10 @@ def _worker(rank, world, conn, scenarios):
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_one_process_per_rank_through_ipc_handles(ddgi, world):
+def test_one_process_per_rank_through_ipc_handles(ddgi, oracle, world):
     """2 / 4 processes, one GPU: the peers' textures are mapped with hipIpcOpenMemHandle, the flags cross the process
     boundary.  This is the multi-rank path of bench.py --exchange p2p, executed at ranks > 0 on the test box."""
-    want = [_expected(ddgi, name, mode, frames, read_at) for name, mode, _, frames, read_at in SCENARIOS]
+    want = [_expected(ddgi, name, mode, frames, read_at, oracle) for name, mode, _, frames, read_at in SCENARIOS]
     ctx = mp.get_context("spawn")
     pipes = [ctx.Pipe() for _ in range(world)]
     procs = [ctx.Process(target=_worker, args=(r, world, pipes[r][1], SCENARIOS), daemon=True) for r in range(world)]
@@ -123,7 +137,7 @@ def test_one_process_per_rank_through_ipc_handles(ddgi, world):
         results = gather("results")
         for r in range(world):
             for k, (name, mode, pipelined, _, _) in enumerate(SCENARIOS):
-                assert results[r][k] == want[k], f"rank {r}, {name} {mode} pipelined={pipelined}: gathered field differs from the unsharded engine's"
+                assert results[r][k] == want[k], f"rank {r}, {name} {mode} pipelined={pipelined}: gathered field differs from the unsharded engine's / the oracle's"
     finally:
         for p in procs:
             p.join(timeout=20)
