@@ -333,24 +333,68 @@ static int ensure_scene(ddgi_engine* e, int scene)
     return DDGI_OK;
 }
 
+// The memoised lattice tables are 70 MB of device memory and the same for every handle: ONE copy per device, shared by the
+// handles of the process on that device and freed with the last of them (a process driving 8 sharded handles on one device — the
+// p2p tests — used to hold 560 MB of them).
+namespace {
+struct NoiseDevice
+{
+    float* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int refs = 0;
+};
+std::mutex g_noise_mu;
+std::map<int, NoiseDevice> g_noise_dev;
+}  // namespace
+
 static int ensure_noise(ddgi_engine* e)
 {
     if (e->noise.n2 || !e->tuning.noise_lut) return DDGI_OK;
-    const NoiseLutHost& h = noise_lut_host();
-    const std::vector<float>* src[5] = {&h.n2, &h.n1, &h.wp, &h.wall, &h.r1};
-    for (int i = 0; i < 5; ++i)
+    std::lock_guard<std::mutex> lock(g_noise_mu);
+    NoiseDevice& nd = g_noise_dev[e->device];
+    if (nd.refs == 0)
     {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_noise[i]), src[i]->size() * sizeof(float)));
-        HIP_TRY(hipMemcpy(e->d_noise[i], src[i]->data(), src[i]->size() * sizeof(float), hipMemcpyHostToDevice));
+        const NoiseLutHost& h = noise_lut_host();
+        const std::vector<float>* src[5] = {&h.n2, &h.n1, &h.wp, &h.wall, &h.r1};
+        for (int i = 0; i < 5; ++i)
+        {
+            hipError_t he = hipMalloc(reinterpret_cast<void**>(&nd.d[i]), src[i]->size() * sizeof(float));
+            if (he == hipSuccess) he = hipMemcpy(nd.d[i], src[i]->data(), src[i]->size() * sizeof(float), hipMemcpyHostToDevice);
+            if (he != hipSuccess)
+            {
+                for (auto& p : nd.d)
+                {
+                    if (p) (void)hipFree(p);
+                    p = nullptr;
+                }
+                return fail(he == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY : DDGI_ERR_HIP, "uploading the noise lattice tables failed: %s", hipGetErrorString(he));
+            }
+        }
     }
-    e->noise.n2 = e->d_noise[0];
-    e->noise.n1 = e->d_noise[1];
-    e->noise.wp = e->d_noise[2];
-    e->noise.wall = e->d_noise[3];
-    e->noise.r1 = e->d_noise[4];
+    nd.refs += 1;
+    e->noise_shared = true;
+    e->noise.n2 = nd.d[0];
+    e->noise.n1 = nd.d[1];
+    e->noise.wp = nd.d[2];
+    e->noise.wall = nd.d[3];
+    e->noise.r1 = nd.d[4];
     if (e->tuning.lut_off & 1) e->noise.wall = nullptr;  // profiling
     if (e->tuning.lut_off & 2) e->noise.r1 = nullptr;
     return DDGI_OK;
+}
+
+static void release_noise(ddgi_engine* e)
+{
+    if (!e->noise_shared) return;
+    std::lock_guard<std::mutex> lock(g_noise_mu);
+    auto it = g_noise_dev.find(e->device);
+    if (it != g_noise_dev.end() && --it->second.refs == 0)
+    {
+        for (auto& p : it->second.d)
+            if (p) (void)hipFree(p);
+        g_noise_dev.erase(it);
+    }
+    e->noise_shared = false;
+    e->noise = NoiseLut{};
 }
 
 static int upload_local_rays(ddgi_engine* e)
@@ -468,8 +512,7 @@ int ddgi_destroy(ddgi_handle e)
     if (e->d_wf_cold) (void)hipFree(e->d_wf_cold);
     if (e->d_wf_dir) (void)hipFree(e->d_wf_dir);
     if (e->d_radiance) (void)hipFree(e->d_radiance);
-    for (auto& p : e->d_noise)
-        if (p) (void)hipFree(p);
+    release_noise(e);
     for (auto& d : e->dev_scene)
     {
         if (d.bits) (void)hipFree(d.bits);

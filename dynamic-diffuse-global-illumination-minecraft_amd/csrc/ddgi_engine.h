@@ -95,8 +95,8 @@ struct ddgi_engine
         bool vis_more_valid[3] = {false, false, false};
     } dev_scene[4];
 
-    // memoised lattice hashes on device
-    float* d_noise[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // memoised lattice hashes on device: one copy per device, shared by the process's handles (ddgi_engine.cpp: ensure_noise)
+    bool noise_shared = false;
     NoiseLut noise{};
 
     // rays
