@@ -250,7 +250,7 @@ def main():
                          "p2p: every rank pushes its slab into its peers' textures (ddgi_exchange_p2p_*, IPC-mapped buffers).  "
                          "If RCCL cannot be brought up (an error, or no answer within --rccl-timeout seconds) the run falls back to p2p and says so")
     ap.add_argument("--rccl-timeout", type=float, default=90.0)
-    ap.add_argument("--frames-in-flight", type=int, default=None, help="tuning \"frames_in_flight\" (default: the library's, 2 = the reference's MAX_FRAMES_IN_FLIGHT)")
+    ap.add_argument("--frames-in-flight", type=int, default=None, help="tuning \"frames_in_flight\" (default: the library's, 4; the reference's host runs MAX_FRAMES_IN_FLIGHT = 2 ahead)")
     args = ap.parse_args()
     if args.workload == "c5" and args.mode != "ddgi":
         raise SystemExit("--workload c5 is S-Dyn (4 dynamic lights + temporal hysteresis): run it with --mode ddgi")
@@ -496,8 +496,9 @@ def main():
         },
     }
     out["tuning"] = {"march_waves": eng.get_tuning("march_waves_measured"), "frames_in_flight": fif,
-                     "note": "march_waves: waves of a 16-wave workgroup that march (the rest shade), measured by ddgi_tune() before the warm-up; frames_in_flight: updates one launch "
-                             "may work on (2 = the reference's MAX_FRAMES_IN_FLIGHT, src/rvpt/rvpt.h:23): an update submitted while its predecessor runs is continued by the predecessor's workgroups"}
+                     "note": "march_waves: waves of a 16-wave workgroup that march (the rest shade), measured by ddgi_tune() before the warm-up; frames_in_flight: the most updates one launch "
+                             "may work on (the reference's host runs MAX_FRAMES_IN_FLIGHT = 2 ahead, src/rvpt/rvpt.h:23; the timed loop submits its steps back to back): an update submitted while its "
+                             "predecessor runs is continued by the predecessor's workgroups"}
     if fallback:
         out["config"]["exchange_fallback"] = fallback
     if ddgi_mode:
@@ -604,7 +605,7 @@ def main():
     if extras and not ddgi_mode and not sharded:
         # ---- what frames in flight is worth: the same loop with every launch tracing its own update only, and with four ----
         sweep = {}
-        for n in (1, 4):
+        for n in (1, 2, 4):
             if n == fif:
                 continue
             eng.set_tuning("frames_in_flight", n)

@@ -26,9 +26,11 @@ struct Tuning
     int aq_pool = 0, wf_pool = 0, wf_maxpool = 0, wf_threads = 1024;
     int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
     int blend_merge = 1;    // DDGI blend: up to this many HALF depth groups (of 16 probes) per CU, depth and irradiance run as one launch
-    int frames_in_flight = 2;  // REF mode: probe updates a launch may work on at once (the reference's MAX_FRAMES_IN_FLIGHT, src/rvpt/rvpt.h:23): an update
-                               // submitted while its predecessor runs, with the same inputs, is continued by the predecessor's workgroups instead of
-                               // waiting for their drain (ddgi_engine.cpp: ddgi_probe_update; k_probe_trace_aq); 1: every launch traces its own update only
+    int frames_in_flight = 4;  // REF mode: the MOST probe updates one launch may work on (how many it does is up to the host: an update is continued only
+                               // if it was submitted while its predecessor still ran — the reference's host runs MAX_FRAMES_IN_FLIGHT = 2 ahead,
+                               // src/rvpt/rvpt.h:23, a loop that never waits runs as far ahead as this allows): such an update, with the same inputs, is
+                               // traced by the predecessor's workgroups instead of waiting for their drain (ddgi_engine.cpp: ddgi_probe_update;
+                               // k_probe_trace_aq); 1: every launch traces its own update only
     int timing = 1;         // per-update events for ddgi_last_update_ms / ddgi_update_history_ms (0: none — saves the stream ~6 us per update)
     int fast_march = 0;     // tolerance mode: marches skip empty space (NOT bit-exact; tests/test_gpu_fast_march.py states the tolerance)
     int light_vis = 1;      // per-voxel light-feeler classes (k_light_visibility): 0 = march every feeler

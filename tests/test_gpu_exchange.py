@@ -53,7 +53,7 @@ def test_ref_mode_exchange_matches_the_plain_engine(ddgi, comm1, pipelined):
             rgb, cage = eng.sample(pos, nrm)
             assert np.array_equal(_bits(rgb), _bits(want[k][1][0])) and np.array_equal(cage, want[k][1][1])
         if pipelined:
-            assert len(set(ptrs)) == 3 and eng.get_tuning("texture_pairs") == 4   # a ring of 2 x frames_in_flight pairs, one after the other
+            assert len(set(ptrs)) == 3 and eng.get_tuning("texture_pairs") == 2 * eng.get_tuning("frames_in_flight")   # a ring of 2 x frames_in_flight pairs, one after the other
             with pytest.raises(ddgi.DDGIError):
                 eng.bind_textures(ptrs[0], ptrs[1])          # the pipelined exchange owns the pairs
         else:

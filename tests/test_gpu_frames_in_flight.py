@@ -113,7 +113,7 @@ def test_c3_updates_are_continued_and_bit_exact(ddgi, oracle):
         albedo = eng.read_textures()[0]
         continued = eng.get_tuning("continued_workgroups") - before
         assert np.array_equal(albedo, want)
-        assert continued >= 3 * 128, f"only {continued} workgroups went on with a later update's rays in 3 groups of 2 updates"
+        assert continued >= 3 * 128, f"only {continued} workgroups went on with a later update's rays in 6 back-to-back updates"
         # the same with one update per launch
         eng.set_tuning("frames_in_flight", 1)
         before = eng.get_tuning("continued_workgroups")
