@@ -286,7 +286,9 @@ def main():
         # cannot take the rendezvous down with it, and the fallback to the peer-to-peer transport can be agreed on
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        with _c_stdout_to_stderr():             # (gloo announces its connections on the C-level stdout; the line below must be the only one there)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
 
     def all_ok(flag):
         if not sharded:
