@@ -973,7 +973,10 @@ __global__ __launch_bounds__(256) void k_probe_sample_ddgi(const SampleArgs A)
                                    f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]}, cage);
     A.rgb[3 * i] = out.x, A.rgb[3 * i + 1] = out.y, A.rgb[3 * i + 2] = out.z;
     if (A.cage)
-        for (int k = 0; k < 8; ++k) A.cage[8 * i + k] = cage[k];
+    {
+        int4* q = reinterpret_cast<int4*>(A.cage + 8 * static_cast<size_t>(i));  // 32 bytes per point: two 16-byte stores
+        q[0] = int4{cage[0], cage[1], cage[2], cage[3]}, q[1] = int4{cage[4], cage[5], cage[6], cage[7]};
+    }
 }
 
 // ---- launchers -----------------------------------------------------------------------------------

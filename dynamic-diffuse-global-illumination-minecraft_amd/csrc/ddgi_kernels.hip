@@ -265,13 +265,16 @@ __global__ __launch_bounds__(256) void k_probe_sample_ref(const SampleArgs A)
     if (k >= A.n) return;
     const uint32_t i = A.perm ? A.perm[k] : k;
     int cage[8];
-    const f3 out = diffuse_gi_ref(A.grid, A.albedo, f3{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]},
-                                  f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]}, s_unorm, cage, A.box);
+    const f3 p{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]}, nr{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]};
+    const f3 out = A.box ? diffuse_gi_ref<true>(A.grid, A.albedo, p, nr, s_unorm, cage, A.box) : diffuse_gi_ref<false>(A.grid, A.albedo, p, nr, s_unorm, cage, nullptr);
     A.rgb[3 * i] = out.x;
     A.rgb[3 * i + 1] = out.y;
     A.rgb[3 * i + 2] = out.z;
-    if (A.cage)
-        for (int k = 0; k < 8; ++k) A.cage[8 * i + k] = cage[k];
+    if (A.cage)  // (8 indices = 32 bytes per point: two 16-byte stores instead of eight 4-byte ones at a 32-byte stride)
+    {
+        int4* q = reinterpret_cast<int4*>(A.cage + 8 * static_cast<size_t>(i));
+        q[0] = int4{cage[0], cage[1], cage[2], cage[3]}, q[1] = int4{cage[4], cage[5], cage[6], cage[7]};
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,31 +283,45 @@ __global__ __launch_bounds__(256) void k_probe_sample_ref(const SampleArgs A)
 // plus its clipped 5x5 box, divided by the count (intersection.glsl:1213-1239).  get_diffuse_gi asks for it 8 times per shaded
 // point — 208 gathers and 624 rgba8 conversions per point, the same few thousand sums over and over.  This kernel evaluates it
 // ONCE per texel, in the reference's order of additions (so every value has the bits the per-point evaluation would give), into
-// a float4 table [slab slot][ry][rx]; the sampler then loads one table entry per cage corner (diffuse_gi_ref's `box`).
+// a float4 table (layout below); the sampler then loads one table entry per cage corner (diffuse_gi_ref's `box`).
 // One workgroup per tile: the tile's texels are converted once into three float planes in LDS, every lane sums its own box.
 // The engine rebuilds the table lazily — the first large sample batch after a probe update pays for it (ddgi_engine.cpp).
 // ------------------------------------------------------------------------------------------------
+// TABLE LAYOUT (round 4): texel-major, [ry][rx][slab slot].  The 8 corners of a cage are asked for the SAME texel, and two of
+// them are x-neighbours — consecutive slab slots: their entries are 32 contiguous bytes, so a point's 8 entries cost about 5
+// 64-byte sectors through L2 instead of 8 (tile-major, a corner's entry shared its sector with other TEXELS of its tile, which
+// this point never reads).  The build keeps its stores sector-sized: a workgroup takes kTiles consecutive slots and every group
+// of kTiles lanes writes the kTiles x 16 bytes of one texel side by side.
+template <int kTiles>
 __global__ __launch_bounds__(256) void k_sample_box_filter(const GridK G, const uint32_t* __restrict__ albedo, float4* __restrict__ box, uint32_t n_probes)
 {
     extern __shared__ __attribute__((aligned(16))) float box_lds[];
     const int n = G.n, s = G.sx, sh = G.sy;
     float* unorm = box_lds;
-    float *pr = box_lds + 256, *pg = pr + n, *pb = pg + n;
+    float* planes = box_lds + 256;  // [tile][r, g, b][n]
     unorm[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;  // blockDim.x == 256
-    for (uint32_t slot = blockIdx.x; slot < n_probes; slot += gridDim.x)
+    const uint32_t n_groups = (n_probes + kTiles - 1) / kTiles;
+    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x)
     {
-        __syncthreads();  // the previous tile's planes are no longer read (and the table is written)
-        const uint32_t* __restrict__ tile = albedo + static_cast<size_t>(slot) * n;
-        for (int t = threadIdx.x; t < n; t += 256)
+        __syncthreads();  // the previous group's planes are no longer read (and the table is written)
+        const uint32_t slot0 = g * kTiles;
+        const uint32_t tiles = min(static_cast<uint32_t>(kTiles), n_probes - slot0);
+        const uint32_t* __restrict__ src = albedo + static_cast<size_t>(slot0) * n;
+        for (uint32_t t = threadIdx.x; t < tiles * static_cast<uint32_t>(n); t += 256)
         {
-            const uint32_t v = tile[t];
-            pr[t] = unorm[v & 255u], pg[t] = unorm[(v >> 8) & 255u], pb[t] = unorm[(v >> 16) & 255u];
+            const uint32_t v = src[t];
+            float* pl = planes + static_cast<size_t>(t / n) * 3 * n;
+            const uint32_t tt = t % n;
+            pl[tt] = unorm[v & 255u], pl[n + tt] = unorm[(v >> 8) & 255u], pl[2 * n + tt] = unorm[(v >> 16) & 255u];
         }
         __syncthreads();
-        for (int t = threadIdx.x; t < n; t += 256)
+        for (uint32_t o = threadIdx.x; o < static_cast<uint32_t>(kTiles) * n; o += 256)
         {
-            const f3 v = sample_box_ref(s, sh, t % s, t / s, [&](int off) { return f3{pr[off], pg[off], pb[off]}; });
-            box[static_cast<size_t>(slot) * n + t] = float4{v.x, v.y, v.z, 0.0f};
+            const uint32_t which = o % kTiles, t = o / kTiles;  // kTiles consecutive lanes: one texel of kTiles consecutive slots
+            if (which >= tiles) continue;
+            const float *pr = planes + static_cast<size_t>(which) * 3 * n, *pg = pr + n, *pb = pg + n;
+            const f3 v = sample_box_ref(s, sh, static_cast<int>(t % s), static_cast<int>(t / s), [&](int off) { return f3{pr[off], pg[off], pb[off]}; });
+            box[static_cast<size_t>(t) * n_probes + slot0 + which] = float4{v.x, v.y, v.z, 0.0f};
         }
     }
 }
@@ -312,10 +329,15 @@ __global__ __launch_bounds__(256) void k_sample_box_filter(const GridK G, const 
 hipError_t launch_sample_box_filter(const GridK& grid, const uint32_t* albedo, float4* box, int num_cus, hipStream_t stream)
 {
     const uint32_t n_probes = static_cast<uint32_t>(grid.cx) * grid.cy * grid.cz;
-    const size_t lds = (256 + static_cast<size_t>(3) * grid.n) * sizeof(float);
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_sample_box_filter), static_cast<int>(lds));
+    const bool four = grid.n <= 1024;  // (4 tiles' planes in LDS: 48 KB at 1024 texels per tile)
+    const size_t lds = (256 + static_cast<size_t>(3) * grid.n * (four ? 4 : 1)) * sizeof(float);
+    const void* fn = four ? reinterpret_cast<const void*>(k_sample_box_filter<4>) : reinterpret_cast<const void*>(k_sample_box_filter<1>);
+    hipError_t e = ensure_dynamic_lds(fn, static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sample_box_filter, dim3(std::min<uint32_t>(n_probes, static_cast<uint32_t>(num_cus) * 8u)), dim3(256), lds, stream, grid, albedo, box, n_probes);
+    const uint32_t groups = four ? (n_probes + 3u) / 4u : n_probes;
+    const dim3 grid_dim(std::min<uint32_t>(groups, static_cast<uint32_t>(num_cus) * 8u));
+    if (four) hipLaunchKernelGGL(k_sample_box_filter<4>, grid_dim, dim3(256), lds, stream, grid, albedo, box, n_probes);
+    else hipLaunchKernelGGL(k_sample_box_filter<1>, grid_dim, dim3(256), lds, stream, grid, albedo, box, n_probes);
     return hipGetLastError();
 }
 

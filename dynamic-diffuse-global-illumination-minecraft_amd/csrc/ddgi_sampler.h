@@ -66,8 +66,11 @@ DDGI_D f3 sample_probe_ref(const GridK& G, const uint32_t* albedo, const uint32_
 
 // get_diffuse_gi (intersection.glsl:1306-1409), REF mode: rgb for one shading point; cage[8] receives
 // the probe_index_1d of the 8 cage corners, or -1 everywhere when the shader returns magenta.
-// box (optional): sample_probe's value for EVERY texel of every tile, tabulated by k_sample_box_filter — [slab slot][ry][rx] float4;
+// box (optional): sample_probe's value for EVERY texel of every tile, tabulated by k_sample_box_filter — [ry][rx][slab slot] float4;
 // then a corner costs one 16-byte load instead of 26 gathers and 78 conversions.
+// kBatch: ask for the 8 table entries up front (k_probe_sample_ref: the batch is bound by the entries' latency); the pixel kernel
+// (k_render_primary), whose registers are spoken for by the camera ray's march, takes them corner by corner.
+template <bool kBatch = false>
 DDGI_D f3 diffuse_gi_ref(const GridK& G, const uint32_t* albedo, f3 pos, f3 nrm_raw, const float* s_unorm, int* cage, const float4* box = nullptr)
 {
     const f3 N = normalize3(nrm_raw);
@@ -99,16 +102,9 @@ DDGI_D f3 diffuse_gi_ref(const GridK& G, const uint32_t* albedo, f3 pos, f3 nrm_
             sample_texel_ref(G, N, rx, ry);
             box_off = ry * G.sx + rx;
         }
-        for (int k = 0; k < 8 && ok; ++k)
-        {
+        // one corner of the cage (intersection.glsl:1331-1404): its weight, and its sample_probe value into the sum
+        auto corner = [&](int k, int idx, f3 smp) {
             const int ox = (k >> 2) & 1, oy = (k >> 1) & 1, oz = k & 1;  // Q7 corner order
-            const int sx = bx + ox + G.cx / 2, sy = by + oy + G.cy / 2, sz = bz + oz + G.cz / 2;  // Q4
-            const int idx = sy * G.cx * G.cz + sz * G.cx + sx;
-            if (idx < 0 || idx >= n_probes)
-            {
-                ok = false;
-                break;
-            }
             cage[k] = idx;
             const f3 tri{ox ? alpha.x : 1.0f - alpha.x, oy ? alpha.y : 1.0f - alpha.y, oz ? alpha.z : 1.0f - alpha.z};
             const f3 probe_pos = base_world + f3{static_cast<float>(ox * G.side), static_cast<float>(oy * G.side), static_cast<float>(oz * G.side)};
@@ -119,16 +115,51 @@ DDGI_D f3 diffuse_gi_ref(const GridK& G, const uint32_t* albedo, f3 pos, f3 nrm_
             const float crush = 0.2f;
             if (weight < crush) weight *= weight * weight * (1.f / (crush * crush));  // unreachable (Q11)
             weight *= tri.x * tri.y * tri.z;
-            f3 smp;
-            if (box)
-            {
-                const float4 v = box[static_cast<size_t>(slab_slot(G, idx)) * G.n + box_off];  // (idx is a valid probe here)
-                smp = f3{v.x, v.y, v.z};
-            }
-            else
-                smp = sample_probe_ref(G, albedo, albedo, idx, N, s_unorm);
             irradiance = irradiance + smp * weight;
             sum_weight += weight;
+        };
+        auto corner_index = [&](int k) {
+            const int sx = bx + ((k >> 2) & 1) + G.cx / 2, sy = by + ((k >> 1) & 1) + G.cy / 2, sz = bz + (k & 1) + G.cz / 2;  // Q4
+            return sy * G.cx * G.cz + sz * G.cx + sx;
+        };
+        if constexpr (kBatch)
+        {
+            // (with the table only.)  ALL EIGHT entries are asked for before the first is used: taken corner by corner each load
+            // stands behind the previous corner's range check (a possible `break`), i.e. eight trips to memory one after the other —
+            // and the batch is bound by exactly that latency, whatever the table's layout (7.5 -> 10 G points/s on scattered points).
+            // A cage with a corner out of range reads nothing and returns magenta.
+            int idx[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) idx[k] = corner_index(k), ok = ok && idx[k] >= 0 && idx[k] < n_probes;
+            if (ok)
+            {
+                float4 tab[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tab[k] = box[static_cast<size_t>(box_off) * n_probes + slab_slot(G, idx[k])];  // texel-major: [texel][slab slot]
+#pragma unroll
+                for (int k = 0; k < 8; ++k) corner(k, idx[k], f3{tab[k].x, tab[k].y, tab[k].z});
+            }
+        }
+        else
+        {
+            for (int k = 0; k < 8 && ok; ++k)
+            {
+                const int idx = corner_index(k);
+                if (idx < 0 || idx >= n_probes)
+                {
+                    ok = false;
+                    break;
+                }
+                f3 smp;
+                if (box)
+                {
+                    const float4 v = box[static_cast<size_t>(box_off) * n_probes + slab_slot(G, idx)];  // (idx is a valid probe here)
+                    smp = f3{v.x, v.y, v.z};
+                }
+                else
+                    smp = sample_probe_ref(G, albedo, albedo, idx, N, s_unorm);
+                corner(k, idx, smp);
+            }
         }
         if (ok) out = div3(irradiance, sum_weight);
     }
@@ -184,16 +215,20 @@ DDGI_D f3 diffuse_gi_ddgi(const GridK& G, const float* irradiance, const float* 
         f3 irr = mk3(0, 0, 0);
         float sum_w = 0.0f;
         const int n_probes = G.cx * G.cy * G.cz;
+        // (the corners' range check comes first, for all eight: with a possible `break` inside the loop below every corner's
+        // tile fetches would have to wait for the corner before — eight round trips to memory in a row)
+#pragma unroll
         for (int k = 0; k < 8; ++k)
+        {
+            const int sx = bx + ((k >> 2) & 1) + G.cx / 2, sy = by + ((k >> 1) & 1) + G.cy / 2, sz = bz + (k & 1) + G.cz / 2;
+            const int idx = sy * G.cx * G.cz + sz * G.cx + sx;
+            ok = ok && idx >= 0 && idx < n_probes;
+        }
+        for (int k = 0; k < 8 && ok; ++k)
         {
             const int ox = (k >> 2) & 1, oy = (k >> 1) & 1, oz = k & 1;                            // Q7
             const int sx = bx + ox + G.cx / 2, sy = by + oy + G.cy / 2, sz = bz + oz + G.cz / 2;  // Q4
             const int idx = sy * G.cx * G.cz + sz * G.cx + sx;
-            if (idx < 0 || idx >= n_probes)
-            {
-                ok = false;
-                break;
-            }
             cage[k] = idx;
             const f3 tri{ox ? alpha.x : 1.0f - alpha.x, oy ? alpha.y : 1.0f - alpha.y, oz ? alpha.z : 1.0f - alpha.z};
             const f3 probe_pos = base_world + f3{static_cast<float>(ox * G.side), static_cast<float>(oy * G.side), static_cast<float>(oz * G.side)};
