@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void k_render_primary(const RenderArgs A)
     }
     auto gi = [&]() {
         return A.irradiance ? diffuse_gi_ddgi(T.grid, A.irradiance, A.depth, info.pos, info.normal, cage)
-                            : diffuse_gi_ref(T.grid, A.albedo, info.pos, info.normal, s_unorm, cage, A.box);
+                            : (A.box ? diffuse_gi_ref<true>(T.grid, A.albedo, info.pos, info.normal, s_unorm, cage, A.box)
+                                     : diffuse_gi_ref<false>(T.grid, A.albedo, info.pos, info.normal, s_unorm, cage, nullptr));
     };
     if (probe_seen) out = mk3(0, 1, 1);  // probe colour, integrators.glsl:65,199
     else switch (A.render_mode)
