@@ -1319,10 +1319,11 @@ int ddgi_synchronize(ddgi_handle e)
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->chain_break = true;  // nothing is in flight: the next update starts a group of its own —
     {
-        // — of its own in the ring as well: the next update's number moves up to the next group's first (every rank of a sharded
-        // grid synchronises at the same points of its frame loop, so the ranks' pair indices stay in step)
+        // — of its own in the ring as well: the next update's number moves up to the next group's first
+        // — unless the handle exchanges its textures with other ranks: which pair an update writes is a function of its number on
+        // EVERY rank, and one rank may synchronise where another does not
         const unsigned long long g = static_cast<unsigned long long>(std::max(1, std::min(ddgi_chain_len(e), e->np)));
-        if (e->np % static_cast<int>(g) == 0) e->ring_k = (e->ring_k + g - 1) / g * g;
+        if (!e->xch.transport && !e->xch.p2p && e->np % static_cast<int>(g) == 0) e->ring_k = (e->ring_k + g - 1) / g * g;
     }
     return check_kernel_status(e);
 }
