@@ -30,6 +30,9 @@ int wf_pool_size(int nwords, bool multi_light, size_t lds_limit, int threads, in
 hipError_t launch_probe_trace_wf(const TraceArgs& args, int threads, int pool, int grid_blocks, uint32_t* work_counter, hipStream_t stream);
 hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t stream);
 int aq_pool_size(int nwords, size_t lds_limit);
+int aq_threads();
+int aq_wgs_per_cu();
+int aq_pool_usual();
 int aq_pool_size_fast(int nwords_skip, size_t lds_limit, bool plain);
 hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, const AqChain& chain, uint32_t* status, hipStream_t stream);
 size_t blend_weights_floats(int n);
@@ -940,13 +943,14 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     // the barrier-free queue kernel (k_probe_trace_aq) whenever its pool fits; "trace_kernel" = 1 asks for the
     // round-based k_probe_trace_wf (cross-check), which also serves the utilisation counters
     const bool force_rounds = tn.trace_kernel == 1 || (a.stats != nullptr && tn.trace_kernel != 3) || p.wf_threads != 1024;
-    p.use_async = p.pool > 0 && !force_rounds && aq_pool_size(a.scene.nwords, 160 * 1024) > 0;
+    const size_t aq_lds = 160 * 1024 / static_cast<size_t>(aq_wgs_per_cu());
+    p.use_async = p.pool > 0 && !force_rounds && aq_pool_size(a.scene.nwords, aq_lds) > 0;
     // "fast_march": the tolerance-mode march (ddgi_device.h: fast_march_step) — the queue kernel only, and only when its pool
     // fits next to the scene's skip field; otherwise the update runs the exact march ("fast_march_active" tells)
     p.fast = false;
     if (p.use_async && tn.fast_march && a.stats == nullptr && tn.ablate == 0)
     {
-        const int fast_pool = aq_pool_size_fast(a.scene.nwords_skip, 160 * 1024, a.nl == 1);
+        const int fast_pool = aq_pool_size_fast(a.scene.nwords_skip, aq_lds, a.nl == 1);
         if (fast_pool > 0)
         {
             p.fast = true;
@@ -957,8 +961,8 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     e->fast_march_active = p.fast;
     if (p.use_async && !p.fast)
     {
-        p.pool = std::min(1344, aq_pool_size(a.scene.nwords, 160 * 1024));  // what fits next to the cave's bitmap at 72 B per slot; more buys nothing (C3: 1024: 2.56 ms, 1152: 2.37, 1344: 2.11, 1472: 2.13)
-        if (tn.aq_pool > 0) p.pool = std::min(aq_pool_size(a.scene.nwords, 160 * 1024), std::max(1024, tn.aq_pool / 64 * 64));
+        p.pool = std::min(aq_pool_usual(), aq_pool_size(a.scene.nwords, aq_lds));  // what fits next to the cave's bitmap at 72 B per slot; more buys nothing (C3: 1024: 2.56 ms, 1152: 2.37, 1344: 2.11, 1472: 2.13)
+        if (tn.aq_pool > 0) p.pool = std::min(aq_pool_size(a.scene.nwords, aq_lds), std::max(aq_wgs_per_cu() == 1 ? 1024 : 320, tn.aq_pool / 64 * 64));
     }
     if (p.ddgi_mode && p.pool <= 0) return fail(DDGI_ERR_UNSUPPORTED, "DDGI mode: the ray pool does not fit in LDS next to the scene bitmap");
     if (p.pool > 0)
@@ -981,7 +985,7 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
         // one persistent workgroup per CU unless the launch is tiny (the launcher sizes the ray claims
         // so that every workgroup gets several: launch_probe_trace_wf)
         const uint32_t chunks = (a.n_rays + 255u) / 256u;
-        p.grid = static_cast<uint32_t>(e->num_cus * wf_blocks_per_cu);
+        p.grid = static_cast<uint32_t>(e->num_cus * (p.use_async ? aq_wgs_per_cu() : wf_blocks_per_cu));
         if (p.grid > chunks) p.grid = chunks;
         const size_t slots = static_cast<size_t>(p.grid) * p.pool;
         if (slots > e->wf_cold_slots)
@@ -1107,7 +1111,7 @@ static int measure_march_waves(ddgi_engine* e, const TracePlan& p, int start, in
     for (int dir = -1; dir <= 1; dir += 2)
     {
         bool moved = false;
-        for (int mw = march_waves + dir; mw >= 2 && mw <= 12; mw += dir)
+        for (int mw = march_waves + dir; mw >= 2 && mw <= std::min(12, aq_threads() / 64 - 2); mw += dir)
         {
             if (int rc = timed(mw, &ms)) return rc;
             if (ms >= best_ms) break;
@@ -1115,7 +1119,7 @@ static int measure_march_waves(ddgi_engine* e, const TracePlan& p, int start, in
         }
         if (moved) break;  // downhill in this direction: the other one was uphill
     }
-    if (e->tuning.verbose) std::fprintf(stderr, "[ddgi] queue kernel: %d march waves / %d event waves for this configuration\n", march_waves, 16 - march_waves);
+    if (e->tuning.verbose) std::fprintf(stderr, "[ddgi] queue kernel: %d march waves / %d event waves for this configuration\n", march_waves, aq_threads() / 64 - march_waves);
     *out = march_waves;
     return DDGI_OK;
 }
@@ -1136,7 +1140,7 @@ static int choose_march_waves(ddgi_engine* e, const TracePlan& p, bool may_block
         *out = it->second;
         return DDGI_OK;
     }
-    int mw = e->aq_last > 0 ? e->aq_last : (p.fast ? 4 : 5);
+    int mw = e->aq_last > 0 ? e->aq_last : std::max(2, (p.fast ? 4 : 5) * aq_threads() / 1024);
     if (force_measure || (may_block && tn.autotune && tn.ablate == 0))
     {
         if (int rc = measure_march_waves(e, p, mw, &mw)) return rc;

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void k_sample_box_filter(const GridK G, const 
             if (which >= tiles) continue;
             const float *pr = planes + static_cast<size_t>(which) * 3 * n, *pg = pr + n, *pb = pg + n;
             const f3 v = sample_box_ref(s, sh, static_cast<int>(t % s), static_cast<int>(t / s), [&](int off) { return f3{pr[off], pg[off], pb[off]}; });
-            box[static_cast<size_t>(t) * n_probes + slot0 + which] = float4{v.x, v.y, v.z, 0.0f};
+            box[box_index(t, slot0 + which, static_cast<uint32_t>(n), n_probes)] = float4{v.x, v.y, v.z, 0.0f};
         }
     }
 }
@@ -351,46 +351,151 @@ hipError_t launch_sample_box_filter(const GridK& grid, const uint32_t* albedo, f
 //   k_sample_bins     every bin reserves a contiguous range of the permutation (one atomic per bin — no scan needed)
 //   k_sample_scatter  perm[range start + arrival number] = point
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sample_keys(const GridK G, const float* __restrict__ pos, uint32_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ hist)
+//
+// Round 4: no global atomics.  Device-scope atomics on MI355X are resolved beyond the XCDs' L2s, at ~15 G per second: the
+// histogram's and the scatter's 1.44 M atomic adds took 98 + 72 us — more than the sample kernel they were to speed up (141 us).
+// Now every workgroup counts its own contiguous run of points in LDS (an LDS atomic returns the point's rank inside its run and
+// bin for free), the counts go out as one coalesced row per workgroup, one small kernel turns the table of rows into offsets, and
+// the scatter is a plain store.  Bins are COARSE — the cage's slot index shifted so that at most kSampleBins fit the LDS
+// histogram (C3: 8 consecutive cages along x per bin): locality is all the grouping is for.
+constexpr uint32_t kSampleBins = 32768;  // LDS histogram entries per workgroup (16-bit counters: a run holds fewer than 65 536 points)
+constexpr uint32_t kSampleRuns = 256;    // workgroups = contiguous runs of the batch
+
+DDGI_D uint32_t sample_key(const GridK& G, const float* __restrict__ pos, uint32_t i, uint32_t shift)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     const float side = static_cast<float>(G.side);
     // (grouping only: any point lands in SOME bin; the sample kernels redo get_diffuse_gi's arithmetic exactly)
     const int bx = gl_int(floorf((pos[3 * i] - G.origin[0]) / side)) + G.cx / 2;
     const int by = gl_int(floorf((pos[3 * i + 1] - G.origin[1]) / side)) + G.cy / 2;
     const int bz = gl_int(floorf((pos[3 * i + 2] - G.origin[2]) / side)) + G.cz / 2;
-    uint32_t key = static_cast<uint32_t>(G.cx) * G.cy * G.cz;
+    uint32_t key = static_cast<uint32_t>(G.cx) * G.cy * G.cz;  // outside the field
     if (bx >= 0 && bx < G.cx && by >= 0 && by < G.cy && bz >= 0 && bz < G.cz) key = static_cast<uint32_t>((bz * G.cy + by) * G.cx + bx);
-    keys[i] = key;
-    atomicAdd(&hist[key], 1u);
+    return key >> shift;
 }
-__global__ __launch_bounds__(256) void k_sample_bins(uint32_t n_bins, const uint32_t* __restrict__ hist, uint32_t* __restrict__ start, uint32_t* __restrict__ cursor)
+// run r = points [r * per_run, (r + 1) * per_run): keys[i], rank[i] (arrival number inside its run and bin), counts[r][bin]
+__global__ __launch_bounds__(1024) void k_sample_count(const GridK G, const float* __restrict__ pos, uint32_t n, uint32_t per_run, uint32_t shift, uint32_t n_bins,
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ rank, uint32_t* __restrict__ counts)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_bins) return;
-    const uint32_t c = hist[b];
-    start[b] = c ? atomicAdd(cursor, c) : 0u;
+    // 16-bit counters, two to a word (LDS has 32-bit atomics): the add returns the word, the bin's half of it is the rank
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    const uint32_t n_words = (n_bins + 1u) / 2u;
+    for (uint32_t b = threadIdx.x; b < n_words; b += 1024) hist[b] = 0u;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * per_run, hi = min(n, lo + per_run);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024)
+    {
+        const uint32_t key = sample_key(G, pos, i, shift);
+        keys[i] = key;
+        const uint32_t sh = (key & 1u) * 16u;
+        rank[i] = (atomicAdd(&hist[key >> 1], 1u << sh) >> sh) & 0xffffu;
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < n_bins; b += 1024) counts[static_cast<size_t>(blockIdx.x) * n_bins + b] = (hist[b >> 1] >> ((b & 1u) * 16u)) & 0xffffu;
 }
-__global__ __launch_bounds__(256) void k_sample_scatter(uint32_t n, const uint32_t* __restrict__ keys, uint32_t* __restrict__ start, uint32_t* __restrict__ perm)
+// counts[r][bin] -> the exclusive sum over the runs before r, per bin (in place); totals[bin] = the bin's points.
+// A workgroup = 16 bins x 16 lanes per bin, each lane scanning kSampleRuns / 16 consecutive runs (a chain of 16 instead of 256).
+__global__ __launch_bounds__(256) void k_sample_scan_runs(uint32_t n_runs, uint32_t n_bins, uint32_t* __restrict__ counts, uint32_t* __restrict__ totals)
+{
+    constexpr uint32_t kPer = kSampleRuns / 16;
+    __shared__ uint32_t part[16][17];
+    const uint32_t bl = threadIdx.x & 15u, chunk = threadIdx.x >> 4, b = blockIdx.x * 16u + bl;
+    uint32_t c[kPer];
+    uint32_t acc = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k)
+    {
+        const uint32_t r = chunk * kPer + k;
+        c[k] = (b < n_bins && r < n_runs) ? counts[static_cast<size_t>(r) * n_bins + b] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k)
+    {
+        const uint32_t v = c[k];
+        c[k] = acc;
+        acc += v;
+    }
+    part[chunk][bl] = acc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t q = 0; q < chunk; ++q) before += part[q][bl];
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k)
+    {
+        const uint32_t r = chunk * kPer + k;
+        if (b < n_bins && r < n_runs) counts[static_cast<size_t>(r) * n_bins + b] = c[k] + before;
+    }
+    if (chunk == 15u && b < n_bins) totals[b] = before + acc;
+}
+// totals[bin] -> base[bin] = the exclusive sum over the bins before it (one workgroup; at most kSampleBins = 4 per lane)
+__global__ __launch_bounds__(1024) void k_sample_scan_bins(uint32_t n_bins, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t scan[1024];
+    constexpr uint32_t kPer = kSampleBins / 1024;
+    uint32_t v[kPer], mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k)
+    {
+        const uint32_t b = threadIdx.x * kPer + k;
+        v[k] = b < n_bins ? totals[b] : 0u;
+        mine += v[k];
+    }
+    scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1)
+    {
+        const uint32_t add = threadIdx.x >= off ? scan[threadIdx.x - off] : 0u;
+        __syncthreads();
+        scan[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t base = scan[threadIdx.x] - mine;
+#pragma unroll
+    for (uint32_t k = 0; k < kPer; ++k)
+    {
+        const uint32_t b = threadIdx.x * kPer + k;
+        if (b < n_bins) totals[b] = base;
+        base += v[k];
+    }
+}
+__global__ __launch_bounds__(256) void k_sample_place(uint32_t n, uint32_t per_run, uint32_t n_bins, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ rank,
+                                                      const uint32_t* __restrict__ before, const uint32_t* __restrict__ base, uint32_t* __restrict__ perm)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    perm[atomicAdd(&start[keys[i]], 1u)] = i;  // (start doubles as the bin's fill pointer)
+    const uint32_t key = keys[i];
+    perm[base[key] + before[static_cast<size_t>(i / per_run) * n_bins + key] + rank[i]] = i;
 }
 
-// scratch: keys[n] | perm[n] | hist[n_bins] | start[n_bins] | cursor[1]   (uint32 each)
-size_t sample_group_scratch_words(uint32_t n, uint32_t n_probes) { return 2 * static_cast<size_t>(n) + 2 * (static_cast<size_t>(n_probes) + 1) + 1; }
+static void sample_bins(uint32_t n_probes, uint32_t& shift, uint32_t& n_bins)
+{
+    shift = 0;
+    while ((n_probes >> shift) + 1u > kSampleBins) ++shift;  // (the last fine key is n_probes: "outside the field")
+    n_bins = (n_probes >> shift) + 1u;
+}
+// scratch: keys[n] | rank[n] | perm[n] | counts[kSampleRuns x n_bins] | totals[n_bins]   (uint32 each)
+size_t sample_group_scratch_words(uint32_t n, uint32_t n_probes)
+{
+    uint32_t shift, n_bins;
+    sample_bins(n_probes, shift, n_bins);
+    return 3 * static_cast<size_t>(n) + static_cast<size_t>(kSampleRuns + 1) * n_bins;
+}
 
 hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t n, uint32_t* scratch, const uint32_t** perm_out, hipStream_t stream)
 {
-    const uint32_t n_bins = static_cast<uint32_t>(grid.cx) * grid.cy * grid.cz + 1u;
-    uint32_t *keys = scratch, *perm = keys + n, *hist = perm + n, *start = hist + n_bins, *cursor = start + n_bins;
-    hipError_t e = hipMemsetAsync(hist, 0, (2 * static_cast<size_t>(n_bins) + 1) * sizeof(uint32_t), stream);
+    uint32_t shift, n_bins;
+    sample_bins(static_cast<uint32_t>(grid.cx) * grid.cy * grid.cz, shift, n_bins);
+    // (a run's 16-bit counters: fewer than 65 536 points per run — more runs than kSampleRuns for batches beyond 16 M points)
+    const uint32_t n_runs = std::max<uint32_t>(std::min<uint32_t>(kSampleRuns, (n + 1023u) / 1024u), (n + 65534u) / 65535u);
+    if (n_runs > kSampleRuns) return hipErrorInvalidValue;  // (ddgi_engine.cpp splits batches of more than 2^24 points)
+    const uint32_t per_run = (n + n_runs - 1u) / n_runs;
+    uint32_t *keys = scratch, *rank = keys + n, *perm = rank + n, *counts = perm + n, *totals = counts + static_cast<size_t>(kSampleRuns) * n_bins;
+    const size_t lds = static_cast<size_t>((n_bins + 1u) / 2u) * sizeof(uint32_t);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_sample_count), static_cast<int>(kSampleBins * 2));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sample_keys, dim3((n + 255u) / 256u), dim3(256), 0, stream, grid, pos, n, keys, hist);
-    hipLaunchKernelGGL(k_sample_bins, dim3((n_bins + 255u) / 256u), dim3(256), 0, stream, n_bins, hist, start, cursor);
-    hipLaunchKernelGGL(k_sample_scatter, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, keys, start, perm);
+    hipLaunchKernelGGL(k_sample_count, dim3(n_runs), dim3(1024), lds, stream, grid, pos, n, per_run, shift, n_bins, keys, rank, counts);
+    hipLaunchKernelGGL(k_sample_scan_runs, dim3((n_bins + 15u) / 16u), dim3(256), 0, stream, n_runs, n_bins, counts, totals);
+    hipLaunchKernelGGL(k_sample_scan_bins, dim3(1), dim3(1024), 0, stream, n_bins, totals);
+    hipLaunchKernelGGL(k_sample_place, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, per_run, n_bins, keys, rank, counts, totals, perm);
     *perm_out = perm;
     return hipGetLastError();
 }

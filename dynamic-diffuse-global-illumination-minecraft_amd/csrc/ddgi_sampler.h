@@ -70,6 +70,16 @@ DDGI_D f3 sample_probe_ref(const GridK& G, const uint32_t* albedo, const uint32_
 // then a corner costs one 16-byte load instead of 26 gathers and 78 conversions.
 // kBatch: ask for the 8 table entries up front (k_probe_sample_ref: the batch is bound by the entries' latency); the pixel kernel
 // (k_render_primary), whose registers are spoken for by the camera ray's march, takes them corner by corner.
+// The table's layout: 0 = tile-major [slab slot][ry][rx] (a tile's entries are one contiguous run: k_sample_box_filter writes 4 KB at
+// a time), 1 = texel-major [ry][rx][slab slot] (a cage's two x-neighbours share 32 contiguous bytes)
+#ifndef DDGI_BOX_TEXEL_MAJOR
+#define DDGI_BOX_TEXEL_MAJOR 1
+#endif
+DDGI_D size_t box_index(uint32_t texel, uint32_t slot, uint32_t texels_per_tile, uint32_t n_slots)
+{
+    return DDGI_BOX_TEXEL_MAJOR ? static_cast<size_t>(texel) * n_slots + slot : static_cast<size_t>(slot) * texels_per_tile + texel;
+}
+
 template <bool kBatch = false>
 DDGI_D f3 diffuse_gi_ref(const GridK& G, const uint32_t* albedo, f3 pos, f3 nrm_raw, const float* s_unorm, int* cage, const float4* box = nullptr)
 {
@@ -135,7 +145,7 @@ DDGI_D f3 diffuse_gi_ref(const GridK& G, const uint32_t* albedo, f3 pos, f3 nrm_
             {
                 float4 tab[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) tab[k] = box[static_cast<size_t>(box_off) * n_probes + slab_slot(G, idx[k])];  // texel-major: [texel][slab slot]
+                for (int k = 0; k < 8; ++k) tab[k] = box[box_index(static_cast<uint32_t>(box_off), static_cast<uint32_t>(slab_slot(G, idx[k])), static_cast<uint32_t>(G.n), static_cast<uint32_t>(n_probes))];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) corner(k, idx[k], f3{tab[k].x, tab[k].y, tab[k].z});
             }
@@ -153,7 +163,7 @@ DDGI_D f3 diffuse_gi_ref(const GridK& G, const uint32_t* albedo, f3 pos, f3 nrm_
                 f3 smp;
                 if (box)
                 {
-                    const float4 v = box[static_cast<size_t>(box_off) * n_probes + slab_slot(G, idx)];  // (idx is a valid probe here)
+                    const float4 v = box[box_index(static_cast<uint32_t>(box_off), static_cast<uint32_t>(slab_slot(G, idx)), static_cast<uint32_t>(G.n), static_cast<uint32_t>(n_probes))];  // (idx is a valid probe here)
                     smp = f3{v.x, v.y, v.z};
                 }
                 else

@@ -1212,7 +1212,22 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
 // write the entries; consumers claim indices below `tail` with a compare-and-swap on `head`, wait for
 // the entry to become valid (!= 0xffff) and invalidate it.
 // =================================================================================================
-constexpr uint32_t kAqCap = 2048;
+#ifndef DDGI_AQ_T
+#define DDGI_AQ_T 1024  // lanes per workgroup of k_probe_trace_aq
+#endif
+#ifndef DDGI_AQ_WGS
+#define DDGI_AQ_WGS 1   // workgroups resident per CU (each with 160 KB / DDGI_AQ_WGS of LDS)
+#endif
+#ifndef DDGI_AQ_CAP
+#define DDGI_AQ_CAP 2048
+#endif
+#ifndef DDGI_AQ_POOL_CT
+#define DDGI_AQ_POOL_CT 1344
+#endif
+constexpr int kAqThreads = DDGI_AQ_T;
+constexpr int kAqWgsPerCU = DDGI_AQ_WGS;
+constexpr int kAqMinPool = kAqWgsPerCU == 1 ? 1024 : 320;
+constexpr uint32_t kAqCap = DDGI_AQ_CAP;
 constexpr uint32_t kAqCapFast = 1536;  // the fast build's compile-time pool (1280) + slack: a ring index is reused only after 256 later claims
 #ifndef DDGI_AQ_FAST_STEPS
 #define DDGI_AQ_FAST_STEPS 12
@@ -1300,10 +1315,10 @@ DDGI_D void aq_push(uint16_t* ring, uint32_t* tail, bool pred, uint32_t value, i
 // kPool > 0: the pool size is a compile-time constant, so every pool array is the LDS base plus a constant
 // offset (folded into the ds instructions: no address arithmetic, one SGPR instead of eleven).
 template <bool kStats, int kPool, class Cfg>
-__global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, const int pool_size, const int march_waves, const AqChain C, uint32_t* __restrict__ status)
+__global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_probe_trace_aq(const TraceArgs A, const int pool_size, const int march_waves, const AqChain C, uint32_t* __restrict__ status)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t wf_lds[];
-    constexpr int T = 1024;
+    constexpr int T = kAqThreads;
     const int tid = threadIdx.x;
     // Every launch on a handle has a sequence number; launch s claims its rays from counters[s % 8].  The counter launch s + 4 will
     // use is zeroed here instead of by a fill kernel in front of every launch (5 us of kernel and a dependency of its own per
@@ -1823,7 +1838,7 @@ __global__ __launch_bounds__(1024, 4) void k_probe_trace_aq(const TraceArgs A, c
     if (status && lane == 0 && aq_load(&sh->abort) != 0u) atomicOr(status, 1u);  // the safety net tripped: the output is not valid
 }
 
-constexpr int kAqPool = 1344;      // the usual pool (ddgi_engine.cpp); other sizes take the generic instantiation
+constexpr int kAqPool = DDGI_AQ_POOL_CT;      // the usual pool (ddgi_engine.cpp); other sizes take the generic instantiation
 constexpr int kAqPoolFast = 1280;  // the fast build's: 16 dwords per slot and rings of 1536 entries next to the cave's 52 KB skip field
 
 // fast: nwords = the skip field's, 16 dwords per slot; ring_cap: entries per ring (k_probe_trace_aq: kCap)
@@ -1839,9 +1854,12 @@ static size_t aq_lds_bytes(int nwords, int pool, bool fast = false, size_t ring_
 int aq_pool_size(int nwords, size_t lds_limit)
 {
     int pool = static_cast<int>(kAqCap);
-    while (pool >= 1024 && aq_lds_bytes(nwords, pool) > lds_limit) pool -= 64;
-    return pool >= 1024 ? pool : 0;
+    while (pool >= kAqMinPool && aq_lds_bytes(nwords, pool) > lds_limit) pool -= 64;
+    return pool >= kAqMinPool ? pool : 0;
 }
+int aq_threads() { return kAqThreads; }
+int aq_wgs_per_cu() { return kAqWgsPerCU; }
+int aq_pool_usual() { return kAqPool; }
 
 // The fast build's pool for a skip field of nwords_skip words.  plain (one light: the compile-time instantiation, whose
 // rings hold kAqCapFast entries): kAqPoolFast when that fits.  Otherwise the largest pool that fits next to rings of kAqCap
@@ -1860,7 +1878,7 @@ static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, in
     const size_t lds = Cfg::kFast ? aq_lds_bytes(args.scene.nwords_skip, pool, true, kPool > 0 ? kAqCapFast : kAqCap) : aq_lds_bytes(args.scene.nwords, pool);
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_probe_trace_aq<kStats, kPool, Cfg>), 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_probe_trace_aq<kStats, kPool, Cfg>), dim3(grid_blocks), dim3(1024), lds, stream, args, pool, march_waves, chain, status);
+    hipLaunchKernelGGL((k_probe_trace_aq<kStats, kPool, Cfg>), dim3(grid_blocks), dim3(kAqThreads), lds, stream, args, pool, std::min(march_waves, kAqThreads / 64 - 1), chain, status);
     return hipGetLastError();
 }
 
