@@ -607,7 +607,7 @@ def main():
     if extras and not ddgi_mode and not sharded:
         # ---- what frames in flight is worth: the same loop with every launch tracing its own update only, and with four ----
         sweep = {}
-        for n in (1, 2, 4):
+        for n in (1, 2, 4, 8):
             if n == fif:
                 continue
             eng.set_tuning("frames_in_flight", n)

@@ -196,12 +196,17 @@ void ddgi_texture_bytes(int mode, const ddgi_irradiance_field& f, int rays_per_p
 // Updates one launch of the queue kernel may work on (tuning "frames_in_flight"): REF mode on the handle's own textures only —
 // DDGI mode's updates differ from frame to frame (ray rotation, RNG keys, animated lights), and a host that holds pointers to a
 // pair (ddgi_bind_textures, ddgi_device_textures) expects the handle to stay on it.  The pair a ray writes travels in the top
-// two bits of its texel index (ddgi_trace_wf.hip: kDstPairShift).
+// three bits of its texel index (ddgi_trace_wf.hip: kDstPairShift).
 static int chain_len_for(const ddgi_engine* e, size_t albedo_bytes)
 {
     if (e->mode != DDGI_MODE_REF || e->pin_pair || e->caller_tex) return 1;
-    if (albedo_bytes / 4 >= (static_cast<size_t>(1) << 30)) return 1;
-    return std::min(kAqChainMax, std::max(1, e->tuning.frames_in_flight));
+    if (albedo_bytes / 4 >= (static_cast<size_t>(1) << 29)) return 1;
+    int len = std::min(kAqChainMax, std::max(1, e->tuning.frames_in_flight));
+    // What a longer chain hides is a constant per launch (the drain: ~0.25 ms), worth nothing on updates of tens of milliseconds —
+    // and a ring of 8 (16 under the pipelined exchange) pairs of a large grid is memory better left to the host: rings beyond 2 GiB
+    // are halved down to two pairs.  (A function of the configuration only: every rank of a sharded grid comes to the same length.)
+    while (len > 2 && albedo_bytes * 2 * static_cast<size_t>(len) > (static_cast<size_t>(2) << 30)) len /= 2;
+    return len;
 }
 int ddgi_chain_len(const ddgi_engine* e) { return chain_len_for(e, e->tex_bytes[0]); }
 
@@ -969,10 +974,10 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     {
         if (!e->d_work)
         {
-            // [1] kernel status, [3] the round kernel's counter, [8 .. 15] the queue kernel's ray counters: launch s uses [8 + s % 8] and zeroes
-            // the one of launch s + 4 (ddgi_types.h: AqChain).  `pub`: the host's ring of published continuations, read by running launches.
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_work), 16 * sizeof(uint32_t)));
-            HIP_TRY(hipMemsetAsync(e->d_work, 0, 16 * sizeof(uint32_t), e->stream));
+            // [1] kernel status, [3] the round kernel's counter, [8 .. 8 + kAqCounters) the queue kernel's ray counters: launch s uses [8 + s % kAqCounters] and zeroes
+            // the one of launch s + kAqChainMax (ddgi_types.h: AqChain).  `pub`: the host's ring of published continuations, read by running launches.
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_work), (8 + kAqCounters) * sizeof(uint32_t)));
+            HIP_TRY(hipMemsetAsync(e->d_work, 0, (8 + kAqCounters) * sizeof(uint32_t), e->stream));
             e->launch_seq = 0;
         }
         if (!e->pub)
@@ -1045,8 +1050,8 @@ static int launch_aq_numbered(ddgi_engine* e, const TracePlan& p, int march_wave
     {
         // a launch failed after its number was handed out: the counter it was to zero may be stale.  Start over on a clean ring.
         HIP_TRY(hipStreamSynchronize(e->stream));
-        HIP_TRY(hipMemsetAsync(e->d_work + 8, 0, 8 * sizeof(uint32_t), e->stream));
-        e->launch_seq = (e->launch_seq + 15u) & ~7u;
+        HIP_TRY(hipMemsetAsync(e->d_work + 8, 0, kAqCounters * sizeof(uint32_t), e->stream));
+        e->launch_seq = (e->launch_seq + 2u * kAqCounters - 1u) & ~(kAqCounters - 1u);
         e->counters_dirty = false;
         publish = false, chain_max = 0;
     }

@@ -26,7 +26,7 @@ struct Tuning
     int aq_pool = 0, wf_pool = 0, wf_maxpool = 0, wf_threads = 1024;
     int wf_fetch = 0, wf_tail = 0, wf_chunk = 0, wf_drain = 0, wait_threshold = 64;
     int blend_merge = 1;    // DDGI blend: up to this many HALF depth groups (of 16 probes) per CU, depth and irradiance run as one launch
-    int frames_in_flight = 4;  // REF mode: the MOST probe updates one launch may work on (how many it does is up to the host: an update is continued only
+    int frames_in_flight = 8;  // REF mode: the MOST probe updates one launch may work on (how many it does is up to the host: an update is continued only
                                // if it was submitted while its predecessor still ran — the reference's host runs MAX_FRAMES_IN_FLIGHT = 2 ahead,
                                // src/rvpt/rvpt.h:23, a loop that never waits runs as far ahead as this allows): such an update, with the same inputs, is
                                // traced by the predecessor's workgroups instead of waiting for their drain (ddgi_engine.cpp: ddgi_probe_update;
@@ -121,7 +121,7 @@ struct ddgi_engine
     void* tex_prev[2] = {nullptr, nullptr};  // DDGI blend: where the previous update's tiles are, when not in tex (pipelined exchange)
     size_t tex_bytes[2] = {0, 0};
 
-    static constexpr int kMaxPairs = 8;  // 2 x the most updates one launch works on (ddgi_types.h: kAqChainMax)
+    static constexpr int kMaxPairs = 16;  // 2 x the most updates one launch works on (ddgi_types.h: kAqChainMax)
     static constexpr int kRing = 64;  // timing history: one event triple per recent update
     hipEvent_t ev[kRing][3] = {};
     bool ev_has_blend[kRing] = {};    // the update recorded ev[2] (DDGI mode: after the blend); otherwise ev[1] is its end

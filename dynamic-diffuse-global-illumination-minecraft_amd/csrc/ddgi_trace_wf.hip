@@ -63,7 +63,7 @@ enum : uint32_t
 };
 
 // REF mode, frames in flight (k_probe_trace_aq): WfCold::dst = texel index | (update's distance from the launch's own) << 30
-constexpr uint32_t kDstPairShift = 30;
+constexpr uint32_t kDstPairShift = 29;  // (kAqChainMax = 8 pairs: three bits)
 constexpr uint32_t kDstTexelMask = (1u << kDstPairShift) - 1u;
 
 struct WfShared  // control block at the start of dynamic LDS (32 dwords)
@@ -432,7 +432,7 @@ DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst
     }
     else
     {
-        // (a ray of a CHAINED update — k_probe_trace_aq, frames in flight — carries in dst[31:30] how many texture pairs after the
+        // (a ray of a CHAINED update — k_probe_trace_aq, frames in flight — carries in dst[31:29] how many texture pairs after the
         // launch's own its update writes; the pairs of a handle lie pair_words apart)
         const uint32_t at = A.pair_words ? (dst & kDstTexelMask) + (dst >> kDstPairShift) * A.pair_words : dst;
         A.albedo[at] = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (255u << 24);
@@ -1320,17 +1320,17 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
     extern __shared__ __attribute__((aligned(16))) uint32_t wf_lds[];
     constexpr int T = kAqThreads;
     const int tid = threadIdx.x;
-    // Every launch on a handle has a sequence number; launch s claims its rays from counters[s % 8].  The counter launch s + 4 will
+    // Every launch on a handle has a sequence number; launch s claims its rays from counters[s % 16].  The counter launch s + 8 will
     // use is zeroed here instead of by a fill kernel in front of every launch (5 us of kernel and a dependency of its own per
-    // update): its last user, launch s - 4, ended before this one started (stream order), and its next user starts after this
-    // one has ended — a launch claims rays of at most kAqChainMax - 1 = 3 launches after itself (below).
-    if (blockIdx.x == 0 && tid == 0) C.counters[(C.seq + 4u) & 7u] = 0u;
+    // update): its last user, launch s - 8, ended before this one started (stream order), and its next user starts after this
+    // one has ended — a launch claims rays of at most kAqChainMax - 1 = 7 launches after itself (below).
+    if (blockIdx.x == 0 && tid == 0) C.counters[(C.seq + kAqChainMax) & (kAqCounters - 1u)] = 0u;
     // FRAMES IN FLIGHT.  When the rays of this launch's update are used up, the workgroups would drain — all of them at once, for
     // the life of their last rays (a ray's 8 bounces are a dependent chain: 0.25 ms of thinning pool per launch).  If the host has
     // already submitted the NEXT update, and that update is the same work into the next texture pair (C.pub, written by
     // ddgi_probe_update before it launches that update's own kernel), the workgroups go on with ITS rays instead, up to
     // C.chain_max updates ahead.  That update's own launch then finds its counter used up and leaves at once (here).
-    if (tid == 0) wf_lds[0] = __hip_atomic_load(C.counters + (C.seq & 7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) wf_lds[0] = __hip_atomic_load(C.counters + (C.seq & (kAqCounters - 1u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (wf_lds[0] >= A.n_rays) return;
     const int lane = tid & 63;
@@ -1736,7 +1736,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 {
                     atomicAdd(&sh->live, k);  // counted before they exist, so that `live` never reads 0 early
                     cs = aq_load(&sh->cur_seq);
-                    rbase = atomicAdd(C.counters + (cs & 7u), k);
+                    rbase = atomicAdd(C.counters + (cs & (kAqCounters - 1u)), k);
                 }
                 rbase = lane_bcast(rbase, 0);
                 if (C.chain_max) cs = lane_bcast(cs, 0);
@@ -1882,7 +1882,7 @@ static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, in
     return hipGetLastError();
 }
 
-// chain.counters[chain.seq % 8] must be zero: every launch zeroes the counter of the launch four after it (k_probe_trace_aq)
+// chain.counters[chain.seq % kAqCounters] must be zero: every launch zeroes the counter of the launch kAqChainMax after it (k_probe_trace_aq)
 hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_blocks, int march_waves, const AqChain& chain, uint32_t* status, hipStream_t stream)
 {
     if (args.fast_march)

@@ -114,14 +114,15 @@ struct TraceArgs
 };
 
 // k_probe_trace_aq's place in the handle's sequence of launches (ddgi_engine.cpp: "frames in flight").  Launch `seq` claims its
-// rays from counters[seq % 8]; when they are used up and the host has published launch seq + 1 as a CONTINUATION (the same
+// rays from counters[seq % kAqCounters]; when they are used up and the host has published launch seq + 1 as a CONTINUATION (the same
 // work into the next texture pair: pub[(seq + 1) % kAqPubRing] == seq + 2), the launch's workgroups go on with that update's
 // rays instead of draining — up to chain_max updates ahead.
 constexpr uint32_t kAqPubRing = 64;  // entries of the host's ring of published continuations (pinned host memory)
-constexpr int kAqChainMax = 4;       // updates one launch can work on (its own + 3): the counters ring holds 2 x that
+constexpr int kAqChainMax = 8;       // updates one launch can work on (its own + 7): the counters ring holds 2 x that
+constexpr uint32_t kAqCounters = 2 * kAqChainMax;
 struct AqChain
 {
-    uint32_t* counters;   // device: 8 ray counters
+    uint32_t* counters;   // device: kAqCounters ray counters
     uint32_t* continued;  // device: counts the workgroups that went on with a later update (ddgi_get_tuning "continued_workgroups")
     const uint32_t* pub;  // pinned host memory, device-visible: kAqPubRing words
     uint32_t seq;

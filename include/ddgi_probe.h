@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DDGI_ABI_VERSION 4 /* 4: tuning "frames_in_flight" (default 4): the handle owns a ring of texture pairs, ddgi_device_textures pins the current one;
+#define DDGI_ABI_VERSION 4 /* 4: tuning "frames_in_flight" (default 8): the handle owns a ring of texture pairs, ddgi_device_textures pins the current one;
                               3: ddgi_exchange_p2p_*, ddgi_exchange_transport, ddgi_scene_skip_field; tuning "fast_march", "sample_box"; "autotune" off by default */
 
 /* ---- wire formats: byte-identical to the reference's UBO/SSBO records ------------------------ */
@@ -206,7 +206,7 @@ int ddgi_tune(ddgi_handle h);
  *   "march_waves"   n > 0 pins the split (waves that march, of 16); 0 = per configuration            [DDGI_AQ_MARCH]
  *   "trace_kernel"  0 auto, 1 round-based, 2 ray per lane, 3 queues (cross-checks)   [DDGI_TRACE_KERNEL=rounds|lane|queues]
  *   "frames_in_flight"  REF mode.  The reference's host contract is MAX_FRAMES_IN_FLIGHT = 2 with a fence per frame (src/rvpt/rvpt.h:23,
- *                   rvpt.cpp:277-278): frame k + 1 is submitted while frame k runs.  n (default 4 = the most, 1 = off) is an UPPER BOUND on
+ *                   rvpt.cpp:277-278): frame k + 1 is submitted while frame k runs.  n (default 8 = the most, 1 = off) is an UPPER BOUND on
  *                   the updates one launch works on: the handle keeps n texture pairs (2 n under the pipelined exchange), updates come
  *                   in aligned groups of n, and an update submitted as the SAME WORK as its predecessor (same configuration, rays, lights,
  *                   tuning — nothing but probe updates, exchanges, samples, renders and reads on the handle in between) while the
@@ -216,7 +216,8 @@ int ddgi_tune(ddgi_handle h);
  *                   like the reference, gets two per launch; a loop that never waits gets n.  Results are unchanged bit for bit; every
  *                   update still has its own launch in stream order, so everything enqueued behind an update sees it complete — but an
  *                   update's end event can fire up to n - 1 updates late (its launch went on with its successors' rays): a host that
- *                   consumes every update at once loses nothing and gains nothing.  Changing it blocks and re-makes the ring (the
+ *                   consumes every update at once loses nothing and gains nothing.  Rings of more than 2 GiB (C4-sized grids and beyond, where
+ *                   the drain is a fraction of a percent of an update) are halved, down to two pairs.  Changing it blocks and re-makes the ring (the
  *                   textures carry over); set it before the exchange is attached.                              [DDGI_FRAMES_IN_FLIGHT]
  *   "timing"        1 (default): every update records two (REF) or three (DDGI) events on its stream for ddgi_last_update_ms /
  *                   ddgi_update_history_ms; 0: none — the queries then fail with DDGI_ERR_NOT_READY, and a stream of

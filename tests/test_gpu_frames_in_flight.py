@@ -26,7 +26,7 @@ def _oracle_albedo(oracle, name, seed):
     return oracle.probe_update(f, oracle.make_settings(scene, 8), rays)[0]
 
 
-@pytest.mark.parametrize("fif", [1, 2, 3, 4])
+@pytest.mark.parametrize("fif", [1, 2, 3, 4, 8])
 @pytest.mark.parametrize("name", ["cave_small", "c2_cornell"])
 def test_back_to_back_updates_with_new_rays_every_other_group(ddgi, oracle, name, fif):
     """Groups of back-to-back updates (nothing between them: the continuation's precondition), new ray jitter before every

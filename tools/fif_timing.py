@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Steady-state time per probe update of ONE rank's slab of the bench workload (C3, REF) at world = 1, 2, 4, 8 and
-frames_in_flight = 1, 2, 4 (GPU box, one GPU): wall clock over a run of back-to-back updates, no per-update events
+frames_in_flight = 1, 2, 4, 8 (GPU box, one GPU): wall clock over a run of back-to-back updates, no per-update events
 (a continued update has no kernel time of its own).  What strong scaling can reach before any exchange cost."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +11,7 @@ N = int(os.environ.get("FIF_UPDATES", "48"))
 fast = os.environ.get("FIF_FAST", "0") == "1"
 base = {}
 for world in (1, 2, 4, 8):
-    for fif in (1, 2, 4):
+    for fif in (1, 2, 4, 8):
         eng = ddgi_amd.ProbeEngine(ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"]),
                                    ddgi_amd.make_settings(w["scene"], w["max_bounces"]), rank=world // 2, world=world)
         eng.set_tuning("frames_in_flight", fif)
