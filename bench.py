@@ -241,7 +241,7 @@ def main():
                          "(64x32x64 probes x 512 rays) on however many GPUs are given; c5 (with --mode ddgi): S-Dyn, 128x64x128 probes "
                          "x 256 rays, 4 animated lights + hysteresis")
     ap.add_argument("--no-fast-march", action="store_true", help="skip the extra timed run of the opt-in tolerance-mode march (N = 1, REF)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the sampler block, the frames_in_flight 1 / 4 runs and the set-up timings (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sampler block, the frames_in_flight 1 / 2 / 4 runs and the set-up timings (profiling runs)")
     ap.add_argument("--mode", choices=["ref", "ddgi"], default="ref",
                     help="ref (default): the reference's live behaviour, the headline metric; ddgi: in-kernel Fibonacci rays + "
                          "octahedral irradiance/depth blend with hysteresis (trace + blend per step)")
@@ -250,7 +250,7 @@ def main():
                          "p2p: every rank pushes its slab into its peers' textures (ddgi_exchange_p2p_*, IPC-mapped buffers).  "
                          "If RCCL cannot be brought up (an error, or no answer within --rccl-timeout seconds) the run falls back to p2p and says so")
     ap.add_argument("--rccl-timeout", type=float, default=90.0)
-    ap.add_argument("--frames-in-flight", type=int, default=None, help="tuning \"frames_in_flight\" (default: the library's, 4; the reference's host runs MAX_FRAMES_IN_FLIGHT = 2 ahead)")
+    ap.add_argument("--frames-in-flight", type=int, default=None, help="tuning \"frames_in_flight\" (default: the library's, 8; the reference's host runs MAX_FRAMES_IN_FLIGHT = 2 ahead)")
     args = ap.parse_args()
     if args.workload == "c5" and args.mode != "ddgi":
         raise SystemExit("--workload c5 is S-Dyn (4 dynamic lights + temporal hysteresis): run it with --mode ddgi")

@@ -241,6 +241,9 @@ DDGI_D uint32_t primary_bucket(uint32_t fl) { return (fl & kFlagDeadHint) ? kBuc
 // What the shared event code may know at compile time.  CfgRuntime reads everything from the arguments;
 // CfgPlain<kMode> is the common case — one light, no profiling switches, REF (0) or DDGI (1) output —
 // whose light loops and mode branches fold away (fewer instructions, far fewer scalar registers to spill).
+#ifndef DDGI_INLINE_STEPS
+#define DDGI_INLINE_STEPS 2  // voxel steps an event lane takes itself for the march it sets up (one light; see wf_post_march)
+#endif
 // kFast: the tolerance-mode build (ddgi_device.h: fast_march_step) — the scene in LDS is the 2-bit skip field instead of the
 // occupancy bitmap, a slot keeps |rd| instead of rd (16 dwords), the rings hold 1536 entries.
 template <bool kFastT>
@@ -248,6 +251,7 @@ struct CfgRuntimeT
 {
     static constexpr int kNl = 0;
     static constexpr bool kFast = kFastT;
+    static constexpr int kInline = 1;
     static DDGI_D int nl(const TraceArgs& A) { return A.nl; }
 #ifdef DDGI_PROFILING  // the ablation / fault-injection switches exist only in the profiling build (make prof)
     static DDGI_D int ablate(const TraceArgs& A) { return A.ablate; }
@@ -265,6 +269,7 @@ struct CfgMulti
 {
     static constexpr int kNl = kNlT;
     static constexpr bool kFast = kFastT;
+    static constexpr int kInline = 1;
     static DDGI_D int nl(const TraceArgs& A) { return kNlT > 0 ? kNlT : A.nl; }
     static DDGI_D int ablate(const TraceArgs&) { return 0; }
     static DDGI_D bool ddgi(const TraceArgs&) { return kMode != 0; }
@@ -274,22 +279,21 @@ struct CfgPlain
 {
     static constexpr int kNl = 1;
     static constexpr bool kFast = kFastT;
+    static constexpr int kInline = DDGI_INLINE_STEPS;
     static DDGI_D int nl(const TraceArgs&) { return 1; }
     static DDGI_D int ablate(const TraceArgs&) { return 0; }
     static DDGI_D bool ddgi(const TraceArgs&) { return kMode != 0; }
 };
 
-// The first kInlineSteps voxel steps are taken right here, by the event lane that sets the march up: 57 % of the cave
+// The first Cfg::kInline voxel steps are taken right here, by the event lane that sets the march up: 57 % of the cave
 // workload's marches end with their FIRST step (probes inside rock, rays that start in a corner of the surface's relief),
 // and for those a trip through the march queue and a 24-step burst is all overhead.  More than one inline step does not
 // pay: only another 4 % of the marches end within steps 2..4, and those steps run at 18 of 64 lanes (ddgi_trace_stats,
-// sections "inline step"; 4 steps: 2.134 ms, 2: 2.136, 1: 2.109 on C3).  Returns -1 when the march goes on (the slot is
+// sections "inline step"; 4 steps: 2.134 ms, 2: 2.136, 1: 2.109 on C3) — round 2's finding; with frames in flight (no drain,
+// the event and the march waves both near their limits) a second inline step is worth 1.2 % on the one-light instantiations
+// (C3 1.615 -> 1.595 ms; 3 steps: 1.615, 4: 1.64) and costs 0.5 % on the four-light one (S-Dyn): Cfg::kInline.  Returns -1 when the march goes on (the slot is
 // ready for the march queue, resuming at (t, iterations) like a parked march), else the event bucket of the finished march
 // (the slot is in its event state).
-#ifndef DDGI_INLINE_STEPS
-#define DDGI_INLINE_STEPS 1
-#endif
-constexpr int kInlineSteps = DDGI_INLINE_STEPS;
 
 // Profiling aid of the counters build of the queue kernel (kStats): how many lanes are active where.  at(id) is called
 // at the start of a section of event code: every active lane counts itself, the first active lane counts the visit.
@@ -358,7 +362,7 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
     }
     P.tl[slot] = tl;
     const uint32_t base_flags = (feeler ? kFlagFeeler : 0u) | (static_cast<uint32_t>(lid + 1) << 12);
-    if (kInlineSteps > 0)
+    if (Cfg::kInline > 0)
     {
         const f3 hi = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
         bool occ = false, fin = false;
@@ -384,7 +388,7 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
             m.t = 0.0f, m.tl = tl, m.it = 0, m.lid = lid, m.cell = 0;
             m.p = ray_at(o, dn, 0.0f);
 #pragma unroll
-            for (int k = 0; k < kInlineSteps; ++k)
+            for (int k = 0; k < Cfg::kInline; ++k)
                 if (!fin)
                 {
                     DDGI_PROBE(lp, 8 + (k < 3 ? k : 3));  // sections 8..11: inline steps 1, 2, 3, 4+
@@ -403,7 +407,7 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
             const bool block_wins = occ && (t_end < tl);
             return static_cast<int>(feeler ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock));
         }
-        P.flags[slot] = kSlotMarch | base_flags | (static_cast<uint32_t>(kInlineSteps) << 4);
+        P.flags[slot] = kSlotMarch | base_flags | (static_cast<uint32_t>(Cfg::kFast ? 1 : Cfg::kInline) << 4);
         return -1;
     }
     P.t[slot] = 0.0f;
@@ -795,7 +799,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt;
                     if (lambert_zero && finite_albedo)
                         lit_done = true;  // contributes +0
-                    else if (Cfg::nl(A) == 1 && kInlineSteps > 0)
+                    else if (Cfg::nl(A) == 1 && Cfg::kInline > 0)
                     {
                         // The single light's feeler.  intersect_scene's sphere half for it (does the ray reach the light's
                         // sphere at all, and where) is evaluated once, for the table's "lit" class and for the feeler's march.
@@ -1242,6 +1246,9 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
 #ifndef DDGI_EVENT_PRIO
 #define DDGI_EVENT_PRIO 1
 #endif
+#ifndef DDGI_AQ_REFILL_FIRST
+#define DDGI_AQ_REFILL_FIRST 0
+#endif
 #ifndef DDGI_AQ_THIN
 #define DDGI_AQ_THIN 0
 #endif
@@ -1659,11 +1666,20 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             uint32_t avail = 0;
             uint32_t head_seen = 0;
             if (lane < kAqEventQueues) head_seen = aq_load(&sh->eq_head[lane]), avail = aq_load(&sh->eq_tail[lane]) - head_seen;
+#if DDGI_AQ_REFILL_FIRST
+            if (lane == kAqEventQueues) avail = aq_load(&sh->fq_tail) - aq_load(&sh->fq_head);
+#endif
             if (avail > kCap) avail = 0;  // a claim in flight can make tail - head wrap for an instant
-            const unsigned long long full = __ballot(avail >= 64u);
+            const unsigned long long full = __ballot(avail >= 64u && lane < kAqEventQueues);
             const bool no_more = aq_load(&sh->no_more) != 0u;
+#if DDGI_AQ_REFILL_FIRST
+            // new rays BEFORE full event groups whenever 64 slots are free: the pool stays full, the march waves' lanes with it
+            const bool refill_first = !no_more && lane_bcast(avail, kAqEventQueues) >= 64u;
+#else
+            constexpr bool refill_first = false;
+#endif
 
-            if (full != 0ull)
+            if (full != 0ull && !refill_first)
             {
                 // 1) a full group, dearest bucket first
                 b = static_cast<uint32_t>(__ffsll(static_cast<long long>(full)) - 1);
