@@ -241,6 +241,9 @@ DDGI_D uint32_t primary_bucket(uint32_t fl) { return (fl & kFlagDeadHint) ? kBuc
 // What the shared event code may know at compile time.  CfgRuntime reads everything from the arguments;
 // CfgPlain<kMode> is the common case — one light, no profiling switches, REF (0) or DDGI (1) output —
 // whose light loops and mode branches fold away (fewer instructions, far fewer scalar registers to spill).
+#ifndef DDGI_VIS_EARLY
+#define DDGI_VIS_EARLY 1  // the feeler class of a hit is asked for before its albedo is evaluated (wf_event)
+#endif
 #ifndef DDGI_INLINE_STEPS
 #define DDGI_INLINE_STEPS 2  // voxel steps an event lane takes itself for the march it sets up (one light; see wf_post_march)
 #endif
@@ -782,6 +785,11 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     const f3 nh = axis_normal ? hnrm : normalize3(hnrm);
                     const bool lambert_zero = Cfg::nl(A) == 1 && dot3(nh, to_light) <= 0.0f && !(Cfg::ablate(A) & 4);
                     const bool ordinary = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z))) < 0x1.0p20f;
+                    // The feeler class of the hit's (voxel, face) is asked for BEFORE the albedo: its index depends on the hit alone, and the
+                    // byte's way from L2 passes under the albedo's arithmetic instead of standing in front of the feeler decision.
+                    int vis_entry = 0;
+                    const bool vis_early = DDGI_VIS_EARLY && Cfg::nl(A) == 1 && block_wins && axis_normal && !lambert_zero;
+                    const uint32_t vis_early_class = vis_early ? light_vis_class(A, hpos, hnrm, vis_entry) : kVisUnknown;
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary)) DDGI_PROBE(lp, 1);  // section 1: albedo
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary))
                         hcol = (Cfg::ablate(A) & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
@@ -793,8 +801,9 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     // Is the feeler's outcome certain (k_light_visibility)?  Then its march, queue trip and event are
                     // skipped: the light-sphere test it would start with (does the ray reach the sphere at all) and
                     // get_direct_lighting's arithmetic are evaluated right here, on the same values.
-                    int vis_entry = 0;
-                    const uint32_t vis = (Cfg::nl(A) == 1 && block_wins && axis_normal && !(lambert_zero && finite_albedo)) ? light_vis_class(A, hpos, hnrm, vis_entry) : kVisUnknown;
+                    // (a hit with lambert == 0 whose albedo is not finite — the moss / mold pattern's 0/0 — needs the class after all)
+                    const uint32_t vis = vis_early ? vis_early_class
+                                                   : ((Cfg::nl(A) == 1 && block_wins && axis_normal && !(lambert_zero && finite_albedo)) ? light_vis_class(A, hpos, hnrm, vis_entry) : kVisUnknown);
                     if ((Cfg::ablate(A) & 16) && A.stats && block_wins) atomicAdd(&A.stats[(lambert_zero && finite_albedo) ? 59 : (vis == kVisListed ? 63 : 56 + vis)], 1ull);  // profiling build: feeler classes
                     ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt;
                     if (lambert_zero && finite_albedo)

@@ -4,15 +4,15 @@
 T=${1:-a}; R=r04
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/profiles_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# the bench line (REF, C3, library defaults: frames_in_flight 2) and the DDGI line
+# the bench line (REF, C3, library defaults: frames_in_flight 8) and the DDGI line
 timeout 400 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/${R}_${T}_bench.json 2> /dev/null
 timeout 200 python $ROOT/bench.py --mode ddgi --steps 20 --warmup 5 > $OUT/${R}_${T}_ddgi_bench.json 2> /dev/null
 MW=$(python -c "import json;print(json.load(open('$OUT/${R}_${T}_bench.json')).get('tuning',{}).get('march_waves',7))" 2>/dev/null || echo 7)
 # kernel trace of the same command (wave split pinned to what the bench measured, so that every launch is the steady-state kernel).
-# With frames in flight the launches alternate: a group's first launch traces both updates, the continued update's own launch is
+# With frames in flight the launches alternate: a group's first launch traces up to eight updates, the continued update's own launch is
 # empty — the AVERAGE over the launches is the time per update, which is what bench.py's roofline.kernel_ms is too.
 DDGI_AQ_MARCH=$MW timeout 200 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$T -o ref --output-format csv -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fast-march --no-extras > /dev/null 2>&1
-python $ROOT/tools/profile_summary.py $ROOT/gpurun_out/prof_$T/ref "bench.py --steps 20 --warmup 5 (REF, frames_in_flight 4, the default) with DDGI_AQ_MARCH=$MW, the split the bench measured" > $OUT/${R}_${T}_ref_kernel_stats.txt
+python $ROOT/tools/profile_summary.py $ROOT/gpurun_out/prof_$T/ref "bench.py --steps 20 --warmup 5 (REF, frames_in_flight 8, the default) with DDGI_AQ_MARCH=$MW, the split the bench measured" > $OUT/${R}_${T}_ref_kernel_stats.txt
 DDGI_FRAMES_IN_FLIGHT=1 DDGI_AQ_MARCH=$MW timeout 200 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$T -o ref1 --output-format csv -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fast-march --no-extras > /dev/null 2>&1
 python $ROOT/tools/profile_summary.py $ROOT/gpurun_out/prof_$T/ref1 "the same with DDGI_FRAMES_IN_FLIGHT=1: every launch traces its own update only" > $OUT/${R}_${T}_ref_fif1_kernel_stats.txt
 timeout 200 rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_$T -o ddgi --output-format csv -- python $ROOT/bench.py --mode ddgi --steps 20 --warmup 5 > /dev/null 2>&1
