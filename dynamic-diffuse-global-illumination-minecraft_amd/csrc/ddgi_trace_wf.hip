@@ -1255,6 +1255,12 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
 #ifndef DDGI_EVENT_PRIO
 #define DDGI_EVENT_PRIO 1
 #endif
+#ifndef DDGI_AQ_THIN_WAITS
+#define DDGI_AQ_THIN_WAITS 4
+#endif
+#ifndef DDGI_AQ_THIN_NAP
+#define DDGI_AQ_THIN_NAP 4
+#endif
 #ifndef DDGI_AQ_REFILL_FIRST
 #define DDGI_AQ_REFILL_FIRST 0
 #endif
@@ -1516,7 +1522,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
         }
         f3 hi_v = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
         asm volatile("" : "+v"(hi_v.x), "+v"(hi_v.y), "+v"(hi_v.z));
-        int trips = 0;
+        int trips = 0, thin_waits = 0;
         for (;;)
         {
             if (++guard > (1u << 23)) sh->abort = 1u;
@@ -1561,6 +1567,17 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 if ((aq_load(&sh->no_more) != 0u && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
                 __builtin_amdgcn_s_sleep(DDGI_AQ_SLEEP);
                 continue;
+            }
+            if (kAqThinTrip > 0)
+            {
+                // a thin wave waits a moment for more marches instead of spending a whole burst's instructions on a few lanes
+                if (__popcll(__ballot(any)) < kAqThinTrip && thin_waits < DDGI_AQ_THIN_WAITS && aq_load(&sh->no_more) == 0u)
+                {
+                    ++thin_waits;
+                    __builtin_amdgcn_s_sleep(DDGI_AQ_THIN_NAP);
+                    continue;
+                }
+                thin_waits = 0;
             }
             guard = 0;
             if (kStats)
