@@ -1634,6 +1634,25 @@ static v3 oct_decode(v2 o)
     return normalize3(v);
 }
 
+/* test hooks (tests/test_independent_restatement.py): a20 on arrays of n vectors */
+void oracle_oct_encode(const float* v, int n, float* out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        v2 r = oct_encode(V3(v[3 * i], v[3 * i + 1], v[3 * i + 2]));
+        out[2 * i] = r.x, out[2 * i + 1] = r.y;
+    }
+}
+void oracle_oct_decode(const float* uv, int n, float* out)
+{
+    for (int i = 0; i < n; i++)
+    {
+        v2 o = {uv[2 * i], uv[2 * i + 1]};
+        v3 r = oct_decode(o);
+        out[3 * i] = r.x, out[3 * i + 1] = r.y, out[3 * i + 2] = r.z;
+    }
+}
+
 /* direction of interior texel (x, y) in [1, side-2]^2 of a side x side tile */
 static v3 texel_dir(int x, int y, int side)
 {

@@ -243,6 +243,22 @@ def update_lights(scene, time, base):
     return out
 
 
+def oct_encode(v):
+    """a20 (octahedral.glsl:16-23) on an (n, 3) array of vectors -> (n, 2)"""
+    v = np.ascontiguousarray(v, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((len(v), 2), dtype=np.float32)
+    lib().oracle_oct_encode(v.ctypes.data_as(C.c_void_p), len(v), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def oct_decode(uv):
+    """a20 (octahedral.glsl:28-34) on an (n, 2) array -> (n, 3)"""
+    uv = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros((len(uv), 3), dtype=np.float32)
+    lib().oracle_oct_decode(uv.ctypes.data_as(C.c_void_p), len(uv), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def frame_rotation(frame):
     m = np.zeros(9, dtype=np.float32)
     lib().oracle_frame_rotation(C.c_uint32(frame), m.ctypes.data_as(C.c_void_p))

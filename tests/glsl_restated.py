@@ -25,6 +25,9 @@ Covered (file:line of /root/reference/assets/shaders):
     probe_pass.comp:45-71        wang_hash, rand_xorshift, rand              :150-178  calculate_random_dir_hemisphere
     probe_pass.comp:180-215      get_direct_lighting                         :253-303  main
     structs.glsl:54-89           the shipped light tables
+The dormant pieces DDGI mode switches on, restated the same way:
+    probe_pass.comp:217-251      update_lights             :298-299  mix(old, new, hysteresis)
+    octahedral.glsl:16-34        octEncode, octDecode (signNotZero: g3dmath's, +1 for x >= 0 else -1)
 """
 import ctypes as C
 
@@ -802,3 +805,63 @@ def get_diffuse_gi(pos, normal, albedo, distance, counts, side, origin, s):
             irradiance = vadd(irradiance, vscale(sample, weight))
             sum_weight = f32(sum_weight + weight)
         return vdiv(irradiance, sum_weight), cage
+
+
+# ---- the dormant pieces (DDGI mode) ------------------------------------------------------------------------
+def update_lights(scene, time, lights):
+    """probe_pass.comp:217-251 on one scene's table [(intensity, col, pos)] -> the moved positions.  GLSL globals are
+    initialised per invocation: the offsets apply to the table as shipped / as given, once.  Literals without a suffix are
+    floats (GLSL has no implicit double), `(i + 1) * 2` and `(i / 2) * 4` are integer expressions converted when they meet
+    the float, and a * b * c groups from the left."""
+    time = f32(time)
+    out = []
+    for i, (_, _, pos) in enumerate(lights):
+        x, y, z = pos
+        if scene == 0:
+            t = f32(f32(0.05) * time)
+            if i == 0:
+                z = f32(z + f32(f32(10) * cos(f32(t * f32(0.1)))))
+            else:
+                x = f32(x + f32(f32((i + 1) * 2) * sin(f32(t * f32(0.5)))))
+                y = f32(y + f32(f32((i // 2) * 4) * sin(f32(t * f32(0.5)))))
+                z = f32(z + f32(f32((i + 1) * 2) * cos(f32(t * f32(0.5)))))
+        elif scene == 1:
+            t = f32(f32(0.005) * time)
+            x = f32(x + f32(f32(i + 1) * sin(t)))
+            y = f32(y + f32(f32((i // 2) * 4) * sin(t)))
+            z = f32(z + f32(f32(i + 1) * cos(t)))
+        elif scene == 2:
+            d = f32(f32(0.00005) * time)
+            x, y, z = f32(x + d), f32(y + d), f32(z + d)
+        out.append((x, y, z))
+    return out
+
+
+def sign_not_zero(x):
+    return ONE if x >= ZERO else f32(-1.0)
+
+
+def oct_encode(v):
+    """octahedral.glsl:16-23"""
+    l1norm = f32(f32(abs(v[0]) + abs(v[1])) + abs(v[2]))
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = f32(ONE / l1norm)
+        rx, ry = f32(v[0] * inv), f32(v[1] * inv)
+    if v[2] < ZERO:
+        rx, ry = f32(f32(ONE - abs(ry)) * sign_not_zero(rx)), f32(f32(ONE - abs(rx)) * sign_not_zero(ry))
+    return rx, ry
+
+
+def oct_decode(o):
+    """octahedral.glsl:28-34"""
+    x, y = f32(o[0]), f32(o[1])
+    z = f32(f32(ONE - abs(x)) - abs(y))
+    if z < ZERO:
+        x, y = f32(f32(ONE - abs(y)) * sign_not_zero(x)), f32(f32(ONE - abs(x)) * sign_not_zero(y))
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        return normalize(v3(x, y, z))
+
+
+def hysteresis_mix(old, new, hysteresis):
+    """probe_pass.comp:298-299: color = mix(old, new, hysteresis) — GLSL's mix puts the weight `hysteresis` on the NEW value"""
+    return mix(f32(old), f32(new), f32(hysteresis))

@@ -438,3 +438,65 @@ def _c1_chunk(args):
         c = G.probe_ray_color(index, o, d, scene, 8)
         albedo[y_probe * s + int(info[2]), x_probe * s + int(info[1])] = (G.unorm8(c[0]), G.unorm8(c[1]), G.unorm8(c[2]), 255)
     return albedo
+
+
+# ---- the dormant pieces DDGI mode switches on (rows a18-a20) ---------------------------------------------------------------
+f32 = np.float32
+
+
+def test_update_lights_restated_twice(oracle):
+    """probe_pass.comp:217-251 for the three shipped tables, the commented four-light cave table (structs.glsl:65-68: light
+    indices up to 3 exercise (i + 1) * 2 and (i / 2) * 4) and times from a frame's +2 steps to hours of them."""
+    from tests import glsl_restated as G
+    oracle.set_arith(False)
+    try:
+        rng = np.random.default_rng(31)
+        times = np.concatenate([np.arange(0.0, 400.0, 2.0), rng.uniform(0.0, 1.0e6, 1500), [1.0e7, 3.0e8]]).astype(np.float32)
+        four = np.zeros(4, dtype=oracle.LIGHT_DTYPE)
+        four["intensity"] = 40.0
+        four["col"] = 1.0
+        four["pos"] = [(4, 17.5, 8.5), (-14, 12, 5), (20, 10, -18), (-2, 22, 30)]
+        n = 0
+        for scene in (0, 1, 2):
+            for base in (oracle.shipped_lights(scene), four):
+                table = [(f32(b["intensity"]), tuple(f32(c) for c in b["col"]), tuple(f32(c) for c in b["pos"])) for b in base]
+                for t in times:
+                    want = oracle.update_lights(scene, float(t), base)["pos"]
+                    got = np.array(G.update_lights(scene, t, table), dtype=np.float32)
+                    assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), (scene, float(t), want, got)
+                    n += len(base)
+        assert n > 10000
+    finally:
+        oracle.set_arith(True)
+
+
+def test_oct_encode_decode_restated_twice(oracle):
+    """octahedral.glsl:16-34 on 10^5 unit vectors / points of the [-1, 1] square (axes, octant borders, the folded half)."""
+    from tests import glsl_restated as G
+    oracle.set_arith(False)
+    try:
+        rng = np.random.default_rng(37)
+        v = rng.normal(size=(N_POINT, 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        v = v.astype(np.float32)
+        v[:6] = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+        v[6:200, 2] *= 0.0           # the fold line z = 0
+        v[200:400, 0] = 0.0          # signNotZero(+-0)
+        v[300:400, 0] = -0.0
+        enc = oracle.oct_encode(v)
+        uv = rng.uniform(-1.0, 1.0, size=(N_POINT, 2)).astype(np.float32)
+        uv[:4] = [(1, 1), (-1, 1), (0, 0), (1, -1)]
+        uv[4:300, 0] = 0.0
+        dec = oracle.oct_decode(uv)
+        step = max(1, N_POINT // 20000)   # (python scalars: a spread 20 000 of each, the special rows all)
+        rows = sorted(set(range(0, 400)) | set(range(0, N_POINT, step)))
+        for i in rows:
+            e = G.oct_encode(tuple(f32(c) for c in v[i]))
+            assert _bits(e[0]) == _bits(enc[i, 0]) and _bits(e[1]) == _bits(enc[i, 1]), (i, v[i], e, enc[i])
+            d = G.oct_decode(tuple(f32(c) for c in uv[i]))
+            assert all(_bits(d[k]) == _bits(dec[i, k]) for k in range(3)), (i, uv[i], d, dec[i])
+        # and the pair is what it claims to be: decode(encode(v)) == v to rounding
+        back = oracle.oct_decode(enc)
+        assert np.abs(back[400:] - v[400:]).max() < 1e-6   # (the rows above were bent off the unit sphere on purpose)
+    finally:
+        oracle.set_arith(True)
