@@ -1255,6 +1255,12 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
 #ifndef DDGI_EVENT_PRIO
 #define DDGI_EVENT_PRIO 1
 #endif
+#ifndef DDGI_AQ_SPEC_BURST
+#define DDGI_AQ_SPEC_BURST 0  // march waves: the occupancy lookup off the dependent chain (experiment: +2.4 %, off)
+#endif
+#ifndef DDGI_MARCH_PRIO
+#define DDGI_MARCH_PRIO 0  // s_setprio of the (exact) march waves; the event waves run at DDGI_EVENT_PRIO
+#endif
 #ifndef DDGI_AQ_THIN_WAITS
 #define DDGI_AQ_THIN_WAITS 4
 #endif
@@ -1509,6 +1515,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
         // half the cycles): two independent chains interleaved in one wave march nearly twice as many rays per wave, so that
         // fewer of the workgroup's 16 waves have to march and more of them run events — which is what limits the kernel.
         constexpr int kM = kLaneMarches;
+        if (DDGI_MARCH_PRIO > 0) __builtin_amdgcn_s_setprio(DDGI_MARCH_PRIO);
         March m[kM];
         uint32_t slot[kM], fl[kM];
         bool have[kM];
@@ -1601,7 +1608,65 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             uint32_t bucket[kM];
 #pragma unroll
             for (int q = 0; q < kM; ++q) finished[q] = false, bucket[q] = 0;
-            if (any)
+            if (kM == 1 && DDGI_AQ_SPEC_BURST && any)
+            {
+                // THE SPECULATIVE BURST (experiment; docs/LAB_NOTES.md "Round 4").  In march_step_frozen the bit a step looks up
+                // decides whether the NEXT step moves: the trip to the LDS and the index arithmetic in front of it sit on the march's
+                // dependent chain — 18 instructions and a memory access per step, of which 7 move the ray.  Here every lane keeps
+                // stepping whatever it finds (positions past a march's end are looked up clamped into the box like any other), t
+                // after the first step at which the march ended is recorded on the side, position and cell are recomputed from it
+                // after the burst — bit for bit what march_step_frozen leaves behind.
+                March& M = m[0];
+                bool seen = !have[0] || (near_limit && kMarchIters - M.it <= 0);
+                float rec_t = M.t;
+                if (near_limit)
+                {
+#pragma unroll
+                    for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
+                    {
+                        const bool occ_s = march_step_burst(M, A.scene, s_bits, hi_v);
+                        rec_t = seen ? rec_t : M.t;
+                        seen = seen | occ_s | (M.t >= M.tl) | (kMarchIters - M.it <= sub + 1);
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
+                    {
+                        const bool occ_s = march_step_burst(M, A.scene, s_bits, hi_v);
+                        rec_t = seen ? rec_t : M.t;
+                        seen = seen | occ_s | (M.t >= M.tl);
+                    }
+                }
+                M.t = rec_t;
+                M.p = ray_at(M.ro, M.dn, M.t);
+                {
+                    const float kx = __builtin_amdgcn_fmed3f(ceilf(M.p.x), A.scene.lo_f[0], hi_v.x);
+                    const float ky = __builtin_amdgcn_fmed3f(ceilf(M.p.y), A.scene.lo_f[1], hi_v.y);
+                    const float kz = __builtin_amdgcn_fmed3f(ceilf(M.p.z), A.scene.lo_f[2], hi_v.z);
+                    M.cell = static_cast<int>(fmaf(kz, A.scene.nxy_f, fmaf(ky, A.scene.nx_f, kx)));
+                }
+                const uint32_t* __restrict__ bits_base = s_bits - (A.scene.bias32 >> 5);
+                if (have[0])
+                {
+                    const bool occ = __builtin_amdgcn_ubfe(bits_base[M.cell >> 5], static_cast<uint32_t>(M.cell), 1u) != 0u;
+                    M.it += kAqStepsPerTrip;
+                    bool f = seen;
+                    if (!f && ((trips & 3) == 3)) f = march_escaped(M, A.scene);
+                    if (f)
+                    {
+                        const uint32_t hf = !occ ? 0u : ((fl[0] & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(M.p), M.cell)), M.p, false));
+                        P.t[slot[0]] = M.t;
+                        P.flags[slot[0]] = (fl[0] & 0xf000u) | ((fl[0] & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl[0] & kFlagFeeler) | hf;
+                        const bool block_wins = occ && (M.t < M.tl);
+                        bucket[0] = (fl[0] & kFlagFeeler) ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock);
+                        have[0] = false;
+                        finished[0] = true;
+                    }
+                }
+            }
+            else if (any)
             {
                 bool fin[kM];
                 if (near_limit)
