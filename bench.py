@@ -449,10 +449,13 @@ def main():
         valu = {"useful_lane_ops_per_s": lane_ops / (kernel_ms * 1e-3), "lane_peak_per_s": VALU_LANE_PEAK,
                 "frac_of_lane_peak": lane_ops / (kernel_ms * 1e-3) / VALU_LANE_PEAK, "lane_use": issue["valu_lane_use"], "valu_busy": issue["valu_busy"],
                 "valu_issue_cycles_frac": issue["valu_wave_instructions_per_launch"] * 2.0 / (1024 * 2.4e9 * kernel_ms * 1e-3),
+                "valu_issue_frac_of_measured_peak": issue["valu_wave_instructions_per_launch"] * 2.5 / (1024 * 2.4e9 * kernel_ms * 1e-3),
                 "note": "instruction count and lane use REPLAYED from " + issue["replayed_from"] + " (the build those counters were taken on), time measured by this run; "
                         "lane peak = 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (a wave64 VALU instruction issues over 2 cycles on CDNA4); valu_issue_cycles_frac = the share of "
-                        "the SIMDs' cycles in which a VALU instruction issues: the kernel is bound by the LATENCY of its 16 waves' dependent instruction streams "
-                        "(4 per SIMD at 128 VGPRs), not by the issue rate"}
+                        "the SIMDs' cycles in which a VALU instruction issues at 2 cycles each; valu_issue_frac_of_measured_peak prices an instruction at the 2.5 cycles per "
+                        "SIMD a stream of independent v_fma_f32 from 8 waves reaches on this chip (profiles/r04_exec_mask_rate.txt, r04_valu_latency.txt), before "
+                        "the quarter-rate and packed instructions in the mix are counted: the kernel's time follows its instruction count — wave splits, "
+                        "priorities, workgroup shapes and more ILP in the march waves all leave the count and the time where they are (docs/LAB_NOTES.md, Round 4)"}
     out = {
         "metric": "probe_rays_per_sec",
         "value": total_rays / (elapsed / args.steps),

@@ -48,9 +48,16 @@ for case in range(n_cases):
                 O.ddgi_update(f, st, frame, o_irr, o_dep, lights=None if lights is None else np.array(lights, dtype=O.LIGHT_DTYPE))
                 ok &= np.array_equal(irr.view(np.uint32), o_irr.view(np.uint32)) and np.array_equal(dep.view(np.uint32), o_dep.view(np.uint32))
         else:
+            # (frames in flight: a random ring length and a random run of back-to-back updates of the same work — the raster read
+            # behind the last one must be the oracle's whichever launch traced it)
+            fif = int(rng.choice([1, 2, 3, 4, 8]))
+            n_up = int(rng.integers(1, 12))
+            eng.set_tuning("frames_in_flight", fif)
             eng.generate_probe_rays(seed=1)
-            eng.probe_update()
+            for _ in range(n_up):
+                eng.probe_update()
             got, _ = eng.read_textures()
+            tag += f" fif {fif} x {n_up} updates"
             rays = O.generate_probe_rays(f, O.new_rand_state(1))
             want, _ = O.probe_update(f, st, rays, lights=None if lights is None else np.array(lights, dtype=O.LIGHT_DTYPE))
             ok = np.array_equal(got, want)
