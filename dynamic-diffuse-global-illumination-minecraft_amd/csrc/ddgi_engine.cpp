@@ -1618,6 +1618,18 @@ int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, si
             return DDGI_OK;
         }
     }
+    // The grouping kernels count a contiguous run of the batch per workgroup in 16-bit LDS counters (256 runs of fewer than 65 536
+    // points): a larger batch is sampled in pieces of at most kGroupChunk points, one after the other on the stream.
+    constexpr size_t kGroupChunk = (static_cast<size_t>(1) << 24) - 65536;
+    if (e->tuning.sample_group && n > kGroupChunk)
+    {
+        for (size_t off = 0; off < n; off += kGroupChunk)
+        {
+            const size_t m = std::min(kGroupChunk, n - off);
+            if (int rc = ddgi_sample_device(e, d_pos + 3 * off, d_nrm + 3 * off, m, d_rgb + 3 * off, d_cage ? d_cage + 8 * off : nullptr)) return rc;
+        }
+        return DDGI_OK;
+    }
     if (e->tuning.sample_group && n >= 4096)  // a batch worth grouping by cage (small ones are launch-latency bound anyway)
     {
         const size_t words = sample_group_scratch_words(a.n, static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.cz);

@@ -162,6 +162,58 @@ def test_sample_paths_agree(ddgi, oracle, name):
     assert 0.02 < inside.mean() < 1.0, inside.mean()
 
 
+def test_grouped_batch_beyond_2p24_points_is_sampled_in_pieces(ddgi, oracle):
+    """The grouping kernels count runs of a batch in 16-bit counters (256 runs of fewer than 65 536 points): a batch of more than
+    2^24 points goes through in pieces.  Every point of a 2^24 + 70 001 point batch grouped by cage must equal the same batch
+    ungrouped, bit for bit, and the oracle on a spread sample — with the per-texel table off, so that the grouped path is the
+    one that runs (REF), and in DDGI mode, which has no table."""
+    import torch
+
+    name = "cave_small"
+    counts, side, s, origin, scene = CONFIGS[name]
+    n = (1 << 24) + 70001
+    g = torch.Generator(device="cuda").manual_seed(5)
+    half = torch.tensor([c * side * 0.55 for c in counts], dtype=torch.float32, device="cuda")
+    pos = (torch.rand((n, 3), generator=g, device="cuda") * 2 - 1) * half + torch.tensor(origin, dtype=torch.float32, device="cuda")
+    nrm = torch.randn((n, 3), generator=g, device="cuda")
+    out = {}
+    with _engine(ddgi, name) as eng:
+        eng.generate_probe_rays(seed=1)
+        eng.probe_update()
+        eng.set_tuning("sample_box", 0)
+        for group in (1, 0):
+            eng.set_tuning("sample_group", group)
+            rgb = torch.full((n, 3), -1.0, dtype=torch.float32, device="cuda")
+            cage = torch.full((n, 8), -7, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()        # (the engine runs on its own stream)
+            eng.sample_device(pos.data_ptr(), nrm.data_ptr(), n, rgb.data_ptr(), cage.data_ptr())
+            eng.synchronize()
+            torch.cuda.synchronize()
+            out[group] = (rgb, cage)
+        assert torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][0].view(torch.int32), out[0][0].view(torch.int32))
+        pick = torch.cat([torch.arange(0, n, 4099, device="cuda"), torch.arange(n - 3000, n, device="cuda")])   # (incl. the last piece)
+        albedo, distance = eng.read_textures()
+        want_rgb, want_cage = oracle.sample(oracle.make_field(counts, side, s, origin), albedo, distance, pos[pick].cpu().numpy(), nrm[pick].cpu().numpy())
+        assert np.array_equal(out[1][1][pick].cpu().numpy(), want_cage)
+        assert np.array_equal(out[1][0][pick].cpu().numpy().view(np.uint32), want_rgb.view(np.uint32))
+        assert 0.1 < (want_cage[:, 0] >= 0).mean() < 1.0
+        # DDGI mode: no table, always grouped
+        del out
+        eng.set_mode(ddgi.MODE_DDGI)
+        for _ in range(2):
+            eng.probe_update()
+        res = {}
+        for group in (1, 0):
+            eng.set_tuning("sample_group", group)
+            rgb = torch.full((n, 3), -1.0, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            eng.sample_device(pos.data_ptr(), nrm.data_ptr(), n, rgb.data_ptr(), None)
+            eng.synchronize()
+            torch.cuda.synchronize()
+            res[group] = rgb
+        assert torch.equal(res[1].view(torch.int32), res[0].view(torch.int32))
+
+
 def test_sharded_slabs_equal_the_full_grid(ddgi, oracle):
     """z-slab sharding: rank r of 2 fills exactly its slab of the slab-major
     texture and nothing else; the union equals the unsharded result."""
