@@ -23,6 +23,25 @@ for k in range(n):
         print("MISMATCH at update", k, h, ref)
         sys.exit(1)
 print("REF mode: %d updates, one digest %s (%.1f s)" % (n, ref[:16], time.time() - t0))
+# frames in flight: runs of back-to-back updates of random length with random host delays in between — some submissions reach a
+# predecessor that still runs (and are continued by its workgroups), some find the stream idle, some arrive as it drains
+rng = np.random.default_rng(7)
+t0 = time.time()
+total = cont0 = 0
+for fif in (8, 4, 2, 3):
+    eng.set_tuning("frames_in_flight", fif)
+    for rep in range(max(1, n // 4)):
+        run = int(rng.integers(1, 21))
+        for _ in range(run):
+            eng.probe_update()
+            if rng.random() < 0.3:
+                time.sleep(float(rng.uniform(0.0, 0.003)))
+        total += run
+        h = hashlib.sha256(eng.read_textures()[0].tobytes()).hexdigest()
+        if h != ref:
+            print("MISMATCH after a run of", run, "updates at frames_in_flight", fif, h, ref)
+            sys.exit(1)
+print("REF mode, frames in flight 8 / 4 / 2 / 3: %d updates in random runs, %d workgroup continuations, one digest (%.1f s)" % (total, eng.get_tuning("continued_workgroups"), time.time() - t0))
 eng.set_mode(ddgi_amd.MODE_DDGI)
 ref = None
 for k in range(n // 4):
