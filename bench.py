@@ -245,10 +245,12 @@ def main():
     ap.add_argument("--mode", choices=["ref", "ddgi"], default="ref",
                     help="ref (default): the reference's live behaviour, the headline metric; ddgi: in-kernel Fibonacci rays + "
                          "octahedral irradiance/depth blend with hysteresis (trace + blend per step)")
-    ap.add_argument("--exchange", choices=["rccl", "p2p"], default="rccl",
-                    help="N > 1: how the ranks' slabs are exchanged — rccl (default): one in-place ncclAllGather per texture; "
-                         "p2p: every rank pushes its slab into its peers' textures (ddgi_exchange_p2p_*, IPC-mapped buffers).  "
-                         "If RCCL cannot be brought up (an error, or no answer within --rccl-timeout seconds) the run falls back to p2p and says so")
+    ap.add_argument("--exchange", choices=["auto", "rccl", "p2p"], default="auto",
+                    help="N > 1: how the ranks' slabs are exchanged — p2p: every rank pushes its slab into its peers' textures "
+                         "(ddgi_exchange_p2p_*, IPC-mapped buffers: copies between GPUs, which overlap the trace kernel's persistent workgroups); "
+                         "rccl: one in-place ncclAllGather per texture; auto (default): p2p, checked on one exchanged update, else rccl.  "
+                         "A transport that cannot be brought up (an error, or for RCCL no answer within --rccl-timeout seconds) is given up "
+                         "for the other one, and the line says so (config.exchange_fallback)")
     ap.add_argument("--rccl-timeout", type=float, default=90.0)
     ap.add_argument("--frames-in-flight", type=int, default=None, help="tuning \"frames_in_flight\" (default: the library's, 8; the reference's host runs MAX_FRAMES_IN_FLIGHT = 2 ahead)")
     args = ap.parse_args()
@@ -274,8 +276,8 @@ def main():
     one_gpu = os.environ.get("DDGI_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local_rank = 0
-        if world > 1 and args.exchange != "p2p":
-            raise SystemExit("DDGI_BENCH_ONE_GPU=1 needs --exchange p2p (RCCL refuses two ranks on one device)")
+        if world > 1 and args.exchange == "rccl":
+            raise SystemExit("DDGI_BENCH_ONE_GPU=1 needs --exchange p2p or auto (RCCL refuses two ranks on one device)")
     torch.cuda.set_device(local_rank)
     # DDGI_BENCH_FORCE_DIST=1: run the N > 1 code path (RCCL group, pipelined exchange) with a single rank — a smoke test of
     # that path on a one-GPU box
@@ -324,10 +326,11 @@ def main():
     exchanging = False
     transport = "none"
     fallback = None
-    if sharded and (args.exchange == "rccl" or world == 1):
+
+    def try_rccl():
         # the engine issues the RCCL all-gather itself (include/ddgi_probe.h: ddgi_exchange_*): rank 0 makes the
         # 128-byte RCCL id, torch.distributed carries it to the other ranks, every rank joins the communicator.
-        # Bounded: an error or no answer within --rccl-timeout on ANY rank sends every rank to the peer-to-peer transport.
+        # Bounded: an error or no answer within --rccl-timeout on ANY rank makes every rank give the transport up.
         def bring_up():
             with _c_stdout_to_stderr():
                 c = ddgi_amd.comm_create(ids[0], world, rank, local_rank)
@@ -337,29 +340,89 @@ def main():
         with _c_stdout_to_stderr():
             ok, res = _call_bounded(ddgi_amd.comm_unique_id, args.rccl_timeout) if rank == 0 else (True, None)
         ids = [res if (rank == 0 and ok) else None]
-        if sharded:
-            dist.broadcast_object_list(ids, src=0)
+        dist.broadcast_object_list(ids, src=0)
         ok = ids[0] is not None
         if ok:
             ok, res = _call_bounded(bring_up, args.rccl_timeout)
-        if ok:
-            comm = res
         if all_ok(ok):
-            exchanging, transport = True, "rccl"
-        else:
-            fallback = "RCCL transport not available (%s on rank %d%s): fell back to --exchange p2p" % (
-                "ok" if ok else str(res)[:200], rank, "" if ok else ", this rank")
-            if ok:
-                eng.exchange_init(None)
-            if world == 1:
-                raise SystemExit(fallback + " — and there is no peer to exchange with at world 1")
-    if sharded and not exchanging and world > 1:
-        # peer-to-peer: every rank publishes its buffers (512 bytes), torch.distributed carries the addresses around
-        mine = eng.exchange_p2p_export(pipelined=True)
+            return True, res, None
+        if ok:
+            eng.exchange_init(None)
+        return False, None, "RCCL transport not available (%s on rank %d%s)" % ("ok" if ok else str(res)[:200], rank, "" if ok else ", this rank")
+
+    def try_p2p():
+        # peer-to-peer: every rank publishes its buffers (512 bytes), torch.distributed carries the addresses around, every rank
+        # maps its peers' textures (IPC) and pushes its slab into them.  An error on ANY rank makes every rank give the transport up;
+        # in REF mode (updates are idempotent) one exchanged update is checked before the transport is trusted: every rank must
+        # hold the same gathered field (its bytes against the unsharded engine and the oracle are checked after the timed region).
+        import hashlib
+
+        why = None
+        try:
+            if os.environ.get("DDGI_BENCH_FAIL_P2P") == "1":   # (fault injection: exercises the fallback's control flow)
+                raise RuntimeError("DDGI_BENCH_FAIL_P2P")
+            mine = eng.exchange_p2p_export(pipelined=True)
+        except Exception as e:                      # noqa: BLE001 (whatever the binding raises: the transport is not available)
+            mine, why = None, "export: " + str(e)[:160]
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
-        eng.exchange_p2p_init(everyone)
-        exchanging, transport = True, "p2p"
+        ok = all(a is not None for a in everyone)
+        if ok:
+            try:
+                eng.exchange_p2p_init(everyone)
+            except Exception as e:                  # noqa: BLE001
+                ok, why = False, "init: " + str(e)[:160]
+        attached = ok
+        ok = all_ok(ok)
+        if ok and not ddgi_mode:
+            digest = None
+            try:
+                for _ in range(2):
+                    eng.probe_update()
+                    eng.exchange()
+                eng.exchange_finish()
+                torch.cuda.synchronize()
+                eng.synchronize()
+                digest = hashlib.sha1(np.ascontiguousarray(eng.read_textures()[0]).tobytes()).hexdigest()
+            except Exception as e:                  # noqa: BLE001
+                why = "first exchange: " + str(e)[:160]
+            digests = [None] * world
+            dist.all_gather_object(digests, digest)
+            ok = digest is not None and all(d == digests[0] for d in digests)
+            if not ok and why is None:
+                why = "the ranks' gathered fields differ after the first exchange"
+            ok = all_ok(ok)
+        if ok:
+            return True, None
+        if attached:
+            try:
+                eng.exchange_init(None)
+            except Exception:                       # noqa: BLE001
+                pass
+        return False, "peer-to-peer transport not available (%s, rank %d)" % (why or "another rank gave up", rank)
+
+    if sharded:
+        # auto (default): peer-to-peer first — its pushes are copies between GPUs, which run beside the trace kernel's persistent
+        # workgroups (they fill every CU's registers and LDS: an RCCL kernel gets a CU only between two launches), RCCL if it fails
+        order = {"auto": ["p2p", "rccl"], "rccl": ["rccl", "p2p"], "p2p": ["p2p"]}[args.exchange]
+        if world == 1:
+            order = ["rccl"]                        # (DDGI_BENCH_FORCE_DIST: the one-rank RCCL group)
+        reasons = []
+        for cand in order:
+            if cand == "rccl":
+                ok, c, why = try_rccl()
+                if ok:
+                    comm = c
+            else:
+                ok, why = try_p2p()
+            if ok:
+                exchanging, transport = True, cand
+                break
+            reasons.append(why)
+        if reasons:
+            fallback = "; ".join(reasons) + (": fell back to %s" % transport if exchanging else "")
+        if not exchanging:
+            raise SystemExit("no exchange transport could be brought up: " + "; ".join(reasons))
 
     pinned_split = bool(os.environ.get("DDGI_AQ_MARCH"))  # (profiling runs pin the split so that every launch is the steady-state kernel)
     frame_time = [0.0]

@@ -25,7 +25,7 @@ timeout 400 bash tools/pmc_run.sh $T > /dev/null 2>&1; python tools/pmc_traffic.
 unset DDGI_AQ_MARCH DDGI_FRAMES_IN_FLIGHT
 # what frames in flight is worth per slab; the N > 1 bench path with 4 ranks on this one GPU (functional)
 timeout 300 python tools/fif_timing.py 2>/dev/null | grep world > $OUT/${R}_${T}_fif_timing.txt
-DDGI_BENCH_ONE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29519 $ROOT/bench.py --gpus 4 --exchange p2p > $OUT/${R}_${T}_bench_p2p_4ranks_one_gpu.json 2> /dev/null
+DDGI_BENCH_ONE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29519 $ROOT/bench.py --gpus 4 > $OUT/${R}_${T}_bench_p2p_4ranks_one_gpu.json 2> /dev/null
 timeout 300 python bench.py --workload c4 --steps 5 --warmup 2 > $OUT/${R}_${T}_c4_bench.json 2> /dev/null
 timeout 400 python bench.py --workload c5 --mode ddgi --steps 12 > $OUT/${R}_${T}_c5_sdyn_ddgi_bench.json 2> /dev/null
 ls -la $OUT
