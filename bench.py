@@ -474,6 +474,22 @@ def main():
         eng.tune()                              # the march/event wave split of this configuration, measured once (blocks; outside the timed region)
         setup_ms["ddgi_tune"] = (time.perf_counter() - t_setup) * 1e3
 
+    # N > 1 on separate GPUs: the queue kernel's persistent workgroups fill every CU, so whatever part of the exchange runs as a
+    # KERNEL (an RCCL collective; a peer copy, if the runtime does it with a shader instead of a copy engine) waits for a launch to
+    # end — unless a few CUs are left free for it ("reserve_cus").  Which it is on this box is measured, not guessed: the same
+    # short run of updates with their exchanges at 0 / 2 / 4 reserved CUs, the maximum over the ranks, the fastest stays.
+    reserve_sweep = None
+    if exchanging and world > 1 and not ddgi_mode and os.environ.get("DDGI_RESERVE_CUS") is None:
+        reserve_sweep = {}
+        for r in (0, 2, 4):
+            eng.set_tuning("reserve_cus", r)
+            reserve_sweep[str(r)] = timed(16, 4) / 16 * 1e3
+        best = min(reserve_sweep, key=lambda k: reserve_sweep[k])
+        if reserve_sweep["0"] <= reserve_sweep[best] * 1.01:
+            best = "0"                          # (within a percent: the full machine)
+        eng.set_tuning("reserve_cus", int(best))
+        reserve_sweep["chosen"] = int(best)
+
     elapsed = timed(args.steps, max(0, args.warmup - 1))   # (the first update above is the first warm-up step)
 
     # kernel durations of the timed steps: HIP events recorded on the launch stream by the engine.  With frames in flight a
@@ -595,6 +611,7 @@ def main():
         out["multi_gpu"] = {
             "transport": transport, "pipelined": True, "ranks_seen": sorted(r["rank"] for r in per_rank), "per_rank": per_rank,
             "ms_per_step_without_exchange": no_x, "exchange_ms_exposed": ms_per_step - no_x,
+            "reserve_cus_ms_per_step": reserve_sweep,
             "note": "exchange_ms_exposed = ms_per_step minus the same timed loop without ddgi_exchange: what the pipelined all-gather costs the critical path",
         }
         gathered = eng.read_textures() if not ddgi_mode else eng.read_tiles()   # a consumer: waits for the latest exchange by itself

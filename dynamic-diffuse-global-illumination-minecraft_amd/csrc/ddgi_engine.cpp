@@ -94,6 +94,7 @@ static const TuningKey kTuningKeys[] = {
     {"lut_off", &Tuning::lut_off, "DDGI_LUT_OFF"},
     {"timing", &Tuning::timing, "DDGI_TIMING"},
     {"frames_in_flight", &Tuning::frames_in_flight, "DDGI_FRAMES_IN_FLIGHT"},
+    {"reserve_cus", &Tuning::reserve_cus, "DDGI_RESERVE_CUS"},
     {"verbose", &Tuning::verbose, "DDGI_VERBOSE"},
 #ifdef DDGI_PROFILING
     {"ablate", &Tuning::ablate, "DDGI_ABLATE"},
@@ -991,6 +992,7 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
         // so that every workgroup gets several: launch_probe_trace_wf)
         const uint32_t chunks = (a.n_rays + 255u) / 256u;
         p.grid = static_cast<uint32_t>(e->num_cus * (p.use_async ? aq_wgs_per_cu() : wf_blocks_per_cu));
+        if (p.use_async && tn.reserve_cus > 0) p.grid = static_cast<uint32_t>(std::max(1, static_cast<int>(p.grid) - tn.reserve_cus * aq_wgs_per_cu()));
         if (p.grid > chunks) p.grid = chunks;
         const size_t slots = static_cast<size_t>(p.grid) * p.pool;
         if (slots > e->wf_cold_slots)

@@ -38,6 +38,8 @@ struct Tuning
     int sample_group = 1;   // ddgi_sample*: handle the points of a batch cage by cage (0: in the order given)
     int noise_lut = 1;      // memoised lattice hashes (0: compute every hash)
     int lut_off = 0;        // profiling: 1 = no wall table, 2 = no random1 table
+    int reserve_cus = 0;    // the queue kernel leaves this many CUs without a workgroup — its persistent workgroups fill a CU's registers and LDS, so a copy or
+                            // collective KERNEL of a multi-GPU exchange otherwise finds no CU until a launch ends (copy-engine transfers need none)
     int verbose = 0;
     int ablate = 0;         // profiling build only (-DDDGI_PROFILING): ablations / fault injection
 };

@@ -219,6 +219,9 @@ int ddgi_tune(ddgi_handle h);
  *                   consumes every update at once loses nothing and gains nothing.  Rings of more than 2 GiB (C4-sized grids and beyond, where
  *                   the drain is a fraction of a percent of an update) are halved, down to two pairs.  Changing it blocks and re-makes the ring (the
  *                   textures carry over); set it before the exchange is attached.                              [DDGI_FRAMES_IN_FLIGHT]
+ *   "reserve_cus"   n > 0: the queue kernel launches n workgroups fewer than the device has CUs.  Its persistent workgroups take a
+ *                   CU's registers and LDS whole, so a KERNEL of a multi-GPU exchange (an RCCL collective, a shader copy) otherwise
+ *                   finds no CU until a launch ends; transfers by the copy engines need none.  0 (default)     [DDGI_RESERVE_CUS]
  *   "timing"        1 (default): every update records two (REF) or three (DDGI) events on its stream for ddgi_last_update_ms /
  *                   ddgi_update_history_ms; 0: none — the queries then fail with DDGI_ERR_NOT_READY, and a stream of
  *                   back-to-back updates loses ~6 us per update less to the command processor                [DDGI_TIMING]

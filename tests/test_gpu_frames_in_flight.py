@@ -135,3 +135,19 @@ def test_device_textures_pins_the_pair(ddgi):
             eng.probe_update()
             assert eng.device_textures()["tex0"] == p0
         assert np.array_equal(eng.read_textures()[0], want)
+
+
+def test_reserved_cus_leave_the_result_alone(ddgi, oracle):
+    """Tuning "reserve_cus": the queue kernel launches fewer workgroups than there are CUs (room for an exchange's kernels on a
+    sharded grid) — same texels, chains of updates included."""
+    name = "cave_small"
+    want = _oracle_albedo(oracle, name, 1)
+    with _engine(ddgi, name) as eng:
+        eng.generate_probe_rays(seed=1, reseed=True)
+        for reserve in (3, 0, 250):
+            eng.set_tuning("reserve_cus", reserve)
+            assert eng.get_tuning("reserve_cus") == reserve
+            for _ in range(5):
+                eng.probe_update()
+            albedo, distance = eng.read_textures()
+            assert np.array_equal(albedo, want) and not distance.any(), reserve
