@@ -244,6 +244,9 @@ DDGI_D uint32_t primary_bucket(uint32_t fl) { return (fl & kFlagDeadHint) ? kBuc
 #ifndef DDGI_VIS_EARLY
 #define DDGI_VIS_EARLY 1  // the feeler class of a hit is asked for before its albedo is evaluated (wf_event)
 #endif
+#ifndef DDGI_INLINE_FEELER
+#define DDGI_INLINE_FEELER 0  // inline steps of a FEELER's march where the bounce rays take more than one (0: as many)
+#endif
 #ifndef DDGI_INLINE_STEPS
 #define DDGI_INLINE_STEPS 2  // voxel steps an event lane takes itself for the march it sets up (one light; see wf_post_march)
 #endif
@@ -367,6 +370,8 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
     const uint32_t base_flags = (feeler ? kFlagFeeler : 0u) | (static_cast<uint32_t>(lid + 1) << 12);
     if (Cfg::kInline > 0)
     {
+        // (a feeler's and a bounce ray's marches may take different numbers of inline steps: DDGI_INLINE_FEELER, 0 = the same)
+        const int n_inline = (feeler && DDGI_INLINE_FEELER > 0 && Cfg::kInline > 1) ? DDGI_INLINE_FEELER : Cfg::kInline;
         const f3 hi = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
         bool occ = false, fin = false;
         float t_end;
@@ -391,7 +396,7 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
             m.t = 0.0f, m.tl = tl, m.it = 0, m.lid = lid, m.cell = 0;
             m.p = ray_at(o, dn, 0.0f);
 #pragma unroll
-            for (int k = 0; k < Cfg::kInline; ++k)
+            for (int k = 0; k < n_inline; ++k)
                 if (!fin)
                 {
                     DDGI_PROBE(lp, 8 + (k < 3 ? k : 3));  // sections 8..11: inline steps 1, 2, 3, 4+
@@ -410,7 +415,7 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
             const bool block_wins = occ && (t_end < tl);
             return static_cast<int>(feeler ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock));
         }
-        P.flags[slot] = kSlotMarch | base_flags | (static_cast<uint32_t>(Cfg::kFast ? 1 : Cfg::kInline) << 4);
+        P.flags[slot] = kSlotMarch | base_flags | (static_cast<uint32_t>(Cfg::kFast ? 1 : n_inline) << 4);
         return -1;
     }
     P.t[slot] = 0.0f;
