@@ -298,7 +298,12 @@ __global__ __launch_bounds__(256) void k_sample_box_filter(const GridK G, const 
     extern __shared__ __attribute__((aligned(16))) float box_lds[];
     const int n = G.n, s = G.sx, sh = G.sy;
     float* unorm = box_lds;
-    float* planes = box_lds + 256;  // [tile][r, g, b][n]
+    float* planes = box_lds + 256;  // [tile][r, g, b][n], tiles kPad words apart
+    // (kTiles consecutive lanes sum the SAME texel of kTiles tiles: with the tiles' planes 3 n words apart — a multiple of 32 for any
+    // n the engine makes — the four lanes of a texel sat on one LDS bank, a 4-way conflict on every one of the 78 reads per lane;
+    // 8 words of padding per tile put the 8 texels x 4 tiles of a half wave on 32 different banks)
+    constexpr int kPad = kTiles > 1 ? 8 : 0;
+    const size_t tile_words = static_cast<size_t>(3) * n + kPad;
     unorm[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;  // blockDim.x == 256
     const uint32_t n_groups = (n_probes + kTiles - 1) / kTiles;
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x)
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256) void k_sample_box_filter(const GridK G, const 
         for (uint32_t t = threadIdx.x; t < tiles * static_cast<uint32_t>(n); t += 256)
         {
             const uint32_t v = src[t];
-            float* pl = planes + static_cast<size_t>(t / n) * 3 * n;
+            float* pl = planes + static_cast<size_t>(t / n) * tile_words;
             const uint32_t tt = t % n;
             pl[tt] = unorm[v & 255u], pl[n + tt] = unorm[(v >> 8) & 255u], pl[2 * n + tt] = unorm[(v >> 16) & 255u];
         }
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256) void k_sample_box_filter(const GridK G, const 
         {
             const uint32_t which = o % kTiles, t = o / kTiles;  // kTiles consecutive lanes: one texel of kTiles consecutive slots
             if (which >= tiles) continue;
-            const float *pr = planes + static_cast<size_t>(which) * 3 * n, *pg = pr + n, *pb = pg + n;
+            const float *pr = planes + static_cast<size_t>(which) * tile_words, *pg = pr + n, *pb = pg + n;
             const f3 v = sample_box_ref(s, sh, static_cast<int>(t % s), static_cast<int>(t / s), [&](int off) { return f3{pr[off], pg[off], pb[off]}; });
             box[box_index(t, slot0 + which, static_cast<uint32_t>(n), n_probes)] = float4{v.x, v.y, v.z, 0.0f};
         }
@@ -330,7 +335,7 @@ hipError_t launch_sample_box_filter(const GridK& grid, const uint32_t* albedo, f
 {
     const uint32_t n_probes = static_cast<uint32_t>(grid.cx) * grid.cy * grid.cz;
     const bool four = grid.n <= 1024;  // (4 tiles' planes in LDS: 48 KB at 1024 texels per tile)
-    const size_t lds = (256 + static_cast<size_t>(3) * grid.n * (four ? 4 : 1)) * sizeof(float);
+    const size_t lds = (256 + (static_cast<size_t>(3) * grid.n + 8) * (four ? 4 : 1)) * sizeof(float);
     const void* fn = four ? reinterpret_cast<const void*>(k_sample_box_filter<4>) : reinterpret_cast<const void*>(k_sample_box_filter<1>);
     hipError_t e = ensure_dynamic_lds(fn, static_cast<int>(lds));
     if (e != hipSuccess) return e;
