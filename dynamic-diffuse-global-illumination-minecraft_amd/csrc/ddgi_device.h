@@ -56,19 +56,78 @@ DDGI_D float axis_inv(float d) { return d == 0.0f ? __builtin_inff() : pm::rcp_u
 // or 0 / inf / NaN when that normalisation was degenerate — never in (0, 2^-96), the part of the line pm::rcp_sqrt_core gets wrong
 DDGI_D f3 normalize3_of_unit(f3 d) { return d * pm::rcp_sqrt_core(dot3(d, d)); }
 
+// ---- the per-update part of a launch's arguments (ddgi_types.h: UpdK), as the trace code reads it ----------------------------
+// UpdOfArgs: straight from the kernel's own arguments (k_probe_trace_ref, k_probe_trace_wf, k_render_primary).
+// UpdOfRing: from a record of the queue kernel's per-update ring, through the constant address space — with a wave-uniform
+// record (k_probe_trace_aq makes it so) every access is a scalar load placed where the value is used, like a kernel argument's.
+struct UpdOfArgs
+{
+    const TraceArgs& A;
+    DDGI_D LightK light(int i) const { return A.lights[i]; }
+    DDGI_D f3 light_pos(int i) const { return f3{A.lights[i].pos[0], A.lights[i].pos[1], A.lights[i].pos[2]}; }
+    DDGI_D void rot(float m9[9]) const
+    {
+        for (int k = 0; k < 9; ++k) m9[k] = A.rot[k];
+    }
+    DDGI_D uint32_t frame_key() const { return A.frame_key; }
+    DDGI_D const float4* rays() const { return A.rays; }
+    DDGI_D float* rad_rgb() const { return A.rad_rgb; }
+    DDGI_D float* rad_dd() const { return A.rad_dd; }
+    DDGI_D const uint8_t* vis() const { return A.vis; }
+    DDGI_D const uint32_t* vis_occ() const { return A.vis_occ; }
+    DDGI_D const uint8_t* vis_more(int k) const { return A.vis_more[k]; }
+};
+struct UpdOfRing
+{
+    typedef const __attribute__((address_space(4))) uint32_t* Words;
+    Words w;
+    static constexpr int kLights = offsetof(UpdK, lights) / 4, kRot = offsetof(UpdK, rot) / 4, kKey = offsetof(UpdK, frame_key) / 4, kRays = offsetof(UpdK, rays) / 4,
+                         kRgb = offsetof(UpdK, rad_rgb) / 4, kDd = offsetof(UpdK, rad_dd) / 4, kVis = offsetof(UpdK, vis) / 4, kOcc = offsetof(UpdK, vis_occ) / 4,
+                         kMore = offsetof(UpdK, vis_more) / 4;
+    DDGI_D explicit UpdOfRing(const uint32_t* record) : w(reinterpret_cast<Words>(reinterpret_cast<uintptr_t>(record))) {}
+    DDGI_D float f(int i) const { return __uint_as_float(w[i]); }
+    template <class T>
+    DDGI_D T* ptr(int i) const
+    {
+        // (through the global address space: a pointer made from an integer is otherwise generic — flat_load / flat_store)
+        typedef __attribute__((address_space(1))) T* Global;
+        return (T*)reinterpret_cast<Global>(static_cast<uintptr_t>(w[i]) | (static_cast<uintptr_t>(w[i + 1]) << 32));
+    }
+    DDGI_D LightK light(int i) const
+    {
+        const int o = kLights + 7 * i;
+        LightK L;
+        L.intensity = f(o), L.col[0] = f(o + 1), L.col[1] = f(o + 2), L.col[2] = f(o + 3), L.pos[0] = f(o + 4), L.pos[1] = f(o + 5), L.pos[2] = f(o + 6);
+        return L;
+    }
+    DDGI_D f3 light_pos(int i) const { return f3{f(kLights + 7 * i + 4), f(kLights + 7 * i + 5), f(kLights + 7 * i + 6)}; }
+    DDGI_D void rot(float m9[9]) const
+    {
+        for (int k = 0; k < 9; ++k) m9[k] = f(kRot + k);
+    }
+    DDGI_D uint32_t frame_key() const { return w[kKey]; }
+    DDGI_D const float4* rays() const { return ptr<const float4>(kRays); }
+    DDGI_D float* rad_rgb() const { return ptr<float>(kRgb); }
+    DDGI_D float* rad_dd() const { return ptr<float>(kDd); }
+    DDGI_D const uint8_t* vis() const { return ptr<const uint8_t>(kVis); }
+    DDGI_D const uint32_t* vis_occ() const { return ptr<const uint32_t>(kOcc); }
+    DDGI_D const uint8_t* vis_more(int k) const { return ptr<const uint8_t>(kMore + 2 * k); }
+};
+static_assert(sizeof(LightK) == 28, "UpdOfRing::light reads a light as 7 consecutive words");
+
 // The light-sphere half of intersect_scene (intersection.glsl:1264-1279): nearest hit of the ray
 // (o, d) with the radius-0.1 spheres around the lights; +inf / -1 if none.
 // Unit-sphere quadratic in a space scaled by 10 (x/0.1 := x*10, P5).
 // kNl > 0: the number of lights is known at compile time (the queue kernel's one-light instantiation)
-template <int kNl = 0>
-DDGI_D void light_spheres(f3 o, f3 d, const TraceArgs& A, float& tl_out, int& lid_out)
+template <int kNl = 0, class Upd>
+DDGI_D void light_spheres(f3 o, f3 d, const TraceArgs& A, const Upd& U, float& tl_out, int& lid_out)
 {
     float closest = __builtin_inff();
     int lid = -1;
     const int nl = kNl > 0 ? kNl : A.nl;
     for (int i = 0; i < nl; ++i)
     {
-        const f3 lp{A.lights[i].pos[0], A.lights[i].pos[1], A.lights[i].pos[2]};
+        const f3 lp = U.light_pos(i);
         const f3 so = (o - lp) * 10.0f;
         const f3 sd = d * 10.0f;
         const float qa = dot3(sd, sd);
@@ -105,7 +164,7 @@ DDGI_D void start_march(March& m, f3 o, f3 d, const TraceArgs& A)
     m.p = o;
     m.t = 0.0f;
     m.it = 0;
-    light_spheres<0>(o, d, A, m.tl, m.lid);
+    light_spheres<0>(o, d, A, UpdOfArgs{A}, m.tl, m.lid);
 }
 
 // Raw linear cell index of voxel id (x,y,z) clamped into the baked box.  Outside the box the world is

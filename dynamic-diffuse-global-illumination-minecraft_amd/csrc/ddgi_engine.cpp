@@ -180,6 +180,7 @@ static int validate_tile(const ddgi_irradiance_field* f, int tx, int ty)
 constexpr int kMaxDdgiRays = 4096;  // DDGI mode: rays per probe (the cross-check blend kernel keeps 28 B per ray in LDS)
 
 static int check_kernel_status(ddgi_engine* e);
+static void free_vis_tables(ddgi_engine::DevScene& d);
 
 // Byte sizes of the two probe textures of a configuration.
 void ddgi_texture_bytes(int mode, const ddgi_irradiance_field& f, int rays_per_probe, size_t bytes[2])
@@ -194,10 +195,10 @@ void ddgi_texture_bytes(int mode, const ddgi_irradiance_field& f, int rays_per_p
         bytes[0] = bytes[1] = probes * static_cast<size_t>(rays_per_probe) * 4;
 }
 
-// Updates one launch of the queue kernel may work on (tuning "frames_in_flight"): REF mode on the handle's own textures only —
-// DDGI mode's updates differ from frame to frame (ray rotation, RNG keys, animated lights), and a host that holds pointers to a
-// pair (ddgi_bind_textures, ddgi_device_textures) expects the handle to stay on it.  The pair a ray writes travels in the top
-// three bits of its texel index (ddgi_trace_wf.hip: kDstPairShift).
+// REF mode: updates one launch of the queue kernel may work on (tuning "frames_in_flight") = texture pairs a group of updates takes,
+// on the handle's own textures only — a host that holds pointers to a pair (ddgi_bind_textures, ddgi_device_textures) expects the
+// handle to stay on it.  The pair a ray writes travels in the top three bits of its texel index (ddgi_trace_wf.hip: kDstPairShift).
+// (DDGI mode's trace writes ray records, not textures: its group is the ring of record buffers, rec_ring_len below.)
 static int chain_len_for(const ddgi_engine* e, size_t albedo_bytes)
 {
     if (e->mode != DDGI_MODE_REF || e->pin_pair || e->caller_tex) return 1;
@@ -210,6 +211,23 @@ static int chain_len_for(const ddgi_engine* e, size_t albedo_bytes)
     return len;
 }
 int ddgi_chain_len(const ddgi_engine* e) { return chain_len_for(e, e->tex_bytes[0]); }
+
+// DDGI mode: ray-record buffers the handle keeps = updates one launch may work on.  The blend of update k reads the records of
+// update k behind that update's own launch, while a launch may already be tracing k + 1 ..: every update of a group has its own
+// buffer (20 B per ray: C3 84 MB, C4 1.3 GB, C5 5.4 GB — the ring stays below 16 GiB of the 288).
+static int rec_ring_len(const ddgi_engine* e, size_t rec_bytes, size_t local_rays)
+{
+    if (local_rays >= (static_cast<size_t>(1) << 29)) return 1;  // (the update a ray belongs to travels in the top three bits of its index)
+    int len = std::min(kAqChainMax, std::max(1, e->tuning.frames_in_flight));
+    while (len > 1 && rec_bytes * static_cast<size_t>(len) > (static_cast<size_t>(16) << 30)) len /= 2;
+    return len;
+}
+int ddgi_group_len(const ddgi_engine* e)
+{
+    if (e->mode == DDGI_MODE_DDGI) return std::max(1, e->nrec);
+    if (e->caller_tex || (e->pin_pair && !e->xch.pipelined)) return 1;
+    return std::max(1, std::min(ddgi_chain_len(e), e->np));
+}
 
 // Pairs the handle's ring should hold: one per update a launch may work on; twice that (at least two) when the multi-GPU
 // exchange is pipelined — the all-gathers of one group's pairs run while the next group's are written.
@@ -516,6 +534,8 @@ int ddgi_destroy(ddgi_handle e)
     if (e->d_blend_w) (void)hipFree(e->d_blend_w);
     if (e->d_work) (void)hipFree(e->d_work);
     if (e->pub) (void)hipHostFree(e->pub);
+    if (e->upd_host) (void)hipHostFree(e->upd_host);
+    if (e->upd_dev) (void)hipFree(e->upd_dev);
     for (auto& m : e->milestone)
         if (m) (void)hipEventDestroy(m);
     if (e->d_wf_cold) (void)hipFree(e->d_wf_cold);
@@ -527,11 +547,7 @@ int ddgi_destroy(ddgi_handle e)
         if (d.bits) (void)hipFree(d.bits);
         if (d.types) (void)hipFree(d.types);
         if (d.skip) (void)hipFree(d.skip);
-        if (d.vis) (void)hipFree(d.vis);
-        if (d.vis_occ) (void)hipFree(d.vis_occ);
-        if (d.vis_list) (void)hipFree(d.vis_list);
-        for (auto& v : d.vis_more)
-            if (v) (void)hipFree(v);
+        free_vis_tables(d);
     }
     for (auto& triple : e->ev)
         for (auto& ev : triple)
@@ -786,6 +802,105 @@ static unsigned long long aq_config_key(const ddgi_engine* e, const TraceArgs& a
     return h | 1ull;
 }
 
+static void free_vis_tables(ddgi_engine::DevScene& d)
+{
+    for (auto& set : d.vis_set)
+    {
+        for (auto& v : set.vis)
+            if (v) (void)hipFree(v);
+        if (set.occ) (void)hipFree(set.occ);
+        set = ddgi_engine::DevScene::VisSet{};
+    }
+    if (d.vis_list) (void)hipFree(d.vis_list);
+    d.vis_list = nullptr, d.n_vis_list = -1;
+}
+
+// ---- light-feeler classes (ddgi_visibility.hip) ------------------------------------------------------------------------
+// Which feelers need no march: one table per light (the first kVisLights) and light position, in sets (ddgi_engine.h: VisSet).
+
+static bool vis_set_holds(const ddgi_engine::DevScene::VisSet& set, const LightK* lights, int nl)
+{
+    for (int li = 0; li < nl && li < kVisLights; ++li)
+        if (!set.vis[li] || !set.valid[li] || std::memcmp(set.light[li], lights[li].pos, sizeof(set.light[li])) != 0) return false;
+    return true;
+}
+
+// A set that holds the tables of exactly these light positions, complete before launch `before_seq` starts (computed by kernels
+// that stand in front of it in the stream); -1: none.  any_seq: computed at all (the caller's own launch stands behind them).
+static int find_vis_set(const ddgi_engine* e, int scene, const LightK* lights, int nl, bool any_seq, uint32_t before_seq)
+{
+    const ddgi_engine::DevScene& d = e->dev_scene[scene];
+    for (int k = 0; k < kAqChainMax; ++k)
+        if (vis_set_holds(d.vis_set[k], lights, nl) && (any_seq || static_cast<int32_t>(d.vis_set[k].launch_seq - before_seq) <= 0)) return k;
+    return -1;
+}
+
+// Makes set `k` hold the tables of these light positions: allocates what is missing, runs k_light_visibility for every light whose
+// table is missing or stale (on the handle's stream: complete before the next launch starts).
+static int fill_vis_set(ddgi_engine* e, int scene, const SceneK& sk, const LightK* lights, int nl, int k)
+{
+    ddgi_engine::DevScene& d = e->dev_scene[scene];
+    const int n_vox = (sk.hi[0] - sk.lo[0] + 1) * (sk.hi[1] - sk.lo[1] + 1) * (sk.hi[2] - sk.lo[2] + 1);
+    if (d.n_vis_list < 0)
+    {
+        // the voxels a feeler can start in, once per scene: empty with an occupied face neighbour (clamped lookups: outside
+        // the box the world is the extrusion of the border layer)
+        const SceneBake& bk = scene == 3 ? e->user_scene : baked_scene(scene);
+        std::vector<int32_t> list;
+        for (int z = bk.lo[2]; z <= bk.hi[2]; ++z)
+            for (int y = bk.lo[1]; y <= bk.hi[1]; ++y)
+                for (int x = bk.lo[0]; x <= bk.hi[0]; ++x)
+                {
+                    if (bk.block_at(x, y, z) > 0) continue;
+                    const int r = ((z - bk.lo[2]) * bk.dim[1] + (y - bk.lo[1])) * bk.dim[0] + (x - bk.lo[0]);
+                    const int nb[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};  // face = 2 axis + (+ side)
+                    for (int fc = 0; fc < 6; ++fc)
+                        if (bk.block_at(x + nb[fc][0], y + nb[fc][1], z + nb[fc][2]) > 0) list.push_back(r * 8 + fc);
+                }
+        if (!list.empty())
+        {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d.vis_list), list.size() * sizeof(int32_t)));
+            HIP_TRY(hipMemcpy(d.vis_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+        d.n_vis_list = static_cast<int>(list.size());
+    }
+    ddgi_engine::DevScene::VisSet& set = d.vis_set[k];
+    for (int li = 0; li < nl && li < kVisLights; ++li)
+    {
+        if (!set.vis[li])
+        {
+            // one class byte per (voxel, face); light 0 also lists the occupied voxels of a kVisListed bundle (written and read only
+            // for entries of that class: no initialisation; 128 B per voxel — a user scene of more than 4 M voxels goes without
+            // lists, i.e. without the class).  Allocated into locals and committed together: a failure half way (a large user
+            // scene) must not leave a table without its lists behind for the next update to trip over
+            uint8_t* vis = nullptr;
+            uint32_t* occ = nullptr;
+            hipError_t he = hipMalloc(reinterpret_cast<void**>(&vis), static_cast<size_t>(n_vox) * 8);
+            if (he == hipSuccess) he = hipMemsetAsync(vis, 0, static_cast<size_t>(n_vox) * 8, e->stream);
+            const size_t occ_bytes = static_cast<size_t>(n_vox) * 8 * kVisListMax * sizeof(uint32_t);
+            if (he == hipSuccess && li == 0 && !set.occ && occ_bytes <= (static_cast<size_t>(512) << 20)) he = hipMalloc(reinterpret_cast<void**>(&occ), occ_bytes);
+            if (he != hipSuccess)
+            {
+                if (vis) (void)hipFree(vis);
+                if (occ) (void)hipFree(occ);
+                return fail(he == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY : DDGI_ERR_HIP, "allocating the light-feeler classes failed: %s", hipGetErrorString(he));
+            }
+            set.vis[li] = vis;
+            if (occ) set.occ = occ;
+            set.valid[li] = false;
+        }
+        if (!set.valid[li] || std::memcmp(set.light[li], lights[li].pos, sizeof(set.light[li])) != 0)
+        {
+            // (lights 1 ..: classes only — no lists of occupied voxels: the event of a hit under several lights does not use them)
+            HIP_TRY(launch_light_visibility(sk, lights[li].pos, d.vis_list, d.n_vis_list, set.vis[li], li == 0 ? set.occ : nullptr, e->stream));
+            std::memcpy(set.light[li], lights[li].pos, sizeof(set.light[li]));
+            set.valid[li] = true;
+            set.launch_seq = e->launch_seq;  // (launches before this one stand IN FRONT of the table's kernel in the stream)
+        }
+    }
+    return DDGI_OK;
+}
+
 // One probe update's trace launch, fully decided: arguments, kernel, pool, grid.  Built by plan_trace (which
 // also makes sure every buffer the launch needs exists), used by ddgi_probe_update and ddgi_tune.
 struct TracePlan
@@ -829,106 +944,39 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
         const uint32_t local_probes = static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.czl;
         p.rec_rgb = rec_rgb_floats(local_probes, static_cast<uint32_t>(a.grid.n));
         const size_t rec_floats = p.rec_rgb + rec_dd_floats(local_probes, static_cast<uint32_t>(a.grid.n));
-        if (rec_floats > e->d_radiance_capacity || e->d_radiance_rays != a.grid.n)
+        int want = rec_ring_len(e, rec_floats * sizeof(float), local_rays);
+        if (!e->d_radiance || rec_floats != e->rec_stride || want != e->nrec || e->d_radiance_rays != a.grid.n)
         {
-            // (re)allocated zeroed: the records of padding rays / padding probes are never written and must read as 0
-            if (e->d_radiance) (void)hipFree(e->d_radiance);
+            // (re)allocated zeroed: the records of padding rays / padding probes are never written and must read as 0.  A ring of
+            // `want` buffers (frames in flight); if that much memory is not to be had, one buffer and no continuation.
+            if (e->d_radiance) (void)hipFree(e->d_radiance);  // (waits for the device: no launch is still writing records)
             e->d_radiance = nullptr;
-            e->d_radiance_capacity = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_radiance), rec_floats * sizeof(float)));
-            HIP_TRY(hipMemsetAsync(e->d_radiance, 0, rec_floats * sizeof(float), e->stream));
-            e->d_radiance_capacity = rec_floats;
+            e->d_radiance_capacity = 0, e->rec_stride = 0, e->nrec = 1;
+            hipError_t he = hipMalloc(reinterpret_cast<void**>(&e->d_radiance), rec_floats * sizeof(float) * static_cast<size_t>(want));
+            if (he == hipErrorOutOfMemory && want > 1)
+            {
+                (void)hipGetLastError();
+                want = 1;
+                he = hipMalloc(reinterpret_cast<void**>(&e->d_radiance), rec_floats * sizeof(float));
+            }
+            HIP_TRY(he);
+            HIP_TRY(hipMemsetAsync(e->d_radiance, 0, rec_floats * sizeof(float) * static_cast<size_t>(want), e->stream));
+            e->d_radiance_capacity = rec_floats * static_cast<size_t>(want);
             e->d_radiance_rays = a.grid.n;
+            e->rec_stride = rec_floats, e->nrec = want;
+            e->chain_break = true;
         }
         animate_lights(scene, e->settings.time, e->lights[scene], a.nl, a.lights);
         a.ddgi = 1;
         a.frame_key = frame_key(e->frame);
         frame_rotation(e->frame, a.rot);
-        a.rad_rgb = e->d_radiance;
+        a.rad_rgb = e->d_radiance;  // (buffer 0; ddgi_probe_update moves the update to the buffer of its number)
         a.rad_dd = e->d_radiance + p.rec_rgb;
         a.rays = nullptr;
         a.n_rays = static_cast<uint32_t>(local_rays);
     }
-    // which feelers need no march (ddgi_visibility.hip): one table per light (the first kVisLights), recomputed when the light has moved
-    if (a.nl >= 1 && tn.light_vis && tn.trace_kernel != 2)
-    {
-        ddgi_engine::DevScene& d = e->dev_scene[scene];
-        const int n_vox = (a.scene.hi[0] - a.scene.lo[0] + 1) * (a.scene.hi[1] - a.scene.lo[1] + 1) * (a.scene.hi[2] - a.scene.lo[2] + 1);
-        if (!d.vis)
-        {
-            // the voxels a feeler can start in, once per scene: empty with an occupied face neighbour (clamped lookups: outside
-            // the box the world is the extrusion of the border layer)
-            const SceneBake& bk = scene == 3 ? e->user_scene : baked_scene(scene);
-            std::vector<int32_t> list;
-            for (int z = bk.lo[2]; z <= bk.hi[2]; ++z)
-                for (int y = bk.lo[1]; y <= bk.hi[1]; ++y)
-                    for (int x = bk.lo[0]; x <= bk.hi[0]; ++x)
-                    {
-                        if (bk.block_at(x, y, z) > 0) continue;
-                        const int r = ((z - bk.lo[2]) * bk.dim[1] + (y - bk.lo[1])) * bk.dim[0] + (x - bk.lo[0]);
-                        const int nb[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};  // face = 2 axis + (+ side)
-                        for (int fc = 0; fc < 6; ++fc)
-                            if (bk.block_at(x + nb[fc][0], y + nb[fc][1], z + nb[fc][2]) > 0) list.push_back(r * 8 + fc);
-                    }
-            // allocated into locals and committed together: a failure half way (a large user scene) must not leave a table
-            // without its lists behind for the next update to trip over
-            uint8_t* vis = nullptr;
-            uint32_t* vis_occ = nullptr;
-            int32_t* vis_list = nullptr;
-            hipError_t he = hipMalloc(reinterpret_cast<void**>(&vis), static_cast<size_t>(n_vox) * 8);  // one class byte per (voxel, face)
-            if (he == hipSuccess) he = hipMemsetAsync(vis, 0, static_cast<size_t>(n_vox) * 8, e->stream);
-            // (the lists are written and read only for entries of class kVisListed: no initialisation; 128 B per voxel — a user scene
-            // of more than 4 M voxels goes without lists, i.e. without the class)
-            const size_t occ_bytes = static_cast<size_t>(n_vox) * 8 * kVisListMax * sizeof(uint32_t);
-            if (he == hipSuccess && occ_bytes <= (static_cast<size_t>(512) << 20)) he = hipMalloc(reinterpret_cast<void**>(&vis_occ), occ_bytes);
-            if (he == hipSuccess && !list.empty())
-            {
-                he = hipMalloc(reinterpret_cast<void**>(&vis_list), list.size() * sizeof(int32_t));
-                if (he == hipSuccess) he = hipMemcpy(vis_list, list.data(), list.size() * sizeof(int32_t), hipMemcpyHostToDevice);
-            }
-            if (he != hipSuccess)
-            {
-                if (vis) (void)hipFree(vis);
-                if (vis_occ) (void)hipFree(vis_occ);
-                if (vis_list) (void)hipFree(vis_list);
-                return fail(he == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY : DDGI_ERR_HIP, "allocating the light-feeler classes failed: %s", hipGetErrorString(he));
-            }
-            d.vis = vis, d.vis_occ = vis_occ, d.vis_list = vis_list;
-            d.n_vis_list = static_cast<int>(list.size());
-        }
-        if (!d.vis_valid || std::memcmp(d.vis_light, a.lights[0].pos, sizeof(d.vis_light)) != 0)
-        {
-            HIP_TRY(launch_light_visibility(a.scene, a.lights[0].pos, d.vis_list, d.n_vis_list, d.vis, d.vis_occ, e->stream));
-            std::memcpy(d.vis_light, a.lights[0].pos, sizeof(d.vis_light));
-            d.vis_valid = true;
-        }
-        a.vis = d.vis;
-        a.vis_occ = d.vis_occ;
-        // lights 1 ..: classes only (no lists of occupied voxels: the event of a hit under several lights does not use them)
-        for (int li = 1; li < a.nl && li < kVisLights; ++li)
-        {
-            uint8_t*& v = d.vis_more[li - 1];
-            if (!v)
-            {
-                hipError_t he = hipMalloc(reinterpret_cast<void**>(&v), static_cast<size_t>(n_vox) * 8);
-                if (he == hipSuccess) he = hipMemsetAsync(v, 0, static_cast<size_t>(n_vox) * 8, e->stream);
-                if (he != hipSuccess)
-                {
-                    if (v) (void)hipFree(v);
-                    v = nullptr;
-                    return fail(he == hipErrorOutOfMemory ? DDGI_ERR_OUT_OF_MEMORY : DDGI_ERR_HIP, "allocating the light-feeler classes failed: %s", hipGetErrorString(he));
-                }
-                d.vis_more_valid[li - 1] = false;
-            }
-            if (!d.vis_more_valid[li - 1] || std::memcmp(d.vis_more_light[li - 1], a.lights[li].pos, sizeof(d.vis_more_light[li - 1])) != 0)
-            {
-                HIP_TRY(launch_light_visibility(a.scene, a.lights[li].pos, d.vis_list, d.n_vis_list, v, nullptr, e->stream));
-                std::memcpy(d.vis_more_light[li - 1], a.lights[li].pos, sizeof(d.vis_more_light[li - 1]));
-                d.vis_more_valid[li - 1] = true;
-            }
-            a.vis_more[li - 1] = v;
-        }
-    }
+    // (the light-feeler classes — a.vis, a.vis_occ, a.vis_more — are assigned by assign_vis, once the caller knows whether the
+    // update continues its predecessor)
     a.albedo = static_cast<uint32_t*>(e->tex[0]);
     a.distance = static_cast<uint32_t*>(e->tex[1]);
     a.wait_threshold = tn.wait_threshold;
@@ -988,6 +1036,18 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
             HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->pub_dev), e->pub, 0));
             for (auto& m : e->milestone) HIP_TRY(hipEventCreateWithFlags(&m, hipEventDisableTiming));
         }
+        if (!e->upd_host)
+        {
+            // the per-update records (ddgi_types.h: UpdK): written here by the host, copied into the device ring by the kernel's workgroups
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->upd_host), kAqPubRing * sizeof(UpdK), hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(e->upd_host, 0, kAqPubRing * sizeof(UpdK));
+            HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->upd_host_dev), e->upd_host, 0));
+        }
+        if (!e->upd_dev)
+        {
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->upd_dev), kAqCounters * sizeof(UpdK)));
+            HIP_TRY(hipMemsetAsync(e->upd_dev, 0, kAqCounters * sizeof(UpdK), e->stream));
+        }
         // one persistent workgroup per CU unless the launch is tiny (the launcher sizes the ray claims
         // so that every workgroup gets several: launch_probe_trace_wf)
         const uint32_t chunks = (a.n_rays + 255u) / 256u;
@@ -1028,13 +1088,109 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
     return DDGI_OK;
 }
 
-// What a launch is, for "is the next update the same work": every argument of the kernel but the textures it writes, and the
-// kernel's shape.  (What the arguments POINT at — rays, scene, tables — is covered by ddgi_engine::chain_break: every entry point
-// that can change any of it sets it.)
+// The light-feeler classes of plan p's update (a.vis, a.vis_occ, a.vis_more).
+//   follows (in / out; null: a launch outside the sequence of updates, ddgi_tune): the update would be published as the
+//     continuation of its predecessor.  A launch that goes on with this update's rays reads the update's tables — so they must be
+//     complete before the CHAIN'S FIRST launch starts, i.e. computed by kernels submitted in front of it.  Are there none (the
+//     lights have moved to where nobody expected them), the update is not continued: *follows = false, it starts a chain of its
+//     own behind the kernels that compute its tables — what every update with moved lights did before round 5.
+//   chain_ahead: the updates a chain that starts with this update may go on to.  Their tables are made NOW, for the light
+//     positions they are expected to have: the same lights (REF mode, ddgi_set_lights apart), or update_lights at the times the
+//     host's steps so far lead to (DDGI mode: the reference adds 2 to RenderSettings::time per frame, src/rvpt/rvpt.cpp:281).
+//     As many updates ahead as the host has lately been running ahead (ddgi_engine::runahead): a host that waits for every
+//     update pays for no prediction.  A prediction that does not come true costs its kernel (34 us on the cave), never a result.
+static int assign_vis(ddgi_engine* e, TracePlan& p, bool* follows, int chain_ahead)
+{
+    TraceArgs& a = p.a;
+    a.vis = nullptr, a.vis_occ = nullptr;
+    for (auto& v : a.vis_more) v = nullptr;
+    const Tuning& tn = e->tuning;
+    if (!(a.nl >= 1 && tn.light_vis && tn.trace_kernel != 2)) return DDGI_OK;
+    const int scene = a.scene_id;
+    ddgi_engine::DevScene& d = e->dev_scene[scene];
+    int k = -1;
+    if (follows && *follows)
+    {
+        k = find_vis_set(e, scene, a.lights, a.nl, false, e->chain_first_seq);
+        if (k < 0) *follows = false;
+    }
+    if (k < 0)
+    {
+        k = find_vis_set(e, scene, a.lights, a.nl, true, 0u);
+        unsigned used = 0u;
+        auto victim = [&]() {  // a set this call has not used: the least recently computed one
+            int best = -1;
+            for (int i = 0; i < kAqChainMax; ++i)
+                if (!((used >> i) & 1u) && (best < 0 || static_cast<int32_t>(d.vis_set[i].launch_seq - d.vis_set[best].launch_seq) < 0)) best = i;
+            return best;
+        };
+        if (k < 0)
+        {
+            k = victim();
+            if (int rc = fill_vis_set(e, scene, a.scene, a.lights, a.nl, k)) return rc;
+        }
+        used |= 1u << k;
+        const int n_pred = follows ? std::min(e->runahead, std::min(chain_ahead, kAqChainMax - 1)) : 0;
+        if (n_pred > 0 && p.ddgi_mode)
+        {
+            const float dt = e->have_last_time ? e->settings.time - e->last_time : 0.0f;
+            float t = e->settings.time;
+            LightK pl[kMaxLights];
+            for (int j = 1; j <= n_pred; ++j)
+            {
+                t += dt;  // (as the host's own `time += step` rounds)
+                animate_lights(scene, t, e->lights[scene], a.nl, pl);
+                int kk = find_vis_set(e, scene, pl, a.nl, true, 0u);
+                if (kk < 0)
+                {
+                    kk = victim();
+                    if (kk < 0) break;
+                    if (int rc = fill_vis_set(e, scene, a.scene, pl, a.nl, kk)) return rc;
+                }
+                used |= 1u << kk;
+            }
+        }
+    }
+    const ddgi_engine::DevScene::VisSet& set = d.vis_set[k];
+    a.vis = set.vis[0];
+    a.vis_occ = set.occ;
+    for (int li = 1; li < a.nl && li < kVisLights; ++li) a.vis_more[li - 1] = set.vis[li];
+    return DDGI_OK;
+}
+
+// The part of a launch's arguments that may differ between the updates one launch works on (ddgi_types.h: UpdK).
+static UpdK upd_of(const TraceArgs& a)
+{
+    UpdK u;
+    std::memset(&u, 0, sizeof u);
+    for (int i = 0; i < kMaxLights; ++i) u.lights[i] = a.lights[i];
+    for (int i = 0; i < 9; ++i) u.rot[i] = a.rot[i];
+    u.frame_key = a.frame_key;
+    u.rays = a.rays, u.rad_rgb = a.rad_rgb, u.rad_dd = a.rad_dd;
+    u.vis = a.vis, u.vis_occ = a.vis_occ;
+    for (int i = 0; i < kVisLights - 1; ++i) u.vis_more[i] = a.vis_more[i];
+    return u;
+}
+
+// What a launch is, for "can the predecessor's launch go on with this update's rays": every argument of the kernel but the textures
+// it writes, and the kernel's shape.  DDGI mode: also without the per-update record (upd_of: lights, rotation, key, ray / record
+// buffers, feeler classes) — its kernels read those per update.  REF mode's kernels read them from their own arguments: equal
+// byte for byte, or no continuation.  (What the other arguments POINT at — scene, noise tables, the rays — is covered by
+// ddgi_engine::chain_break: every entry point that can change any of it sets it.)
 static unsigned long long plan_hash(const TracePlan& p, int march_waves)
 {
     TraceArgs a = p.a;
     a.albedo = a.distance = nullptr;
+    if (p.ddgi_mode)
+    {
+        std::memset(a.lights, 0, sizeof a.lights);
+        std::memset(a.rot, 0, sizeof a.rot);
+        a.frame_key = 0;
+        a.rays = nullptr, a.rad_rgb = a.rad_dd = nullptr;
+    }
+    // (the feeler classes follow from the scene and the lights' positions: assign_vis gives equal lights the same tables, or says no)
+    a.vis = nullptr, a.vis_occ = nullptr;
+    for (auto& v : a.vis_more) v = nullptr;
     unsigned long long h = 1469598103934665603ull;
     const unsigned char* b = reinterpret_cast<const unsigned char*>(&a);
     for (size_t i = 0; i < sizeof a; ++i) h = (h ^ b[i]) * 1099511628211ull;
@@ -1065,9 +1221,15 @@ static int launch_aq_numbered(ddgi_engine* e, const TracePlan& p, int march_wave
         if (seq >= 32u) HIP_TRY(hipEventSynchronize(e->milestone[m]));  // (recorded 32 launches ago)
         HIP_TRY(hipEventRecord(e->milestone[m], e->stream));
     }
+    // The update's record (ddgi_types.h: UpdK), written before the release store that publishes the update: its own launch's
+    // workgroups read it, and those of a predecessor's launch that goes on with its rays.
+    if (!publish) e->chain_first_seq = seq;
+    *(reinterpret_cast<UpdK*>(e->upd_host) + static_cast<size_t>(seq & (kAqPubRing - 1u))) = upd_of(p.a);
     // (a slot still holds what launch seq - 64 left there, which is never seq + 1)
     __atomic_store_n(&e->pub[seq & (kAqPubRing - 1u)], publish ? seq + 1u : 0u, __ATOMIC_RELEASE);
     AqChain c;
+    c.upd_host = e->upd_host_dev;
+    c.upd_dev = e->upd_dev;
     c.counters = e->d_work + 8;
     c.continued = e->d_work + 4;
     c.pub = e->pub_dev;
@@ -1168,6 +1330,7 @@ int ddgi_tune(ddgi_handle e)
     TracePlan p;
     if (int rc = plan_trace(e, p)) return rc;
     if (!p.use_async) return DDGI_OK;  // nothing to tune for the other trace kernels
+    if (int rc = assign_vis(e, p, nullptr, 0)) return rc;
     int mw = 0;
     return choose_march_waves(e, p, true, true, &mw);
 }
@@ -1200,11 +1363,26 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     // whatever that one left is traced there, and everything stream-ordered behind an update's launch sees the update complete.
     // Which pair an update writes and where it stands in its group depend on the NUMBER of the update only (ring_k: updates since
     // the ring was made) — every rank of a sharded grid must pick the same pair whatever it decides locally about continuing.
-    const int group = (e->caller_tex || (e->pin_pair && !e->xch.pipelined)) ? 1 : std::max(1, std::min(ddgi_chain_len(e), e->np));
-    const int pos = e->np % group == 0 ? static_cast<int>(e->ring_k % static_cast<unsigned long long>(group)) : 0;
-    const bool can_chain = group > 1 && e->np % group == 0 && p.pool > 0 && p.use_async && !p.ddgi_mode && a.stats == nullptr && !measure_split;
+    // DDGI mode (round 5): the trace writes ray records, not textures — a group is the ring of record buffers (plan_trace), update k
+    // writes buffer k % nrec, and what differs from update to update (rotation, key, animated lights, the buffer) travels in the
+    // update's record (ddgi_types.h: UpdK), which the kernel reads per update.
+    const int group = ddgi_group_len(e);
+    const bool ring_fits = p.ddgi_mode || e->np % group == 0;
+    const int pos = ring_fits ? static_cast<int>(e->ring_k % static_cast<unsigned long long>(group)) : 0;
+    const bool can_chain = group > 1 && ring_fits && p.pool > 0 && p.use_async && a.stats == nullptr && !measure_split;
+    if (p.ddgi_mode)
+    {
+        a.rad_rgb = e->d_radiance + static_cast<size_t>(pos) * e->rec_stride;
+        a.rad_dd = a.rad_rgb + p.rec_rgb;
+    }
     const unsigned long long hash = plan_hash(p, march_waves);
-    const bool follows = can_chain && pos > 0 && !e->chain_break && hash == e->chain_hash;
+    // (how far the host runs ahead of its blocking calls: updates that arrive with nothing but updates / exchanges / consumers since
+    // their predecessor raise it, a blocking call that found nothing to continue lowers it — assign_vis predicts that far)
+    if (!e->chain_break) e->runahead = std::min(kAqChainMax - 1, e->runahead + 1);
+    else if (e->chain_published == 0) e->runahead = std::max(0, e->runahead - 1);
+    if (e->chain_break) e->chain_published = 0;
+    bool follows = can_chain && pos > 0 && !e->chain_break && hash == e->chain_hash;
+    if (int rc = assign_vis(e, p, &follows, can_chain ? group - 1 - pos : 0)) return rc;
     // (what the handle goes back to when the update cannot be launched: consumers keep reading the latest finished update)
     struct Saved
     {
@@ -1227,8 +1405,9 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         // pipelined exchange: the pairs this launch may write — its own and the ones it may continue into — must have left for the
         // other ranks (the launch that may continue waits for the rest of its group's pairs as well: a continued update has no
         // wait of its own that the predecessor's launch would see)
-        if (!follows)
-            if (int rc = ddgi_exchange_before_update(e, pair, can_chain ? group - pos : 1)) return rc;
+        // (DDGI mode: the textures are written by the update's own blend, behind this wait, whoever traces its rays)
+        if (!follows || p.ddgi_mode)
+            if (int rc = ddgi_exchange_before_update(e, pair, (can_chain && !p.ddgi_mode) ? group - pos : 1)) return rc;
         for (int i = 0; i < 2; ++i)
         {
             e->tex_prev[i] = pair != e->pair_cur ? e->tex[i] : nullptr;  // DDGI blend: where the previous update's tiles are, when not in place
@@ -1241,7 +1420,8 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     a.albedo = static_cast<uint32_t*>(e->tex[0]);
     a.distance = static_cast<uint32_t*>(e->tex[1]);
     const int chain_max = can_chain ? group - 1 - pos : 0;
-    a.pair_words = can_chain ? static_cast<uint32_t>(e->tex_bytes[0] / 4) : 0u;
+    // (!= 0 also tells the kernel that rays carry their update in dst[31:29]; DDGI mode's rays write records: any non-zero value)
+    a.pair_words = can_chain ? (p.ddgi_mode ? 1u : static_cast<uint32_t>(e->tex_bytes[0] / 4)) : 0u;
     if (measure_split)
         if (int rc = choose_march_waves(e, p, true, false, &march_waves)) return rc;
 
@@ -1295,6 +1475,9 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         e->frame += 1;
     }
     saved.launched = true;
+    if (follows) e->chain_published += 1;
+    e->last_dt = e->have_last_time ? e->settings.time - e->last_time : 0.0f;
+    e->last_time = e->settings.time, e->have_last_time = true;
     e->chain_hash = hash, e->chain_break = measure_split || !can_chain;
     e->ring_k += 1;
     e->box_of = nullptr;  // the textures change: the sampler's per-texel table is stale
@@ -1333,8 +1516,8 @@ int ddgi_synchronize(ddgi_handle e)
         // — of its own in the ring as well: the next update's number moves up to the next group's first
         // — unless the handle exchanges its textures with other ranks: which pair an update writes is a function of its number on
         // EVERY rank, and one rank may synchronise where another does not
-        const unsigned long long g = static_cast<unsigned long long>(std::max(1, std::min(ddgi_chain_len(e), e->np)));
-        if (!e->xch.transport && !e->xch.p2p && e->np % static_cast<int>(g) == 0) e->ring_k = (e->ring_k + g - 1) / g * g;
+        const unsigned long long g = static_cast<unsigned long long>(ddgi_group_len(e));
+        if (!e->xch.transport && !e->xch.p2p && (e->mode == DDGI_MODE_DDGI || e->np % static_cast<int>(g) == 0)) e->ring_k = (e->ring_k + g - 1) / g * g;
     }
     return check_kernel_status(e);
 }
@@ -1950,11 +2133,7 @@ static int fill_user_scene(ddgi_engine* e, const int lo[3], const int dim[3], co
     if (d.bits) (void)hipFree(d.bits);
     if (d.types) (void)hipFree(d.types);
     if (d.skip) (void)hipFree(d.skip);
-    if (d.vis) (void)hipFree(d.vis);
-    if (d.vis_occ) (void)hipFree(d.vis_occ);
-    if (d.vis_list) (void)hipFree(d.vis_list);
-    for (auto& v : d.vis_more)
-        if (v) (void)hipFree(v);
+    free_vis_tables(d);
     d = ddgi_engine::DevScene{};
     e->user_scene = std::move(b);
     return DDGI_OK;

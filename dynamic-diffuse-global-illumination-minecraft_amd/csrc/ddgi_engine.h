@@ -88,15 +88,20 @@ struct ddgi_engine
         uint32_t* skip = nullptr;           // the fast march's skip field (ddgi_host.h: build_skip_field)
         SceneK k{};
         bool ready = false;
-        uint8_t* vis = nullptr;             // k_light_visibility table for the scene's single light
-        uint32_t* vis_occ = nullptr;        // ... its listed voxels (kVisListed), kVisListMax per (voxel, face)
-        int32_t* vis_list = nullptr;        // the (voxel, face) pairs it classifies: empty voxel, occupied on the face's other side
-        int n_vis_list = 0;
-        float vis_light[3] = {0, 0, 0};     // ... computed for this light position
-        bool vis_valid = false;
-        uint8_t* vis_more[3] = {nullptr, nullptr, nullptr};  // the same table for lights 1..3 of a scene with several lights (no lists)
-        float vis_more_light[3][3] = {};
-        bool vis_more_valid[3] = {false, false, false};
+        // light-feeler classes (k_light_visibility): kAqChainMax SETS of tables, each for one position of the scene's lights — the one
+        // the latest update uses and, with frames in flight and lights that move (DDGI mode: update_lights(time)), the ones
+        // PREDICTED for the updates a launch may go on with: a continued update's tables must be complete before the launch that
+        // traces its rays starts (ddgi_engine.cpp: assign_vis)
+        struct VisSet
+        {
+            uint8_t* vis[kVisLights] = {};  // one class byte per (voxel, face) and light
+            uint32_t* occ = nullptr;        // light 0: the listed voxels of class kVisListed, kVisListMax per (voxel, face)
+            float light[kVisLights][3] = {};
+            bool valid[kVisLights] = {};
+            uint32_t launch_seq = 0;        // the handle's launch_seq when a table of the set was last (re)computed: launches from this one on see it complete
+        } vis_set[kAqChainMax];
+        int32_t* vis_list = nullptr;        // the (voxel, face) pairs that are classified: empty voxel, occupied on the face's other side
+        int n_vis_list = -1;                // (-1: not built yet)
     } dev_scene[4];
 
     // memoised lattice hashes on device: one copy per device, shared by the process's handles (ddgi_engine.cpp: ensure_noise)
@@ -137,6 +142,19 @@ struct ddgi_engine
     uint32_t* pub = nullptr;                // pinned host memory, kAqPubRing words (the kernel reads it through pub_dev)
     uint32_t* pub_dev = nullptr;
     hipEvent_t milestone[2] = {nullptr, nullptr};  // recorded every 16 launches: bounds how far the host runs ahead of the ring
+    // the per-update records of the queue kernel (ddgi_types.h: UpdK): what may differ between the updates one launch works on
+    uint32_t* upd_host = nullptr;           // pinned host memory: kAqPubRing x 2 records — [seq % kAqPubRing][own view, continued view]
+    uint32_t* upd_host_dev = nullptr;       // ... as the device sees it
+    uint32_t* upd_dev = nullptr;            // device: 2 x kAqCounters records, filled by the kernel's workgroups
+    uint32_t chain_first_seq = 0;           // the launch that started the current chain: the earliest launch that may go on with the next update's rays
+    int chain_published = 0;                // updates published as continuations since the handle last had nothing in flight
+    int runahead = 0;                       // how far the host has lately been submitting updates ahead of a blocking call (0 .. kAqChainMax - 1): how many
+                                            // updates ahead the light-feeler tables are predicted when a chain starts
+    float last_time = 0.0f, last_dt = 0.0f;  // RenderSettings::time of the latest update and its step (DDGI mode: the lights' animation is predicted with it)
+    bool have_last_time = false;
+    int nrec = 1;                           // DDGI mode: ray-record buffers in d_radiance — an update writes buffer (its number % nrec), so that the blend of
+                                            // update k can read its records while a launch is already tracing update k + 1 (frames in flight)
+    size_t rec_stride = 0;                  // ... floats per buffer
     unsigned long long ring_k = 0;          // updates since the ring of texture pairs was made: update k writes pair k % np
     bool chain_break = true;                // something other than a probe update has touched the handle since: the next update starts a group
     unsigned long long chain_hash = 0;      // what the latest update's launch was (ddgi_engine.cpp: plan_hash)
@@ -182,7 +200,8 @@ GridK ddgi_make_grid(const ddgi_engine* e);
 void ddgi_texture_bytes(int mode, const ddgi_irradiance_field& f, int rays_per_probe, size_t bytes[2]);
 int ddgi_alloc_texture_pair(ddgi_engine* e, const size_t bytes[2], int np, void* out[2]);  // a ring of np pairs, zeroed
 inline void* ddgi_pair_ptr(const ddgi_engine* e, int pair, int i) { return static_cast<uint8_t*>(e->own_tex[i]) + static_cast<size_t>(pair) * e->tex_bytes[i]; }
-int ddgi_chain_len(const ddgi_engine* e);           // updates one launch may work on (1: no continuation)
+int ddgi_chain_len(const ddgi_engine* e);           // REF mode: updates one launch may work on = texture pairs a group takes (1: no continuation)
+int ddgi_group_len(const ddgi_engine* e);           // updates one launch may work on in the handle's mode (REF: pairs of the ring; DDGI: ray-record buffers)
 int ddgi_pairs_wanted(const ddgi_engine* e, bool pipelined);
 int ddgi_resize_ring(ddgi_engine* e, int np);       // blocks; the current pair's contents move to pair 0 of the new ring
 // exchange hooks called by the engine (no-ops without an initialised exchange)

@@ -214,24 +214,24 @@ constexpr uint32_t kBucketRefill = 7;  // an empty slot that can take a new ray
 // +-(light_k - hit_k).  Hits expected dead are shaded in groups of their own (kBucketDead), so that a group
 // runs EITHER the albedo + feeler set-up OR the bounce set-up, not both at half occupancy.  wf_event decides
 // exactly, whatever the bucket; a wrong hint costs time only.  p: the march position at the hit.
-DDGI_D bool dead_feeler_hint(f3 p, const LightK& L)
+DDGI_D bool dead_feeler_hint(f3 p, f3 light)
 {
     const f3 cell = cell_id(p);
     const float dx = p.x - (cell.x - 0.5f), dy = p.y - (cell.y - 0.5f), dz = p.z - (cell.z - 0.5f);
     const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
-    float d = dz, pk = p.z, lk = L.pos[2];
-    if (ax >= ay && ax >= az) d = dx, pk = p.x, lk = L.pos[0];
-    else if (ay >= az) d = dy, pk = p.y, lk = L.pos[1];
+    float d = dz, pk = p.z, lk = light.z;
+    if (ax >= ay && ax >= az) d = dx, pk = p.x, lk = light.x;
+    else if (ay >= az) d = dy, pk = p.y, lk = light.y;
     const float to_light = lk - pk;  // (the hit position is p + 0.001 n: irrelevant at this resolution)
     return d > 0.0f ? to_light <= 0.001f : to_light >= -0.001f;
 }
 
 // flags bits [20:16] + [3] of a march that ended in an occupied voxel of block type `type` at position p
-template <class Cfg>
-DDGI_D uint32_t hit_flags(const TraceArgs& A, uint32_t type, f3 p, bool feeler)
+template <class Cfg, class Upd>
+DDGI_D uint32_t hit_flags(const TraceArgs& A, const Upd& U, uint32_t type, f3 p, bool feeler)
 {
     uint32_t f = kFlagHit | (type << 16);
-    if (Cfg::nl(A) == 1 && !feeler && type != 12u && type != 13u && dead_feeler_hint(p, A.lights[0])) f |= kFlagDeadHint;  // (12, 13: albedo may be NaN, see wf_event)
+    if (Cfg::nl(A) == 1 && !feeler && type != 12u && type != 13u && dead_feeler_hint(p, U.light_pos(0))) f |= kFlagDeadHint;  // (12, 13: albedo may be NaN, see wf_event)
     return f;
 }
 DDGI_D uint32_t primary_bucket(uint32_t fl) { return (fl & kFlagDeadHint) ? kBucketDead : shade_bucket(static_cast<int>((fl >> 16) & 15u)); }
@@ -252,12 +252,18 @@ DDGI_D uint32_t primary_bucket(uint32_t fl) { return (fl & kFlagDeadHint) ? kBuc
 #endif
 // kFast: the tolerance-mode build (ddgi_device.h: fast_march_step) — the scene in LDS is the 2-bit skip field instead of the
 // occupancy bitmap, a slot keeps |rd| instead of rd (16 dwords), the rings hold 1536 entries.
+// kRecords: the queue kernel reads the per-update part of its arguments (ddgi_types.h: UpdK) from the ring of per-update records —
+// the DDGI instantiations (rotation, key and lights differ from update to update) and the generic one.  The REF instantiations
+// read their own arguments: the reference's live path re-submits the same work every frame, a launch goes on with an update
+// only if that part is equal byte for byte (ddgi_engine.cpp: plan_hash) — and arguments cost a C3 update 2.5 % less than records
+// (they can be re-loaded anywhere; a record's values are held in registers or spilled).
 template <bool kFastT>
 struct CfgRuntimeT
 {
     static constexpr int kNl = 0;
     static constexpr bool kFast = kFastT;
     static constexpr int kInline = 1;
+    static constexpr bool kRecords = true;
     static DDGI_D int nl(const TraceArgs& A) { return A.nl; }
 #ifdef DDGI_PROFILING  // the ablation / fault-injection switches exist only in the profiling build (make prof)
     static DDGI_D int ablate(const TraceArgs& A) { return A.ablate; }
@@ -276,6 +282,7 @@ struct CfgMulti
     static constexpr int kNl = kNlT;
     static constexpr bool kFast = kFastT;
     static constexpr int kInline = 1;
+    static constexpr bool kRecords = kMode != 0;
     static DDGI_D int nl(const TraceArgs& A) { return kNlT > 0 ? kNlT : A.nl; }
     static DDGI_D int ablate(const TraceArgs&) { return 0; }
     static DDGI_D bool ddgi(const TraceArgs&) { return kMode != 0; }
@@ -286,6 +293,7 @@ struct CfgPlain
     static constexpr int kNl = 1;
     static constexpr bool kFast = kFastT;
     static constexpr int kInline = DDGI_INLINE_STEPS;
+    static constexpr bool kRecords = kMode != 0;
     static DDGI_D int nl(const TraceArgs&) { return 1; }
     static DDGI_D int ablate(const TraceArgs&) { return 0; }
     static DDGI_D bool ddgi(const TraceArgs&) { return kMode != 0; }
@@ -349,15 +357,15 @@ struct InlineEnd  // how a march that ended within its first (inline) steps ende
 
 // kUnitDir: d is the output of a normalisation or of hemisphere_dir (every march an event posts; not the rays of a refill,
 // which are the caller's) — see normalize3_of_unit
-template <class Cfg, bool kUnitDir = false>
-DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, bool feeler, const TraceArgs& A, const uint32_t* s_bits, InlineEnd* end = nullptr,
+template <class Cfg, bool kUnitDir = false, class Upd>
+DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, bool feeler, const TraceArgs& A, const Upd& U, const uint32_t* s_bits, InlineEnd* end = nullptr,
                          bool have_spheres = false, float tl_in = 0.0f, int lid_in = -1, LaneProbe* lp = nullptr)
 {
     DDGI_PROBE(lp, feeler ? 2 : 6);  // sections 2 / 6: a feeler's / a primary march's set-up
     // have_spheres: the caller has already evaluated light_spheres(o, d) -> (tl_in, lid_in)
     float tl = tl_in;
     int lid = lid_in;
-    if (!have_spheres) light_spheres<Cfg::kNl>(o, d, A, tl, lid);
+    if (!have_spheres) light_spheres<Cfg::kNl>(o, d, A, U, tl, lid);
     const f3 dn = kUnitDir ? normalize3_of_unit(d) : normalize3(d);
     st3(P.ro, slot, o);
     st3(P.dn, slot, dn);
@@ -409,7 +417,7 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
         if (fin)
         {
             // (a feeler only asks whether a block was hit, not which)
-            const uint32_t hf = !occ ? 0u : (feeler ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(p_end), cell_end)), p_end, false));
+            const uint32_t hf = !occ ? 0u : (feeler ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, U, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(p_end), cell_end)), p_end, false));
             P.flags[slot] = base_flags | (feeler ? kSlotEvFeeler : kSlotEvPrimary) | hf;
             if (end) end->t = t_end, end->tl = tl, end->occ = occ;
             const bool block_wins = occ && (t_end < tl);
@@ -424,22 +432,27 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
 }
 
 // DDGI mode, bounce 0: the probe ray's hit distance, clamped as the depth blend wants it, and its square
-DDGI_D void wf_store_distance(const TraceArgs& A, uint32_t dst, float t)
+// (dst: a ray of a CHAINED update carries its update in dst[31:29] — A.pair_words != 0 says that launches of this handle chain)
+template <class Upd>
+DDGI_D void wf_store_distance(const TraceArgs& A, const Upd& U, uint32_t dst, float t)
 {
     const float d = gl_min(t, static_cast<float>(A.grid.side) * 1.5f);
+    if (A.pair_words) dst &= kDstTexelMask;
     const uint32_t n = static_cast<uint32_t>(A.grid.n), pl = dst / n, i = dst - pl * n;
     const uint32_t n_pad = rec_ray_pad(n);
-    A.rad_dd[rec_dd_index(pl, i, n_pad, 0)] = d, A.rad_dd[rec_dd_index(pl, i, n_pad, 1)] = d * d;
+    float* rad_dd = U.rad_dd();
+    rad_dd[rec_dd_index(pl, i, n_pad, 0)] = d, rad_dd[rec_dd_index(pl, i, n_pad, 1)] = d * d;
 }
 
-template <class Cfg>
-DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst, const TraceArgs& A)
+template <class Cfg, class Upd>
+DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst, const TraceArgs& A, const Upd& U)
 {
     const f3 c = div3(color, static_cast<float>(A.max_bounces));  // Q14: always /max_bounces
     if (Cfg::ddgi(A))
     {
+        if (A.pair_words) dst &= kDstTexelMask;  // (a chained update's ray: its update's ray records are U's)
         const uint32_t n = static_cast<uint32_t>(A.grid.n), n_pad = rec_ray_pad(n), pl = dst / n, i = dst - pl * n;  // (the distance was written at bounce 0)
-        float* rec = A.rad_rgb + rec_rgb_index(pl, i, n_pad, 0);
+        float* rec = U.rad_rgb() + rec_rgb_index(pl, i, n_pad, 0);
         rec[0] = c.x, rec[static_cast<size_t>(n_pad) * 32] = c.y, rec[static_cast<size_t>(n_pad) * 64] = c.z;  // channel stride: n_pad * 32
     }
     else
@@ -456,8 +469,8 @@ DDGI_D void wf_finish_ray(const WfPool& P, uint32_t slot, f3 color, uint32_t dst
 // End of get_direct_lighting for one hit: accumulate, then bounce or finish (probe_pass.comp:286-292).
 // Returns true when the ray bounces; the caller then posts the march (o, d) — every path of an event
 // group shares ONE wf_post_march call site, so divergent lanes do not run its code twice.
-template <class Cfg>
-DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A, f3& o, f3& d, LaneProbe* lp = nullptr)
+template <class Cfg, class Upd>
+DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contribution, f3 hpos, f3 hnrm, uint32_t cnt, const TraceArgs& A, const Upd& U, f3& o, f3& d, LaneProbe* lp = nullptr)
 {
     DDGI_PROBE(lp, 5);  // section 5: accumulate + hemisphere sample
     const f3 color = v3of(c.col) + contribution;
@@ -470,7 +483,7 @@ DDGI_D bool wf_lighting_done(const WfPool& P, uint32_t slot, WfCold& c, f3 contr
         d = (Cfg::ablate(A) & 2) ? normalize3(hnrm + mk3(0.3f, 0.2f, 0.1f)) : hemisphere_dir(hnrm, c.rng);
         return true;
     }
-    wf_finish_ray<Cfg>(P, slot, color, c.dst, A);
+    wf_finish_ray<Cfg>(P, slot, color, c.dst, A, U);
     return false;
 }
 
@@ -496,14 +509,16 @@ DDGI_D int light_vis_entry(const TraceArgs& A, f3 o, f3 n)
     const int face = (ax ? 0 : (ay ? 2 : 4)) + ((n.x + n.y + n.z) < 0.0f ? 1 : 0);  // 2 axis + (the block that was hit is on the + side)
     return idx * 8 + face;
 }
-DDGI_D uint32_t light_vis_class(const TraceArgs& A, f3 o, f3 n, int& entry)
+template <class Upd>
+DDGI_D uint32_t light_vis_class(const TraceArgs& A, const Upd& U, f3 o, f3 n, int& entry)
 {
     entry = 0;
-    if (!A.vis) return kVisUnknown;
+    const uint8_t* vis = U.vis();
+    if (!vis) return kVisUnknown;
     const int en = light_vis_entry(A, o, n);
     if (en < 0) return kVisUnknown;
     entry = en;
-    return A.vis[en];
+    return vis[en];
 }
 
 
@@ -515,9 +530,10 @@ DDGI_D uint32_t light_vis_class(const TraceArgs& A, f3 o, f3 n, int& entry)
 // every side (ten times that) never has a position inside it; every "misses" needs a comparison that comes out true (a NaN
 // decides nothing).
 constexpr float kListGrow = 4.0e-4f;
-DDGI_D bool listed_feeler_clear(const TraceArgs& A, int entry, f3 o, f3 dn, float t_light)
+template <class Upd>
+DDGI_D bool listed_feeler_clear(const Upd& U, int entry, f3 o, f3 dn, float t_light)
 {
-    const uint4 packed4 = *reinterpret_cast<const uint4*>(A.vis_occ + static_cast<size_t>(entry) * kVisListMax);
+    const uint4 packed4 = *reinterpret_cast<const uint4*>(U.vis_occ() + static_cast<size_t>(entry) * kVisListMax);
     const uint32_t packed[kVisListMax] = {packed4.x, packed4.y, packed4.z, packed4.w};
     const f3 cell = cell_id(o);  // the start voxel
     const f3 inv{__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y), __builtin_amdgcn_rcpf(dn.z)};
@@ -578,23 +594,23 @@ DDGI_D void feeler_outcome(const LightK& L, f3 hpos, f3 nh, f3 hcol, bool any_hi
 //               li's own (or none); otherwise the feeler is marched.
 //   kVisListed (light 0's table has them) counts as unknown here.
 // The table's guarantee is about the start patch (voxel, face) only, which all of a hit's feelers share: one entry for all lights.
-template <class Cfg>
-DDGI_D int decided_feelers(const TraceArgs& A, int li, bool on_axis_face, f3 hpos, f3 hnrm, f3 nh, f3 hcol, f3& direct, int& nvis, f3& contribution, bool& early)
+template <class Cfg, class Upd>
+DDGI_D int decided_feelers(const TraceArgs& A, const Upd& U, int li, bool on_axis_face, f3 hpos, f3 hnrm, f3 nh, f3 hcol, f3& direct, int& nvis, f3& contribution, bool& early)
 {
     const int nl = Cfg::nl(A);
-    if (!on_axis_face || !A.vis) return li;
+    if (!on_axis_face || !U.vis()) return li;
     const int en = light_vis_entry(A, hpos, hnrm);
     if (en < 0) return li;
     while (li < nl && li < kVisLights)
     {
-        const uint8_t* table = li == 0 ? A.vis : A.vis_more[li - 1];
+        const uint8_t* table = li == 0 ? U.vis() : U.vis_more(li - 1);
         const uint32_t cls = table ? table[en] : kVisUnknown;
         if (cls != kVisLit && cls != kVisShadow) break;
-        const LightK& L = A.lights[li];
+        const LightK L = U.light(li);
         const f3 to_light = normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos);
         float ftl = __builtin_inff();
         int flid = -1;
-        light_spheres<Cfg::kNl>(hpos, to_light, A, ftl, flid);
+        light_spheres<Cfg::kNl>(hpos, to_light, A, U, ftl, flid);
         bool any, block;
         if (cls == kVisLit)
             block = false, any = ftl < __builtin_inff();
@@ -615,8 +631,8 @@ DDGI_D int decided_feelers(const TraceArgs& A, int li, bool on_axis_face, f3 hpo
 // posted that goes on (return 1: its state is in the pool arrays, its shading record stored), when the new
 // march already ended within its first steps (return 2 + the event bucket it now waits in), or 0 when the ray
 // is finished (it has written its output and left the slot empty).
-template <class Cfg>
-DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits, uint32_t b, uint32_t slot, uint32_t r, bool r_valid, LaneProbe* lp = nullptr, uint32_t dst_tag = 0u)
+template <class Cfg, class Upd>
+DDGI_D int wf_event(const TraceArgs& A, const Upd& U, const WfPool& P, const uint32_t* s_bits, uint32_t b, uint32_t slot, uint32_t r, bool r_valid, LaneProbe* lp = nullptr, uint32_t dst_tag = 0u)
 {
     DDGI_PROBE(lp, 0);  // section 0: the event (all lanes of the group)
     const GridK& G = A.grid;
@@ -643,13 +659,15 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 // in-kernel ray generation: probe position + rotated spherical Fibonacci direction
                 const int pxz = p - y * G.cx * G.cz;
                 ray_o = probe_position(G, pxz % G.cx, y, pxz / G.cx);
-                ray_d = fibonacci_dir(i, rays_per_probe, A.rot);
-                c.dst = r;  // pl * n + i
-                c.rng = wang_hash(global_ray ^ A.frame_key);
+                float rot[9];
+                U.rot(rot);
+                ray_d = fibonacci_dir(i, rays_per_probe, rot);
+                c.dst = r | dst_tag;  // pl * n + i
+                c.rng = wang_hash(global_ray ^ U.frame_key());
             }
             else
             {
-                const float4* rec = A.rays + 3 * static_cast<size_t>(r);
+                const float4* rec = U.rays() + 3 * static_cast<size_t>(r);
                 const float4 ra = rec[0], rb = rec[1], rc = rec[2];
                 ray_o = mk3(ra.x, ra.y, ra.z);
                 ray_d = mk3(rb.x, rb.y, rb.z);
@@ -660,7 +678,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             c.cnt = 0u;
             set3(c.col, mk3(0, 0, 0));
             set3(c.hn, mk3(0, 0, 0));
-            const int pb = wf_post_march<Cfg>(P, slot, c, ray_o, ray_d, false, A, s_bits, nullptr, false, 0.0f, -1, lp);
+            const int pb = wf_post_march<Cfg>(P, slot, c, ray_o, ray_d, false, A, U, s_bits, nullptr, false, 0.0f, -1, lp);
             store_cold<Cfg::kFast>(P, slot, c, false);
             return pb < 0 ? 1 : 2 + pb;
         }
@@ -680,16 +698,16 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             contribution = mk3(0, 0, 0);
             for (;;)
             {
-                li = decided_feelers<Cfg>(A, li, on_axis_face, hpos, hnrm, nh, hcol, direct, nvis, contribution, early);
+                li = decided_feelers<Cfg>(A, U, li, on_axis_face, hpos, hnrm, nh, hcol, direct, nvis, contribution, early);
                 if (early || li >= Cfg::nl(A)) break;
-                const LightK& L = A.lights[li];
+                const LightK L = U.light(li);
                 const f3 to_light = normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos);
                 c.cnt = cnt_low | (static_cast<uint32_t>(li) << 8) | (static_cast<uint32_t>(nvis) << 12);
                 float ftl = inf;
                 int flid = -1;
-                light_spheres<Cfg::kNl>(hpos, to_light, A, ftl, flid);
+                light_spheres<Cfg::kNl>(hpos, to_light, A, U, ftl, flid);
                 InlineEnd fe;
-                const bool inline_end = wf_post_march<Cfg, true>(P, slot, c, hpos, to_light, true, A, s_bits, &fe, true, ftl, flid, lp) >= 0;
+                const bool inline_end = wf_post_march<Cfg, true>(P, slot, c, hpos, to_light, true, A, U, s_bits, &fe, true, ftl, flid, lp) >= 0;
                 if (!inline_end)
                 {
                     if (multi_light) P.dirbuf[slot] = float4{direct.x, direct.y, direct.z, 0.0f};
@@ -721,8 +739,8 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
             const bool first_bounce = Cfg::ddgi(A) && (c.cnt & 255u) == 0u;
             if (!any_hit)
             {
-                if (first_bounce) wf_store_distance(A, c.dst, kMissDistance);
-                wf_finish_ray<Cfg>(P, slot, v3of(c.col), c.dst, A);  // probe_pass.comp:288-290 break
+                if (first_bounce) wf_store_distance(A, U, c.dst, kMissDistance);
+                wf_finish_ray<Cfg>(P, slot, v3of(c.col), c.dst, A, U);  // probe_pass.comp:288-290 break
             }
             else
             {
@@ -766,18 +784,18 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 else
                 {
                     th = tl;
-                    const LightK& L = A.lights[static_cast<int>((fl >> 12) & 15u) - 1];
-                    const f3 lp{L.pos[0], L.pos[1], L.pos[2]};
+                    // (the light whose sphere was hit; one light: it is that one)
+                    const f3 lp = U.light_pos(Cfg::kNl == 1 ? 0 : static_cast<int>((fl >> 12) & 15u) - 1);
                     nraw = ray_at((ro - lp) * 10.0f, rd * 10.0f, th);  // sphere-space position
                 }
-                if (first_bounce) wf_store_distance(A, c.dst, th);  // Isect.t of the probe ray
+                if (first_bounce) wf_store_distance(A, U, c.dst, th);  // Isect.t of the probe ray
                 const f3 hnrm = axis_normal ? nraw : normalize3(nraw);
                 const f3 hpos = ray_at(ro, rd, th) + hnrm * 0.001f;
                 set3(c.hn, hnrm);
                 const uint32_t cnt = c.cnt & 255u;  // light index 0, no visible light yet
                 if (Cfg::nl(A) > 0)
                 {
-                    const LightK& L = A.lights[0];
+                    const LightK L = U.light(0);
                     const f3 to_light = normalize3(f3{L.pos[0], L.pos[1], L.pos[2]} - hpos);
                     // Dead-feeler elimination (single light): whatever the feeler finds, the hit's
                     // direct light is scaled by lambert = clamp(dot(n, to_light), 0, 1)
@@ -794,7 +812,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     // byte's way from L2 passes under the albedo's arithmetic instead of standing in front of the feeler decision.
                     int vis_entry = 0;
                     const bool vis_early = DDGI_VIS_EARLY && Cfg::nl(A) == 1 && block_wins && axis_normal && !lambert_zero;
-                    const uint32_t vis_early_class = vis_early ? light_vis_class(A, hpos, hnrm, vis_entry) : kVisUnknown;
+                    const uint32_t vis_early_class = vis_early ? light_vis_class(A, U, hpos, hnrm, vis_entry) : kVisUnknown;
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary)) DDGI_PROBE(lp, 1);  // section 1: albedo
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary))
                         hcol = (Cfg::ablate(A) & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
@@ -808,7 +826,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                     // get_direct_lighting's arithmetic are evaluated right here, on the same values.
                     // (a hit with lambert == 0 whose albedo is not finite — the moss / mold pattern's 0/0 — needs the class after all)
                     const uint32_t vis = vis_early ? vis_early_class
-                                                   : ((Cfg::nl(A) == 1 && block_wins && axis_normal && !(lambert_zero && finite_albedo)) ? light_vis_class(A, hpos, hnrm, vis_entry) : kVisUnknown);
+                                                   : ((Cfg::nl(A) == 1 && block_wins && axis_normal && !(lambert_zero && finite_albedo)) ? light_vis_class(A, U, hpos, hnrm, vis_entry) : kVisUnknown);
                     if ((Cfg::ablate(A) & 16) && A.stats && block_wins) atomicAdd(&A.stats[(lambert_zero && finite_albedo) ? 59 : (vis == kVisListed ? 63 : 56 + vis)], 1ull);  // profiling build: feeler classes
                     ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt;
                     if (lambert_zero && finite_albedo)
@@ -820,7 +838,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                         float ftl = inf;
                         int flid = -1;
                         if (vis != kVisShadow) DDGI_PROBE(lp, 3);  // section 3: sphere test of the feeler
-                        if (vis != kVisShadow) light_spheres<Cfg::kNl>(hpos, to_light, A, ftl, flid);
+                        if (vis != kVisShadow) light_spheres<Cfg::kNl>(hpos, to_light, A, U, ftl, flid);
                         bool feeler_any = true, feeler_block = true;  // kVisShadow: a block before the light (t_block < t_light, or no sphere hit at all)
                         if (vis == kVisLit) feeler_block = false, feeler_any = ftl < inf;
                         else if (vis == kVisUnknown || vis == kVisListed)
@@ -832,8 +850,8 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                             InlineEnd fe;
                             // (a listed patch: the feeler's own ray against the few occupied voxels of its bundle, before it is queued)
                             bool clear = false;
-                            const bool inline_end = wf_post_march<Cfg, true>(P, slot, c, hpos, to_light, true, A, s_bits, &fe, true, ftl, flid, lp) >= 0;
-                            if (!inline_end && vis == kVisListed) clear = listed_feeler_clear(A, vis_entry, hpos, normalize3_of_unit(to_light), ftl);
+                            const bool inline_end = wf_post_march<Cfg, true>(P, slot, c, hpos, to_light, true, A, U, s_bits, &fe, true, ftl, flid, lp) >= 0;
+                            if (!inline_end && vis == kVisListed) clear = listed_feeler_clear(U, vis_entry, hpos, normalize3_of_unit(to_light), ftl);
                             if (!inline_end && !clear)
                             {
                                 store_cold<Cfg::kFast>(P, slot, c, true);  // (hn and the albedo travel with the marched feeler)
@@ -891,7 +909,7 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 const bool is_axis = (fabsf(hnrm.x) + fabsf(hnrm.y) + fabsf(hnrm.z) == 1.0f) &&
                                      (fabsf(hnrm.x) == 1.0f || fabsf(hnrm.y) == 1.0f || fabsf(hnrm.z) == 1.0f);
                 const f3 nh = is_axis ? hnrm : normalize3(hnrm);  // identity for a unit axis vector
-                feeler_outcome(A.lights[li], hpos, nh, hcol, any_hit, block_wins, direct, nvis, contribution, early);
+                feeler_outcome(U.light(Cfg::kNl == 1 ? 0 : li), hpos, nh, hcol, any_hit, block_wins, direct, nvis, contribution, early);
             }
             li += 1;
             if (!early && li < Cfg::nl(A))
@@ -905,10 +923,10 @@ DDGI_D int wf_event(const TraceArgs& A, const WfPool& P, const uint32_t* s_bits,
                 contribution = nvis == 1 ? hcol * direct : div3(hcol * direct, static_cast<float>(nvis));  // x / 1.0f == x
             ld_contribution = contribution, ld_hpos = hpos, ld_hnrm = hnrm, ld_cnt = cnt, lit_done = true;
         }
-        if (lit_done) posted = wf_lighting_done<Cfg>(P, slot, c, ld_contribution, ld_hpos, ld_hnrm, ld_cnt, A, mo, md, lp);
+        if (lit_done) posted = wf_lighting_done<Cfg>(P, slot, c, ld_contribution, ld_hpos, ld_hnrm, ld_cnt, A, U, mo, md, lp);
         if (posted)
         {
-            const int pb = wf_post_march<Cfg, true>(P, slot, c, mo, md, as_feeler, A, s_bits, nullptr, false, 0.0f, -1, lp);  // md: to_light or a hemisphere sample
+            const int pb = wf_post_march<Cfg, true>(P, slot, c, mo, md, as_feeler, A, U, s_bits, nullptr, false, 0.0f, -1, lp);  // md: to_light or a hemisphere sample
 #ifdef DDGI_LAP
             DDGI_PROBE(lp, 12);  // write-back
 #endif
@@ -1060,7 +1078,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
             if (valid)
             {
                 slot = P.event_list[sh->bucket_base[b] + e];
-                posted = wf_event<CfgRuntime>(A, P, s_bits, b, slot, ray_cur + e, ray_cur + e < ray_end) == 1;  // (a march that ended at once waits in its event state for the next round)
+                posted = wf_event<CfgRuntime>(A, UpdOfArgs{A}, P, s_bits, b, slot, ray_cur + e, ray_cur + e < ray_end) == 1;  // (a march that ended at once waits in its event state for the next round)
             }
             const uint32_t at = wave_append(posted, &sh->n_march[cur_list], lane);
             if (posted) (P.march_list[0] + cur_list * PS)[at] = static_cast<uint16_t>(slot);
@@ -1157,7 +1175,7 @@ __global__ __launch_bounds__(T, T * kBlocksPerCU / 256) void k_probe_trace_wf(co
                     if (!fin && ((trips & 3) == 3)) fin = march_escaped(m, A.scene);
                     if (fin)
                     {
-                        const uint32_t hf = !occ ? 0u : ((fl & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<CfgRuntime>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
+                        const uint32_t hf = !occ ? 0u : ((fl & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<CfgRuntime>(A, UpdOfArgs{A}, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
                         P.t[slot] = m.t;
                         P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | hf;
                         have = false;
@@ -1272,6 +1290,9 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
 #ifndef DDGI_MARCH_PRIO
 #define DDGI_MARCH_PRIO 0  // s_setprio of the (exact) march waves; the event waves run at DDGI_EVENT_PRIO
 #endif
+#ifndef DDGI_AQ_TRIP_ARGS
+#define DDGI_AQ_TRIP_ARGS 1  // the event waves read the kernel's arguments afresh in every trip (args_of_this_trip)
+#endif
 #ifndef DDGI_AQ_THIN_WAITS
 #define DDGI_AQ_THIN_WAITS 4
 #endif
@@ -1303,6 +1324,19 @@ struct AqShared  // control block at the start of dynamic LDS (32 dwords)
     uint32_t pad[32 - 4 - 2 * kAqEventQueues - 4];
 };
 static_assert(sizeof(AqShared) == 32 * 4, "control block is 32 dwords");
+
+// The queue kernel's arguments as an event group reads them.  The kernel is one persistent loop around a very large body; its
+// arguments are invariant loads, which the optimizer hoists out of that loop — a hundred scalars live across everything, most
+// of them spilled into VGPR lanes and read back with a v_readlane (a VALU slot, on the unit that bounds the kernel) at every
+// use.  Read through a pointer the optimizer cannot see through, once per trip of the loop, they are loaded where a trip
+// uses them (s_load: the scalar unit's time) and are dead at its end.  kFirstArg: TraceArgs is the kernel's first argument.
+DDGI_D const TraceArgs& args_of_this_trip()
+{
+    typedef const __attribute__((address_space(4))) TraceArgs* KernArg;
+    KernArg kp = (KernArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return *(const TraceArgs*)kp;
+}
 
 DDGI_D uint32_t aq_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
@@ -1351,6 +1385,21 @@ DDGI_D void aq_push(uint16_t* ring, uint32_t* tail, bool pred, uint32_t value, i
     if (pred) ring[at % kCap] = static_cast<uint16_t>(value);
 }
 
+template <bool kRecords>
+struct UpdSource;
+template <>
+struct UpdSource<true>
+{
+    typedef UpdOfRing Type;
+    static DDGI_D UpdOfRing make(const TraceArgs&, const uint32_t* record) { return UpdOfRing(record); }
+};
+template <>
+struct UpdSource<false>
+{
+    typedef UpdOfArgs Type;
+    static DDGI_D UpdOfArgs make(const TraceArgs& A, const uint32_t*) { return UpdOfArgs{A}; }
+};
+
 // kPool > 0: the pool size is a compile-time constant, so every pool array is the LDS base plus a constant
 // offset (folded into the ds instructions: no address arithmetic, one SGPR instead of eleven).
 template <bool kStats, int kPool, class Cfg>
@@ -1374,6 +1423,28 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
     if (wf_lds[0] >= A.n_rays) return;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    // THE PER-UPDATE RECORDS (ddgi_types.h: UpdK).  What differs from one update to the next — lights, DDGI mode's rotation and key, ray
+    // and record buffers, feeler classes — is not read from the kernel's arguments but from a ring of records: a ray of update
+    // C.seq + t (t in dst[31:29]) is shaded with record t.  The host has written the launch's own record into pinned memory before
+    // the launch; every workgroup copies it into the device ring here (the same bytes from every workgroup), and the record of an
+    // update it goes on with when it gets there (event waves, below).  The events then read it with scalar loads (UpdOfRing).
+    auto upd_record = [&](uint32_t t) -> const uint32_t* {
+        return C.upd_dev + ((C.seq + t) & (kAqCounters - 1u)) * kUpdWords;
+    };
+    auto copy_record = [&](uint32_t seq_of) {  // one wave: pinned host [seq_of] -> the device ring
+        const uint32_t* src = C.upd_host + (seq_of & (kAqPubRing - 1u)) * kUpdWords;
+        uint32_t* dst = C.upd_dev + (seq_of & (kAqCounters - 1u)) * kUpdWords;
+        const uint32_t v0 = __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t v1 = __hip_atomic_load(src + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        dst[lane] = v0, dst[64 + lane] = v1;
+        // In this XCD's L2 before anything of this workgroup reads it (the waves of a workgroup read through the scalar cache of
+        // their own CU, which has never held these lines in this launch): the stores' completion is all that takes — a
+        // workgroup-scope release, i.e. a wait.  (An agent-scope fence here writes back and invalidates the XCD's L2, once per
+        // workgroup and update: the noise tables and block types every event reads went with it — 3.5 % of a C3 update.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    };
+    if (Cfg::kRecords && wave == 0) copy_record(C.seq);
+    typedef UpdSource<Cfg::kRecords> Upd;
     const uint32_t PS = kPool > 0 ? static_cast<uint32_t>(kPool) : static_cast<uint32_t>(pool_size);
     const int fetch_lanes = A.wf_fetch > 0 ? A.wf_fetch : kWfFetchLanes;
 
@@ -1414,6 +1485,8 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
     if (tid == 0) sh->fq_tail = PS, sh->cur_seq = C.seq;
     __syncthreads();
 
+    // (the march waves' only use of a record is the routing HINT of a hit — dead_feeler_hint, never a result: the launch's own)
+    const typename Upd::Type U0 = Upd::make(A, upd_record(0u));
     const float inf = __builtin_inff();
     unsigned int guard = 0;  // safety net: consecutive polls without work (about 1 s of them trips it); never spin forever on the GPU
     unsigned long long st_a = 0, st_b = 0;  // utilisation counters: trips / groups, and the lanes that had work in them
@@ -1495,7 +1568,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 if (!fin && (trips & 1)) fin = march_escaped(m, A.scene);
                 if (fin)
                 {
-                    const uint32_t hf = !occ ? 0u : ((fl & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
+                    const uint32_t hf = !occ ? 0u : ((fl & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, U0, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
                     P.t[slot] = m.t;
                     P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | hf;
                     const bool block_wins = occ && (m.t < m.tl);
@@ -1667,7 +1740,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                     if (!f && ((trips & 3) == 3)) f = march_escaped(M, A.scene);
                     if (f)
                     {
-                        const uint32_t hf = !occ ? 0u : ((fl[0] & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(M.p), M.cell)), M.p, false));
+                        const uint32_t hf = !occ ? 0u : ((fl[0] & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, U0, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(M.p), M.cell)), M.p, false));
                         P.t[slot[0]] = M.t;
                         P.flags[slot[0]] = (fl[0] & 0xf000u) | ((fl[0] & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl[0] & kFlagFeeler) | hf;
                         const bool block_wins = occ && (M.t < M.tl);
@@ -1723,7 +1796,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                     if (!f && ((trips & 3) == 3)) f = march_escaped(m[q], A.scene);
                     if (f)
                     {
-                        const uint32_t hf = !occ ? 0u : ((fl[q] & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m[q].p), m[q].cell)), m[q].p, false));
+                        const uint32_t hf = !occ ? 0u : ((fl[q] & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, U0, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m[q].p), m[q].cell)), m[q].p, false));
                         P.t[slot[q]] = m[q].t;
                         P.flags[slot[q]] = (fl[q] & 0xf000u) | ((fl[q] & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl[q] & kFlagFeeler) | hf;
                         const bool block_wins = occ && (m[q].t < m[q].tl);
@@ -1764,6 +1837,9 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
         for (;;)
         {
             if (++guard > (1u << 23)) sh->abort = 1u;
+#if DDGI_AQ_TRIP_ARGS
+            const TraceArgs& A = args_of_this_trip();  // (shadows the kernel's parameter for the trip)
+#endif
             // Which group?  Lanes 0..5 look at one event queue each (polling is paid in VALU issue slots that
             // the marching waves of the same SIMD want, so it is kept to a handful of instructions).
             uint32_t b = 0, base = 0, k = 0;
@@ -1884,13 +1960,15 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if (r_valid)
                 {
-                    const uint32_t dst_tag = C.chain_max ? (cs - C.seq) << kDstPairShift : 0u;  // which texture pair after the launch's own
-                    const int rc = wf_event<Cfg>(A, P, s_bits, kBucketRefill, slot, r, true, kStats ? &probe : nullptr, dst_tag);
+                    const uint32_t tag = C.chain_max ? cs - C.seq : 0u;  // which update after the launch's own (its texture pair, its record)
+                    const typename Upd::Type U = Upd::make(A, upd_record(tag));
+                    const int rc = wf_event<Cfg>(A, U, P, s_bits, kBucketRefill, slot, r, true, kStats ? &probe : nullptr, tag << kDstPairShift);
                     posted = rc == 1;
                     if (rc >= 2) ev_bucket = rc - 2;
                 }
                 freed = valid && !r_valid;  // more slots than rays left: hand them back
                 const uint32_t n_back = static_cast<uint32_t>(__popcll(__ballot(freed)));
+                uint32_t used_up = 0;  // 1: this update's rays are used up; 2: and the next update is published as its continuation
                 if (lane == 0)
                 {
                     if (n_back) atomicSub(&sh->live, n_back);
@@ -1898,20 +1976,45 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                     {
                         // this update's rays are used up.  Has the host submitted the next one as a continuation of this one (its
                         // sequence number + 1 in its slot of the pinned host ring)?  Then go on with its rays; else the launch ends.
-                        bool go_on = false;
-                        if (cs - C.seq < C.chain_max) go_on = __hip_atomic_load(C.pub + ((cs + 1u) & (kAqPubRing - 1u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == cs + 2u;
-                        if (go_on && atomicCAS(&sh->cur_seq, cs, cs + 1u) == cs) atomicAdd(C.continued, 1u);  // (another wave may have got there first)
-                        else if (aq_load(&sh->cur_seq) == cs) __hip_atomic_store(&sh->no_more, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        used_up = 1u;
+                        if (cs - C.seq < C.chain_max && __hip_atomic_load(C.pub + ((cs + 1u) & (kAqPubRing - 1u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == cs + 2u) used_up = 2u;  // (the record's loads below are issued after this value has arrived, and bypass the caches like it)
                     }
+                }
+                if (Cfg::kRecords && C.chain_max && lane_bcast(used_up, 0) == 2u) copy_record(cs + 1u);  // that update's record, before any of its rays starts here
+                if (lane == 0 && used_up)
+                {
+                    if (used_up == 2u && atomicCAS(&sh->cur_seq, cs, cs + 1u) == cs) atomicAdd(C.continued, 1u);  // (another wave may have got there first)
+                    else if (aq_load(&sh->cur_seq) == cs) __hip_atomic_store(&sh->no_more, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             else
             {
+                bool mine = valid;
+                uint32_t t = 0u;  // which update after the launch's own the group's rays belong to
                 if (valid)
                 {
                     slot = aq_take<kCap>(ring_eq + b * kCap, base + lane, &sh->abort);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const int rc = wf_event<Cfg>(A, P, s_bits, b, slot, 0u, false, kStats ? &probe : nullptr);
+                }
+                if (Cfg::kRecords && C.chain_max)
+                {
+                    // A group is shaded with ONE record, wave-uniform (scalar loads, like kernel arguments): that of its first ray's
+                    // update.  Where one update ends and the next begins a few groups hold rays of both: the others go back to the
+                    // end of the queue they came from (their state is untouched) and are shaded with a later group.
+                    const uint32_t tagv = valid ? P.dst[slot] >> kDstPairShift : 0u;
+                    t = lane_bcast(tagv, 0);  // (lane 0 is valid: k > 0)
+                    const bool other = valid && tagv != t;
+                    if (__ballot(other) != 0ull)
+                    {
+                        const uint32_t at = wave_append(other, &sh->eq_tail[b], lane);
+                        if (other) (ring_eq + b * kCap)[at % kCap] = static_cast<uint16_t>(slot);
+                        mine = valid && !other;
+                    }
+                }
+                if (mine)
+                {
+                    const typename Upd::Type U = Upd::make(A, upd_record(t));
+                    const int rc = wf_event<Cfg>(A, U, P, s_bits, b, slot, 0u, false, kStats ? &probe : nullptr);
                     posted = rc == 1;
                     if (rc >= 2) ev_bucket = rc - 2;  // the new march ended within its first steps: straight to its event queue
                     freed = rc == 0;                  // the ray is finished: its output is written, the slot is empty

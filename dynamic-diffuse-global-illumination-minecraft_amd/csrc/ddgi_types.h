@@ -120,6 +120,32 @@ struct TraceArgs
 constexpr uint32_t kAqPubRing = 64;  // entries of the host's ring of published continuations (pinned host memory)
 constexpr int kAqChainMax = 8;       // updates one launch can work on (its own + 7): the counters ring holds 2 x that
 constexpr uint32_t kAqCounters = 2 * kAqChainMax;
+// What may DIFFER between two updates that one launch works on (round 5): the lights (ddgi_set_lights, or animated by
+// RenderSettings::time — probe_pass.comp:217-251), DDGI mode's per-frame ray rotation and RNG key, where the rays come from
+// and where the ray records go, and the light-feeler classes that belong to the lights' positions.  The queue kernel reads these
+// from a ring indexed by the update's sequence number instead of from its own arguments: a ray carries in dst[31:29] which
+// update after the launch's own it belongs to, an event group runs with the record of ITS update (k_probe_trace_aq).
+// The host writes an update's record into pinned memory before it publishes the update (AqChain::upd_host); a workgroup copies it
+// into the device ring (AqChain::upd_dev) when it starts (its launch's own update) / when it moves on to the update (a continued
+// one) and reads it from there with scalar loads.  The feeler classes a record points at must be complete before the first launch
+// that may read it starts: ddgi_engine.cpp: assign_vis.
+struct UpdK
+{
+    LightK lights[kMaxLights];
+    float rot[9];
+    uint32_t frame_key;
+    const float4* rays;
+    float* rad_rgb;
+    float* rad_dd;
+    const uint8_t* vis;
+    const uint32_t* vis_occ;
+    const uint8_t* vis_more[kVisLights - 1];
+    uint32_t pad[128 - 7 * kMaxLights - 10 - 2 * (5 + kVisLights - 1)];
+};
+constexpr uint32_t kUpdWords = 128;
+static_assert(sizeof(UpdK) == kUpdWords * 4, "one record of the per-update ring is 128 dwords: a wave copies it with two dwords per lane");
+static_assert(offsetof(UpdK, rays) % 8 == 0, "pointers of the record are read as 64-bit words");
+
 struct AqChain
 {
     uint32_t* counters;   // device: kAqCounters ray counters
@@ -127,6 +153,8 @@ struct AqChain
     const uint32_t* pub;  // pinned host memory, device-visible: kAqPubRing words
     uint32_t seq;
     uint32_t chain_max;   // 0: this launch works on its own update only
+    const uint32_t* upd_host;  // pinned host memory, device-visible: kAqPubRing records (UpdK) — [seq % kAqPubRing]
+    uint32_t* upd_dev;         // device: kAqCounters records — [seq % kAqCounters]
 };
 
 // DDGI-mode ray records, laid out as the B operand of the blend's MFMA contraction (ddgi_blend_sample.hip): for local
