@@ -248,9 +248,9 @@ def main():
     ap.add_argument("--exchange", choices=["auto", "rccl", "p2p"], default="auto",
                     help="N > 1: how the ranks' slabs are exchanged — p2p: every rank pushes its slab into its peers' textures "
                          "(ddgi_exchange_p2p_*, IPC-mapped buffers: copies between GPUs, which overlap the trace kernel's persistent workgroups); "
-                         "rccl: one in-place ncclAllGather per texture; auto (default): p2p, checked on one exchanged update, else rccl.  "
-                         "A transport that cannot be brought up (an error, or for RCCL no answer within --rccl-timeout seconds) is given up "
-                         "for the other one, and the line says so (config.exchange_fallback)")
+                         "rccl: one in-place ncclAllGather per texture; auto (default): BOTH are brought up and timed on a short run, the timed "
+                         "region runs under the faster (multi_gpu.by_transport reports both).  A transport that cannot be brought up (an error, "
+                         "or for RCCL no answer within --rccl-timeout seconds) is reported by name with the reason (config.exchange_fallback)")
     ap.add_argument("--rccl-timeout", type=float, default=90.0)
     ap.add_argument("--frames-in-flight", type=int, default=None, help="tuning \"frames_in_flight\" (default: the library's, 8; the reference's host runs MAX_FRAMES_IN_FLIGHT = 2 ahead)")
     args = ap.parse_args()
@@ -258,6 +258,11 @@ def main():
         raise SystemExit("--workload c5 is S-Dyn (4 dynamic lights + temporal hysteresis): run it with --mode ddgi")
     if args.warmup is None:
         args.warmup = 8 if args.workload == "c5" else 5
+
+    if os.environ.get("DDGI_BENCH_WATCHDOG"):   # (diagnostics: every rank's Python stack on stderr every so many seconds — where a run that does not end is)
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["DDGI_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
 
     import torch
     import torch.distributed as dist
@@ -401,28 +406,33 @@ def main():
                 pass
         return False, "peer-to-peer transport not available (%s, rank %d)" % (why or "another rank gave up", rank)
 
-    if sharded:
-        # auto (default): peer-to-peer first — its pushes are copies between GPUs, which run beside the trace kernel's persistent
-        # workgroups (they fill every CU's registers and LDS: an RCCL kernel gets a CU only between two launches), RCCL if it fails
-        order = {"auto": ["p2p", "rccl"], "rccl": ["rccl", "p2p"], "p2p": ["p2p"]}[args.exchange]
-        if world == 1:
-            order = ["rccl"]                        # (DDGI_BENCH_FORCE_DIST: the one-rank RCCL group)
-        reasons = []
-        for cand in order:
-            if cand == "rccl":
-                ok, c, why = try_rccl()
-                if ok:
-                    comm = c
-            else:
-                ok, why = try_p2p()
+    def attach(cand):
+        """Brings transport `cand` up on every rank (collective).  -> (ok, why)"""
+        nonlocal comm, exchanging, transport
+        if cand == "rccl":
+            ok, c, why = try_rccl()
             if ok:
-                exchanging, transport = True, cand
-                break
-            reasons.append(why)
-        if reasons:
-            fallback = "; ".join(reasons) + (": fell back to %s" % transport if exchanging else "")
-        if not exchanging:
-            raise SystemExit("no exchange transport could be brought up: " + "; ".join(reasons))
+                comm = c
+        else:
+            ok, why = try_p2p()
+        if ok:
+            exchanging, transport = True, cand
+        return ok, why
+
+    def detach():
+        """Every rank lets go of its transport (collective): nothing in flight, peers' mappings closed, communicator destroyed."""
+        nonlocal comm, exchanging, transport
+        fence()
+        if sharded:
+            dist.barrier()                      # every rank has stopped pushing before any rank unmaps / frees
+        eng.exchange_init(None)
+        if comm is not None:
+            with _c_stdout_to_stderr():
+                ddgi_amd.comm_destroy(comm)
+            comm = None
+        exchanging, transport = False, "none"
+        if sharded:
+            dist.barrier()
 
     pinned_split = bool(os.environ.get("DDGI_AQ_MARCH"))  # (profiling runs pin the split so that every launch is the steady-state kernel)
     frame_time = [0.0]
@@ -474,21 +484,60 @@ def main():
         eng.tune()                              # the march/event wave split of this configuration, measured once (blocks; outside the timed region)
         setup_ms["ddgi_tune"] = (time.perf_counter() - t_setup) * 1e3
 
-    # N > 1 on separate GPUs: the queue kernel's persistent workgroups fill every CU, so whatever part of the exchange runs as a
-    # KERNEL (an RCCL collective; a peer copy, if the runtime does it with a shader instead of a copy engine) waits for a launch to
-    # end — unless a few CUs are left free for it ("reserve_cus").  Which it is on this box is measured, not guessed: the same
-    # short run of updates with their exchanges at 0 / 2 / 4 reserved CUs, the maximum over the ranks, the fastest stays.
+    # ---- N > 1: which transport, decided by measurement ----------------------------------------------------------------------
+    # Two transports serve the same all-gather (csrc/ddgi_exchange.cpp): peer-to-peer pushes into IPC-mapped textures (copies between
+    # GPUs, no CU needed) and RCCL's ncclAllGather (kernels: the queue kernel's persistent workgroups fill every CU, so a collective
+    # kernel finds a CU only between two launches — unless a few CUs are left free for it, tuning "reserve_cus").  `--exchange auto`
+    # brings BOTH up, one after the other, times the same short run of updates + exchanges under each (at 0 / 2 / 4 reserved CUs;
+    # the maximum over the ranks), and runs the timed region under the faster; the line reports both (multi_gpu.by_transport),
+    # a transport that could not be brought up by name with the reason.
+    by_transport = {}
     reserve_sweep = None
-    if exchanging and world > 1 and not ddgi_mode and os.environ.get("DDGI_RESERVE_CUS") is None:
-        reserve_sweep = {}
-        for r in (0, 2, 4):
-            eng.set_tuning("reserve_cus", r)
-            reserve_sweep[str(r)] = timed(16, 4) / 16 * 1e3
-        best = min(reserve_sweep, key=lambda k: reserve_sweep[k])
-        if reserve_sweep["0"] <= reserve_sweep[best] * 1.01:
-            best = "0"                          # (within a percent: the full machine)
-        eng.set_tuning("reserve_cus", int(best))
-        reserve_sweep["chosen"] = int(best)
+    if sharded:
+        order = {"auto": ["p2p", "rccl"], "rccl": ["rccl"], "p2p": ["p2p"]}[args.exchange]
+        if world == 1:
+            order = ["rccl"]                        # (DDGI_BENCH_FORCE_DIST: the one-rank RCCL group)
+        sweep_reserve = world > 1 and not ddgi_mode and os.environ.get("DDGI_RESERVE_CUS") is None
+        for cand in order:
+            ok, why = attach(cand)
+            if not ok:
+                by_transport[cand] = {"available": False, "reason": why}
+                continue
+            info = {"available": True, "ranks_in_communicator": eng.exchange_ranks() if cand == "rccl" else world}
+            if world > 1:
+                sweep = {}
+                r0 = eng.get_tuning("reserve_cus")
+                for r in ((0, 2, 4) if sweep_reserve else (r0,)):
+                    eng.set_tuning("reserve_cus", r)
+                    sweep[str(r)] = timed(16, 4) / 16 * 1e3
+                best = min(sweep, key=lambda k: sweep[k])
+                if "0" in sweep and sweep["0"] <= sweep[best] * 1.01:
+                    best = "0"                      # (within a percent: the full machine)
+                info.update(reserve_cus_ms_per_step=sweep, reserve_cus=int(best), ms_per_step=sweep[best])
+                eng.set_tuning("reserve_cus", r0)
+            by_transport[cand] = info
+            if len(order) > 1:
+                detach()
+        usable = [c for c in order if by_transport[c].get("available")]
+        verdict = torch.tensor([len(usable)], dtype=torch.int32)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN)
+        if not usable or verdict.item() == 0:
+            raise SystemExit("no exchange transport could be brought up: " + json.dumps(by_transport))
+        winner = min(usable, key=lambda c: by_transport[c].get("ms_per_step", 0.0))
+        pick = [winner]
+        dist.broadcast_object_list(pick, src=0)     # (rank 0's clock decides; the times are maxima over the ranks already)
+        winner = pick[0]
+        if len(order) > 1:
+            ok, why = attach(winner)
+            if not ok:
+                raise SystemExit("the chosen transport (%s) did not come up a second time: %s" % (winner, why))
+        reserve_sweep = by_transport[winner].get("reserve_cus_ms_per_step")
+        if reserve_sweep is not None:
+            reserve_sweep = dict(reserve_sweep, chosen=by_transport[winner]["reserve_cus"])
+            eng.set_tuning("reserve_cus", by_transport[winner]["reserve_cus"])
+        refused = [c + ": " + str(by_transport[c].get("reason")) for c in order if not by_transport[c].get("available")]
+        if refused:
+            fallback = "; ".join(refused) + ": ran with " + winner
 
     elapsed = timed(args.steps, max(0, args.warmup - 1))   # (the first update above is the first warm-up step)
 
@@ -612,7 +661,10 @@ def main():
             "transport": transport, "pipelined": True, "ranks_seen": sorted(r["rank"] for r in per_rank), "per_rank": per_rank,
             "ms_per_step_without_exchange": no_x, "exchange_ms_exposed": ms_per_step - no_x,
             "reserve_cus_ms_per_step": reserve_sweep,
-            "note": "exchange_ms_exposed = ms_per_step minus the same timed loop without ddgi_exchange: what the pipelined all-gather costs the critical path",
+            "by_transport": by_transport,
+            "note": "exchange_ms_exposed = ms_per_step minus the same timed loop without ddgi_exchange: what the pipelined all-gather costs the critical path; "
+                    "by_transport: both transports brought up one after the other and timed on the same 16 updates + exchanges (maximum over the ranks) at 0 / 2 / 4 "
+                    "CUs left free for the exchange's kernels — the timed region ran under the faster (`transport`); one that could not be brought up says why",
         }
         gathered = eng.read_textures() if not ddgi_mode else eng.read_tiles()   # a consumer: waits for the latest exchange by itself
         if rank == 0:
@@ -635,6 +687,32 @@ def main():
                 solo.generate_probe_rays(seed=w["seed"])
                 solo.probe_update()
                 want = solo.read_textures()
+            # (c) the like-for-like denominator of the speed-up: the SAME box, ONE GPU, one unsharded handle, the same frames in
+            # flight and timing loop (the other ranks wait at the barrier below; their GPUs idle)
+            solo.set_tuning("frames_in_flight", fif)
+            if not pinned_split:
+                solo.tune()
+            st1 = ddgi_amd.make_settings(w["scene"], w["max_bounces"])
+            solo_frame = [frames_issued[0]]
+
+            def solo_run(n):
+                for _ in range(n):
+                    if ddgi_mode:
+                        solo_frame[0] += 1
+                        st1.time = 2.0 * solo_frame[0]
+                        solo.probe_update(st1)
+                    else:
+                        solo.probe_update()
+                solo.synchronize()
+
+            solo_run(max(2, args.warmup))
+            t0 = time.perf_counter()
+            solo_run(args.steps)
+            one_gpu_ms = (time.perf_counter() - t0) / args.steps * 1e3
+            out["multi_gpu"]["one_gpu_same_box_ms_per_step"] = one_gpu_ms
+            out["multi_gpu"]["speedup_vs_one_gpu"] = one_gpu_ms / ms_per_step
+            out["multi_gpu"]["speedup_note"] = ("one unsharded handle on rank 0's GPU of this box, frames_in_flight %d like the ranks, %d updates back to back after %d of warm-up, wall clock; "
+                                               "the other ranks' GPUs idle meanwhile%s" % (fif, args.steps, max(2, args.warmup), " (DDGI_BENCH_ONE_GPU: every rank shares that GPU — not a measurement of scaling)" if one_gpu else ""))
             solo.close()
             sha = [hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest() for a in gathered]
             sha_want = [hashlib.sha1(np.ascontiguousarray(a).tobytes()).hexdigest() for a in want]

@@ -974,8 +974,14 @@ __global__ __launch_bounds__(256) void k_probe_sample_ddgi(const SampleArgs A)
     A.rgb[3 * i] = out.x, A.rgb[3 * i + 1] = out.y, A.rgb[3 * i + 2] = out.z;
     if (A.cage)
     {
-        int4* q = reinterpret_cast<int4*>(A.cage + 8 * static_cast<size_t>(i));  // 32 bytes per point: two 16-byte stores
-        q[0] = int4{cage[0], cage[1], cage[2], cage[3]}, q[1] = int4{cage[4], cage[5], cage[6], cage[7]};
+        int32_t* q1 = A.cage + 8 * static_cast<size_t>(i);  // 32 bytes per point: two 16-byte stores where the caller's buffer is 16-byte aligned
+        if ((reinterpret_cast<uintptr_t>(A.cage) & 15u) == 0u)
+        {
+            int4* q = reinterpret_cast<int4*>(q1);
+            q[0] = int4{cage[0], cage[1], cage[2], cage[3]}, q[1] = int4{cage[4], cage[5], cage[6], cage[7]};
+        }
+        else
+            for (int c = 0; c < 8; ++c) q1[c] = cage[c];
     }
 }
 

@@ -199,7 +199,7 @@ void ddgi_texture_bytes(int mode, const ddgi_irradiance_field& f, int rays_per_p
 // on the handle's own textures only — a host that holds pointers to a pair (ddgi_bind_textures, ddgi_device_textures) expects the
 // handle to stay on it.  The pair a ray writes travels in the top three bits of its texel index (ddgi_trace_wf.hip: kDstPairShift).
 // (DDGI mode's trace writes ray records, not textures: its group is the ring of record buffers, rec_ring_len below.)
-static int chain_len_for(const ddgi_engine* e, size_t albedo_bytes)
+static int chain_len_for(const ddgi_engine* e, size_t albedo_bytes, bool pipelined)
 {
     if (e->mode != DDGI_MODE_REF || e->pin_pair || e->caller_tex) return 1;
     if (albedo_bytes / 4 >= (static_cast<size_t>(1) << 29)) return 1;
@@ -207,10 +207,11 @@ static int chain_len_for(const ddgi_engine* e, size_t albedo_bytes)
     // What a longer chain hides is a constant per launch (the drain: ~0.25 ms), worth nothing on updates of tens of milliseconds —
     // and a ring of 8 (16 under the pipelined exchange) pairs of a large grid is memory better left to the host: rings beyond 2 GiB
     // are halved down to two pairs.  (A function of the configuration only: every rank of a sharded grid comes to the same length.)
-    while (len > 2 && albedo_bytes * 2 * static_cast<size_t>(len) > (static_cast<size_t>(2) << 30)) len /= 2;
+    // (the pipelined exchange doubles the ring: counted)
+    while (len > 2 && albedo_bytes * 2 * static_cast<size_t>(len) * (pipelined ? 2 : 1) > (static_cast<size_t>(2) << 30)) len /= 2;
     return len;
 }
-int ddgi_chain_len(const ddgi_engine* e) { return chain_len_for(e, e->tex_bytes[0]); }
+int ddgi_chain_len(const ddgi_engine* e) { return chain_len_for(e, e->tex_bytes[0], e->xch.pipelined); }
 
 // DDGI mode: ray-record buffers the handle keeps = updates one launch may work on.  The blend of update k reads the records of
 // update k behind that update's own launch, while a launch may already be tracing k + 1 ..: every update of a group has its own
@@ -233,7 +234,7 @@ int ddgi_group_len(const ddgi_engine* e)
 // exchange is pipelined — the all-gathers of one group's pairs run while the next group's are written.
 int ddgi_pairs_wanted(const ddgi_engine* e, bool pipelined)
 {
-    const int len = ddgi_chain_len(e);
+    const int len = chain_len_for(e, e->tex_bytes[0], pipelined);
     return pipelined ? std::max(2, 2 * len) : len;
 }
 
@@ -266,7 +267,7 @@ static int alloc_textures(ddgi_engine* e)
     size_t bytes[2];
     texture_bytes(e->mode, e->field, make_grid(e).n, bytes);
     e->caller_tex = false;
-    const int np = chain_len_for(e, bytes[0]);  // (the ring's length follows the NEW configuration)
+    const int np = chain_len_for(e, bytes[0], false);  // (the ring's length follows the NEW configuration; ddgi_exchange_release above: no exchange)
     void* fresh[2];
     if (int rc = alloc_texture_pair(e, bytes, np, fresh)) return rc;
     for (int i = 0; i < 2; ++i)
@@ -307,6 +308,21 @@ int ddgi_resize_ring(ddgi_engine* e, int np)
         e->tex_prev[i] = nullptr;
     }
     e->np = np, e->pair_cur = 0, e->ring_k = 0, e->chain_break = true;
+    e->box_of = nullptr;
+    return DDGI_OK;
+}
+
+int ddgi_rebase_ring(ddgi_engine* e)
+{
+    if (e->caller_tex) return DDGI_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->pair_cur != 0)
+    {
+        for (int i = 0; i < 2; ++i) HIP_TRY(hipMemcpyAsync(e->own_tex[i], ddgi_pair_ptr(e, e->pair_cur, i), e->tex_bytes[i], hipMemcpyDeviceToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    for (int i = 0; i < 2; ++i) e->tex[i] = e->own_tex[i], e->tex_prev[i] = nullptr;
+    e->pair_cur = 0, e->ring_k = 0, e->chain_break = true;
     e->box_of = nullptr;
     return DDGI_OK;
 }
@@ -623,7 +639,7 @@ int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const dd
     size_t bytes[2];
     texture_bytes(e->mode, *field, field->sqrt_rays_per_probe * field->sqrt_rays_per_probe, bytes);
     void* fresh[2];
-    const int np = chain_len_for(e, bytes[0]);  // (the exchange, if any, is set up again afterwards: ddgi_exchange_release below)
+    const int np = chain_len_for(e, bytes[0], false);  // (the exchange, if any, is set up again afterwards: ddgi_exchange_release below)
     if (int rc = alloc_texture_pair(e, bytes, np, fresh)) return rc;
     if (carried > 0)
     {
@@ -1396,6 +1412,7 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
             for (int i = 0; i < 2; ++i) e->tex[i] = tex[i], e->tex_prev[i] = prev[i];
             e->pair_cur = pair_cur;
             e->chain_break = true;
+            if (e->xch.transport) e->xch.desync = true;  // (this rank's count of updates has fallen behind its peers': ddgi_exchange says so)
         }
     } saved{e, {e->tex[0], e->tex[1]}, {e->tex_prev[0], e->tex_prev[1]}, e->pair_cur};
     if (!e->caller_tex)
@@ -1771,9 +1788,17 @@ static void release_sample_box_if_borrowed(ddgi_engine* e)
     if (e->caller_tex || e->pin_pair) e->box_of = nullptr;
 }
 
+// try_box: the batch may go through the per-texel table (false: the caller — the chunk loop below — has found there is none)
+static int sample_device(ddgi_engine* e, const float* d_pos, const float* d_nrm, size_t n, float* d_rgb, int32_t* d_cage, bool try_box);
+
 int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, size_t n, float* d_rgb, int32_t* d_cage)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
+    return sample_device(e, d_pos, d_nrm, n, d_rgb, d_cage, true);
+}
+
+static int sample_device(ddgi_engine* e, const float* d_pos, const float* d_nrm, size_t n, float* d_rgb, int32_t* d_cage, bool try_box)
+{
     e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if (n == 0) return DDGI_OK;
     if (!d_pos || !d_nrm || !d_rgb) return fail(DDGI_ERR_INVALID_ARGUMENT, "null device pointer");
@@ -1791,7 +1816,7 @@ int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, si
     a.n = static_cast<uint32_t>(n);
     // REF mode, a large batch (or the table is there already): sample_probe comes from its per-texel table — built now if the
     // textures have changed since it was last built (one pass over the texels, ~ the cost of sampling 100 000 points directly)
-    if (e->mode == DDGI_MODE_REF && e->tuning.sample_box && (sample_box_pays(e, n) || e->box_of == e->tex[0]))
+    if (try_box && e->mode == DDGI_MODE_REF && e->tuning.sample_box && (sample_box_pays(e, n) || e->box_of == e->tex[0]))
     {
         bool usable = false;
         if (int rc = ensure_sample_box(e, a.grid, &usable)) return rc;
@@ -1811,7 +1836,9 @@ int ddgi_sample_device(ddgi_handle e, const float* d_pos, const float* d_nrm, si
         for (size_t off = 0; off < n; off += kGroupChunk)
         {
             const size_t m = std::min(kGroupChunk, n - off);
-            if (int rc = ddgi_sample_device(e, d_pos + 3 * off, d_nrm + 3 * off, m, d_rgb + 3 * off, d_cage ? d_cage + 8 * off : nullptr)) return rc;
+            // (whether the per-texel table serves this batch was decided above, once: a table that could not be allocated is not
+            // asked for again per chunk — a stream synchronisation and a failing multi-GB allocation each time)
+            if (int rc = sample_device(e, d_pos + 3 * off, d_nrm + 3 * off, m, d_rgb + 3 * off, d_cage ? d_cage + 8 * off : nullptr, false)) return rc;
         }
         return DDGI_OK;
     }

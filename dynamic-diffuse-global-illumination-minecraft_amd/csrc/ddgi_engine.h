@@ -182,6 +182,7 @@ struct ddgi_engine
         void* comm = nullptr;   // RCCL: ncclComm_t; caller-owned unless made by ddgi_comm_create
         P2P* p2p = nullptr;     // peer-to-peer: mapped peer buffers, flags, per-peer streams
         bool pipelined = false;                 // the exchange of a pair runs on comm_stream while later updates write other pairs of the ring
+        bool desync = false;                    // an update failed while attached: this rank's update count no longer matches its peers' (ddgi_exchange refuses)
         hipStream_t comm_stream = nullptr;
         hipEvent_t written = nullptr;           // handle's stream: the update's kernels have finished
         hipEvent_t sent[kMaxPairs] = {};        // comm stream: pair i's last exchange is over (RCCL) / this rank's slab has left (p2p)
@@ -204,6 +205,7 @@ int ddgi_chain_len(const ddgi_engine* e);           // REF mode: updates one lau
 int ddgi_group_len(const ddgi_engine* e);           // updates one launch may work on in the handle's mode (REF: pairs of the ring; DDGI: ray-record buffers)
 int ddgi_pairs_wanted(const ddgi_engine* e, bool pipelined);
 int ddgi_resize_ring(ddgi_engine* e, int np);       // blocks; the current pair's contents move to pair 0 of the new ring
+int ddgi_rebase_ring(ddgi_engine* e);               // blocks; the same ring, counted from update 0 again: the current pair's contents move to pair 0
 // exchange hooks called by the engine (no-ops without an initialised exchange)
 int ddgi_exchange_before_update(ddgi_engine* e, int first_pair, int n_pairs);  // pipelined: the stream waits for the last exchanges of the pairs a launch may write
 int ddgi_exchange_wait_latest(ddgi_engine* e);     // consumers: the handle's stream waits until the latest pair is complete

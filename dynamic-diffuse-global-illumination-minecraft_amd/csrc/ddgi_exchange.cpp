@@ -35,6 +35,7 @@
 #include <cstring>
 #include <mutex>
 #include <random>
+#include <thread>
 #include <vector>
 
 #include "ddgi_engine.h"
@@ -299,6 +300,7 @@ struct PendingSent
 {
     ddgi_engine* e;
     int pair;
+    std::thread::id owner;  // the thread whose bracket the exchange was recorded in: only ITS ncclGroupEnd puts the collective on its stream
 };
 thread_local int g_group_depth = 0;
 // (one list for the process, under a lock: a handle destroyed from another thread than the one that exchanged must still be
@@ -353,6 +355,13 @@ namespace {
 int exchange_common_setup(ddgi_engine* e, bool pipelined, bool always_streams)
 {
     ddgi_engine::Exchange& x = e->xch;
+    // Which pair of the ring an update writes — and a peer's push lands in — is a function of the update's NUMBER since the ring
+    // was made (ddgi_engine::ring_k).  The ranks attach their exchange together but may have done different numbers of updates
+    // before (asymmetric warm-up, one rank's failed update): every attachment starts the count over, on pair 0, with the
+    // current contents.
+    if (!e->caller_tex)
+        if (int rc = ddgi_rebase_ring(e)) return rc;
+    x.desync = false;
     if (pipelined)
     {
         if (e->caller_tex) return fail(DDGI_ERR_INVALID_ARGUMENT, "the pipelined exchange alternates the handle's own texture pairs: unbind caller textures first");
@@ -437,10 +446,19 @@ int ddgi_exchange_group_end(void)
         // the collectives recorded inside the bracket are on their streams NOW: this is where "exchange over" is in stream order
         // (every pending handle gets its event, whatever happens to another one's: a pair left without it would be overwritten by
         // the update after next while its all-gather may still be reading it; the first error is what the call returns)
+        // (only this thread's: another thread's bracket may still be open — its all-gathers are not on their streams yet)
         std::vector<PendingSent> pending;
         {
             std::lock_guard<std::mutex> lock(g_group_mu);
-            pending.swap(g_group_pending);
+            const std::thread::id me = std::this_thread::get_id();
+            for (auto it = g_group_pending.begin(); it != g_group_pending.end();)
+                if (it->owner == me)
+                {
+                    pending.push_back(*it);
+                    it = g_group_pending.erase(it);
+                }
+                else
+                    ++it;
         }
         int first_rc = DDGI_OK;
         for (const PendingSent& ps : pending)
@@ -576,11 +594,34 @@ int ddgi_exchange_transport(ddgi_handle e, int* transport, int* pipelined)
     return DDGI_OK;
 }
 
+int ddgi_exchange_ranks(ddgi_handle e, int* ranks)
+{
+    if (!e || !ranks) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/ranks");
+    *ranks = 0;
+    const ddgi_engine::Exchange& x = e->xch;
+    if (x.transport == DDGI_EXCHANGE_RCCL)
+    {
+        if (int rc = rccl_ready()) return rc;
+        NCCL_TRY(rccl().CommCount(x.comm, ranks));
+    }
+    else if (x.transport == DDGI_EXCHANGE_P2P && x.p2p)
+    {
+        int n = 1;
+        for (int q = 0; q < static_cast<int>(x.p2p->peers.size()); ++q)
+            if (q != e->rank && x.p2p->peers[static_cast<size_t>(q)].ring[0] && x.p2p->peers[static_cast<size_t>(q)].flags) n += 1;
+        *ranks = n;
+    }
+    return DDGI_OK;
+}
+
 int ddgi_exchange(ddgi_handle e)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     ddgi_engine::Exchange& x = e->xch;
     if (!x.transport) return fail(DDGI_ERR_NOT_READY, "ddgi_exchange before ddgi_exchange_init / ddgi_exchange_p2p_init");
+    if (x.desync)
+        return fail(DDGI_ERR_NOT_READY, "an update of this rank failed while the exchange was attached: its count of updates — which texture pair an update writes and a "
+                                        "peer's slab lands in — no longer matches the other ranks'.  Attach the exchange again on EVERY rank (ddgi_exchange_init / ddgi_exchange_p2p_export + _init)");
     HIP_TRY(hipSetDevice(e->device));
     e->box_of = nullptr;  // the other ranks' slabs are about to change: the sampler's per-texel table is stale
     if (x.transport == DDGI_EXCHANGE_P2P) return p2p_exchange(e);
@@ -612,7 +653,7 @@ int ddgi_exchange(ddgi_handle e)
             // update only come after ddgi_exchange_group_end, which records it.
             x.sent_valid[e->pair_cur] = false;
             std::lock_guard<std::mutex> lock(g_group_mu);
-            g_group_pending.push_back(PendingSent{e, e->pair_cur});
+            g_group_pending.push_back(PendingSent{e, e->pair_cur, std::this_thread::get_id()});
         }
         else
         {

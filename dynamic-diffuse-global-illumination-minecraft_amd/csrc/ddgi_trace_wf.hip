@@ -1290,6 +1290,24 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
 #ifndef DDGI_MARCH_PRIO
 #define DDGI_MARCH_PRIO 0  // s_setprio of the (exact) march waves; the event waves run at DDGI_EVENT_PRIO
 #endif
+#ifndef DDGI_AQ_REQUEUE
+#define DDGI_AQ_REQUEUE 0  // (experiment, round 5: measured slower, off) march waves: every burst starts from the queue, unfinished marches are queued
+                           // again.  Lanes per burst 30.6 -> 40.2 of 64, bursts per ray 0.23 -> 0.18 — and C3 1.578 -> 1.647 ms at every wave split
+                           // (profiles/r05_requeue_split_sweep.txt): a march wave's throughput is its bursts' latency, and a burst that fetches all
+                           // 64 lanes and writes the unfinished ones back is longer than one that tops a few lanes up; the fill threshold never waits
+                           // (1 / 32 / 48 / 60 entries: the same times — the queue is deep whenever the march side is the limit)
+#endif
+#ifndef DDGI_AQ_FILL
+#define DDGI_AQ_FILL 48  // ... and starts only when the queue holds this many marches (or after DDGI_AQ_FILL_WAITS naps of DDGI_AQ_FILL_NAP x 64 cycles)
+#endif
+#ifndef DDGI_AQ_FILL_WAITS
+#define DDGI_AQ_FILL_WAITS 6
+#endif
+#ifndef DDGI_AQ_FILL_NAP
+#define DDGI_AQ_FILL_NAP 4
+#endif
+constexpr uint32_t kAqFill = DDGI_AQ_FILL;
+constexpr int kAqFillWaits = DDGI_AQ_FILL_WAITS;
 #ifndef DDGI_AQ_TRIP_ARGS
 #define DDGI_AQ_TRIP_ARGS 1  // the event waves read the kernel's arguments afresh in every trip (args_of_this_trip)
 #endif
@@ -1490,6 +1508,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
     const float inf = __builtin_inff();
     unsigned int guard = 0;  // safety net: consecutive polls without work (about 1 s of them trips it); never spin forever on the GPU
     unsigned long long st_a = 0, st_b = 0;  // utilisation counters: trips / groups, and the lanes that had work in them
+    unsigned long long st_useful = 0;       // counters build: lane-steps of the march bursts that moved a march (the others stood still: frozen or no march)
     LaneProbe probe;                        // (counters build only)
 #ifdef DDGI_LAP
     if (kStats)
@@ -1589,7 +1608,132 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             }
         }
     }
+#if DDGI_AQ_REQUEUE
     else if (wave < march_waves)
+    {
+        // ================= march waves (round 5): every burst starts from the queue =================
+        // Per C3 update the march waves used to issue 0.7 G of the kernel's 1.1 G VALU wave-instructions at 26 of 64 lanes: a wave
+        // kept its unfinished marches from burst to burst and topped its idle lanes up with whatever the queue held at that moment —
+        // and the queue held little, because seven waves were emptying it as fast as the events filled it.  A march in the middle of
+        // its steps is nothing but (t, iterations) next to the slot's origin and direction — what an event leaves for a march it has
+        // taken the first steps of — so a wave that has finished a burst writes that back and queues the unfinished slots again, like
+        // the finished ones go to their event queues.  Then every burst starts with an empty wave, and a wave starts one only when
+        // the queue can FILL it (kAqFill entries, or what there is after a bounded wait): the marches in flight share few, full
+        // bursts, the other march waves sleep — which is issue time for the event waves on their SIMDs.
+        if (DDGI_MARCH_PRIO > 0) __builtin_amdgcn_s_setprio(DDGI_MARCH_PRIO);
+        March m;
+        m.ro = m.rd = m.dn = m.inv = m.cc = m.p = mk3(0, 0, 0);  // (a lane without a march takes zero-length steps from this state: every index it computes is inside the bitmap)
+        m.t = 0.0f, m.tl = inf, m.it = 0, m.lid = -1, m.cell = 0;
+        f3 hi_v = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
+        asm volatile("" : "+v"(hi_v.x), "+v"(hi_v.y), "+v"(hi_v.z));
+        int waited = 0, bursts = 0;
+        for (;;)
+        {
+            if (++guard > (1u << 23)) sh->abort = 1u;
+            uint32_t avail = 0;
+            if (lane == 0)
+            {
+                avail = aq_load(&sh->mq_tail) - aq_load(&sh->mq_head);
+                if (avail > kCap) avail = 0;  // a claim in flight can make tail - head wrap for an instant
+            }
+            avail = lane_bcast(avail, 0);
+            const bool draining = aq_load(&sh->no_more) != 0u;
+            if (avail == 0u || (avail < kAqFill && waited < kAqFillWaits && !draining))
+            {
+                if ((avail == 0u && draining && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
+                if (avail != 0u) ++waited;
+                if (avail != 0u) __builtin_amdgcn_s_sleep(DDGI_AQ_FILL_NAP);
+                else __builtin_amdgcn_s_sleep(DDGI_AQ_SLEEP);
+                continue;
+            }
+            uint32_t base = 0, k = 0;
+            if (lane == 0) k = aq_claim(&sh->mq_head, &sh->mq_tail, 64u, base);
+            k = lane_bcast(k, 0), base = lane_bcast(base, 0);
+            if (k == 0u) continue;  // (another wave was quicker)
+            waited = 0;
+            guard = 0;
+            const bool have = static_cast<uint32_t>(lane) < k;
+            uint32_t slot = 0, fl = 0;
+            if (have)
+            {
+                slot = aq_take<kCap>(ring_mq, base + lane, &sh->abort);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                fl = P.flags[slot];
+                m.ro = ld3(P.ro, slot);
+                m.dn = ld3(P.dn, slot);
+                m.inv = f3{axis_inv(m.dn.x), axis_inv(m.dn.y), axis_inv(m.dn.z)};  // P5; recomputed, not stored
+                m.t = P.t[slot];
+                m.tl = P.tl[slot];
+                m.it = static_cast<int>((fl >> 4) & 255u);
+                m.cc = f3{m.dn.x >= 0.0f ? 1.0f : 0.0f, m.dn.y >= 0.0f ? 1.0f : 0.0f, m.dn.z >= 0.0f ? 1.0f : 0.0f};
+                m.p = ray_at(m.ro, m.dn, m.t);
+            }
+            if (kStats) st_a += 1, st_b += k, st_q[5] += 1, st_q[7] += k;
+            // The burst: kAqStepsPerTrip unrolled steps without exec-mask predication — a march that has ended, or a lane without
+            // one, takes steps of length 0 (march_step_frozen); whether the cell reached is occupied is read once after the burst
+            // (m.cell); the test against grid_march's iteration limit is in the steps only when a lane can reach it in this burst.
+            const bool near_limit = __ballot(have && kMarchIters - m.it < kAqStepsPerTrip) != 0ull;
+            bool fin = !have;
+            if (near_limit)
+            {
+                fin = fin || (kMarchIters - m.it <= 0);
+#pragma unroll
+                for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
+                {
+                    if (kStats) st_useful += static_cast<unsigned long long>(__popcll(__ballot(!fin)));
+                    fin = fin | march_step_frozen(m, A.scene, s_bits, hi_v, fin) | (m.t >= m.tl) | (kMarchIters - m.it <= sub + 1);
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
+                {
+                    if (kStats) st_useful += static_cast<unsigned long long>(__popcll(__ballot(!fin)));
+                    fin = fin | march_step_frozen(m, A.scene, s_bits, hi_v, fin) | (m.t >= m.tl);
+                }
+            }
+            bool finished = false, again = false;
+            uint32_t bucket = 0;
+            if (have)
+            {
+                const uint32_t* __restrict__ bits_base = s_bits - (A.scene.bias32 >> 5);
+                const bool occ = __builtin_amdgcn_ubfe(bits_base[m.cell >> 5], static_cast<uint32_t>(m.cell), 1u) != 0u;  // (march_step_frozen's own test)
+                m.it += kAqStepsPerTrip;
+                bool f = fin;
+                // (a march that has left the box for good can only miss: looked for in every fourth burst of the wave)
+                if (!f && (bursts & 3) == 3) f = march_escaped(m, A.scene);
+                P.t[slot] = m.t;
+                if (f)
+                {
+                    const uint32_t hf = !occ ? 0u : ((fl & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, U0, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
+                    P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | hf;
+                    const bool block_wins = occ && (m.t < m.tl);
+                    bucket = (fl & kFlagFeeler) ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock);
+                    finished = true;
+                }
+                else
+                {
+                    P.flags[slot] = (fl & ~0xff0u) | (static_cast<uint32_t>(m.it) << 4);  // goes on at (t, iterations), like a march an event has set up
+                    again = true;
+                }
+            }
+            ++bursts;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (__ballot(finished) != 0ull)
+            {
+                // a handful of lanes per queue: one LDS atomic per lane is cheaper than six wave-aggregated appends
+                if (finished)
+                {
+                    const uint32_t at = atomicAdd(&sh->eq_tail[bucket], 1u);
+                    (ring_eq + bucket * kCap)[at % kCap] = static_cast<uint16_t>(slot);
+                }
+            }
+            aq_push<kCap>(ring_mq, &sh->mq_tail, again, slot, lane);
+        }
+    }
+#endif
+    else if (!DDGI_AQ_REQUEUE && wave < march_waves)
     {
         // ================= march waves =================
         // A lane holds kLaneMarches marches at a time and steps them in turn inside one burst.  CDNA4's SIMDs are 32 lanes wide:
@@ -1782,7 +1926,11 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
 #pragma unroll
                         for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
 #pragma unroll
-                            for (int q = 0; q < kM; ++q) fin[q] = fin[q] | march_step_frozen(m[q], A.scene, s_bits, hi_v, fin[q]) | (m[q].t >= m[q].tl);
+                            for (int q = 0; q < kM; ++q)
+                            {
+                                if (kStats) st_useful += static_cast<unsigned long long>(__popcll(__ballot(!fin[q])));  // lanes that take this step for a march
+                                fin[q] = fin[q] | march_step_frozen(m[q], A.scene, s_bits, hi_v, fin[q]) | (m[q].t >= m[q].tl);
+                            }
                     }
                 }
                 const uint32_t* __restrict__ bits_base = s_bits - (A.scene.bias32 >> 5);
@@ -2074,6 +2222,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
         atomicAdd(&A.stats[wave < march_waves ? 0 : 2], st_a);
         atomicAdd(&A.stats[wave < march_waves ? 1 : 3], st_b);
         atomicAdd(&A.stats[4], 1ull);
+        atomicAdd(&A.stats[5], st_useful);
         for (int q = 0; q < 8; ++q) atomicAdd(&A.stats[8 + q], st_q[q]);  // (the slots of the round kernel's cycle counters)
     }
     if (status && lane == 0 && aq_load(&sh->abort) != 0u) atomicOr(status, 1u);  // the safety net tripped: the output is not valid

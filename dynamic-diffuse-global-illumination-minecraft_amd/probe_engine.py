@@ -139,6 +139,7 @@ _SIGNATURES = {
     "ddgi_exchange_p2p_export": (C.c_int, [_VP, C.c_int, _VP]),
     "ddgi_exchange_p2p_init": (C.c_int, [_VP, _VP, C.c_int]),
     "ddgi_exchange_transport": (C.c_int, [_VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ddgi_exchange_ranks": (C.c_int, [_VP, C.POINTER(C.c_int)]),
     "ddgi_exchange_group_begin": (C.c_int, []),
     "ddgi_exchange_group_end": (C.c_int, []),
     "ddgi_comm_unique_id": (C.c_int, [_VP]),
@@ -453,6 +454,12 @@ class ProbeEngine:
         t, pl = C.c_int(), C.c_int()
         _check(self._lib.ddgi_exchange_transport(self._h, C.byref(t), C.byref(pl)))
         return {0: "none", 1: "rccl", 2: "p2p"}[t.value], bool(pl.value)
+
+    def exchange_ranks(self):
+        """Ranks the attached transport spans (ncclCommCount / mapped peers + 1; 0: no exchange)."""
+        n = C.c_int()
+        _check(self._lib.ddgi_exchange_ranks(self._h, C.byref(n)))
+        return n.value
 
     def exchange(self):
         _check(self._lib.ddgi_exchange(self._h))

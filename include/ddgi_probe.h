@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define DDGI_ABI_VERSION 4 /* 4: tuning "frames_in_flight" (default 8): the handle owns a ring of texture pairs, ddgi_device_textures pins the current one;
+#define DDGI_ABI_VERSION 5 /* 5: ddgi_exchange_ranks; frames in flight in DDGI mode (per-update records, a ring of ray-record buffers); attaching an exchange
+                              rebases the ring of texture pairs (every rank starts at pair 0, update 0); d_cage of ddgi_sample_device: 16-byte aligned or slower;
+                              4: tuning "frames_in_flight" (default 8): the handle owns a ring of texture pairs, ddgi_device_textures pins the current one;
                               3: ddgi_exchange_p2p_*, ddgi_exchange_transport, ddgi_scene_skip_field; tuning "fast_march", "sample_box"; "autotune" off by default */
 
 /* ---- wire formats: byte-identical to the reference's UBO/SSBO records ------------------------ */
@@ -340,7 +342,9 @@ int ddgi_device_textures(ddgi_handle h, void** tex0, size_t* tex0_bytes, void** 
  * tiles with inconsistent borders would keep the inconsistency, decaying with the hysteresis. */
 int ddgi_bind_textures(ddgi_handle h, void* tex0, void* tex1);
 
-/* ddgi_sample on device pointers, asynchronous on the handle's stream. */
+/* ddgi_sample on device pointers, asynchronous on the handle's stream.  d_cage_idx8_out (optional): 8 int32 per point; a
+ * 16-byte aligned buffer (anything hipMalloc returns) is written with two 16-byte stores per point, any other with eight
+ * 4-byte ones. */
 int ddgi_sample_device(ddgi_handle h, const float* d_pos_xyz, const float* d_nrm_xyz, size_t n,
                        float* d_rgb_out, int32_t* d_cage_idx8_out);
 
@@ -394,6 +398,9 @@ int ddgi_exchange_p2p_init(ddgi_handle h, const uint8_t* addresses_rank_major, i
 #define DDGI_EXCHANGE_P2P 2
 /* Which transport the handle's exchange uses (DDGI_EXCHANGE_*), and whether it is pipelined. */
 int ddgi_exchange_transport(ddgi_handle h, int* transport, int* pipelined);
+/* How many ranks the attached transport really spans: RCCL — ncclCommCount of the communicator; peer-to-peer — the peers whose
+ * buffers are mapped, plus this rank; 0 without an exchange.  (A benchmark line's proof that the transport saw N ranks.) */
+int ddgi_exchange_ranks(ddgi_handle h, int* ranks);
 
 /* Communicator bootstrap through the same RCCL instance (thin wrappers of ncclGetUniqueId /
  * ncclCommInitRank / ncclCommInitAll / ncclCommDestroy), for hosts that do not link RCCL themselves:

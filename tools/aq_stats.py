@@ -24,6 +24,10 @@ if q[0]:
     print("queues at an event wave's poll: MQ %.0f  FQ %.0f  EQ (all buckets) %.0f slots;  idle polls %.2f of %d;  march bursts: %.2f per ray, "
           "%.1f lanes in flight at the start, %.2f of the fetches found MQ short" % (q[1] / q[0], q[2] / q[0], q[3] / q[0], q[4] / q[0], q[0],
           q[5] / rays, q[7] / max(q[5], 1), q[6] / max(q[5], 1)))
+if st["rounds"]:
+    steps = int(os.environ.get("DDGI_AQ_STEPS_BUILT", "24"))
+    print("march bursts: %.2f useful lane-steps per ray = %.1f per burst of %d x 64 = %.3f of the lane-steps a burst issues; %.1f steps per lane-trip" % (
+        st["rounds"] / rays, st["rounds"] / max(q[5], 1), steps, st["rounds"] / max(q[5], 1) / (steps * 64.0), st["rounds"] / max(lanes, 1)))
 print("feelers per ray (profiling build, ablate 16):", {k: round(v / rays, 3) for k, v in st["feeler_classes"].items()})
 for nm, (visits, lanes) in st["sections"].items():
     if visits:
