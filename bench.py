@@ -252,6 +252,7 @@ def main():
                          "region runs under the faster (multi_gpu.by_transport reports both).  A transport that cannot be brought up (an error, "
                          "or for RCCL no answer within --rccl-timeout seconds) is reported by name with the reason (config.exchange_fallback)")
     ap.add_argument("--rccl-timeout", type=float, default=90.0)
+    ap.add_argument("--p2p-timeout", type=float, default=120.0, help="seconds the peer-to-peer transport gets to map its peers' buffers")
     ap.add_argument("--frames-in-flight", type=int, default=None, help="tuning \"frames_in_flight\" (default: the library's, 8; the reference's host runs MAX_FRAMES_IN_FLIGHT = 2 ahead)")
     args = ap.parse_args()
     if args.workload == "c5" and args.mode != "ddgi":
@@ -373,10 +374,11 @@ def main():
         dist.all_gather_object(everyone, mine)
         ok = all(a is not None for a in everyone)
         if ok:
-            try:
-                eng.exchange_p2p_init(everyone)
-            except Exception as e:                  # noqa: BLE001
-                ok, why = False, "init: " + str(e)[:160]
+            # (bounded like RCCL's bring-up: mapping the peers' rings is a driver call per buffer — 4 ranks' rings of a C5-sized grid,
+            # 12.8 GB each, did not come back within seven minutes on the one-GPU test box)
+            done, res = _call_bounded(lambda: eng.exchange_p2p_init(everyone), args.p2p_timeout)
+            if not done:
+                ok, why = False, "init: " + str(res)[:160]
         attached = ok
         ok = all_ok(ok)
         if ok and not ddgi_mode:
@@ -592,6 +594,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_per_step_at_reference_frames_in_flight": ms_per_step if fif == 2 else None,   # (filled in below at N = 1: the same loop with "frames_in_flight" 2)
+        "value_at_reference_frames_in_flight": total_rays / (elapsed / args.steps) if fif == 2 else None,
         "ms_per_step_without_timing_events": untimed_ms,
         "higher_is_better": True,
         "scaling": "strong",
@@ -764,6 +768,44 @@ def main():
             "note": "1.44 M shading points scattered over the grid after the timed updates; bytes_per_point = 68 B of point I/O + 8 table entries of 16 B "
                     "(algorithmic); l2_sector_GBps counts the 64-byte sectors those scattered entries cost — the kernel is L2-sector bound, DESIGN.md section 4",
         }
+        # the same points in cage-cell order — what a frame's pixels are (neighbouring pixels shade neighbouring cells)
+        cell = np.floor((pos.cpu().numpy() - np.array(w["origin"], dtype=np.float32)) / w["side"]).astype(np.int64)
+        order = torch.from_numpy(np.lexsort((cell[:, 0], cell[:, 1], cell[:, 2]))).cuda()
+        pos, nrm = pos[order].contiguous(), nrm[order].contiguous()
+        sample_batches(3)
+        ordered = sample_batches(20)
+        out["sample"]["cell_ordered"] = {"ms": ordered * 1e3, "points_per_s": n_pts / ordered, "achieved_GBps": n_pts * (io_bytes + table_bytes) / ordered / 1e9,
+                                         "frac_of_hbm_peak": n_pts * (io_bytes + table_bytes) / ordered / 1e9 / HBM_PEAK_GBS,
+                                         "note": "the same 1.44 M points sorted by the grid cell they lie in"}
+        del pos, nrm, rgb, cage, order
+    if extras and ddgi_mode:
+        # ---- DDGI mode's cage sampler (Chebyshev-weighted: intersection.glsl:1306-1409 with the dormant visibility term on) on the tiles the timed updates left ----
+        n_pts = 1600 * 900
+        rng = np.random.default_rng(0)
+        half = np.array(w["counts"], dtype=np.float64) * w["side"] * 0.47
+        pos = torch.from_numpy((rng.uniform(-1, 1, size=(n_pts, 3)) * half + np.array(w["origin"])).astype(np.float32)).cuda()
+        nrm = torch.from_numpy(rng.normal(size=(n_pts, 3)).astype(np.float32)).cuda()
+        rgb = torch.empty((n_pts, 3), dtype=torch.float32, device="cuda")
+        cage = torch.empty((n_pts, 8), dtype=torch.int32, device="cuda")
+
+        def ddgi_batches(k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                eng.sample_device(pos.data_ptr(), nrm.data_ptr(), n_pts, rgb.data_ptr(), cage.data_ptr())
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / k
+
+        ddgi_batches(3)
+        steady = ddgi_batches(20)
+        # per point: position + normal in, rgb + 8 cage indices out (68 B) + per cage corner 4 irradiance texels of 16 B and 4 depth texels of 8 B (bilinear)
+        bpp = 24 + 12 + 32 + 8 * (4 * 16 + 4 * 8)
+        out["sample"] = {"kernel": "k_sample_* (grouping by cage) + k_probe_sample_ddgi", "points": n_pts, "ms": steady * 1e3, "points_per_s": n_pts / steady,
+                         "bytes_per_point": bpp, "achieved_GBps": n_pts * bpp / steady / 1e9, "frac_of_hbm_peak": n_pts * bpp / steady / 1e9 / HBM_PEAK_GBS,
+                         "inside_grid": float((cage[:, 0] >= 0).float().mean()),
+                         "note": "1.44 M shading points scattered over the grid, DDGI mode (irradiance + depth tiles, Chebyshev visibility); bytes_per_point is algorithmic: "
+                                 "68 B of point I/O + 8 corners x (4 irradiance texels of 16 B + 4 depth texels of 8 B); the batch is grouped by cage first "
+                                 "(three small kernels, a third of the time: profiles/r04_e_sample_kernels.txt)"}
         del pos, nrm, rgb, cage
     if extras and not ddgi_mode and not sharded:
         # ---- what frames in flight is worth: the same loop with every launch tracing its own update only, and with four ----
@@ -776,6 +818,11 @@ def main():
             sweep[str(n)] = {"ms_per_step": dt / args.steps * 1e3, "value": total_rays / (dt / args.steps)}
         eng.set_tuning("frames_in_flight", fif)
         sweep[str(fif)] = {"ms_per_step": ms_per_step, "value": out["value"], "headline": True}
+        # the drop-in number: the reference's host runs MAX_FRAMES_IN_FLIGHT = 2 ahead (src/rvpt/rvpt.h:23) — the headline above needs a host that runs
+        # `frames_in_flight` updates ahead
+        if "2" in sweep:
+            out["ms_per_step_at_reference_frames_in_flight"] = sweep["2"]["ms_per_step"]
+            out["value_at_reference_frames_in_flight"] = sweep["2"]["value"]
         out["frames_in_flight"] = dict(sweep, note="tuning \"frames_in_flight\": 1 = every launch traces its own update and drains; n = a launch goes on with up to n - 1 "
                                                    "updates submitted behind it (the timed loop submits its steps back to back, as the contract asks). The headline uses the library's default")
     fast_albedo = None

@@ -208,6 +208,16 @@ DDGI_D bool march_step(March& m, const SceneK& S, const uint32_t* __restrict__ s
 // iteration counter is left to the caller (one add per burst instead of one per step) and the
 // occupancy bit is extracted with v_bfe_u32 (which takes the bit offset modulo 32 by itself).
 typedef float f2v __attribute__((ext_vector_type(2)));
+// ray_at with the y and z components as ONE v_pk_fma_f32 (the same two IEEE fused multiply-adds, one issue slot instead of two)
+DDGI_D f3 ray_at_pk(f3 o, f3 d, float t)
+{
+#if defined(DDGI_RAY_PK) && !DDGI_RAY_PK
+    return ray_at(o, d, t);
+#else
+    const f2v yz = __builtin_elementwise_fma(f2v{d.y, d.z}, f2v{t, t}, f2v{o.y, o.z});
+    return f3{fmaf(d.x, t, o.x), yz.x, yz.y};
+#endif
+}
 DDGI_D bool march_step_burst(March& m, const SceneK& S, const uint32_t* __restrict__ s_bits, f3 hi)
 {
     const float fx = gl_fract(m.p.x), fy = gl_fract(m.p.y), fz = gl_fract(m.p.z);
@@ -216,7 +226,7 @@ DDGI_D bool march_step_burst(March& m, const SceneK& S, const uint32_t* __restri
     const f2v tyz = (f2v{m.cc.y, m.cc.z} - f2v{fy, fz}) * f2v{m.inv.y, m.inv.z};
     const float step = fminf(fminf(tx, tyz.x), tyz.y) + 0.0001f;
     m.t += step;
-    m.p = ray_at(m.ro, m.dn, m.t);
+    m.p = ray_at_pk(m.ro, m.dn, m.t);
     const float kx = __builtin_amdgcn_fmed3f(ceilf(m.p.x), S.lo_f[0], hi.x);
     const float ky = __builtin_amdgcn_fmed3f(ceilf(m.p.y), S.lo_f[1], hi.y);
     const float kz = __builtin_amdgcn_fmed3f(ceilf(m.p.z), S.lo_f[2], hi.z);
@@ -236,7 +246,7 @@ DDGI_D bool march_step_frozen(March& m, const SceneK& S, const uint32_t* __restr
     const f2v tyz = (f2v{m.cc.y, m.cc.z} - f2v{fy, fz}) * f2v{m.inv.y, m.inv.z};
     const float step = fminf(fminf(tx, tyz.x), tyz.y) + 0.0001f;
     m.t += frozen ? 0.0f : step;
-    m.p = ray_at(m.ro, m.dn, m.t);
+    m.p = ray_at_pk(m.ro, m.dn, m.t);
     const float kx = __builtin_amdgcn_fmed3f(ceilf(m.p.x), S.lo_f[0], hi.x);
     const float ky = __builtin_amdgcn_fmed3f(ceilf(m.p.y), S.lo_f[1], hi.y);
     const float kz = __builtin_amdgcn_fmed3f(ceilf(m.p.z), S.lo_f[2], hi.z);

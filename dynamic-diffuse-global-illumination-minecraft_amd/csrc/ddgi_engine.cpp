@@ -95,6 +95,7 @@ static const TuningKey kTuningKeys[] = {
     {"timing", &Tuning::timing, "DDGI_TIMING"},
     {"frames_in_flight", &Tuning::frames_in_flight, "DDGI_FRAMES_IN_FLIGHT"},
     {"reserve_cus", &Tuning::reserve_cus, "DDGI_RESERVE_CUS"},
+    {"prep_stream", &Tuning::prep_stream, "DDGI_PREP_STREAM"},
     {"verbose", &Tuning::verbose, "DDGI_VERBOSE"},
 #ifdef DDGI_PROFILING
     {"ablate", &Tuning::ablate, "DDGI_ABLATE"},
@@ -550,6 +551,14 @@ int ddgi_destroy(ddgi_handle e)
     if (e->d_blend_w) (void)hipFree(e->d_blend_w);
     if (e->d_work) (void)hipFree(e->d_work);
     if (e->pub) (void)hipHostFree(e->pub);
+    if (e->prep_stream)
+    {
+        (void)hipStreamSynchronize(e->prep_stream);
+        (void)hipStreamDestroy(e->prep_stream);
+        (void)hipEventDestroy(e->prep_after);
+        (void)hipEventDestroy(e->prep_done);
+        (void)hipEventDestroy(e->prep_w_done);
+    }
     if (e->upd_host) (void)hipHostFree(e->upd_host);
     if (e->upd_dev) (void)hipFree(e->upd_dev);
     for (auto& m : e->milestone)
@@ -846,15 +855,16 @@ static bool vis_set_holds(const ddgi_engine::DevScene::VisSet& set, const LightK
 static int find_vis_set(const ddgi_engine* e, int scene, const LightK* lights, int nl, bool any_seq, uint32_t before_seq)
 {
     const ddgi_engine::DevScene& d = e->dev_scene[scene];
-    for (int k = 0; k < kAqChainMax; ++k)
-        if (vis_set_holds(d.vis_set[k], lights, nl) && (any_seq || static_cast<int32_t>(d.vis_set[k].launch_seq - before_seq) <= 0)) return k;
+    for (int k = 0; k < 2 * kAqChainMax; ++k)
+        if (!d.vis_set[k].on_prep_stream && vis_set_holds(d.vis_set[k], lights, nl) && (any_seq || static_cast<int32_t>(d.vis_set[k].launch_seq - before_seq) <= 0)) return k;
     return -1;
 }
 
 // Makes set `k` hold the tables of these light positions: allocates what is missing, runs k_light_visibility for every light whose
 // table is missing or stale (on the handle's stream: complete before the next launch starts).
-static int fill_vis_set(ddgi_engine* e, int scene, const SceneK& sk, const LightK* lights, int nl, int k)
+static int fill_vis_set(ddgi_engine* e, int scene, const SceneK& sk, const LightK* lights, int nl, int k, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = e->stream;
     ddgi_engine::DevScene& d = e->dev_scene[scene];
     const int n_vox = (sk.hi[0] - sk.lo[0] + 1) * (sk.hi[1] - sk.lo[1] + 1) * (sk.hi[2] - sk.lo[2] + 1);
     if (d.n_vis_list < 0)
@@ -892,7 +902,7 @@ static int fill_vis_set(ddgi_engine* e, int scene, const SceneK& sk, const Light
             uint8_t* vis = nullptr;
             uint32_t* occ = nullptr;
             hipError_t he = hipMalloc(reinterpret_cast<void**>(&vis), static_cast<size_t>(n_vox) * 8);
-            if (he == hipSuccess) he = hipMemsetAsync(vis, 0, static_cast<size_t>(n_vox) * 8, e->stream);
+            if (he == hipSuccess) he = hipMemsetAsync(vis, 0, static_cast<size_t>(n_vox) * 8, stream);
             const size_t occ_bytes = static_cast<size_t>(n_vox) * 8 * kVisListMax * sizeof(uint32_t);
             if (he == hipSuccess && li == 0 && !set.occ && occ_bytes <= (static_cast<size_t>(512) << 20)) he = hipMalloc(reinterpret_cast<void**>(&occ), occ_bytes);
             if (he != hipSuccess)
@@ -908,10 +918,11 @@ static int fill_vis_set(ddgi_engine* e, int scene, const SceneK& sk, const Light
         if (!set.valid[li] || std::memcmp(set.light[li], lights[li].pos, sizeof(set.light[li])) != 0)
         {
             // (lights 1 ..: classes only — no lists of occupied voxels: the event of a hit under several lights does not use them)
-            HIP_TRY(launch_light_visibility(sk, lights[li].pos, d.vis_list, d.n_vis_list, set.vis[li], li == 0 ? set.occ : nullptr, e->stream));
+            HIP_TRY(launch_light_visibility(sk, lights[li].pos, d.vis_list, d.n_vis_list, set.vis[li], li == 0 ? set.occ : nullptr, stream));
             std::memcpy(set.light[li], lights[li].pos, sizeof(set.light[li]));
             set.valid[li] = true;
             set.launch_seq = e->launch_seq;  // (launches before this one stand IN FRONT of the table's kernel in the stream)
+            set.on_prep_stream = stream != e->stream;  // (... once the handle's stream has waited for the preparation stream: ddgi_probe_update)
         }
     }
     return DDGI_OK;
@@ -1115,6 +1126,7 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
 //     host's steps so far lead to (DDGI mode: the reference adds 2 to RenderSettings::time per frame, src/rvpt/rvpt.cpp:281).
 //     As many updates ahead as the host has lately been running ahead (ddgi_engine::runahead): a host that waits for every
 //     update pays for no prediction.  A prediction that does not come true costs its kernel (34 us on the cave), never a result.
+static int join_prepared(ddgi_engine* e);
 static int assign_vis(ddgi_engine* e, TracePlan& p, bool* follows, int chain_ahead)
 {
     TraceArgs& a = p.a;
@@ -1128,7 +1140,11 @@ static int assign_vis(ddgi_engine* e, TracePlan& p, bool* follows, int chain_ahe
     if (follows && *follows)
     {
         k = find_vis_set(e, scene, a.lights, a.nl, false, e->chain_first_seq);
-        if (k < 0) *follows = false;
+        if (k < 0)
+        {
+            *follows = false;
+            if (int rc = join_prepared(e)) return rc;  // (a chain starts here after all: what the preparation stream has made counts now)
+        }
     }
     if (k < 0)
     {
@@ -1171,6 +1187,90 @@ static int assign_vis(ddgi_engine* e, TracePlan& p, bool* follows, int chain_ahe
     a.vis = set.vis[0];
     a.vis_occ = set.occ;
     for (int li = 1; li < a.nl && li < kVisLights; ++li) a.vis_more[li - 1] = set.vis[li];
+    return DDGI_OK;
+}
+
+// What the preparation stream was given at the previous update (prepare_ahead) becomes the handle's: its stream waits for it —
+// beside the previous blend it is long done — and the tables made there count as complete from the next launch on.
+static int join_prepared_weights(ddgi_engine* e)
+{
+    if (!e->prep_w_pending) return DDGI_OK;
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->prep_w_done, 0));
+    e->prep_w_pending = false;
+    return DDGI_OK;
+}
+// (the tables: only where a chain starts — an update that continues its predecessor could not use them anyway, and its own launch,
+// empty, would wait for kernels that have the whole group's blends to hide behind)
+static int join_prepared(ddgi_engine* e)
+{
+    if (!e->prep_pending) return DDGI_OK;
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->prep_done, 0));
+    e->prep_pending = false;
+    for (auto& d : e->dev_scene)
+        for (auto& set : d.vis_set)
+            if (set.on_prep_stream) set.on_prep_stream = false, set.launch_seq = e->launch_seq;
+    return DDGI_OK;
+}
+
+// DDGI mode, behind an update's trace launch: the next frame's weight tiles and the light-feeler tables of the updates to come, on
+// the preparation stream — beside this update's blend instead of in front of the next update's trace.  `after`: an event already
+// recorded behind the launch (the update's timing event), or null.
+//   weights  frame f + 1's rotation is known (frame_rotation); buffer (f + 1) & 1 was last read by the blend of frame f - 1, which
+//            ended before this update's launch started.
+//   tables   for updates u = 1 .. nrec ahead, at the light positions update_lights gives for time + u x (this update's time step) —
+//            the host's own `time += step` (src/rvpt/rvpt.cpp:281) —, unless a set holds them already; into set kAqChainMax +
+//            (number of that update) % kAqChainMax, whose previous contents belonged to an update traced by launches that ended
+//            before this one did.  A prediction that does not come true is never used (assign_vis compares the positions).
+static int prepare_ahead(ddgi_engine* e, const TracePlan& p, const BlendArgs& b, hipEvent_t after)
+{
+    if (!e->prep_stream)
+    {
+        HIP_TRY(hipStreamCreateWithFlags(&e->prep_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&e->prep_after, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->prep_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->prep_w_done, hipEventDisableTiming));
+    }
+    if (!after)
+    {
+        HIP_TRY(hipEventRecord(e->prep_after, e->stream));
+        after = e->prep_after;
+    }
+    HIP_TRY(hipStreamWaitEvent(e->prep_stream, after, 0));
+    const TraceArgs& a = p.a;
+    {
+        BlendArgs nb = b;
+        frame_rotation(e->frame + 1u, nb.rot);
+        const int wb = static_cast<int>((e->frame + 1u) & 1u);
+        nb.w_sum = e->d_blend_w + static_cast<size_t>(wb) * e->d_blend_w_floats;
+        nb.w = nb.w_sum + 256;
+        HIP_TRY(launch_blend_weights(nb, e->prep_stream));
+        auto& made = e->w_made[wb];
+        made.valid = true, made.frame = e->frame + 1u, made.n = a.grid.n;
+        std::memcpy(made.rot, nb.rot, sizeof made.rot);
+        HIP_TRY(hipEventRecord(e->prep_w_done, e->prep_stream));
+        e->prep_w_pending = true;
+    }
+    if (a.vis && e->have_last_time)
+    {
+        const int scene = a.scene_id;
+        const float dt = e->settings.time - e->last_time;
+        float t = e->settings.time;
+        LightK pl[kMaxLights];
+        for (int u = 1; u <= std::max(1, e->nrec); ++u)
+        {
+            t += dt;
+            animate_lights(scene, t, e->lights[scene], a.nl, pl);
+            if (find_vis_set(e, scene, pl, a.nl, true, 0u) >= 0) continue;
+            bool coming = false;  // (already on its way on the preparation stream)
+            for (int k = kAqChainMax; k < 2 * kAqChainMax; ++k) coming = coming || (e->dev_scene[scene].vis_set[k].on_prep_stream && vis_set_holds(e->dev_scene[scene].vis_set[k], pl, a.nl));
+            if (coming) continue;
+            const int k = kAqChainMax + static_cast<int>((e->updates + static_cast<unsigned long long>(u)) % kAqChainMax);
+            if (e->dev_scene[scene].vis_set[k].on_prep_stream) continue;  // (still waiting for the next chain to start: left alone)
+            if (int rc = fill_vis_set(e, scene, a.scene, pl, a.nl, k, e->prep_stream)) return rc;
+        }
+    }
+    HIP_TRY(hipEventRecord(e->prep_done, e->prep_stream));
+    e->prep_pending = true;
     return DDGI_OK;
 }
 
@@ -1398,6 +1498,9 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     else if (e->chain_published == 0) e->runahead = std::max(0, e->runahead - 1);
     if (e->chain_break) e->chain_published = 0;
     bool follows = can_chain && pos > 0 && !e->chain_break && hash == e->chain_hash;
+    if (int rc = join_prepared_weights(e)) return rc;
+    if (!follows)
+        if (int rc = join_prepared(e)) return rc;
     if (int rc = assign_vis(e, p, &follows, can_chain ? group - 1 - pos : 0)) return rc;
     // (what the handle goes back to when the update cannot be launched: consumers keep reading the latest finished update)
     struct Saved
@@ -1457,22 +1560,30 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         b.irradiance_old = static_cast<const float*>(e->tex_prev[0] ? e->tex_prev[0] : e->tex[0]);
         b.depth_old = static_cast<const float*>(e->tex_prev[1] ? e->tex_prev[1] : e->tex[1]);
         b.n_local_probes = static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.czl;
-        const size_t need = blend_weights_floats(a.grid.n) + 256;
+        const size_t need = (blend_weights_floats(a.grid.n) + 256 + 63) / 64 * 64;
         if (need > e->d_blend_w_floats)
         {
-            if (e->d_blend_w) (void)hipFree(e->d_blend_w);
+            if (e->d_blend_w) (void)hipFree(e->d_blend_w);  // (waits for the device, the preparation stream included)
             e->d_blend_w = nullptr, e->d_blend_w_floats = 0;
-            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_blend_w), need * sizeof(float)));
+            e->w_made[0].valid = e->w_made[1].valid = false;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_blend_w), 2 * need * sizeof(float)));
             e->d_blend_w_floats = need;
         }
-        b.w_sum = e->d_blend_w;
-        b.w = e->d_blend_w + 256;
+        // frame f's weight tiles live in buffer f & 1: they depend on the frame's ray directions only, and the NEXT frame's are made
+        // beside this frame's blend (below) — here only if that did not happen (the first update, ddgi_set_frame, another ray count)
+        const int wb = static_cast<int>(e->frame & 1u);
+        b.w_sum = e->d_blend_w + static_cast<size_t>(wb) * need;
+        b.w = b.w_sum + 256;
         if (e->tuning.blend_kernel == 1) b.w = b.w_sum = nullptr;  // one probe per workgroup, weights in place
         b.force_division = e->tuning.blend_kernel == 2 ? 1u : 0u;
         b.merge_below = static_cast<uint32_t>(e->tuning.blend_merge < 0 ? 0 : e->tuning.blend_merge);
-        // the blend's weight tiles depend on the frame's ray directions only: made before the trace, off the critical path
-        // between the last ray and the first tile
-        HIP_TRY(launch_blend_weights(b, e->stream));
+        auto& made = e->w_made[wb];
+        if (b.w && !(made.valid && made.frame == e->frame && made.n == a.grid.n && std::memcmp(made.rot, b.rot, sizeof made.rot) == 0))
+        {
+            HIP_TRY(launch_blend_weights(b, e->stream));  // (before the trace: off the critical path between the last ray and the first tile)
+            made.valid = true, made.frame = e->frame, made.n = a.grid.n;
+            std::memcpy(made.rot, b.rot, sizeof made.rot);
+        }
     }
     if (p.pool > 0)
     {
@@ -1488,6 +1599,8 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
     if (timing) HIP_TRY(hipEventRecord(ev[1], e->stream));
     if (p.ddgi_mode)
     {
+        if (e->tuning.prep_stream && p.pool > 0 && p.use_async && b.w)
+            if (int rc = prepare_ahead(e, p, b, timing ? ev[1] : nullptr)) return rc;
         HIP_TRY(launch_probe_blend(b, e->num_cus, e->stream));
         e->frame += 1;
     }

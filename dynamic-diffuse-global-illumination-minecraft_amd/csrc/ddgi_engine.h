@@ -40,6 +40,7 @@ struct Tuning
     int lut_off = 0;        // profiling: 1 = no wall table, 2 = no random1 table
     int reserve_cus = 0;    // the queue kernel leaves this many CUs without a workgroup — its persistent workgroups fill a CU's registers and LDS, so a copy or
                             // collective KERNEL of a multi-GPU exchange otherwise finds no CU until a launch ends (copy-engine transfers need none)
+    int prep_stream = 1;    // DDGI mode: the next frame's weight tiles and the predicted light-feeler tables are made on a second stream beside the blend (0: in line)
     int verbose = 0;
     int ablate = 0;         // profiling build only (-DDDGI_PROFILING): ablations / fault injection
 };
@@ -99,7 +100,8 @@ struct ddgi_engine
             float light[kVisLights][3] = {};
             bool valid[kVisLights] = {};
             uint32_t launch_seq = 0;        // the handle's launch_seq when a table of the set was last (re)computed: launches from this one on see it complete
-        } vis_set[kAqChainMax];
+            bool on_prep_stream = false;    // ... by a kernel on the handle's preparation stream that the handle's stream has not waited for yet: not to be used
+        } vis_set[2 * kAqChainMax];         // [0, kAqChainMax): filled on the handle's stream; the rest: predictions made on the preparation stream
         int32_t* vis_list = nullptr;        // the (voxel, face) pairs that are classified: empty voxel, occupied on the face's other side
         int n_vis_list = -1;                // (-1: not built yet)
     } dev_scene[4];
@@ -172,8 +174,23 @@ struct ddgi_engine
     std::map<unsigned long long, int> aq_split;  // configuration key -> measured march/event wave split of the queue kernel
     int aq_last = 0;                             // the most recently measured split (starting point of the next measurement)
     unsigned scene_epoch = 0;                    // bumped when the user scene changes (part of the configuration key)
-    float* d_blend_w = nullptr;  // k_blend_weights output: [256 sums][n][256]
-    size_t d_blend_w_floats = 0;
+    float* d_blend_w = nullptr;  // k_blend_weights output: [256 sums][n][256] — two of them: frame f's is buffer f & 1 (the next frame's is made beside this frame's blend)
+    size_t d_blend_w_floats = 0; // ... floats per buffer
+    // DDGI mode's preparation stream: what the NEXT updates need and this one does not depend on — the next frame's weight tiles (they
+    // follow from its ray rotation alone) and the light-feeler tables of the light positions the coming updates are expected to have —
+    // is made beside this update's blend, whose kernels leave room on every CU (the trace kernel's persistent workgroups do not)
+    hipStream_t prep_stream = nullptr;
+    hipEvent_t prep_after = nullptr;  // handle's stream: this update's trace launch has ended (the preparation starts behind it)
+    hipEvent_t prep_w_done = nullptr; // preparation stream: the next frame's weight tiles are made (the next update waits for it — its blend reads them)
+    hipEvent_t prep_done = nullptr;   // preparation stream: everything given to it so far is done — the tables too (the next CHAIN's first launch waits for it)
+    bool prep_w_pending = false, prep_pending = false;
+    struct
+    {
+        bool valid = false;
+        uint32_t frame = 0;
+        int n = 0;
+        float rot[9] = {};
+    } w_made[2];                      // what each weight buffer holds
     // multi-GPU exchange of the blended textures (ddgi_exchange.cpp): one interface, two transports
     struct P2P;  // peer-to-peer transport state (ddgi_exchange.cpp)
     struct Exchange

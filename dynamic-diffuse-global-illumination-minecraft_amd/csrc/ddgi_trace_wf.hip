@@ -1306,8 +1306,8 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
 #ifndef DDGI_AQ_FILL_NAP
 #define DDGI_AQ_FILL_NAP 4
 #endif
-constexpr uint32_t kAqFill = DDGI_AQ_FILL;
-constexpr int kAqFillWaits = DDGI_AQ_FILL_WAITS;
+[[maybe_unused]] constexpr uint32_t kAqFill = DDGI_AQ_FILL;
+[[maybe_unused]] constexpr int kAqFillWaits = DDGI_AQ_FILL_WAITS;
 #ifndef DDGI_AQ_TRIP_ARGS
 #define DDGI_AQ_TRIP_ARGS 1  // the event waves read the kernel's arguments afresh in every trip (args_of_this_trip)
 #endif

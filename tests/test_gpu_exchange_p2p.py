@@ -21,6 +21,19 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# a quarter of BASELINE's C4 grid (64x32x64 probes x 512 rays in a 32 x 16 ray tile): 16 z-layers, 16.8 M rays, 67 MB per texture —
+# the ring of texture pairs is capped at 2 GiB under the pipelined exchange (8 -> 4 pairs per group), the ray tile is not square
+SHAPES = dict(CONFIGS, c4_slab=((64, 32, 16), 1, 16, (1.4, 0.0, 1.0), 0))
+TILES = {"c4_slab": (32, 16)}
+
+
+def _engine(ddgi, name, **kw):
+    counts, side, s, origin, scene = SHAPES[name]
+    eng = ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8), **kw)
+    if name in TILES:
+        eng.set_ray_tile(*TILES[name])
+    return eng
+
 
 def _digest(*arrays):
     h = hashlib.sha1()
@@ -37,7 +50,7 @@ def _run_frames(ddgi, eng, mode, scene, frames, read_at):
     """Drives `frames` updates (+ exchanges when the handle has one) and returns {frame: digest of the full field}."""
     out = {}
     has_exchange = eng.exchange_transport()[0] != "none"
-    if mode == "ref_static":
+    if mode in ("ref_static", "ref_static_engine"):
         eng.generate_probe_rays(seed=1)   # one ray set, updates back to back: consecutive updates are CONTINUED (frames in flight) across the exchanges
     for frame in range(frames):
         if mode == "ref":
@@ -51,7 +64,7 @@ def _run_frames(ddgi, eng, mode, scene, frames, read_at):
 
 
 def _expected(ddgi, name, mode, frames, read_at, oracle=None):
-    counts, side, s, origin, scene = CONFIGS[name]
+    counts, side, s, origin, scene = SHAPES[name]
     if mode == "ref_static":
         # the oracle's raster (every frame writes the same texels: Q18); `distances` is never assigned
         if name == "c3_cave":
@@ -60,7 +73,7 @@ def _expected(ddgi, name, mode, frames, read_at, oracle=None):
             f = oracle.make_field(counts, side, s, origin)
             want = oracle.probe_update(f, oracle.make_settings(scene, 8), oracle.generate_probe_rays(f, oracle.new_rand_state(1)))[0]
         return {frame: _digest(want, np.zeros_like(want)) for frame in read_at}
-    with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8)) as eng:
+    with _engine(ddgi, name) as eng:
         if mode == "ddgi":
             eng.set_mode(ddgi.MODE_DDGI)
         return _run_frames(ddgi, eng, mode, scene, frames, read_at)
@@ -76,6 +89,11 @@ SCENARIOS = [
     # rays into the next pair of the ring while the previous pairs' slabs are still leaving) — expected = the ORACLE's raster
     ("c2_cornell", "ref_static", True, 6, (2, 5)),
     ("c3_cave", "ref_static", True, 7, (3, 6)),
+    # round 5 — DDGI mode, updates back to back (frames in flight with inputs that change: rotation, key and the animated light travel
+    # in per-update records, the ray records in a ring of buffers), pipelined exchange of the tiles; expected = the unsharded engine
+    ("c3_cave", "ddgi", True, 7, (6,)),
+    # ... and a C4-shaped slab: non-square ray tile, ring of pairs capped at 2 GiB, pipelined; expected = the unsharded engine
+    ("c4_slab", "ref_static_engine", True, 6, (5,)),
 ]
 
 
@@ -88,8 +106,8 @@ def _worker(rank, world, conn, scenarios):
         ddgi.load_library()
         results = []
         for name, mode, pipelined, frames, read_at in scenarios:
-            counts, side, s, origin, scene = CONFIGS[name]
-            eng = ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8), device=0, rank=rank, world=world)
+            scene = SHAPES[name][4]
+            eng = _engine(ddgi, name, device=0, rank=rank, world=world)
             if mode == "ddgi":
                 eng.set_mode(ddgi.MODE_DDGI)
             conn.send(("address", eng.exchange_p2p_export(pipelined)))
