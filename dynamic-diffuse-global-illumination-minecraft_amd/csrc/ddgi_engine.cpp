@@ -196,6 +196,17 @@ void ddgi_texture_bytes(int mode, const ddgi_irradiance_field& f, int rays_per_p
         bytes[0] = bytes[1] = probes * static_cast<size_t>(rays_per_probe) * 4;
 }
 
+// One launch works on at most kChainRays rays: what a chain hides is a constant per launch (the drain, ~0.25 ms), and launches of
+// a quarter of a second run SLOWER than their parts — measured in DDGI mode on one MI355X (tools/ddgi_chain_probe.py,
+// profiles/r05_ddgi_chain_by_grid.txt): 64x32x64 probes x 256 rays, 8 updates per launch: 17.77 -> 17.53 ms per update; 64x64x64, 8 per
+// launch (257 ms): 31.8 -> 33.0; 128x64x64, 4 per launch (268 ms): 63.2 -> 68.8; C5, 2 per launch (262 ms): 128.2 -> 134.0.
+constexpr size_t kChainRays = static_cast<size_t>(64) << 20;
+static int chain_len_for_rays(int len, size_t rays)
+{
+    while (len > 1 && rays * static_cast<size_t>(len) > kChainRays) len /= 2;
+    return len;
+}
+
 // REF mode: updates one launch of the queue kernel may work on (tuning "frames_in_flight") = texture pairs a group of updates takes,
 // on the handle's own textures only — a host that holds pointers to a pair (ddgi_bind_textures, ddgi_device_textures) expects the
 // handle to stay on it.  The pair a ray writes travels in the top three bits of its texel index (ddgi_trace_wf.hip: kDstPairShift).
@@ -210,6 +221,7 @@ static int chain_len_for(const ddgi_engine* e, size_t albedo_bytes, bool pipelin
     // are halved down to two pairs.  (A function of the configuration only: every rank of a sharded grid comes to the same length.)
     // (the pipelined exchange doubles the ring: counted)
     while (len > 2 && albedo_bytes * 2 * static_cast<size_t>(len) * (pipelined ? 2 : 1) > (static_cast<size_t>(2) << 30)) len /= 2;
+    len = chain_len_for_rays(len, albedo_bytes / 4);  // (REF: one texel per ray)
     return len;
 }
 int ddgi_chain_len(const ddgi_engine* e) { return chain_len_for(e, e->tex_bytes[0], e->xch.pipelined); }
@@ -222,7 +234,7 @@ static int rec_ring_len(const ddgi_engine* e, size_t rec_bytes, size_t local_ray
     if (local_rays >= (static_cast<size_t>(1) << 29)) return 1;  // (the update a ray belongs to travels in the top three bits of its index)
     int len = std::min(kAqChainMax, std::max(1, e->tuning.frames_in_flight));
     while (len > 1 && rec_bytes * static_cast<size_t>(len) > (static_cast<size_t>(16) << 30)) len /= 2;
-    return len;
+    return chain_len_for_rays(len, local_rays);
 }
 int ddgi_group_len(const ddgi_engine* e)
 {

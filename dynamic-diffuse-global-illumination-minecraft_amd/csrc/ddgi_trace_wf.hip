@@ -1290,6 +1290,15 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
 #ifndef DDGI_MARCH_PRIO
 #define DDGI_MARCH_PRIO 0  // s_setprio of the (exact) march waves; the event waves run at DDGI_EVENT_PRIO
 #endif
+// tools/valu_attribution.py: comment lines in the kernel's assembly that delimit the march waves' loop (-DDDGI_MARKS=1: analysis builds only)
+#if defined(DDGI_MARKS) && DDGI_MARKS
+#define DDGI_MARK(name) asm volatile("; DDGI_MARK " name)
+#else
+#define DDGI_MARK(name) \
+    do                  \
+    {                   \
+    } while (0)
+#endif
 #ifndef DDGI_AQ_REQUEUE
 #define DDGI_AQ_REQUEUE 0  // (experiment, round 5: measured slower, off) march waves: every burst starts from the queue, unfinished marches are queued
                            // again.  Lanes per burst 30.6 -> 40.2 of 64, bursts per ray 0.23 -> 0.18 — and C3 1.578 -> 1.647 ms at every wave split
@@ -1760,6 +1769,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
         int trips = 0, thin_waits = 0;
         for (;;)
         {
+            DDGI_MARK("march_trip_begin");
             if (++guard > (1u << 23)) sh->abort = 1u;
             unsigned long long idle_mask[kM];
             int n_idle = 0;
@@ -1828,6 +1838,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             // iteration limit is dropped from the steps when no lane of the wave can reach the limit within this burst (all but
             // the last burst of the few marches longer than 101 steps); (3) no exec-mask predication inside the burst: a march that
             // has ended — or a place without a march — takes steps of length 0 (march_step_frozen).
+            DDGI_MARK("march_burst_begin");
             bool near = false;
 #pragma unroll
             for (int q = 0; q < kM; ++q) near = near || (have[q] && kMarchIters - m[q].it < kAqStepsPerTrip);
@@ -1933,6 +1944,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                             }
                     }
                 }
+                DDGI_MARK("march_burst_end");
                 const uint32_t* __restrict__ bits_base = s_bits - (A.scene.bias32 >> 5);
 #pragma unroll
                 for (int q = 0; q < kM; ++q)
@@ -1971,6 +1983,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                         (ring_eq + bucket[q] * kCap)[at % kCap] = static_cast<uint16_t>(slot[q]);
                     }
             }
+            DDGI_MARK("march_trip_end");
         }
     }
     else
@@ -2283,6 +2296,9 @@ hipError_t launch_probe_trace_aq(const TraceArgs& args, int pool, int grid_block
                              : launch_aq<false, kAqPoolFast, CfgPlain<0, true>>(args, pool, grid_blocks, march_waves, chain, status, stream);
         return launch_aq<false, 0, CfgRuntimeT<true>>(args, pool, grid_blocks, march_waves, chain, status, stream);
     }
+    // (the counters build of the headline instantiation — one light, REF, the usual pool: its queue traffic is what tools/aq_stats.py and
+    // tools/valu_attribution.py are about; everything else counts in the generic one, which takes one inline step where this takes two)
+    if (args.stats && pool == kAqPool && args.nl == 1 && args.ablate == 0 && !args.ddgi) return launch_aq<true, kAqPool, CfgPlain<0>>(args, pool, grid_blocks, march_waves, chain, status, stream);
     if (args.stats) return launch_aq<true, 0, CfgRuntime>(args, pool, grid_blocks, march_waves, chain, status, stream);
     if (pool == kAqPool && args.nl == 1 && args.ablate == 0)
         return args.ddgi ? launch_aq<false, kAqPool, CfgPlain<1>>(args, pool, grid_blocks, march_waves, chain, status, stream)

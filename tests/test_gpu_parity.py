@@ -367,3 +367,35 @@ def test_pipelined_exchange_on_a_one_rank_rccl_group(ddgi):
             tex.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_sample_device_cage_buffer_need_not_be_16_byte_aligned(ddgi, oracle):
+    """The 8 cage indices of a point are written with two 16-byte stores when the caller's buffer allows it, with eight 4-byte
+    stores when it does not (a sub-allocated int32 buffer, include/ddgi_probe.h: ddgi_sample_device) — same values, REF and DDGI."""
+    import torch
+
+    name = "cave_small"
+    counts, side, s, origin, scene = CONFIGS[name]
+    pos_h, nrm_h = shading_points(np.random.default_rng(3), counts, side, origin, 5000)
+    pos, nrm = torch.from_numpy(pos_h).cuda(), torch.from_numpy(nrm_h).cuda()
+    n = pos.shape[0]
+    with _engine(ddgi, name) as eng:
+        eng.generate_probe_rays(seed=1)
+        eng.probe_update()
+        for mode in ("ref", "ddgi"):
+            if mode == "ddgi":
+                eng.set_mode(ddgi.MODE_DDGI)
+                eng.probe_update()
+            got = []
+            for off in (0, 1, 3):   # int32 elements: 0, 4 and 12 bytes off a 16-byte boundary
+                rgb = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+                flat = torch.full((n * 8 + 8,), -7, dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()
+                eng.sample_device(pos.data_ptr(), nrm.data_ptr(), n, rgb.data_ptr(), flat.data_ptr() + 4 * off)
+                eng.synchronize()
+                torch.cuda.synchronize()
+                assert (flat[:off] == -7).all() and (flat[off + n * 8:] == -7).all()
+                got.append((flat[off:off + n * 8].clone(), rgb))
+            for cage, rgb in got[1:]:
+                assert torch.equal(cage, got[0][0]) and torch.equal(rgb.view(torch.int32), got[0][1].view(torch.int32)), mode
+            assert (got[0][0] != -7).all()

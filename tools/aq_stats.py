@@ -28,6 +28,7 @@ if st["rounds"]:
     steps = int(os.environ.get("DDGI_AQ_STEPS_BUILT", "24"))
     print("march bursts: %.2f useful lane-steps per ray = %.1f per burst of %d x 64 = %.3f of the lane-steps a burst issues; %.1f steps per lane-trip" % (
         st["rounds"] / rays, st["rounds"] / max(q[5], 1), steps, st["rounds"] / max(q[5], 1) / (steps * 64.0), st["rounds"] / max(lanes, 1)))
+print("counts: march_bursts %d event_groups %d rays %d" % (q[5], groups, rays))
 print("feelers per ray (profiling build, ablate 16):", {k: round(v / rays, 3) for k, v in st["feeler_classes"].items()})
 for nm, (visits, lanes) in st["sections"].items():
     if visits:
