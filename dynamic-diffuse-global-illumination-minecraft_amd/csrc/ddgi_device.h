@@ -256,6 +256,34 @@ DDGI_D bool march_step_frozen(March& m, const SceneK& S, const uint32_t* __restr
     return __builtin_amdgcn_ubfe(base[idx >> 5], static_cast<uint32_t>(idx), 1u) != 0u;
 }
 
+// march_step_frozen WITHOUT a "has ended" state.  A march that has landed in an occupied voxel must stand still for the rest of
+// the burst; the boolean version carries that as a lane mask, which the compiler keeps in an SGPR pair: v_bfe_u32, v_cmp_ne
+// (VALU -> SGPR), s_or_b64, v_cndmask (SGPR -> VALU) per step — a scalar instruction and two trips between the register files on
+// the march's dependent chain.  But a march that stands still looks the SAME voxel up again: the bit of the voxel it is in says
+// "stand still" by itself, step after step.  So a step is v_bfe_i32 (the voxel's bit, sign-extended: `occ`, 0 or ~0) and the next
+// step's length is step & ~occ (v_bfi_b32) — t + 0 == t (t >= +0), hence the same position, voxel and bit as before.
+// occ: the previous step's (0 in front of a burst: a march in flight stands in an empty voxel, and grid_march never looks at the
+// voxel it starts in, intersection.glsl:1059-1069).  A lane without a march steps along a zero direction (inv = 0: the position
+// stays at ro whatever t does) and needs no mask either.
+DDGI_D void march_step_masked(March& m, const SceneK& S, const uint32_t* __restrict__ s_bits, f3 hi, uint32_t& occ)
+{
+    const float fx = gl_fract(m.p.x), fy = gl_fract(m.p.y), fz = gl_fract(m.p.z);
+    const float tx = (m.cc.x - fx) * m.inv.x;
+    const f2v tyz = (f2v{m.cc.y, m.cc.z} - f2v{fy, fz}) * f2v{m.inv.y, m.inv.z};
+    const float step = fminf(fminf(tx, tyz.x), tyz.y) + 0.0001f;
+    uint32_t step_bits;
+    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(step_bits) : "v"(occ), "v"(__float_as_uint(step)));  // occ ? +0.0f : step
+    m.t += __uint_as_float(step_bits);
+    m.p = ray_at_pk(m.ro, m.dn, m.t);
+    const float kx = __builtin_amdgcn_fmed3f(ceilf(m.p.x), S.lo_f[0], hi.x);
+    const float ky = __builtin_amdgcn_fmed3f(ceilf(m.p.y), S.lo_f[1], hi.y);
+    const float kz = __builtin_amdgcn_fmed3f(ceilf(m.p.z), S.lo_f[2], hi.z);
+    const int idx = static_cast<int>(fmaf(kz, S.nxy_f, fmaf(ky, S.nx_f, kx)));
+    m.cell = idx;
+    const uint32_t* __restrict__ base = s_bits - (S.bias32 >> 5);
+    occ = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(base[idx >> 5]), static_cast<uint32_t>(idx), 1u));
+}
+
 // ---- the fast march (tolerance mode, opt-in: ddgi_set_tuning "fast_march") -----------------------------------------
 // grid_march (intersection.glsl:1051-1100) re-derives every step from the position it has reached — t += (distance to
 // the next voxel boundary) + 1e-4 — so the position after crossing a given plane is that plane's t + 1e-4 whatever came

@@ -1306,6 +1306,36 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
                            // 64 lanes and writes the unfinished ones back is longer than one that tops a few lanes up; the fill threshold never waits
                            // (1 / 32 / 48 / 60 entries: the same times — the queue is deep whenever the march side is the limit)
 #endif
+#ifndef DDGI_AQ_TL_AT_END
+#define DDGI_AQ_TL_AT_END 1  // march waves: a march's t is compared with its light sphere's once per burst, not once per step (below)
+#endif
+#ifndef DDGI_AQ_MASKED
+#define DDGI_AQ_MASKED 1  // march waves: the "march has ended" state of a burst as a mask in a VGPR (march_step_masked)
+#endif
+#ifndef DDGI_AQ_EARLY_OUT
+#define DDGI_AQ_EARLY_OUT 0  // march waves: leave a burst at step 6 / 12 / 18 when every march of the wave has ended (0: off)
+#endif
+#ifndef DDGI_AQ_UNIFIED
+#define DDGI_AQ_UNIFIED 0  // every wave of the workgroup serves every queue (below: "unified waves"); the exact march only
+#endif
+#ifndef DDGI_AQ_UNI_PICK
+#define DDGI_AQ_UNI_PICK 2  // among full queues: 0 = new rays, marches, events; 1 = events, marches, new rays; 2 = marches, events, new rays
+#endif
+#ifndef DDGI_AQ_UNI_IDLE
+#define DDGI_AQ_UNI_IDLE 8   // an idle wave's nap when no queue holds anything, in units of 64 cycles
+#endif
+#ifndef DDGI_AQ_UNI_MPRIO
+#define DDGI_AQ_UNI_MPRIO DDGI_EVENT_PRIO  // s_setprio during a march burst (the events run at DDGI_EVENT_PRIO)
+#endif
+#ifndef DDGI_AQ_UNI_T2
+#define DDGI_AQ_UNI_T2 32   // the smaller group a wave settles for first
+#endif
+#ifndef DDGI_AQ_UNI_W32
+#define DDGI_AQ_UNI_W32 1   // naps before a wave settles for a group of DDGI_AQ_UNI_T2..63
+#endif
+#ifndef DDGI_AQ_UNI_W1
+#define DDGI_AQ_UNI_W1 4    // naps before it settles for any group
+#endif
 #ifndef DDGI_AQ_FILL
 #define DDGI_AQ_FILL 48  // ... and starts only when the queue holds this many marches (or after DDGI_AQ_FILL_WAITS naps of DDGI_AQ_FILL_NAP x 64 cycles)
 #endif
@@ -1517,6 +1547,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
     const float inf = __builtin_inff();
     unsigned int guard = 0;  // safety net: consecutive polls without work (about 1 s of them trips it); never spin forever on the GPU
     unsigned long long st_a = 0, st_b = 0;  // utilisation counters: trips / groups, and the lanes that had work in them
+    [[maybe_unused]] unsigned long long st_ma = 0, st_mb = 0;  // unified waves: the march bursts' (st_a / st_b are the event groups')
     unsigned long long st_useful = 0;       // counters build: lane-steps of the march bursts that moved a march (the others stood still: frozen or no march)
     LaneProbe probe;                        // (counters build only)
 #ifdef DDGI_LAP
@@ -1915,7 +1946,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
 #pragma unroll
                     for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
 #pragma unroll
-                        for (int q = 0; q < kM; ++q) fin[q] = fin[q] | march_step_frozen(m[q], A.scene, s_bits, hi_v, fin[q]) | (m[q].t >= m[q].tl) | (kMarchIters - m[q].it <= sub + 1);
+                        for (int q = 0; q < kM; ++q) fin[q] = fin[q] | march_step_frozen(m[q], A.scene, s_bits, hi_v, fin[q]) | (!DDGI_AQ_TL_AT_END && m[q].t >= m[q].tl) | (kMarchIters - m[q].it <= sub + 1);
                 }
                 else
                 {
@@ -1932,17 +1963,41 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                             for (int q = 0; q < 2; ++q) fin[q] = fin[q] | occ2[q] | (m[q].t >= m[q].tl);
                         }
                     }
+                    else if (DDGI_AQ_MASKED && DDGI_AQ_TL_AT_END && kM == 1 && !kStats)
+                    {
+                        // (a lane whose march ended in an earlier burst and that got no new one: its state is that march's — where it
+                        // ended in a voxel, it stands; else it steps on through whatever the clamped lookups give it, unread)
+                        uint32_t occ = 0u;
+#pragma unroll
+                        for (int sub = 0; sub < kAqStepsPerTrip; ++sub) march_step_masked(m[0], A.scene, s_bits, hi_v, occ);
+                        fin[0] = fin[0] | (occ != 0u);
+                    }
                     else
                     {
 #pragma unroll
                         for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
+                        {
+                            if (DDGI_AQ_EARLY_OUT > 0 && kM == 1 && sub > 0 && sub % (DDGI_AQ_EARLY_OUT > 0 ? DDGI_AQ_EARLY_OUT : 1) == 0 && __ballot(!fin[0]) == 0ull) break;  // (every march of the wave has ended)
 #pragma unroll
                             for (int q = 0; q < kM; ++q)
                             {
                                 if (kStats) st_useful += static_cast<unsigned long long>(__popcll(__ballot(!fin[q])));  // lanes that take this step for a march
-                                fin[q] = fin[q] | march_step_frozen(m[q], A.scene, s_bits, hi_v, fin[q]) | (m[q].t >= m[q].tl);
+                                fin[q] = fin[q] | march_step_frozen(m[q], A.scene, s_bits, hi_v, fin[q]) | (!DDGI_AQ_TL_AT_END && m[q].t >= m[q].tl);
                             }
+                        }
                     }
+                }
+                // THE LIGHT SPHERE, ONCE PER BURST.  grid_march (intersection.glsl:1051-1100) knows nothing of the light spheres: it
+                // steps until a voxel is occupied, and intersect_scene keeps the block only if its t is below the nearest sphere's
+                // (:1283-1291).  Ending a march where t passes the sphere's is this kernel's shortcut — every later block loses — and t
+                // only grows, so the test need not sit in every step (a compare and a lane-mask OR in each of 24): a march that has
+                // passed its sphere steps on to the end of the burst (the lanes are there anyway), any block it still finds has
+                // t >= tl and loses as before, and the march ends here.  What an event reads of a march that the light wins is
+                // tl and the light, never t or the hit flags (wf_event: block_wins).
+                if (DDGI_AQ_TL_AT_END)
+                {
+#pragma unroll
+                    for (int q = 0; q < kM; ++q) fin[q] = fin[q] | (m[q].t >= m[q].tl);
                 }
                 DDGI_MARK("march_burst_end");
                 const uint32_t* __restrict__ bits_base = s_bits - (A.scene.bias32 >> 5);
@@ -1995,6 +2050,8 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
         __builtin_amdgcn_s_setprio(DDGI_EVENT_PRIO);
         unsigned guard_rot = static_cast<unsigned>(wave);
         (void)guard_rot;
+        [[maybe_unused]] constexpr bool kUnified = DDGI_AQ_UNIFIED && !Cfg::kFast;
+        [[maybe_unused]] int uni_waited = 0;
         for (;;)
         {
             if (++guard > (1u << 23)) sh->abort = 1u;
@@ -2007,12 +2064,165 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             uint32_t avail = 0;
             uint32_t head_seen = 0;
             if (lane < kAqEventQueues) head_seen = aq_load(&sh->eq_head[lane]), avail = aq_load(&sh->eq_tail[lane]) - head_seen;
+#if DDGI_AQ_UNIFIED
+            // UNIFIED WAVES.  With waves set aside for marching, a march wave steps whatever the queue holds at that moment (30 of 64 lanes
+            // per burst, 0.30 of a burst's lane-steps useful: 54 % of the kernel's VALU instructions) while the slots pile up in front of
+            // the event waves.  Here every wave serves every queue — lane 7 looks at the march queue, lane 8 at the free slots — and takes
+            // a FULL group of whatever there is: 64 marches from the queue for one burst (the unfinished ones are queued again as (t,
+            // iterations), like a march an event has taken the first steps of), 64 events of a bucket, or 64 free slots for new rays;
+            // a wave settles for less only after it has waited.  No wave split to tune, and a burst's instructions carry 64 marches.
+            constexpr int kLaneMq = kAqEventQueues, kLaneFq = kAqEventQueues + 1;
+            if (kUnified && lane == kLaneMq) head_seen = aq_load(&sh->mq_head), avail = aq_load(&sh->mq_tail) - head_seen;
+            if (kUnified && lane == kLaneFq) head_seen = aq_load(&sh->fq_head), avail = aq_load(&sh->fq_tail) - head_seen;
+#endif
 #if DDGI_AQ_REFILL_FIRST
             if (lane == kAqEventQueues) avail = aq_load(&sh->fq_tail) - aq_load(&sh->fq_head);
 #endif
             if (avail > kCap) avail = 0;  // a claim in flight can make tail - head wrap for an instant
             const unsigned long long full = __ballot(avail >= 64u && lane < kAqEventQueues);
             const bool no_more = aq_load(&sh->no_more) != 0u;
+#if DDGI_AQ_UNIFIED
+            bool uni_chosen = false;
+            if (kUnified)
+            {
+                if (kStats) st_q[6] += 1;  // (unified waves: looks at the queues)
+                const bool counts = lane <= kLaneFq && !(no_more && lane == kLaneFq);  // (no new rays: the free queue is not work)
+                const unsigned long long m64 = __ballot(counts && avail >= 64u);
+                int pick = -1;
+                if (m64 != 0ull)
+                {
+                    const unsigned long long ev = m64 & ((1ull << kAqEventQueues) - 1ull);
+#if DDGI_AQ_UNI_PICK == 0
+                    pick = 63 - __clzll(static_cast<long long>(m64));
+#elif DDGI_AQ_UNI_PICK == 1
+                    pick = ev ? 63 - __clzll(static_cast<long long>(ev)) : ((m64 >> kLaneMq) & 1ull ? kLaneMq : kLaneFq);
+#else
+                    pick = (m64 >> kLaneMq) & 1ull ? kLaneMq : (ev ? 63 - __clzll(static_cast<long long>(ev)) : kLaneFq);
+#endif
+                }
+                else
+                {
+                    const unsigned long long m32 = __ballot(counts && avail >= static_cast<uint32_t>(DDGI_AQ_UNI_T2)), m1 = __ballot(counts && avail >= 1u);
+                    if (m1 == 0ull)
+                    {
+                        if ((no_more && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
+                        if (kStats) st_q[4] += 1;
+                        __builtin_amdgcn_s_sleep(DDGI_AQ_UNI_IDLE);
+                        continue;
+                    }
+                    const unsigned long long m = (m32 != 0ull && (no_more || uni_waited >= DDGI_AQ_UNI_W32)) ? m32 : ((no_more || uni_waited >= DDGI_AQ_UNI_W1) ? m1 : 0ull);
+                    if (m == 0ull)
+                    {
+                        ++uni_waited;
+                        __builtin_amdgcn_s_sleep(DDGI_AQ_SLEEP);
+                        continue;
+                    }
+                    pick = 63 - __clzll(static_cast<long long>(m));
+                }
+                const uint32_t h0 = lane_bcast(head_seen, pick), n0 = lane_bcast(avail, pick);
+                uint32_t* const q_head = pick == kLaneMq ? &sh->mq_head : (pick == kLaneFq ? &sh->fq_head : &sh->eq_head[pick]);
+                const uint32_t* const q_tail = pick == kLaneMq ? &sh->mq_tail : (pick == kLaneFq ? &sh->fq_tail : &sh->eq_tail[pick]);
+                if (lane == 0)
+                {
+                    // (the queue held n0 entries above the head this wave has just read: claimed with that value — one trip to the LDS —
+                    // unless another wave got there first)
+                    const uint32_t want = n0 < 64u ? n0 : 64u;
+                    if (atomicCAS(q_head, h0, h0 + want) == h0) k = want, base = h0;
+                    else k = aq_claim(q_head, q_tail, 64u, base);
+                }
+                k = lane_bcast(k, 0), base = lane_bcast(base, 0);
+                if (k == 0u) continue;  // (another wave was quicker)
+                uni_waited = 0;
+                guard = 0;
+                if (pick == kLaneMq)
+                {
+                    // ---- one burst for k marches from the queue ----
+                    March m;
+                    m.ro = m.rd = m.dn = m.inv = m.cc = m.p = mk3(0, 0, 0);  // (a lane without a march takes zero-length steps from this state: every index it computes is inside the bitmap)
+                    m.t = 0.0f, m.tl = inf, m.it = 0, m.lid = -1, m.cell = 0;
+                    f3 hi_v = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
+                    asm volatile("" : "+v"(hi_v.x), "+v"(hi_v.y), "+v"(hi_v.z));
+                    const bool have = static_cast<uint32_t>(lane) < k;
+                    uint32_t slot = 0, fl = 0;
+                    if (have)
+                    {
+                        slot = aq_take<kCap>(ring_mq, base + lane, &sh->abort);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        fl = P.flags[slot];
+                        m.ro = ld3(P.ro, slot);
+                        m.dn = ld3(P.dn, slot);
+                        m.inv = f3{axis_inv(m.dn.x), axis_inv(m.dn.y), axis_inv(m.dn.z)};  // P5; recomputed, not stored
+                        m.t = P.t[slot];
+                        m.tl = P.tl[slot];
+                        m.it = static_cast<int>((fl >> 4) & 255u);
+                        m.cc = f3{m.dn.x >= 0.0f ? 1.0f : 0.0f, m.dn.y >= 0.0f ? 1.0f : 0.0f, m.dn.z >= 0.0f ? 1.0f : 0.0f};
+                        m.p = ray_at(m.ro, m.dn, m.t);
+                    }
+                    if (kStats) st_ma += 1, st_mb += k, st_q[5] += 1, st_q[7] += k;
+                    if (DDGI_AQ_UNI_MPRIO != DDGI_EVENT_PRIO) __builtin_amdgcn_s_setprio(DDGI_AQ_UNI_MPRIO);
+                    DDGI_MARK("march_burst_begin");
+                    const bool near_limit = __ballot(have && kMarchIters - m.it < kAqStepsPerTrip) != 0ull;
+                    bool fin = !have;
+                    if (near_limit)
+                    {
+                        fin = fin || (kMarchIters - m.it <= 0);
+#pragma unroll
+                        for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
+                        {
+                            if (kStats) st_useful += static_cast<unsigned long long>(__popcll(__ballot(!fin)));
+                            fin = fin | march_step_frozen(m, A.scene, s_bits, hi_v, fin) | (m.t >= m.tl) | (kMarchIters - m.it <= sub + 1);
+                        }
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int sub = 0; sub < kAqStepsPerTrip; ++sub)
+                        {
+                            if (kStats) st_useful += static_cast<unsigned long long>(__popcll(__ballot(!fin)));
+                            fin = fin | march_step_frozen(m, A.scene, s_bits, hi_v, fin) | (m.t >= m.tl);
+                        }
+                    }
+                    DDGI_MARK("march_burst_end");
+                    if (DDGI_AQ_UNI_MPRIO != DDGI_EVENT_PRIO) __builtin_amdgcn_s_setprio(DDGI_EVENT_PRIO);
+                    bool finished = false, again = false;
+                    uint32_t bucket = 0;
+                    if (have)
+                    {
+                        const uint32_t* __restrict__ bits_base = s_bits - (A.scene.bias32 >> 5);
+                        const bool occ = __builtin_amdgcn_ubfe(bits_base[m.cell >> 5], static_cast<uint32_t>(m.cell), 1u) != 0u;  // (march_step_frozen's own test)
+                        m.it += kAqStepsPerTrip;
+                        bool f = fin;
+                        // (a march that has left the box for good can only miss)
+                        if (!f) f = march_escaped(m, A.scene);
+                        P.t[slot] = m.t;
+                        if (f)
+                        {
+                            const uint32_t hf = !occ ? 0u : ((fl & kFlagFeeler) ? static_cast<uint32_t>(kFlagHit) : hit_flags<Cfg>(A, U0, static_cast<uint32_t>(hit_block_type(A.scene, A.scene_id, cell_id(m.p), m.cell)), m.p, false));
+                            P.flags[slot] = (fl & 0xf000u) | ((fl & kFlagFeeler) ? kSlotEvFeeler : kSlotEvPrimary) | (fl & kFlagFeeler) | hf;
+                            const bool block_wins = occ && (m.t < m.tl);
+                            bucket = (fl & kFlagFeeler) ? kBucketFeeler : (block_wins ? primary_bucket(hf) : kBucketNoBlock);
+                            finished = true;
+                        }
+                        else
+                        {
+                            P.flags[slot] = (fl & ~0xff0u) | (static_cast<uint32_t>(m.it) << 4);  // goes on at (t, iterations), like a march an event has set up
+                            again = true;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (finished)  // a handful of lanes per queue: one LDS atomic per lane is cheaper than six wave-aggregated appends
+                    {
+                        const uint32_t at = atomicAdd(&sh->eq_tail[bucket], 1u);
+                        (ring_eq + bucket * kCap)[at % kCap] = static_cast<uint16_t>(slot);
+                    }
+                    aq_push<kCap>(ring_mq, &sh->mq_tail, again, slot, lane);
+                    DDGI_MARK("march_trip_end");
+                    continue;
+                }
+                b = pick == kLaneFq ? kBucketRefill : static_cast<uint32_t>(pick);
+                uni_chosen = true;
+            }
+#endif
 #if DDGI_AQ_REFILL_FIRST
             // new rays BEFORE full event groups whenever 64 slots are free: the pool stays full, the march waves' lanes with it
             const bool refill_first = !no_more && lane_bcast(avail, kAqEventQueues) >= 64u;
@@ -2020,6 +2230,12 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             constexpr bool refill_first = false;
 #endif
 
+#if DDGI_AQ_UNIFIED
+            if (uni_chosen)
+            {
+            }
+            else
+#endif
             if (full != 0ull && !refill_first)
             {
                 // 1) a full group
@@ -2234,6 +2450,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
     {
         atomicAdd(&A.stats[wave < march_waves ? 0 : 2], st_a);
         atomicAdd(&A.stats[wave < march_waves ? 1 : 3], st_b);
+        if (st_ma) atomicAdd(&A.stats[0], st_ma), atomicAdd(&A.stats[1], st_mb);
         atomicAdd(&A.stats[4], 1ull);
         atomicAdd(&A.stats[5], st_useful);
         for (int q = 0; q < 8; ++q) atomicAdd(&A.stats[8 + q], st_q[q]);  // (the slots of the round kernel's cycle counters)
@@ -2281,6 +2498,7 @@ static hipError_t launch_aq(const TraceArgs& args, int pool, int grid_blocks, in
     const size_t lds = Cfg::kFast ? aq_lds_bytes(args.scene.nwords_skip, pool, true, kPool > 0 ? kAqCapFast : kAqCap) : aq_lds_bytes(args.scene.nwords, pool);
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_probe_trace_aq<kStats, kPool, Cfg>), 160 * 1024);
     if (e != hipSuccess) return e;
+    if (DDGI_AQ_UNIFIED && !Cfg::kFast) march_waves = 0;  // unified waves: every wave serves every queue
     hipLaunchKernelGGL((k_probe_trace_aq<kStats, kPool, Cfg>), dim3(grid_blocks), dim3(kAqThreads), lds, stream, args, pool, std::min(march_waves, kAqThreads / 64 - 1), chain, status);
     return hipGetLastError();
 }
