@@ -369,7 +369,7 @@ DDGI_D int hit_block_type(const SceneK& S, int scene_id, f3 cell, int raw)
 {
     if (scene_id == 0 && cell.y < -15.0f && (cell.x < S.lo_f[0] || cell.x > S.hi_f[0] || cell.z < S.lo_f[2] || cell.z > S.hi_f[2]))
         return cave_floor_band_type(cell);
-    return S.types[raw - S.bias];
+    return S.types[static_cast<uint32_t>(raw - S.bias)];  // (raw >= bias: the clamped voxel is in the box; unsigned: the base stays in scalar registers)
 }
 
 // march_step_frozen for TWO marches of a lane at once, statement by statement: the two dependent chains alternate in the

@@ -134,13 +134,22 @@ struct NoiseLut
     const float* wall = nullptr;
     const float* r1 = nullptr;    // random1(cell), x fastest
 };
+// table[i] with the byte offset computed in 32 bits (every table is far below 4 GiB): on the device the load then takes the
+// table's base from scalar registers and a 32-bit offset per lane (global_load ... v, s[base:base+1]) instead of a 64-bit
+// address per lane made by v_lshl_add_u64 / v_mad_u64_u32 — VALU instructions, in the kernel the VALU bounds.
+DDGI_HD float lut_f32(const float* table, unsigned i) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (i << 2)); }
+DDGI_HD f2 lut_f32x2(const float* table, unsigned i)  // table[i], table[i + 1] (i need not be even: a dwordx2 load takes any 4-byte alignment)
+{
+    const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (i << 2));
+    return f2{q[0], q[1]};
+}
 constexpr float kWallFbmX = 0.05f;
 DDGI_HD float random1_at(f3 cell, const NoiseLut& L)  // random1 of a voxel id (integer-valued floats)
 {
     const unsigned ux = static_cast<unsigned>(gl_int(cell.x) - lut::kR1Lo0), uy = static_cast<unsigned>(gl_int(cell.y) - lut::kR1Lo1),
                    uz = static_cast<unsigned>(gl_int(cell.z) - lut::kR1Lo2);
     if (L.r1 && ux < static_cast<unsigned>(lut::kR1N0) && uy < static_cast<unsigned>(lut::kR1N1) && uz < static_cast<unsigned>(lut::kR1N2))
-        return L.r1[(uz * static_cast<unsigned>(lut::kR1N1) + uy) * static_cast<unsigned>(lut::kR1N0) + ux];
+        return lut_f32(L.r1, (uz * static_cast<unsigned>(lut::kR1N1) + uy) * static_cast<unsigned>(lut::kR1N0) + ux);
     return random1(cell);
 }
 
@@ -153,8 +162,13 @@ DDGI_HD float interp_noise2D(float x, float y, const NoiseLut& L = NoiseLut())  
     const unsigned ux = static_cast<unsigned>(ix - lut::kN2X0), uy = static_cast<unsigned>(iy - lut::kN2Y0);
     if (L.n2 && ux < static_cast<unsigned>(lut::kN2NX - 1) && uy < static_cast<unsigned>(lut::kN2NY - 1))
     {
-        const float* q = L.n2 + static_cast<size_t>(ux) * lut::kN2NY + uy;
-        a = q[0], c = q[1], b = q[lut::kN2NY], d = q[lut::kN2NY + 1];
+        const unsigned at = ux * static_cast<unsigned>(lut::kN2NY) + uy;  // (< 2^24)
+        unsigned at_next = at + static_cast<unsigned>(lut::kN2NY);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(at_next));  // (its own 32-bit offset: seen as `at` + 47 104 bytes, past a load's immediate, the compiler goes back to a 64-bit address per lane)
+#endif
+        const f2 ac = lut_f32x2(L.n2, at), bd = lut_f32x2(L.n2, at_next);
+        a = ac.x, c = ac.y, b = bd.x, d = bd.y;
     }
     else
     {
@@ -185,15 +199,15 @@ DDGI_HD float fbm2_wall(float y, const NoiseLut& L = NoiseLut())
     {
         float total = 0.0f;
         float freq = 1.0f, amp = 1.0f;
-        const float* row = L.wall - lut::kN2Y0;
+        unsigned row = static_cast<unsigned>(-lut::kN2Y0);
         for (int i = 1; i <= 8; ++i)
         {
             freq *= 2.0f;
             amp *= 0.5f;
             const float yo = y * freq;
-            const float* q = row + gl_int(floorf(yo));
-            total += gl_mix(q[0], q[1], gl_fract(yo)) * amp;
-            row += lut::kN2NY;
+            const f2 q = lut_f32x2(L.wall, row + static_cast<unsigned>(gl_int(floorf(yo))));  // (|iy| < 2047: the sum is a small positive index)
+            total += gl_mix(q.x, q.y, gl_fract(yo)) * amp;
+            row += static_cast<unsigned>(lut::kN2NY);
         }
         return total;
     }
@@ -203,7 +217,7 @@ DDGI_HD float noise1(float i) { return gl_fract(hash_sin(203.311f * i)); }  // :
 DDGI_HD float noise1_at(float i, const NoiseLut& L)
 {
     const unsigned u = static_cast<unsigned>(gl_int(i) - lut::kN1I0);
-    if (L.n1 && u < static_cast<unsigned>(lut::kN1N)) return L.n1[u];
+    if (L.n1 && u < static_cast<unsigned>(lut::kN1N)) return lut_f32(L.n1, u);
     return noise1(i);
 }
 DDGI_HD float interp_noise1D(float x, const NoiseLut& L = NoiseLut())  // :441-448
@@ -234,8 +248,7 @@ DDGI_HD f2 worley_point(f2 cell, const NoiseLut& L)
     const unsigned ux = static_cast<unsigned>(gl_int(cell.x) - lut::kWpC0), uy = static_cast<unsigned>(gl_int(cell.y) - lut::kWpC0);
     if (L.wp && ux < static_cast<unsigned>(lut::kWpN) && uy < static_cast<unsigned>(lut::kWpN))
     {
-        const float* q = L.wp + (static_cast<size_t>(ux) * lut::kWpN + uy) * 2;
-        return f2{q[0], q[1]};
+        return lut_f32x2(L.wp, (ux * static_cast<unsigned>(lut::kWpN) + uy) * 2u);
     }
     return worley_point_eval(cell);
 }

@@ -518,7 +518,7 @@ DDGI_D uint32_t light_vis_class(const TraceArgs& A, const Upd& U, f3 o, f3 n, in
     const int en = light_vis_entry(A, o, n);
     if (en < 0) return kVisUnknown;
     entry = en;
-    return vis[en];
+    return vis[static_cast<uint32_t>(en)];  // (an unsigned 32-bit offset: the table's base stays in scalar registers)
 }
 
 
@@ -533,7 +533,7 @@ constexpr float kListGrow = 4.0e-4f;
 template <class Upd>
 DDGI_D bool listed_feeler_clear(const Upd& U, int entry, f3 o, f3 dn, float t_light)
 {
-    const uint4 packed4 = *reinterpret_cast<const uint4*>(U.vis_occ() + static_cast<size_t>(entry) * kVisListMax);
+    const uint4 packed4 = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(U.vis_occ()) + static_cast<uint32_t>(entry) * static_cast<uint32_t>(kVisListMax * sizeof(uint32_t)));
     const uint32_t packed[kVisListMax] = {packed4.x, packed4.y, packed4.z, packed4.w};
     const f3 cell = cell_id(o);  // the start voxel
     const f3 inv{__builtin_amdgcn_rcpf(dn.x), __builtin_amdgcn_rcpf(dn.y), __builtin_amdgcn_rcpf(dn.z)};
@@ -1312,6 +1312,18 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
 #ifndef DDGI_AQ_MASKED
 #define DDGI_AQ_MASKED 1  // march waves: the "march has ended" state of a burst as a mask in a VGPR (march_step_masked)
 #endif
+#ifndef DDGI_AQ_GIVE_BACK
+#define DDGI_AQ_GIVE_BACK 0  // march waves: a wave left with fewer marches than this hands them back to the queue and naps (0: off)
+#endif
+#ifndef DDGI_AQ_RESTART
+#define DDGI_AQ_RESTART 40   // ... until the queue holds this many marches, or DDGI_AQ_RESTART_WAITS naps of DDGI_AQ_RESTART_NAP x 64 cycles have passed
+#endif
+#ifndef DDGI_AQ_RESTART_WAITS
+#define DDGI_AQ_RESTART_WAITS 8
+#endif
+#ifndef DDGI_AQ_RESTART_NAP
+#define DDGI_AQ_RESTART_NAP 4
+#endif
 #ifndef DDGI_AQ_EARLY_OUT
 #define DDGI_AQ_EARLY_OUT 0  // march waves: leave a burst at step 6 / 12 / 18 when every march of the wave has ended (0: off)
 #endif
@@ -1798,6 +1810,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
         f3 hi_v = f3{A.scene.hi_f[0], A.scene.hi_f[1], A.scene.hi_f[2]};
         asm volatile("" : "+v"(hi_v.x), "+v"(hi_v.y), "+v"(hi_v.z));
         int trips = 0, thin_waits = 0;
+        [[maybe_unused]] bool forced = false;
         for (;;)
         {
             DDGI_MARK("march_trip_begin");
@@ -1843,6 +1856,36 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 if ((aq_load(&sh->no_more) != 0u && aq_load(&sh->live) == 0u) || aq_load(&sh->abort) != 0u) break;
                 __builtin_amdgcn_s_sleep(DDGI_AQ_SLEEP);
                 continue;
+            }
+            if (DDGI_AQ_GIVE_BACK > 0 && kM == 1)
+            {
+                // A THIN WAVE GIVES ITS MARCHES BACK.  A burst costs the same instructions for 10 marches as for 64, and the seven march
+                // waves share ~200 marches in flight: each tops its idle lanes up from a queue the others keep short, and all of them
+                // run half empty.  A wave left with few marches writes them back as (t, iterations) — what an event leaves for a march
+                // it has taken the first steps of — queues them again and naps; the other waves take them into THEIR idle lanes (a fetch
+                // they run anyway).  It starts again when the queue can fill a burst, or after a bounded wait (then with whatever
+                // there is: progress is never held up).
+                const int n_have = __popcll(__ballot(have[0]));
+                if (n_have < DDGI_AQ_GIVE_BACK && !forced && aq_load(&sh->no_more) == 0u)
+                {
+                    if (have[0])
+                    {
+                        P.t[slot[0]] = m[0].t;
+                        P.flags[slot[0]] = (fl[0] & ~0xff0u) | (static_cast<uint32_t>(m[0].it) << 4);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    aq_push<kCap>(ring_mq, &sh->mq_tail, have[0], slot[0], lane);
+                    have[0] = false;
+                    for (int w = 0; w < DDGI_AQ_RESTART_WAITS; ++w)
+                    {
+                        __builtin_amdgcn_s_sleep(DDGI_AQ_RESTART_NAP);
+                        const uint32_t avail = aq_load(&sh->mq_tail) - aq_load(&sh->mq_head);
+                        if (avail >= static_cast<uint32_t>(DDGI_AQ_RESTART) && avail <= kCap) break;
+                    }
+                    forced = true;  // (the next trip runs with what it gets)
+                    continue;
+                }
+                forced = false;
             }
             if (kAqThinTrip > 0)
             {
