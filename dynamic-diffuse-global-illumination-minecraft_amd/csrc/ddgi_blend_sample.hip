@@ -963,13 +963,14 @@ __global__ __launch_bounds__(kBlendBlock) void k_probe_blend(const BlendArgs A)
 // k_probe_sample_ddgi — one lane per shading point
 // ------------------------------------------------------------------------------------------------
 
+template <bool kVec>
 __global__ __launch_bounds__(256) void k_probe_sample_ddgi(const SampleArgs A)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= A.n) return;
     const uint32_t i = A.perm ? A.perm[k] : k;
     int cage[8];
-    const f3 out = diffuse_gi_ddgi(A.grid, A.irradiance, A.depth, f3{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]},
+    const f3 out = diffuse_gi_ddgi<kVec>(A.grid, A.irradiance, A.depth, f3{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]},
                                    f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]}, cage);
     A.rgb[3 * i] = out.x, A.rgb[3 * i + 1] = out.y, A.rgb[3 * i + 2] = out.z;
     if (A.cage)
@@ -1042,7 +1043,10 @@ hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream)
 {
     const unsigned blocks = (args.n + 255u) / 256u;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_probe_sample_ddgi, dim3(blocks), dim3(256), 0, stream, args);
+    // (a texel as one load needs the tiles' base aligned to a texel: the engine's buffers are; textures bound by the host may not be)
+    const bool vec = (reinterpret_cast<uintptr_t>(args.irradiance) & 15u) == 0u && (reinterpret_cast<uintptr_t>(args.depth) & 7u) == 0u;
+    if (vec) hipLaunchKernelGGL(k_probe_sample_ddgi<true>, dim3(blocks), dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL(k_probe_sample_ddgi<false>, dim3(blocks), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -483,4 +483,16 @@ DDGI_D int slab_slot(const GridK& G, int p)
     return (z * G.cy + y) * G.cx + x;
 }
 
+// slab_slot of the probe index sy*cx*cz + sz*cx + sx that get_diffuse_gi makes of a cage corner's grid coordinates
+// (intersection.glsl:1336-1340).  Inside the grid that is (sz*cy + sy)*cx + sx with no arithmetic at all; the reference's
+// index WRAPS where a coordinate is outside (Q4: x == cx is x = 0 of the next z row, ...), and there the index is decoded
+// like any other — two integer divisions, ~70 instructions, which every corner of every shading point used to pay.
+DDGI_D int slab_slot_of_corner(const GridK& G, int sx, int sy, int sz, int idx)
+{
+    const bool inside = static_cast<unsigned>(sx) < static_cast<unsigned>(G.cx) && static_cast<unsigned>(sy) < static_cast<unsigned>(G.cy) && static_cast<unsigned>(sz) < static_cast<unsigned>(G.cz);
+    int slot = (sz * G.cy + sy) * G.cx + sx;
+    if (__builtin_expect(!inside, 0)) slot = slab_slot(G, idx);
+    return slot;
+}
+
 }  // namespace ddgi

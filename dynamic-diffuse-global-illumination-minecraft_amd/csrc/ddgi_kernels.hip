@@ -369,22 +369,21 @@ hipError_t launch_sample_box_filter(const GridK& grid, const uint32_t* albedo, f
 // bin for free), the counts go out as one coalesced row per workgroup, one small kernel turns the table of rows into offsets, and
 // the scatter is a plain store.  Bins are COARSE — the cage's slot index shifted so that at most kSampleBins fit the LDS
 // histogram (C3: 8 consecutive cages along x per bin): locality is all the grouping is for.
-constexpr uint32_t kSampleBins = 32768;  // LDS histogram entries per workgroup (16-bit counters: a run holds fewer than 65 536 points)
+constexpr uint32_t kSampleBins = 8192;   // bins (LDS entries per workgroup: 16-bit counters in k_sample_count — a run holds fewer than 65 536 points — and the 32-bit starts in k_sample_place)
 constexpr uint32_t kSampleRuns = 256;    // workgroups = contiguous runs of the batch
 
-DDGI_D uint32_t sample_key(const GridK& G, const float* __restrict__ pos, uint32_t i, uint32_t shift)
+DDGI_D uint32_t sample_key(const GridK& G, const float* __restrict__ pos, uint32_t i, uint32_t shift, uint32_t n_bins)
 {
     const float side = static_cast<float>(G.side);
     // (grouping only: any point lands in SOME bin; the sample kernels redo get_diffuse_gi's arithmetic exactly)
     const int bx = gl_int(floorf((pos[3 * i] - G.origin[0]) / side)) + G.cx / 2;
     const int by = gl_int(floorf((pos[3 * i + 1] - G.origin[1]) / side)) + G.cy / 2;
     const int bz = gl_int(floorf((pos[3 * i + 2] - G.origin[2]) / side)) + G.cz / 2;
-    uint32_t key = static_cast<uint32_t>(G.cx) * G.cy * G.cz;  // outside the field
-    if (bx >= 0 && bx < G.cx && by >= 0 && by < G.cy && bz >= 0 && bz < G.cz) key = static_cast<uint32_t>((bz * G.cy + by) * G.cx + bx);
-    return key >> shift;
+    if (bx >= 0 && bx < G.cx && by >= 0 && by < G.cy && bz >= 0 && bz < G.cz) return static_cast<uint32_t>((bz * G.cy + by) * G.cx + bx) >> shift;
+    return n_bins - 1u;  // outside the field: the last bin, on its own
 }
 // run r = points [r * per_run, (r + 1) * per_run): keys[i], rank[i] (arrival number inside its run and bin), counts[r][bin]
-__global__ __launch_bounds__(1024) void k_sample_count(const GridK G, const float* __restrict__ pos, uint32_t n, uint32_t per_run, uint32_t shift, uint32_t n_bins,
+__global__ __launch_bounds__(1024) void k_sample_count(const GridK G, const float* __restrict__ pos, uint32_t n, uint32_t per_run, uint32_t shift, uint32_t n_probes, uint32_t n_bins,
                                                        uint32_t* __restrict__ keys, uint32_t* __restrict__ rank, uint32_t* __restrict__ counts)
 {
     // 16-bit counters, two to a word (LDS has 32-bit atomics): the add returns the word, the bin's half of it is the rank
@@ -395,7 +394,7 @@ __global__ __launch_bounds__(1024) void k_sample_count(const GridK G, const floa
     const uint32_t lo = blockIdx.x * per_run, hi = min(n, lo + per_run);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024)
     {
-        const uint32_t key = sample_key(G, pos, i, shift);
+        const uint32_t key = sample_key(G, pos, i, shift, n_bins);
         keys[i] = key;
         const uint32_t sh = (key & 1u) * 16u;
         rank[i] = (atomicAdd(&hist[key >> 1], 1u << sh) >> sh) & 0xffffu;
@@ -437,9 +436,13 @@ __global__ __launch_bounds__(256) void k_sample_scan_runs(uint32_t n_runs, uint3
     }
     if (chunk == 15u && b < n_bins) totals[b] = before + acc;
 }
-// totals[bin] -> base[bin] = the exclusive sum over the bins before it (one workgroup; at most kSampleBins = 4 per lane)
-__global__ __launch_bounds__(1024) void k_sample_scan_bins(uint32_t n_bins, uint32_t* __restrict__ totals)
+// perm[base[key] + before[run][key] + rank[i]] = i, run by run (the workgroups of k_sample_count again).  base[bin] = the exclusive
+// sum of totals[] over the bins before it: every workgroup scans the totals itself (at most kSampleBins words, in LDS) and keeps
+// its run's row of `before` beside them — the bins' bases need no kernel of their own, and a point's two table look-ups are LDS reads.
+__global__ __launch_bounds__(1024) void k_sample_place(uint32_t n, uint32_t per_run, uint32_t n_bins, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ rank,
+                                                       const uint32_t* __restrict__ before, const uint32_t* __restrict__ totals, uint32_t* __restrict__ perm)
 {
+    __shared__ uint32_t start[kSampleBins];  // base[bin] + before[run][bin]
     __shared__ uint32_t scan[1024];
     constexpr uint32_t kPer = kSampleBins / 1024;
     uint32_t v[kPer], mine = 0;
@@ -460,28 +463,26 @@ __global__ __launch_bounds__(1024) void k_sample_scan_bins(uint32_t n_bins, uint
         __syncthreads();
     }
     uint32_t base = scan[threadIdx.x] - mine;
+    const uint32_t* __restrict__ row = before + static_cast<size_t>(blockIdx.x) * n_bins;
 #pragma unroll
     for (uint32_t k = 0; k < kPer; ++k)
     {
         const uint32_t b = threadIdx.x * kPer + k;
-        if (b < n_bins) totals[b] = base;
+        if (b < n_bins) start[b] = base + row[b];
         base += v[k];
     }
-}
-__global__ __launch_bounds__(256) void k_sample_place(uint32_t n, uint32_t per_run, uint32_t n_bins, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ rank,
-                                                      const uint32_t* __restrict__ before, const uint32_t* __restrict__ base, uint32_t* __restrict__ perm)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t key = keys[i];
-    perm[base[key] + before[static_cast<size_t>(i / per_run) * n_bins + key] + rank[i]] = i;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * per_run, hi = min(n, lo + per_run);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 1024) perm[start[keys[i]] + rank[i]] = i;
 }
 
+// Bins are as fine as kSampleBins allows: the sample kernels' waves then hold points of one cage (C3: bins of 4 cages), whose 8
+// probes' tiles they share in the vector cache (bins of 8 cages: k_probe_sample_ddgi 147 -> 207 us per 1.44 M points)
 static void sample_bins(uint32_t n_probes, uint32_t& shift, uint32_t& n_bins)
 {
     shift = 0;
-    while ((n_probes >> shift) + 1u > kSampleBins) ++shift;  // (the last fine key is n_probes: "outside the field")
-    n_bins = (n_probes >> shift) + 1u;
+    while ((n_probes >> shift) + 2u > kSampleBins) ++shift;  // (+ the bin of the points outside the field)
+    n_bins = ((n_probes + (1u << shift) - 1u) >> shift) + 1u;
 }
 // scratch: keys[n] | rank[n] | perm[n] | counts[kSampleRuns x n_bins] | totals[n_bins]   (uint32 each)
 size_t sample_group_scratch_words(uint32_t n, uint32_t n_probes)
@@ -494,19 +495,17 @@ size_t sample_group_scratch_words(uint32_t n, uint32_t n_probes)
 hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t n, uint32_t* scratch, const uint32_t** perm_out, hipStream_t stream)
 {
     uint32_t shift, n_bins;
-    sample_bins(static_cast<uint32_t>(grid.cx) * grid.cy * grid.cz, shift, n_bins);
+    const uint32_t n_probes = static_cast<uint32_t>(grid.cx) * grid.cy * grid.cz;
+    sample_bins(n_probes, shift, n_bins);
     // (a run's 16-bit counters: fewer than 65 536 points per run — more runs than kSampleRuns for batches beyond 16 M points)
     const uint32_t n_runs = std::max<uint32_t>(std::min<uint32_t>(kSampleRuns, (n + 1023u) / 1024u), (n + 65534u) / 65535u);
     if (n_runs > kSampleRuns) return hipErrorInvalidValue;  // (ddgi_engine.cpp splits batches of more than 2^24 points)
     const uint32_t per_run = (n + n_runs - 1u) / n_runs;
     uint32_t *keys = scratch, *rank = keys + n, *perm = rank + n, *counts = perm + n, *totals = counts + static_cast<size_t>(kSampleRuns) * n_bins;
     const size_t lds = static_cast<size_t>((n_bins + 1u) / 2u) * sizeof(uint32_t);
-    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_sample_count), static_cast<int>(kSampleBins * 2));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sample_count, dim3(n_runs), dim3(1024), lds, stream, grid, pos, n, per_run, shift, n_bins, keys, rank, counts);
+    hipLaunchKernelGGL(k_sample_count, dim3(n_runs), dim3(1024), lds, stream, grid, pos, n, per_run, shift, n_probes, n_bins, keys, rank, counts);
     hipLaunchKernelGGL(k_sample_scan_runs, dim3((n_bins + 15u) / 16u), dim3(256), 0, stream, n_runs, n_bins, counts, totals);
-    hipLaunchKernelGGL(k_sample_scan_bins, dim3(1), dim3(1024), 0, stream, n_bins, totals);
-    hipLaunchKernelGGL(k_sample_place, dim3((n + 255u) / 256u), dim3(256), 0, stream, n, per_run, n_bins, keys, rank, counts, totals, perm);
+    hipLaunchKernelGGL(k_sample_place, dim3(n_runs), dim3(1024), 0, stream, n, per_run, n_bins, keys, rank, counts, totals, perm);
     *perm_out = perm;
     return hipGetLastError();
 }

@@ -132,6 +132,9 @@ DDGI_D f3 diffuse_gi_ref(const GridK& G, const uint32_t* albedo, f3 pos, f3 nrm_
             const int sx = bx + ((k >> 2) & 1) + G.cx / 2, sy = by + ((k >> 1) & 1) + G.cy / 2, sz = bz + (k & 1) + G.cz / 2;  // Q4
             return sy * G.cx * G.cz + sz * G.cx + sx;
         };
+        auto corner_slot = [&](int k, int idx) {  // slab_slot(idx) of a corner in range (ddgi_device.h: slab_slot_of_corner)
+            return slab_slot_of_corner(G, bx + ((k >> 2) & 1) + G.cx / 2, by + ((k >> 1) & 1) + G.cy / 2, bz + (k & 1) + G.cz / 2, idx);
+        };
         if constexpr (kBatch)
         {
             // (with the table only.)  ALL EIGHT entries are asked for before the first is used: taken corner by corner each load
@@ -143,9 +146,24 @@ DDGI_D f3 diffuse_gi_ref(const GridK& G, const uint32_t* albedo, f3 pos, f3 nrm_
             for (int k = 0; k < 8; ++k) idx[k] = corner_index(k), ok = ok && idx[k] >= 0 && idx[k] < n_probes;
             if (ok)
             {
+                // the corners' slab slots: with the whole cage inside the grid (ONE test in front of the loads: bx, by, bz and their
+                // successors in range) no index has wrapped and a slot is (sz cy + sy) cx + sx; else every index is decoded
+                const int sx0 = bx + G.cx / 2, sy0 = by + G.cy / 2, sz0 = bz + G.cz / 2;
+                const bool cage_inside = sx0 >= 0 && sx0 + 1 < G.cx && sy0 >= 0 && sy0 + 1 < G.cy && sz0 >= 0 && sz0 + 1 < G.cz;
+                uint32_t slot[8];
+                if (cage_inside)
+                {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) slot[k] = static_cast<uint32_t>(((sz0 + (k & 1)) * G.cy + sy0 + ((k >> 1) & 1)) * G.cx + sx0 + ((k >> 2) & 1));
+                }
+                else
+                {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) slot[k] = static_cast<uint32_t>(slab_slot(G, idx[k]));
+                }
                 float4 tab[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) tab[k] = box[box_index(static_cast<uint32_t>(box_off), static_cast<uint32_t>(slab_slot(G, idx[k])), static_cast<uint32_t>(G.n), static_cast<uint32_t>(n_probes))];
+                for (int k = 0; k < 8; ++k) tab[k] = box[box_index(static_cast<uint32_t>(box_off), slot[k], static_cast<uint32_t>(G.n), static_cast<uint32_t>(n_probes))];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) corner(k, idx[k], f3{tab[k].x, tab[k].y, tab[k].z});
             }
@@ -163,7 +181,7 @@ DDGI_D f3 diffuse_gi_ref(const GridK& G, const uint32_t* albedo, f3 pos, f3 nrm_
                 f3 smp;
                 if (box)
                 {
-                    const float4 v = box[box_index(static_cast<uint32_t>(box_off), static_cast<uint32_t>(slab_slot(G, idx)), static_cast<uint32_t>(G.n), static_cast<uint32_t>(n_probes))];  // (idx is a valid probe here)
+                    const float4 v = box[box_index(static_cast<uint32_t>(box_off), static_cast<uint32_t>(corner_slot(k, idx)), static_cast<uint32_t>(G.n), static_cast<uint32_t>(n_probes))];  // (idx is a valid probe here)
                     smp = f3{v.x, v.y, v.z};
                 }
                 else
@@ -181,30 +199,94 @@ DDGI_D f3 diffuse_gi_ref(const GridK& G, const uint32_t* albedo, f3 pos, f3 nrm_
     return out;
 }
 
-template <int kSide, int kCh>
-DDGI_D void tile_fetch(const float* tile, f3 dir, float* out)
+// Where a direction lands in a bordered kSide x kSide octahedral tile: the four texels of the bilinear fetch (offsets in texels)
+// and the two weights.  The same for every tile that is asked for the same direction — all 8 irradiance tiles of a cage are
+// asked for the shading normal — so a caller works it out once.
+struct TileCoords
+{
+    int o00, o01, o10, o11;  // (y0, x0), (y0, x1), (y1, x0), (y1, x1)
+    float tx, ty;
+};
+template <int kSide>
+DDGI_D TileCoords tile_coords(f3 dir)
 {
     const f2 uv = oct_encode(normalize3(dir));
     const float inner = static_cast<float>(kSide - 2);
     const float fx = (uv.x * 0.5f + 0.5f) * inner + 0.5f;  // texel-centre coordinate inside the bordered tile
     const float fy = (uv.y * 0.5f + 0.5f) * inner + 0.5f;
     const float bx = floorf(fx), by = floorf(fy);
-    const float tx = fx - bx, ty = fy - by;
     int x0 = gl_int(bx), y0 = gl_int(by);
     int x1 = x0 + 1, y1 = y0 + 1;
     x0 = max(x0, 0), y0 = max(y0, 0);
     x1 = min(x1, kSide - 1), y1 = min(y1, kSide - 1);
-    for (int c = 0; c < kCh; ++c)
+    return TileCoords{y0 * kSide + x0, y0 * kSide + x1, y1 * kSide + x0, y1 * kSide + x1, fx - bx, fy - by};
+}
+// kVec: a texel's kCh floats come as ONE load (the tile's base is aligned to kCh floats: the engine's own buffers are; textures
+// bound by the host are checked, launch_probe_sample_ddgi) — 4 loads per fetch instead of 4 kCh
+template <int kCh, bool kVec = false>
+DDGI_D void tile_gather(const float* tile, const TileCoords& c, float* out)
+{
+    float a[kCh], b[kCh], cc[kCh], d[kCh];
+    if constexpr (kVec && kCh == 4)
     {
-        const float a = tile[(y0 * kSide + x0) * kCh + c], b = tile[(y0 * kSide + x1) * kCh + c];
-        const float cc = tile[(y1 * kSide + x0) * kCh + c], d = tile[(y1 * kSide + x1) * kCh + c];
-        out[c] = gl_mix(gl_mix(a, b, tx), gl_mix(cc, d, tx), ty);
+        const float4 va = *reinterpret_cast<const float4*>(tile + c.o00 * 4), vb = *reinterpret_cast<const float4*>(tile + c.o01 * 4);
+        const float4 vc = *reinterpret_cast<const float4*>(tile + c.o10 * 4), vd = *reinterpret_cast<const float4*>(tile + c.o11 * 4);
+        a[0] = va.x, a[1] = va.y, a[2] = va.z, a[3] = va.w, b[0] = vb.x, b[1] = vb.y, b[2] = vb.z, b[3] = vb.w;
+        cc[0] = vc.x, cc[1] = vc.y, cc[2] = vc.z, cc[3] = vc.w, d[0] = vd.x, d[1] = vd.y, d[2] = vd.z, d[3] = vd.w;
     }
+    else if constexpr (kVec && kCh == 2)
+    {
+        const float2 va = *reinterpret_cast<const float2*>(tile + c.o00 * 2), vb = *reinterpret_cast<const float2*>(tile + c.o01 * 2);
+        const float2 vc = *reinterpret_cast<const float2*>(tile + c.o10 * 2), vd = *reinterpret_cast<const float2*>(tile + c.o11 * 2);
+        a[0] = va.x, a[1] = va.y, b[0] = vb.x, b[1] = vb.y, cc[0] = vc.x, cc[1] = vc.y, d[0] = vd.x, d[1] = vd.y;
+    }
+    else
+    {
+        for (int ch = 0; ch < kCh; ++ch)
+            a[ch] = tile[c.o00 * kCh + ch], b[ch] = tile[c.o01 * kCh + ch], cc[ch] = tile[c.o10 * kCh + ch], d[ch] = tile[c.o11 * kCh + ch];
+    }
+    for (int ch = 0; ch < kCh; ++ch) out[ch] = gl_mix(gl_mix(a[ch], b[ch], c.tx), gl_mix(cc[ch], d[ch], c.tx), c.ty);
+}
+template <int kSide, int kCh>
+DDGI_D void tile_fetch(const float* tile, f3 dir, float* out)
+{
+    tile_gather<kCh>(tile, tile_coords<kSide>(dir), out);
 }
 
 // get_diffuse_gi with the dormant Chebyshev lines (1363-1383) enabled and octahedral bilinear tile
 // fetches, for one shading point (DDGI mode).
+// Where the sampler's tiles come from: the slab-major tile buffers in HBM.  (A policy, so that another source can stand in: a kernel
+// that staged a bin of cages' 36 tiles in LDS first was built on it in round 5 and measured slower — docs/LAB_NOTES.md.)
+template <bool kVec>
+struct TilesGlobal
+{
+    const float* irradiance;
+    const float* depth;
+    DDGI_D f2 gather_depth(uint32_t slot, const TileCoords& c) const
+    {
+        float o[2];
+        tile_gather<2, kVec>(depth + static_cast<size_t>(slot) * (kDepTile * kDepTile * 2), c, o);
+        return f2{o[0], o[1]};
+    }
+    DDGI_D f3 gather_irradiance(uint32_t slot, const TileCoords& c) const  // (rgb: the sampler does not read alpha)
+    {
+        float o[4];
+        tile_gather<4, kVec>(irradiance + static_cast<size_t>(slot) * (kIrrTile * kIrrTile * 4), c, o);
+        return f3{o[0], o[1], o[2]};
+    }
+};
+
+template <class Tiles>
+DDGI_D f3 diffuse_gi_ddgi_from(const GridK& G, const Tiles& tiles, f3 pos, f3 nrm_raw, int* cage);
+
+template <bool kVec = false>
 DDGI_D f3 diffuse_gi_ddgi(const GridK& G, const float* irradiance, const float* depth, f3 pos, f3 nrm_raw, int* cage)
+{
+    return diffuse_gi_ddgi_from(G, TilesGlobal<kVec>{irradiance, depth}, pos, nrm_raw, cage);
+}
+
+template <class Tiles>
+DDGI_D f3 diffuse_gi_ddgi_from(const GridK& G, const Tiles& tiles, f3 pos, f3 nrm_raw, int* cage)
 {
     const f3 N = normalize3(nrm_raw);
     const f3 origin{G.origin[0], G.origin[1], G.origin[2]};
@@ -225,33 +307,36 @@ DDGI_D f3 diffuse_gi_ddgi(const GridK& G, const float* irradiance, const float* 
         f3 irr = mk3(0, 0, 0);
         float sum_w = 0.0f;
         const int n_probes = G.cx * G.cy * G.cz;
+        const TileCoords irr_at = tile_coords<kIrrTile>(N);  // (all 8 corners are asked for the shading normal)
         // (the corners' range check comes first, for all eight: with a possible `break` inside the loop below every corner's
         // tile fetches would have to wait for the corner before — eight round trips to memory in a row)
+        // (and the cage indices are set here, with constant subscripts: written inside the loop below — which is not unrolled — `cage[k]`
+        // is a chain of ten compares and selects per corner; a cage with a corner out of range is reset to -1 at the end)
 #pragma unroll
         for (int k = 0; k < 8; ++k)
         {
             const int sx = bx + ((k >> 2) & 1) + G.cx / 2, sy = by + ((k >> 1) & 1) + G.cy / 2, sz = bz + (k & 1) + G.cz / 2;
             const int idx = sy * G.cx * G.cz + sz * G.cx + sx;
             ok = ok && idx >= 0 && idx < n_probes;
+            cage[k] = idx;
         }
+#pragma unroll 1  // (eight copies of the corner's body and its two tile fetches do not fit the register file)
         for (int k = 0; k < 8 && ok; ++k)
         {
             const int ox = (k >> 2) & 1, oy = (k >> 1) & 1, oz = k & 1;                            // Q7
             const int sx = bx + ox + G.cx / 2, sy = by + oy + G.cy / 2, sz = bz + oz + G.cz / 2;  // Q4
             const int idx = sy * G.cx * G.cz + sz * G.cx + sx;
-            cage[k] = idx;
             const f3 tri{ox ? alpha.x : 1.0f - alpha.x, oy ? alpha.y : 1.0f - alpha.y, oz ? alpha.z : 1.0f - alpha.z};
             const f3 probe_pos = base_world + f3{static_cast<float>(ox * G.side), static_cast<float>(oy * G.side), static_cast<float>(oz * G.side)};
             const f3 dir = normalize3(probe_pos - pos);
             float tmp = gl_max(0.0001f, (dot3(dir, N) + 1.0f) * 0.5f);
             float weight = tmp * tmp + 0.2f;
-            const size_t slot = static_cast<size_t>(slab_slot(G, idx));
+            const uint32_t slot = static_cast<uint32_t>(slab_slot_of_corner(G, sx, sy, sz, idx));
             // moment visibility test (intersection.glsl:1363-1383, enabled)
             const float dist = length3(pos - probe_pos);
-            float mms[2];
-            tile_fetch<kDepTile, 2>(depth + slot * (kDepTile * kDepTile * 2), f3{-dir.x, -dir.y, -dir.z}, mms);
-            const float mean = mms[0];
-            const float variance = fabsf(mean * mean - mms[1]);
+            const f2 mms = tiles.gather_depth(slot, tile_coords<kDepTile>(f3{-dir.x, -dir.y, -dir.z}));
+            const float mean = mms.x;
+            const float variance = fabsf(mean * mean - mms.y);
             tmp = gl_max(dist - mean, 0.0f);
             float cheb = variance / (variance + tmp * tmp);
             cheb = gl_max(cheb * cheb * cheb, 0.0f);
@@ -260,9 +345,7 @@ DDGI_D f3 diffuse_gi_ddgi(const GridK& G, const float* irradiance, const float* 
             const float crush = 0.2f;
             if (weight < crush) weight *= weight * weight * (1.f / (crush * crush));
             weight *= tri.x * tri.y * tri.z;
-            float c4[4];
-            tile_fetch<kIrrTile, 4>(irradiance + slot * (kIrrTile * kIrrTile * 4), N, c4);
-            irr = irr + f3{c4[0], c4[1], c4[2]} * weight;
+            irr = irr + tiles.gather_irradiance(slot, irr_at) * weight;
             sum_w += weight;
         }
         if (ok) out = div3(irr, sum_w);
