@@ -48,6 +48,40 @@ def test_ddgi_update_and_sample_bit_exact_vs_oracle(ddgi, oracle, name, lights, 
     assert (cage[:, 0] >= 0).mean() > 0.05
 
 
+@pytest.mark.parametrize("name", ["c2_cornell", "cave_odd"])
+def test_ddgi_sample_paths_agree_on_edge_cages_and_grouped_batches(ddgi, oracle, name):
+    """The Chebyshev sampler on a batch large enough to be grouped by cage (k_sample_count / k_sample_scan_runs / k_sample_place) and
+    as it comes: points everywhere (some outside), crowded into one cage, and on the field's last cage layer in x, whose +x corners'
+    probe indices wrap into the next z row (Q4: slab_slot_of_corner must decode those like the reference does).  Both paths equal
+    the oracle bit for bit, cage indices included."""
+    counts, side, s, origin, scene = CONFIGS[name]
+    rng = np.random.default_rng(29)
+    spread, nrm = shading_points(rng, counts, side, origin, 24000)
+    o = np.asarray(origin, dtype=np.float32)
+    crowd = (rng.uniform(0.05, 0.95, size=(5000, 3)) * side + o).astype(np.float32)
+    edge = (rng.uniform(-0.5, 0.5, size=(5000, 3)) * np.float32(side) * np.asarray(counts, dtype=np.float32) + o).astype(np.float32)
+    edge[:, 0] = o[0] + side * (counts[0] // 2 - 0.5)  # the last cage layer in x
+    pos = np.concatenate([spread, crowd, edge]).astype(np.float32)
+    nrm = np.concatenate([nrm, rng.normal(size=(len(pos) - len(nrm), 3)).astype(np.float32)])
+    f = oracle.make_field(counts, side, s, origin)
+    irr, dep = oracle.new_tiles(f)
+    with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8)) as eng:
+        eng.set_mode(ddgi.MODE_DDGI)
+        for frame in range(2):
+            eng.probe_update(ddgi.make_settings(scene, 8, time=2.0 * (frame + 1)))
+            oracle.ddgi_update(f, oracle.make_settings(scene, 8, time=2.0 * (frame + 1)), frame, irr, dep)
+        got = {}
+        for group in (1, 0):
+            eng.set_tuning("sample_group", group)
+            got[group] = eng.sample(pos, nrm)
+    want_rgb, want_cage = oracle.ddgi_sample(f, irr, dep, pos, nrm)
+    for group, (rgb, cage) in got.items():
+        assert np.array_equal(cage, want_cage), f"sample_group {group}"
+        assert np.array_equal(_bits(rgb), _bits(want_rgb)), f"sample_group {group}"
+    inside = want_cage[:, 0] >= 0
+    assert 0.02 < inside.mean() < 1.0, inside.mean()
+
+
 def test_ddgi_temporal_behaviour_and_mode_switch(ddgi):
     counts, side, s, origin, scene = CONFIGS["c1_cornell"]
     with ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin, hysteresis=0.9), ddgi.make_settings(scene, 8)) as eng:
