@@ -1884,7 +1884,8 @@ static bool sample_box_pays(const ddgi_engine* e, size_t n_points)
 static int ensure_sample_box(ddgi_engine* e, const GridK& grid, bool* usable)
 {
     *usable = false;
-    const size_t texels = e->tex_bytes[0] / 4;
+    // (one entry per texel and table slot: the table's 2x2x2 bricks round the probe counts up to even, ddgi_types.h)
+    const size_t texels = static_cast<size_t>(box_slots(grid.cx, grid.cy, grid.cz)) * static_cast<size_t>(grid.n);
     if (texels > e->box_texels)
     {
         HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2148,6 +2149,13 @@ int ddgi_device_textures(ddgi_handle e, void** tex0, size_t* tex0_bytes, void** 
     if (!e->xch.pipelined) e->pin_pair = true;
     e->chain_break = true;
     e->box_of = nullptr;
+    // A pinned handle writes one pair only: the other pairs of a frames-in-flight ring would be memory held for nothing (eight pairs
+    // by default) — the ring shrinks to what a pinned handle uses BEFORE the pointers go out (blocks once; the textures carry over).
+    if (e->pin_pair && !e->caller_tex && !e->xch.transport && !e->xch.p2p && e->np > ddgi_pairs_wanted(e, false))
+    {
+        HIP_TRY(hipSetDevice(e->device));
+        if (int rc = ddgi_resize_ring(e, ddgi_pairs_wanted(e, false))) return rc;
+    }
     if (tex0) *tex0 = e->tex[0];
     if (tex1) *tex1 = e->tex[1];
     if (tex0_bytes) *tex0_bytes = e->tex_bytes[0];

@@ -311,28 +311,38 @@ __global__ __launch_bounds__(256) void k_sample_box_filter(const GridK G, const 
     constexpr int kPad = kTiles > 1 ? 8 : 0;
     const size_t tile_words = static_cast<size_t>(3) * n + kPad;
     unorm[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;  // blockDim.x == 256
-    const uint32_t n_groups = (n_probes + kTiles - 1) / kTiles;
+    // a workgroup takes kTiles consecutive TABLE slots (bricks: the four probes of one z-layer of a brick — wherever their tiles lie)
+    const uint32_t n_slots = box_slots(G.cx, G.cy, G.cz);
+    const uint32_t n_groups = (n_slots + kTiles - 1) / kTiles;
     for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x)
     {
         __syncthreads();  // the previous group's planes are no longer read (and the table is written)
         const uint32_t slot0 = g * kTiles;
-        const uint32_t tiles = min(static_cast<uint32_t>(kTiles), n_probes - slot0);
-        const uint32_t* __restrict__ src = albedo + static_cast<size_t>(slot0) * n;
-        for (uint32_t t = threadIdx.x; t < tiles * static_cast<uint32_t>(n); t += 256)
+        int src_slot[kTiles];  // the tiles' slab slots; -1: no such probe (padding of an odd count, or past the end)
+#pragma unroll
+        for (int w = 0; w < kTiles; ++w) src_slot[w] = slot0 + w < n_slots ? box_slot_to_slab_slot(G.cx, G.cy, G.cz, slot0 + w) : -1;
+        for (uint32_t t = threadIdx.x; t < static_cast<uint32_t>(kTiles) * static_cast<uint32_t>(n); t += 256)
         {
-            const uint32_t v = src[t];
-            float* pl = planes + static_cast<size_t>(t / n) * tile_words;
-            const uint32_t tt = t % n;
+            const uint32_t w = t / n, tt = t % n;
+            int from = src_slot[0];
+#pragma unroll
+            for (int q = 1; q < kTiles; ++q) from = w == static_cast<uint32_t>(q) ? src_slot[q] : from;
+            if (from < 0) continue;
+            const uint32_t v = albedo[static_cast<size_t>(from) * n + tt];
+            float* pl = planes + static_cast<size_t>(w) * tile_words;
             pl[tt] = unorm[v & 255u], pl[n + tt] = unorm[(v >> 8) & 255u], pl[2 * n + tt] = unorm[(v >> 16) & 255u];
         }
         __syncthreads();
         for (uint32_t o = threadIdx.x; o < static_cast<uint32_t>(kTiles) * n; o += 256)
         {
             const uint32_t which = o % kTiles, t = o / kTiles;  // kTiles consecutive lanes: one texel of kTiles consecutive slots
-            if (which >= tiles) continue;
+            int from = src_slot[0];
+#pragma unroll
+            for (int q = 1; q < kTiles; ++q) from = which == static_cast<uint32_t>(q) ? src_slot[q] : from;
+            if (from < 0) continue;
             const float *pr = planes + static_cast<size_t>(which) * tile_words, *pg = pr + n, *pb = pg + n;
             const f3 v = sample_box_ref(s, sh, static_cast<int>(t % s), static_cast<int>(t / s), [&](int off) { return f3{pr[off], pg[off], pb[off]}; });
-            box[box_index(t, slot0 + which, static_cast<uint32_t>(n), n_probes)] = float4{v.x, v.y, v.z, 0.0f};
+            box[box_index(t, slot0 + which, static_cast<uint32_t>(n), n_slots)] = float4{v.x, v.y, v.z, 0.0f};
         }
     }
 }
@@ -345,7 +355,8 @@ hipError_t launch_sample_box_filter(const GridK& grid, const uint32_t* albedo, f
     const void* fn = four ? reinterpret_cast<const void*>(k_sample_box_filter<4>) : reinterpret_cast<const void*>(k_sample_box_filter<1>);
     hipError_t e = ensure_dynamic_lds(fn, static_cast<int>(lds));
     if (e != hipSuccess) return e;
-    const uint32_t groups = four ? (n_probes + 3u) / 4u : n_probes;
+    const uint32_t n_slots = box_slots(grid.cx, grid.cy, grid.cz);
+    const uint32_t groups = four ? (n_slots + 3u) / 4u : n_slots;
     const dim3 grid_dim(std::min<uint32_t>(groups, static_cast<uint32_t>(num_cus) * 8u));
     if (four) hipLaunchKernelGGL(k_sample_box_filter<4>, grid_dim, dim3(256), lds, stream, grid, albedo, box, n_probes);
     else hipLaunchKernelGGL(k_sample_box_filter<1>, grid_dim, dim3(256), lds, stream, grid, albedo, box, n_probes);

@@ -1299,6 +1299,9 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
     {                   \
     } while (0)
 #endif
+#ifndef DDGI_AQ_ROLE_PERM
+#define DDGI_AQ_ROLE_PERM 0xFEDCBA9876543210ull  // rank of every wave in the order in which waves become march waves (k_probe_trace_aq: `role`)
+#endif
 #ifndef DDGI_AQ_REQUEUE
 #define DDGI_AQ_REQUEUE 0  // (experiment, round 5: measured slower, off) march waves: every burst starts from the queue, unfinished marches are queued
                            // again.  Lanes per burst 30.6 -> 40.2 of 64, bursts per ray 0.23 -> 0.18 — and C3 1.578 -> 1.647 ms at every wave split
@@ -1492,6 +1495,10 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
     if (wf_lds[0] >= A.n_rays) return;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    // Which waves march: the `march_waves` waves of lowest RANK (DDGI_AQ_ROLE_PERM: nibble w = rank of wave w; the identity: the first
+    // `march_waves` waves).  A workgroup's waves go round the CU's four SIMDs (wave w on SIMD w & 3), so the ranks decide how march and
+    // event waves are mixed on each SIMD: the identity at 7 gives 2 + 2, 2 + 2, 2 + 2, 1 + 3 (march + event waves).
+    const int role = DDGI_AQ_ROLE_PERM == 0xFEDCBA9876543210ull ? wave : static_cast<int>((static_cast<unsigned long long>(DDGI_AQ_ROLE_PERM) >> (4 * wave)) & 15ull);
     // THE PER-UPDATE RECORDS (ddgi_types.h: UpdK).  What differs from one update to the next — lights, DDGI mode's rotation and key, ray
     // and record buffers, feeler classes — is not read from the kernel's arguments but from a ring of records: a ray of update
     // C.seq + t (t in dst[31:29]) is shaded with record t.  The host has written the launch's own record into pinned memory before
@@ -1572,7 +1579,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
     unsigned long long st_q[8] = {};        // counters build: [0] samples [1..3] sum of MQ / FQ / EQ depths at an event wave's poll, [4] idle polls,
                                             // [5] march bursts, [6] fetches that found MQ short of the idle lanes, [7] lanes in flight at burst start
 
-    if (Cfg::kFast && wave < march_waves)
+    if (Cfg::kFast && role < march_waves)
     {
         // ================= march waves, fast build =================
         // The same loop as below around fast_march_step: a lane's march skips through voxels the skip field calls empty.
@@ -1661,7 +1668,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
         }
     }
 #if DDGI_AQ_REQUEUE
-    else if (wave < march_waves)
+    else if (role < march_waves)
     {
         // ================= march waves (round 5): every burst starts from the queue =================
         // Per C3 update the march waves used to issue 0.7 G of the kernel's 1.1 G VALU wave-instructions at 26 of 64 lanes: a wave
@@ -1785,7 +1792,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
         }
     }
 #endif
-    else if (!DDGI_AQ_REQUEUE && wave < march_waves)
+    else if (!DDGI_AQ_REQUEUE && role < march_waves)
     {
         // ================= march waves =================
         // A lane holds kLaneMarches marches at a time and steps them in turn inside one burst.  CDNA4's SIMDs are 32 lanes wide:
@@ -2477,22 +2484,22 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
         }
     }
 #ifdef DDGI_LAP
-    if (kStats && lane == 0 && wave >= march_waves) probe.at(15);  // close the last lap
+    if (kStats && lane == 0 && role >= march_waves) probe.at(15);  // close the last lap
 #endif
     if (kStats && A.stats)  // ddgi_trace_stats [32 + 2 s], [33 + 2 s]: visits of / lanes active in section s of the event code (LaneProbe)
         for (int s = 0; s < kProbeSections; ++s)
         {
             unsigned long long v = probe.visits[s], l = probe.lanes[s];
 #ifdef DDGI_LAP
-            v = (lane == 0 && probe.lap && wave >= march_waves) ? probe.lap[2 + s] : 0ull;
+            v = (lane == 0 && probe.lap && role >= march_waves) ? probe.lap[2 + s] : 0ull;
 #endif
             for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m), l += __shfl_xor(l, m);
             if (lane == 0 && l) atomicAdd(&A.stats[32 + 2 * s], v), atomicAdd(&A.stats[33 + 2 * s], l);
         }
     if (kStats && A.stats && lane == 0)  // ddgi_trace_stats: [0] march trips, [1] lanes marching in them, [2] event groups, [3] lanes in them, [4] waves
     {
-        atomicAdd(&A.stats[wave < march_waves ? 0 : 2], st_a);
-        atomicAdd(&A.stats[wave < march_waves ? 1 : 3], st_b);
+        atomicAdd(&A.stats[role < march_waves ? 0 : 2], st_a);
+        atomicAdd(&A.stats[role < march_waves ? 1 : 3], st_b);
         if (st_ma) atomicAdd(&A.stats[0], st_ma), atomicAdd(&A.stats[1], st_mb);
         atomicAdd(&A.stats[4], 1ull);
         atomicAdd(&A.stats[5], st_useful);

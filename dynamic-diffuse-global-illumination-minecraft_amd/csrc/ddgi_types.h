@@ -56,6 +56,36 @@ struct GridK
     int z0, czl;  // this rank's z-slab: probes with z in [z0, z0+czl)
 };
 
+// ---- the REF sampler's per-texel table (k_sample_box_filter, ddgi_sampler.h): where a probe's entry sits inside a texel's plane ----
+// DDGI_BOX_LAYOUT  0: tile-major [slab slot][texel];  1: texel-major [texel][slab slot];  2: texel-major in 2x2x2 BRICKS of probes —
+// the 8 entries of the probes (x..x+1, y..y+1, z..z+1), x, y, z even, are ONE 128-byte line (a 2x2 z-layer per 64-byte half), so a cage's
+// 8 entries lie in 1.5^3 = 3.4 lines on average instead of 4.5 (slab order: 4 x-pairs of 32 bytes, an eighth of them across a line end).
+#ifndef DDGI_BOX_LAYOUT
+#define DDGI_BOX_LAYOUT 2
+#endif
+// table slots per texel plane (bricks: the counts rounded up to even)
+inline __host__ __device__ uint32_t box_slots(int cx, int cy, int cz)
+{
+    return DDGI_BOX_LAYOUT == 2 ? 8u * static_cast<uint32_t>((cx + 1) / 2) * static_cast<uint32_t>((cy + 1) / 2) * static_cast<uint32_t>((cz + 1) / 2)
+                                : static_cast<uint32_t>(cx) * static_cast<uint32_t>(cy) * static_cast<uint32_t>(cz);
+}
+// the table slot of probe (x, y, z) (z: the whole grid's, as in a slab slot (z cy + y) cx + x)
+inline __host__ __device__ uint32_t box_slot_xyz(int cx, int cy, int x, int y, int z)
+{
+    if (DDGI_BOX_LAYOUT != 2) return static_cast<uint32_t>((z * cy + y) * cx + x);
+    const int cxh = (cx + 1) >> 1, cyh = (cy + 1) >> 1;
+    return static_cast<uint32_t>((((z >> 1) * cyh + (y >> 1)) * cxh + (x >> 1)) * 8 + ((z & 1) << 2 | (y & 1) << 1 | (x & 1)));
+}
+// ... and back: table slot -> slab slot, or -1 for a slot of the padding (odd counts)
+inline __host__ __device__ int box_slot_to_slab_slot(int cx, int cy, int cz, uint32_t b)
+{
+    if (DDGI_BOX_LAYOUT != 2) return static_cast<int>(b);
+    const int cxh = (cx + 1) >> 1, cyh = (cy + 1) >> 1;
+    const int sub = static_cast<int>(b & 7u), br = static_cast<int>(b >> 3);
+    const int x = 2 * (br % cxh) + (sub & 1), y = 2 * ((br / cxh) % cyh) + ((sub >> 1) & 1), z = 2 * (br / (cxh * cyh)) + (sub >> 2);
+    return (x < cx && y < cy && z < cz) ? (z * cy + y) * cx + x : -1;
+}
+
 // Opts a kernel in to `bytes` of dynamic LDS (more than the 64 KB default) on the CURRENT device, once per
 // (device, kernel): a process may hold handles on several devices (ddgi_engine.cpp).
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
