@@ -758,7 +758,8 @@ def main():
         steady = sample_batches(20)
         setup_ms["sample_box_table_first_batch_after_an_update"] = (first - steady) * 1e3
         io_bytes, table_bytes = 24 + 12 + 32, 8 * 16   # position + normal in, rgb + 8 cage indices out; one 16-byte table entry per cage corner
-        sector_bytes = 8 * 64                          # ... each of which is a 64-byte sector through L2
+        # ... which lie in 1.5^3 = 3.4 lines of 128 bytes on average (the table's 2x2x2 bricks of probes: ddgi_types.h DDGI_BOX_LAYOUT)
+        sector_bytes = 3.375 * 128
         out["sample"] = {
             "kernel": "k_probe_sample_ref (+ k_sample_box_filter once per update)", "points": n_pts, "ms": steady * 1e3, "points_per_s": n_pts / steady,
             "first_batch_after_update_ms": first * 1e3, "bytes_per_point": io_bytes + table_bytes,
@@ -766,7 +767,9 @@ def main():
             "l2_sector_GBps": n_pts * (io_bytes + sector_bytes) / steady / 1e9,
             "inside_grid": float((cage[:, 0] >= 0).float().mean()),
             "note": "1.44 M shading points scattered over the grid after the timed updates; bytes_per_point = 68 B of point I/O + 8 table entries of 16 B "
-                    "(algorithmic); l2_sector_GBps counts the 64-byte sectors those scattered entries cost — the kernel is L2-sector bound, DESIGN.md section 4",
+                    "(algorithmic); l2_sector_GBps counts the 128-byte lines those scattered entries cost (3.4 per point with the table in 2x2x2 bricks of "
+                    "probes, 4.5 in slab order: round 5, 10.5 -> 14.8 G points/s; measured FETCH_SIZE x 2 = 0.58 GB per batch, profiles/r05_i_sample_layout_ab.txt) — "
+                    "the kernel is bound by the lines it pulls through L2, DESIGN.md section 4",
         }
         # the same points in cage-cell order — what a frame's pixels are (neighbouring pixels shade neighbouring cells)
         cell = np.floor((pos.cpu().numpy() - np.array(w["origin"], dtype=np.float32)) / w["side"]).astype(np.int64)

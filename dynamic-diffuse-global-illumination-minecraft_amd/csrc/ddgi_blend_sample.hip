@@ -517,6 +517,28 @@ DDGI_D f16v mfma_step(float a, float b, f16v acc)
 #endif
 }
 
+// the same with kWaits wait states (4 clocks each, 18 .. 32) behind the MFMA; 0: a plain MFMA
+#ifndef DDGI_IRR12_PACE
+#define DDGI_IRR12_PACE 0  // (measured: 18 .. 32 wait states behind every MFMA of the 12-wave irradiance kernel cost 8 %: its waves' loads are prefetches, nothing waits for them)
+#endif
+template <int kWaits>
+DDGI_D f16v mfma_step_waits(float a, float b, f16v acc)
+{
+    if constexpr (kWaits == 0)
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    else
+    {
+        static_assert(kWaits >= 18 && kWaits <= 32, "at least the 18 wait states between a 16-pass MFMA and a read of its result; two s_nop");
+        asm volatile("s_nop 1\n"
+                     "v_mfma_f32_32x32x2_f32 %0, %1, %2, %0\n"
+                     "s_nop 15\n"
+                     "s_nop %3"
+                     : "+v"(acc)
+                     : "v"(a), "v"(b), "n"(kWaits - 17));
+        return acc;
+    }
+}
+
 constexpr int kResN4 = 32;                          // float4 per lane of a resident tile: 128 ray pairs
 constexpr int kResGroupF4 = kResN4 * 64;            // float4 of one group's records (16 probes x 2 moments x 256 rays)
 constexpr int kResServiceWaves = 5;
@@ -845,6 +867,151 @@ __global__ __launch_bounds__(kIrrWaves * 64) void k_probe_blend_irr(const BlendA
     blend_irr_role<DDGI_IRR_DEPTH>(A, rad_rgb, w_tiles, w_sum, sh, blockIdx.x, gridDim.x);
 }
 
+// irradiance, 256 rays per probe: ONE persistent 12-wave workgroup per CU (round 5).  The two-wave kernel above leaves a SIMD to one wave — three
+// chains in turn, with nothing but its own prefetch ring to hide the records' way from HBM, and every wave streams its weight tile from L2 again
+// for every group.  Here a task is a PAIR of groups (64 probes) and a wave is ONE chain: (group of the pair, tile, colour channel) — three waves per
+// SIMD take turns at its matrix pipe, each with its own requests in flight; both irradiance weight tiles (64 KB) are resident in LDS for the life
+// of the workgroup (the A operand is a conflict-free ds_read_b128 per four MFMAs), so the only global traffic of a chain is its own records — the
+// two tiles' waves of a (group, channel) ask for the same lines at the same time, the second finds them in the vector cache.  The epilogue is the
+// two-wave kernel's: lanes = the 64 texels of a tile, a probe's tile is one 1 KB load and one 1 KB store; the 12 waves share a pair's 64 probes.
+constexpr int kIrr12Waves = 12;
+constexpr int kIrr12N4 = 32;  // float4 per lane and stream: 128 ray pairs
+struct Irr12Shared
+{
+    float4 a_tiles[kIrrMTiles][kIrr12N4 * 64];                // the irradiance weight tiles as MFMA A operands (k_blend_weights' layout)
+    float stage_all[2][kIrrMTiles][32 * kIrrStageStride];     // [group of the pair][tile][texel row][3 probe + channel]
+    uint32_t slot_sh[2][2][32];                               // [task parity][group of the pair][probe]
+    uint32_t unsafe[kIrr12Waves];                             // per wave: a sum of its chain lies outside pm::div_prepared's domain
+};
+DDGI_D void blend_irr12_role(const BlendArgs& A, const float* __restrict__ rad_rgb, const float* __restrict__ w_tiles, const float* __restrict__ w_sum, Irr12Shared& sh,
+                             uint32_t first_task, uint32_t task_stride)
+{
+    const GridK& G = A.grid;
+    constexpr int n_pad = 256;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = wave / 6, sub = wave % 6, tile = sub / 3, ch = sub % 3;
+    const float hyst = G.hysteresis;
+    const uint32_t n_groups = (A.n_local_probes + 31u) / 32u, n_tasks = (n_groups + 1u) / 2u;
+    // the weight tiles, once per workgroup
+    {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(w_tiles + static_cast<size_t>(kDepMTiles) * n_pad * 32);
+        float4* dst = &sh.a_tiles[0][0];
+        for (int i = threadIdx.x; i < kIrrMTiles * kIrr12N4 * 64; i += kIrr12Waves * 64) dst[i] = src[i];
+    }
+    // epilogue role (blend_irr_role's): lane = output texel e of the 8x8 tile, borders from their octahedral-wrap source's sums
+    const int e = lane, tx = e & (kIrrTile - 1), ty = e / kIrrTile;
+    int sx = tx, sy = ty;
+    if (tx == 0 || ty == 0 || tx == kIrrTile - 1 || ty == kIrrTile - 1) border_source(tx, ty, kIrrTile, sx, sy);
+    const int c = (sy - 1) * (kIrrTile - 2) + (sx - 1);
+    const float sw = w_sum[kDepInterior + c];
+    const float* stage_src = &sh.stage_all[g][c >> 5][(c & 31) * kIrrStageStride];
+    constexpr uint32_t kMine = 6;  // probes of the group this wave writes: sub, sub + 6, ... (< 32)
+    uint32_t par = 0u;
+    for (uint32_t task = first_task; task < n_tasks; task += task_stride, par ^= 1u)
+    {
+        const uint32_t group = 2u * task + static_cast<uint32_t>(g);
+        const bool group_valid = group < n_groups;  // (wave-uniform; the last pair of an odd number of groups has one)
+        if (threadIdx.x < 64)
+        {
+            const uint32_t gg = 2u * task + (threadIdx.x >> 5);
+            sh.slot_sh[par][threadIdx.x >> 5][threadIdx.x & 31] = static_cast<uint32_t>(blend_tile_slot(G, min(gg * 32u + (threadIdx.x & 31u), A.n_local_probes - 1u)));
+        }
+        __syncthreads();  // (and: the previous task's staging has been read; first trip: the weight tiles are in place)
+        const uint32_t* slots = sh.slot_sh[par][g];
+        float4 old[kMine];
+        f16v acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (group_valid)
+        {
+            const float4* __restrict__ pb = reinterpret_cast<const float4*>(rad_rgb + (static_cast<size_t>(group) * 3 + ch) * n_pad * 32) + lane;
+            const float4* pa = &sh.a_tiles[tile][lane];
+            constexpr int kDepth = 8;
+            float4 bb[kDepth];
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u) bb[u] = pb[static_cast<size_t>(u) * 64];
+            // this wave's old tiles: behind the first operands (loads return in order), with the whole contraction to arrive
+#pragma unroll
+            for (uint32_t j = 0; j < kMine; ++j)
+                old[j] = *reinterpret_cast<const float4*>(A.irradiance_old + static_cast<size_t>(slots[min(static_cast<uint32_t>(sub) + 6u * j, 31u)]) * (kIrrTile * kIrrTile * 4) + e * 4);
+            __builtin_amdgcn_sched_barrier(0);
+            float4 a_next = pa[0];
+#pragma unroll
+            for (int k = 0; k < kIrr12N4; ++k)
+            {
+                const int u = k % kDepth;
+                const float4 a = a_next, b = bb[u];
+                if (k + 1 < kIrr12N4) a_next = pa[(k + 1) * 64];
+                if (k + kDepth < kIrr12N4) bb[u] = pb[static_cast<size_t>(k + kDepth) * 64];
+                __builtin_amdgcn_sched_barrier(0);  // (the requests stay kDepth steps ahead of their use)
+                // (three chains share a SIMD's matrix pipe: a wave that stands at an MFMA while the pipe is busy with another wave's holds the
+                // SIMD's issue port — the third wave's loads wait behind it; so a chain steps aside in s_nop for the other two's turns: mfma_step)
+                acc = mfma_step_waits<DDGI_IRR12_PACE>(a.x, b.x, acc);
+                acc = mfma_step_waits<DDGI_IRR12_PACE>(a.y, b.y, acc);
+                acc = mfma_step_waits<DDGI_IRR12_PACE>(a.z, b.z, acc);
+                acc = mfma_step_waits<DDGI_IRR12_PACE>(a.w, b.w, acc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stage_tile<kIrrStageStride>(sh.stage_all[g][tile], acc, (lane & 31) * 3 + ch, lane >> 5);
+        }
+        {
+            const bool outside = group_valid && sums_outside_div_domain(acc);
+            if (lane == 0) sh.unsafe[wave] = outside ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!group_valid) continue;  // (wave-uniform; the barrier at the top of the next trip is reached by everyone)
+        const uint32_t np = min(32u, A.n_local_probes - group * 32u);
+        uint32_t any_unsafe = A.force_division;
+#pragma unroll
+        for (int w = 0; w < 6; ++w) any_unsafe |= sh.unsafe[6 * g + w];
+        const bool prepared = __builtin_amdgcn_readfirstlane(any_unsafe) == 0u;
+        const pm::DivBy by = pm::div_by(sw > 1e-6f ? sw : __builtin_inff());  // (+inf: quotient +0 where the weight sum is ~0; the sums are >= +0)
+        auto tiles = [&](auto prep) {
+            constexpr bool kPrepared = decltype(prep)::value;
+#pragma unroll
+            for (uint32_t j = 0; j < kMine; ++j)
+            {
+                const uint32_t p = static_cast<uint32_t>(sub) + 6u * j;
+                if (p < np)  // (wave-uniform)
+                {
+                    const float* sp = stage_src + 3 * static_cast<int>(p);
+                    const pm::f2v rg = kPrepared ? pm::div_prepared2(pm::f2v{sp[0], sp[1]}, by) : pm::f2v{sp[0] / by.d, sp[1] / by.d};
+                    const float bl = kPrepared ? pm::div_prepared(sp[2], by) : sp[2] / by.d;
+                    *reinterpret_cast<float4*>(A.irradiance + static_cast<size_t>(slots[p]) * (kIrrTile * kIrrTile * 4) + e * 4) =
+                        float4{gl_mix(old[j].x, rg.x, hyst), gl_mix(old[j].y, rg.y, hyst), gl_mix(old[j].z, bl, hyst), 1.0f};
+                }
+            }
+        };
+        if (prepared)
+            tiles(std::true_type{});
+        else
+            tiles(std::false_type{});
+    }
+}
+__global__ __launch_bounds__(kIrr12Waves * 64) void k_probe_blend_irr12(const BlendArgs A, const float* __restrict__ rad_rgb, const float* __restrict__ w_tiles,
+                                                                        const float* __restrict__ w_sum)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char blend_dyn_lds[];
+    blend_irr12_role(A, rad_rgb, w_tiles, w_sum, *reinterpret_cast<Irr12Shared*>(blend_dyn_lds), blockIdx.x, gridDim.x);
+}
+
+// 256 rays per probe, many probes: ONE launch for the whole blend — a persistent 12-wave workgroup per CU runs its depth groups
+// (blend_depth_resident) and then its pairs of irradiance groups (blend_irr12_role) out of the same dynamic LDS; the second phase starts on a CU
+// as soon as that CU's depth groups are done (no launch boundary, no drain of the whole chip in between).
+union BlendOneShared
+{
+    DepthResShared dep;
+    Irr12Shared irr;
+};
+__global__ __launch_bounds__(kResWaves * 64) void k_probe_blend_one(const BlendArgs A, const float* __restrict__ rad_rgb, const float* __restrict__ rad_dd,
+                                                                      const float* __restrict__ w_tiles, const float* __restrict__ w_sum)
+{
+    static_assert(kResWaves == kIrr12Waves, "both roles are written for 12 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char blend_dyn_lds[];
+    BlendOneShared& sh = *reinterpret_cast<BlendOneShared*>(blend_dyn_lds);
+    blend_depth_resident(A, rad_dd, w_tiles, w_sum, sh.dep, blockIdx.x, gridDim.x);
+    __syncthreads();  // (the depth role's last reads of its staging; every wave comes through here: the role's `return`s are its own)
+    blend_irr12_role(A, rad_rgb, w_tiles, w_sum, sh.irr, blockIdx.x, gridDim.x);
+}
+
 // Few probes (one rank's slab of a sharded grid: fewer depth groups than half the CUs): one launch for both — blocks
 // [0, irr_blocks) take irradiance groups with their first two waves (the other five leave at once), the rest take depth
 // groups: the two contractions are bound by their own latency there and overlap instead of running one after the other.
@@ -1014,6 +1181,23 @@ hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t st
                                static_cast<const float*>(args.w_sum), irr_blocks);
         else
         {
+#ifndef DDGI_IRR12
+#define DDGI_IRR12 1  // 256 rays per probe: the 12-wave persistent irradiance kernel (0: the two-wave kernel everywhere)
+#endif
+#ifndef DDGI_BLEND_ONE
+#define DDGI_BLEND_ONE 0  // 1: depth and irradiance of a 256-ray grid in ONE launch (k_probe_blend_one).  Measured (profiles/r05_i_blend_one_ab.txt, C3): the one kernel
+                          // takes 64.0 us against 42.6 + 22.4 — and the UPDATE gets slower, 1.558 against 1.543 ms: next frame's k_blend_weights runs on the
+                          // preparation stream beside the blend, between two launches it finds CUs at once (28 us), beside one persistent kernel that holds
+                          // every CU for the whole blend it waits (53 us), and the next update waits for it.  Off.
+#endif
+            if (DDGI_BLEND_ONE && DDGI_IRR12 && rec_ray_pad(static_cast<uint32_t>(n)) == 256u)
+            {
+                hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_probe_blend_one), sizeof(BlendOneShared));
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k_probe_blend_one, dim3(std::min<uint32_t>(dep_tasks, static_cast<uint32_t>(num_cus))), dim3(kResWaves * 64), sizeof(BlendOneShared), stream, args,
+                                   args.rad_rgb, args.rad_dd, static_cast<const float*>(args.w), static_cast<const float*>(args.w_sum));
+                return hipGetLastError();
+            }
             if (rec_ray_pad(static_cast<uint32_t>(n)) == 256u)  // the weight tiles fit the register file: persistent workgroups, one per CU
             {
                 hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_probe_blend_depth_res), sizeof(DepthResShared));
@@ -1024,8 +1208,16 @@ hipError_t launch_probe_blend(const BlendArgs& args, int num_cus, hipStream_t st
             else
                 hipLaunchKernelGGL(k_probe_blend_depth, dim3(dep_blocks), dim3(kBlendWaves * 64), 0, stream, args, args.rad_dd, static_cast<const float*>(args.w),
                                    static_cast<const float*>(args.w_sum));
-            hipLaunchKernelGGL(k_probe_blend_irr, dim3(irr_blocks), dim3(kIrrWaves * 64), 0, stream, args, args.rad_rgb, static_cast<const float*>(args.w),
-                               static_cast<const float*>(args.w_sum));
+            if (DDGI_IRR12 && rec_ray_pad(static_cast<uint32_t>(n)) == 256u)
+            {
+                hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(k_probe_blend_irr12), sizeof(Irr12Shared));
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k_probe_blend_irr12, dim3(std::min<uint32_t>((irr_tasks + 1u) / 2u, static_cast<uint32_t>(num_cus))), dim3(kIrr12Waves * 64), sizeof(Irr12Shared), stream, args,
+                                   args.rad_rgb, static_cast<const float*>(args.w), static_cast<const float*>(args.w_sum));
+            }
+            else
+                hipLaunchKernelGGL(k_probe_blend_irr, dim3(irr_blocks), dim3(kIrrWaves * 64), 0, stream, args, args.rad_rgb, static_cast<const float*>(args.w),
+                                   static_cast<const float*>(args.w_sum));
         }
         return hipGetLastError();
     }

@@ -137,9 +137,18 @@ struct NoiseLut
 // table[i] with the byte offset computed in 32 bits (every table is far below 4 GiB): on the device the load then takes the
 // table's base from scalar registers and a 32-bit offset per lane (global_load ... v, s[base:base+1]) instead of a 64-bit
 // address per lane made by v_lshl_add_u64 / v_mad_u64_u32 — VALU instructions, in the kernel the VALU bounds.
-DDGI_HD float lut_f32(const float* table, unsigned i) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (i << 2)); }
+// (DDGI_EXP_LUT_HOT: timing experiment, WRONG colours — every lookup lands in the table's first kilobyte, i.e. in cache: what the tables' misses cost)
+#ifndef DDGI_EXP_LUT_HOT
+#define DDGI_EXP_LUT_HOT 0
+#endif
+DDGI_HD float lut_f32(const float* table, unsigned i)
+{
+    if (DDGI_EXP_LUT_HOT) i &= 255u;
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (i << 2));
+}
 DDGI_HD f2 lut_f32x2(const float* table, unsigned i)  // table[i], table[i + 1] (i need not be even: a dwordx2 load takes any 4-byte alignment)
 {
+    if (DDGI_EXP_LUT_HOT) i &= 255u;
     const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (i << 2));
     return f2{q[0], q[1]};
 }

@@ -35,6 +35,9 @@
 namespace ddgi {
 
 constexpr int kWfStepsPerTrip = 16;  // voxel steps per march-loop trip (burst)
+#ifndef DDGI_EXP_ALBEDO_CONST
+#define DDGI_EXP_ALBEDO_CONST 0  // timing experiment (WRONG colours): every block is grey — what the albedo's arithmetic and table lookups cost together
+#endif
 #ifndef DDGI_AQ_STEPS
 #define DDGI_AQ_STEPS 24
 #endif
@@ -815,7 +818,7 @@ DDGI_D int wf_event(const TraceArgs& A, const Upd& U, const WfPool& P, const uin
                     const uint32_t vis_early_class = vis_early ? light_vis_class(A, U, hpos, hnrm, vis_entry) : kVisUnknown;
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary)) DDGI_PROBE(lp, 1);  // section 1: albedo
                     if (block_wins && (!lambert_zero || type == 12 || type == 13 || !ordinary))
-                        hcol = (Cfg::ablate(A) & 1) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
+                        hcol = ((Cfg::ablate(A) & 1) || DDGI_EXP_ALBEDO_CONST) ? mk3(0.5f, 0.5f, 0.5f) : block_albedo(p, type, nn, A.noise);
 #ifdef DDGI_LAP
                     DDGI_PROBE(lp, 7);  // after the albedo: visibility class, feeler decision
 #endif
