@@ -892,11 +892,20 @@ DDGI_D void blend_irr12_role(const BlendArgs& A, const float* __restrict__ rad_r
     const int g = wave / 6, sub = wave % 6, tile = sub / 3, ch = sub % 3;
     const float hyst = G.hysteresis;
     const uint32_t n_groups = (A.n_local_probes + 31u) / 32u, n_tasks = (n_groups + 1u) / 2u;
+    BLEND_LAP(22);  // (timing build: entry)
     // the weight tiles, once per workgroup
     {
+        // (all of a thread's loads in flight at once: as a loop of load / store pairs every trip waited for its own load — 6 600 cycles from
+        // entry to the first barrier in the timing build, tools/irr12_laps.py)
         const float4* __restrict__ src = reinterpret_cast<const float4*>(w_tiles + static_cast<size_t>(kDepMTiles) * n_pad * 32);
         float4* dst = &sh.a_tiles[0][0];
-        for (int i = threadIdx.x; i < kIrrMTiles * kIrr12N4 * 64; i += kIrr12Waves * 64) dst[i] = src[i];
+        constexpr int kTotal = kIrrMTiles * kIrr12N4 * 64, kThreads = kIrr12Waves * 64, kTrips = (kTotal + kThreads - 1) / kThreads;
+        float4 v[kTrips];
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t) v[t] = src[min(static_cast<int>(threadIdx.x) + t * kThreads, kTotal - 1)];
+#pragma unroll
+        for (int t = 0; t < kTrips; ++t)
+            if (static_cast<int>(threadIdx.x) + t * kThreads < kTotal) dst[threadIdx.x + t * kThreads] = v[t];
     }
     // epilogue role (blend_irr_role's): lane = output texel e of the 8x8 tile, borders from their octahedral-wrap source's sums
     const int e = lane, tx = e & (kIrrTile - 1), ty = e / kIrrTile;
@@ -911,23 +920,26 @@ DDGI_D void blend_irr12_role(const BlendArgs& A, const float* __restrict__ rad_r
     {
         const uint32_t group = 2u * task + static_cast<uint32_t>(g);
         const bool group_valid = group < n_groups;  // (wave-uniform; the last pair of an odd number of groups has one)
+        // the chain's first records: requested before the slots' divisions and the barrier — they need neither
+        constexpr int kDepth = 8;
+        const float4* __restrict__ pb = reinterpret_cast<const float4*>(rad_rgb + (static_cast<size_t>(group_valid ? group : 0u) * 3 + ch) * n_pad * 32) + lane;
+        float4 bb[kDepth];
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) bb[u] = pb[static_cast<size_t>(u) * 64];
         if (threadIdx.x < 64)
         {
             const uint32_t gg = 2u * task + (threadIdx.x >> 5);
             sh.slot_sh[par][threadIdx.x >> 5][threadIdx.x & 31] = static_cast<uint32_t>(blend_tile_slot(G, min(gg * 32u + (threadIdx.x & 31u), A.n_local_probes - 1u)));
         }
+        BLEND_LAP(0);
         __syncthreads();  // (and: the previous task's staging has been read; first trip: the weight tiles are in place)
+        BLEND_LAP(1);
         const uint32_t* slots = sh.slot_sh[par][g];
         float4 old[kMine];
         f16v acc = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         if (group_valid)
         {
-            const float4* __restrict__ pb = reinterpret_cast<const float4*>(rad_rgb + (static_cast<size_t>(group) * 3 + ch) * n_pad * 32) + lane;
             const float4* pa = &sh.a_tiles[tile][lane];
-            constexpr int kDepth = 8;
-            float4 bb[kDepth];
-#pragma unroll
-            for (int u = 0; u < kDepth; ++u) bb[u] = pb[static_cast<size_t>(u) * 64];
             // this wave's old tiles: behind the first operands (loads return in order), with the whole contraction to arrive
 #pragma unroll
             for (uint32_t j = 0; j < kMine; ++j)
@@ -938,6 +950,7 @@ DDGI_D void blend_irr12_role(const BlendArgs& A, const float* __restrict__ rad_r
             for (int k = 0; k < kIrr12N4; ++k)
             {
                 const int u = k % kDepth;
+                if (k % 8 == 1) BLEND_LAP(5 + k / 8);  // (timing build: the second step of every eight)
                 const float4 a = a_next, b = bb[u];
                 if (k + 1 < kIrr12N4) a_next = pa[(k + 1) * 64];
                 if (k + kDepth < kIrr12N4) bb[u] = pb[static_cast<size_t>(k + kDepth) * 64];
@@ -950,6 +963,7 @@ DDGI_D void blend_irr12_role(const BlendArgs& A, const float* __restrict__ rad_r
                 acc = mfma_step_waits<DDGI_IRR12_PACE>(a.w, b.w, acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            BLEND_LAP(2);
             stage_tile<kIrrStageStride>(sh.stage_all[g][tile], acc, (lane & 31) * 3 + ch, lane >> 5);
         }
         {
@@ -957,6 +971,7 @@ DDGI_D void blend_irr12_role(const BlendArgs& A, const float* __restrict__ rad_r
             if (lane == 0) sh.unsafe[wave] = outside ? 1u : 0u;
         }
         __syncthreads();
+        BLEND_LAP(3);
         if (!group_valid) continue;  // (wave-uniform; the barrier at the top of the next trip is reached by everyone)
         const uint32_t np = min(32u, A.n_local_probes - group * 32u);
         uint32_t any_unsafe = A.force_division;
@@ -984,6 +999,7 @@ DDGI_D void blend_irr12_role(const BlendArgs& A, const float* __restrict__ rad_r
             tiles(std::true_type{});
         else
             tiles(std::false_type{});
+        BLEND_LAP(4);
     }
 }
 __global__ __launch_bounds__(kIrr12Waves * 64) void k_probe_blend_irr12(const BlendArgs A, const float* __restrict__ rad_rgb, const float* __restrict__ w_tiles,
@@ -1130,15 +1146,19 @@ __global__ __launch_bounds__(kBlendBlock) void k_probe_blend(const BlendArgs A)
 // k_probe_sample_ddgi — one lane per shading point
 // ------------------------------------------------------------------------------------------------
 
-template <bool kVec>
+template <int kMode>  // 0: a texel's floats one by one, 1: one load per texel (aligned buffers), 2: and 32-bit offsets from the buffers' bases (both below 4 GiB)
 __global__ __launch_bounds__(256) void k_probe_sample_ddgi(const SampleArgs A)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= A.n) return;
     const uint32_t i = A.perm ? A.perm[k] : k;
     int cage[8];
-    const f3 out = diffuse_gi_ddgi<kVec>(A.grid, A.irradiance, A.depth, f3{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]},
-                                   f3{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]}, cage);
+    const f3 p{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]}, nr{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]};
+    f3 out;
+    if constexpr (kMode == 2)
+        out = diffuse_gi_ddgi_from(A.grid, TilesGlobal32{A.irradiance, A.depth}, p, nr, cage);
+    else
+        out = diffuse_gi_ddgi<kMode == 1>(A.grid, A.irradiance, A.depth, p, nr, cage);
     A.rgb[3 * i] = out.x, A.rgb[3 * i + 1] = out.y, A.rgb[3 * i + 2] = out.z;
     if (A.cage)
     {
@@ -1237,8 +1257,16 @@ hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream)
     if (blocks == 0) return hipSuccess;
     // (a texel as one load needs the tiles' base aligned to a texel: the engine's buffers are; textures bound by the host may not be)
     const bool vec = (reinterpret_cast<uintptr_t>(args.irradiance) & 15u) == 0u && (reinterpret_cast<uintptr_t>(args.depth) & 7u) == 0u;
-    if (vec) hipLaunchKernelGGL(k_probe_sample_ddgi<true>, dim3(blocks), dim3(256), 0, stream, args);
-    else hipLaunchKernelGGL(k_probe_sample_ddgi<false>, dim3(blocks), dim3(256), 0, stream, args);
+#ifndef DDGI_SAMPLE_OFF32
+#define DDGI_SAMPLE_OFF32 0
+#endif
+    // (TilesGlobal32 — a texel's address as the buffer's base in scalar registers + a 32-bit offset per lane, the trace kernel's remedy for 64-bit address
+    // arithmetic — takes 16 of a corner's 320 instructions away and makes the batch 7 % SLOWER: 0.214 against 0.200 ms per 1.44 M points; off)
+    const size_t n_slots = static_cast<size_t>(args.grid.cx) * args.grid.cy * args.grid.cz;
+    const bool off32 = DDGI_SAMPLE_OFF32 && vec && n_slots * (kDepTile * kDepTile * 2 * 4) <= 0xffffffffull;  // (the depth tiles are the larger buffer)
+    if (off32) hipLaunchKernelGGL(k_probe_sample_ddgi<2>, dim3(blocks), dim3(256), 0, stream, args);
+    else if (vec) hipLaunchKernelGGL(k_probe_sample_ddgi<1>, dim3(blocks), dim3(256), 0, stream, args);
+    else hipLaunchKernelGGL(k_probe_sample_ddgi<0>, dim3(blocks), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 

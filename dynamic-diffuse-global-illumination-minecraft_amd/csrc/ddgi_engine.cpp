@@ -1876,10 +1876,14 @@ int ddgi_set_frame(ddgi_handle e, uint32_t frame)
 // texels / 8 points on (C3: 0.5 M points; never below 65 536).  *usable = false (and DDGI_OK): no table for this batch — too few
 // points for this grid, or the table could not be allocated (a C5-sized grid's is 4.3 GB): the caller evaluates sample_probe per
 // point, as it would for a small batch.
+// (Measured, round 5: that count holds while the albedo texture stays in the caches — C3's 16 MB: the direct path costs 0.26 ns per point, the pass
+// 11 ps per texel.  On a texture of hundreds of megabytes a point's 8 x 26 gathers miss and cost 1.55 ns (C4, 268 MB: 2.23 ms per 1.44 M points),
+// six times as much, while the pass streams: there the table pays from texels / 64 points on — C4: 1.05 M points, one frame's pixels.)
 static bool sample_box_pays(const ddgi_engine* e, size_t n_points)
 {
     const size_t texels = e->tex_bytes[0] / 4;
-    return n_points >= std::max<size_t>(65536, texels / 8);
+    const size_t per_point = e->tex_bytes[0] > (static_cast<size_t>(64) << 20) ? 64 : 8;
+    return n_points >= std::max<size_t>(65536, texels / per_point);
 }
 static int ensure_sample_box(ddgi_engine* e, const GridK& grid, bool* usable)
 {

@@ -296,6 +296,32 @@ struct TilesGlobal
     }
 };
 
+// The same for tile buffers below 4 GiB each (every grid up to 2 M probes; the engine's own, aligned buffers): a texel's address is the buffer's base —
+// wave-uniform, scalar registers — plus a 32-bit byte offset per lane (global_load ... v, s[base:base+1]) instead of a 64-bit address per lane
+// (v_lshl_add_u64 / v_mad_u64_u32: 16 of a corner's 320 instructions).
+struct TilesGlobal32
+{
+    const float* irradiance;
+    const float* depth;
+    template <class V>
+    static DDGI_D V at(const float* base, uint32_t byte_offset) { return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_offset); }
+    DDGI_D f2 gather_depth(uint32_t slot, const TileCoords& c) const
+    {
+        const uint32_t t = slot * static_cast<uint32_t>(kDepTile * kDepTile * 2 * 4);
+        const float2 a = at<float2>(depth, t + static_cast<uint32_t>(c.o00) * 8u), b = at<float2>(depth, t + static_cast<uint32_t>(c.o01) * 8u);
+        const float2 cc = at<float2>(depth, t + static_cast<uint32_t>(c.o10) * 8u), d = at<float2>(depth, t + static_cast<uint32_t>(c.o11) * 8u);
+        return f2{gl_mix(gl_mix(a.x, b.x, c.tx), gl_mix(cc.x, d.x, c.tx), c.ty), gl_mix(gl_mix(a.y, b.y, c.tx), gl_mix(cc.y, d.y, c.tx), c.ty)};
+    }
+    DDGI_D f3 gather_irradiance(uint32_t slot, const TileCoords& c) const
+    {
+        const uint32_t t = slot * static_cast<uint32_t>(kIrrTile * kIrrTile * 4 * 4);
+        const float4 a = at<float4>(irradiance, t + static_cast<uint32_t>(c.o00) * 16u), b = at<float4>(irradiance, t + static_cast<uint32_t>(c.o01) * 16u);
+        const float4 cc = at<float4>(irradiance, t + static_cast<uint32_t>(c.o10) * 16u), d = at<float4>(irradiance, t + static_cast<uint32_t>(c.o11) * 16u);
+        return f3{gl_mix(gl_mix(a.x, b.x, c.tx), gl_mix(cc.x, d.x, c.tx), c.ty), gl_mix(gl_mix(a.y, b.y, c.tx), gl_mix(cc.y, d.y, c.tx), c.ty),
+                  gl_mix(gl_mix(a.z, b.z, c.tx), gl_mix(cc.z, d.z, c.tx), c.ty)};
+    }
+};
+
 template <class Tiles>
 DDGI_D f3 diffuse_gi_ddgi_from(const GridK& G, const Tiles& tiles, f3 pos, f3 nrm_raw, int* cage);
 

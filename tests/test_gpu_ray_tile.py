@@ -83,6 +83,19 @@ def test_c4_full_size_ref_mode(ddgi, oracle):
         eng.probe_update()
         a2, _ = eng.read_textures()
         rays = eng.get_probe_rays()
+        # the cage sampler on a grid whose albedo texture (268 MB) is far beyond the caches: a frame's worth of points takes sample_probe
+        # from the per-texel table (1.07 GB, 2x2x2 bricks of probes, a 32 x 16 tile) — equal to the per-point path bit for bit
+        rng = np.random.default_rng(5)
+        n_pts = 1_200_000
+        half = np.asarray(c["counts"], dtype=np.float64) * c["side"] * 0.49
+        pos = (rng.uniform(-1, 1, size=(n_pts, 3)) * half + np.asarray(c["origin"])).astype(np.float32)
+        nrm = rng.normal(size=(n_pts, 3)).astype(np.float32)
+        rgb_table, cage_table = eng.sample(pos, nrm)
+        eng.set_tuning("sample_box", 0)
+        rgb_direct, cage_direct = eng.sample(pos, nrm)
+        eng.set_tuning("sample_box", 1)
+    assert np.array_equal(cage_table, cage_direct) and np.array_equal(rgb_table.view(np.uint32), rgb_direct.view(np.uint32))
+    assert (cage_table[:, 0] >= 0).mean() > 0.9
     assert a1.shape == (32 * ty, 64 * 64 * tx, 4)
     assert np.array_equal(a1, a2)                       # Q18: every frame writes the same texels
     assert not d1.any() and (a1[..., 3] == 255).all()
@@ -101,6 +114,9 @@ def test_c4_full_size_ref_mode(ddgi, oracle):
     for p in probes:
         x0, y0 = (int(p) % cxz) * tx, (int(p) // cxz) * ty
         assert np.array_equal(a1[y0:y0 + ty, x0:x0 + tx], want[y0:y0 + ty, x0:x0 + tx]), f"probe {p}"
+    # ... and a slice of the sampled batch against the oracle, on the textures read back
+    want_rgb, want_cage = oracle.sample(f, a1, d1, pos[:20000], nrm[:20000])
+    assert np.array_equal(cage_table[:20000], want_cage) and np.array_equal(rgb_table[:20000].view(np.uint32), want_rgb.view(np.uint32))
 
 
 def test_c4_full_size_ddgi_mode(ddgi, oracle):

@@ -40,4 +40,8 @@ PY
 DDGI_BENCH_ONE_GPU=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29519 $ROOT/bench.py --gpus 4 > $OUT/${R}_${T}_bench_p2p_4ranks_one_gpu.json 2> /dev/null
 timeout 300 python bench.py --workload c4 --steps 5 --warmup 2 > $OUT/${R}_${T}_c4_bench.json 2> /dev/null
 timeout 400 python bench.py --workload c5 --mode ddgi --steps 12 > $OUT/${R}_${T}_c5_sdyn_ddgi_bench.json 2> /dev/null
+# the cage samplers' kernels and counters (REF table path in 2x2x2 bricks, DDGI sampler + grouping)
+bash tools/pmc_sample.sh $R $T > /dev/null 2>&1
+# what HBM delivers to plain streaming kernels on this box
+timeout 120 python tools/hbm_ceiling.py > $OUT/${R}_${T}_hbm_ceiling.txt 2>/dev/null
 ls -la $OUT
