@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_sample_box_filter(const GridK G, const 
     // (kTiles consecutive lanes sum the SAME texel of kTiles tiles: with the tiles' planes 3 n words apart — a multiple of 32 for any
     // n the engine makes — the four lanes of a texel sat on one LDS bank, a 4-way conflict on every one of the 78 reads per lane;
     // 8 words of padding per tile put the 8 texels x 4 tiles of a half wave on 32 different banks)
-    constexpr int kPad = kTiles > 1 ? 8 : 0;
+    constexpr int kPad = kTiles > 1 ? 32 / kTiles : 0;  // (4 tiles: 8 words, 8 tiles: 4 — a half wave's kTiles x (32 / kTiles) texels on 32 different banks)
     const size_t tile_words = static_cast<size_t>(3) * n + kPad;
     unorm[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;  // blockDim.x == 256
     // a workgroup takes kTiles consecutive TABLE slots (bricks: the four probes of one z-layer of a brick — wherever their tiles lie)
@@ -350,15 +350,22 @@ __global__ __launch_bounds__(256) void k_sample_box_filter(const GridK G, const 
 hipError_t launch_sample_box_filter(const GridK& grid, const uint32_t* albedo, float4* box, int num_cus, hipStream_t stream)
 {
     const uint32_t n_probes = static_cast<uint32_t>(grid.cx) * grid.cy * grid.cz;
-    const bool four = grid.n <= 1024;  // (4 tiles' planes in LDS: 48 KB at 1024 texels per tile)
-    const size_t lds = (256 + (static_cast<size_t>(3) * grid.n + 8) * (four ? 4 : 1)) * sizeof(float);
-    const void* fn = four ? reinterpret_cast<const void*>(k_sample_box_filter<4>) : reinterpret_cast<const void*>(k_sample_box_filter<1>);
+    // tiles per workgroup = consecutive table slots it writes per texel: 8 = a whole brick, one full 128-byte line per texel (up to 512 texels per
+    // tile: 50 KB of planes in LDS); 4 = a brick's z-layer, half a line — on a table beyond the Infinity Cache (C4: 1.07 GB) half lines cost the build
+    // its write bandwidth
+#ifndef DDGI_BOX_BUILD_TILES
+#define DDGI_BOX_BUILD_TILES 4  // (8 — a whole brick, full 128-byte lines per texel — measured SLOWER: C3 49.2 against 45.4 us, C4 2.12 against 2.05 ms)
+#endif
+    const int tiles = (DDGI_BOX_BUILD_TILES == 8 && DDGI_BOX_LAYOUT >= 2 && grid.n <= 512) ? 8 : (grid.n <= 1024 ? 4 : 1);  // (4 tiles' planes: 48 KB at 1024 texels per tile)
+    const size_t lds = (256 + (static_cast<size_t>(3) * grid.n + 8) * tiles) * sizeof(float);
+    const void* fn = tiles == 8 ? reinterpret_cast<const void*>(k_sample_box_filter<8>) : tiles == 4 ? reinterpret_cast<const void*>(k_sample_box_filter<4>) : reinterpret_cast<const void*>(k_sample_box_filter<1>);
     hipError_t e = ensure_dynamic_lds(fn, static_cast<int>(lds));
     if (e != hipSuccess) return e;
     const uint32_t n_slots = box_slots(grid.cx, grid.cy, grid.cz);
-    const uint32_t groups = four ? (n_slots + 3u) / 4u : n_slots;
+    const uint32_t groups = (n_slots + static_cast<uint32_t>(tiles) - 1u) / static_cast<uint32_t>(tiles);
     const dim3 grid_dim(std::min<uint32_t>(groups, static_cast<uint32_t>(num_cus) * 8u));
-    if (four) hipLaunchKernelGGL(k_sample_box_filter<4>, grid_dim, dim3(256), lds, stream, grid, albedo, box, n_probes);
+    if (tiles == 8) hipLaunchKernelGGL(k_sample_box_filter<8>, grid_dim, dim3(256), lds, stream, grid, albedo, box, n_probes);
+    else if (tiles == 4) hipLaunchKernelGGL(k_sample_box_filter<4>, grid_dim, dim3(256), lds, stream, grid, albedo, box, n_probes);
     else hipLaunchKernelGGL(k_sample_box_filter<1>, grid_dim, dim3(256), lds, stream, grid, albedo, box, n_probes);
     return hipGetLastError();
 }

@@ -75,6 +75,8 @@ DDGI_D f3 sample_probe_ref(const GridK& G, const uint32_t* albedo, const uint32_
 // are one 128-byte line: a cage's entries come from 3.4 lines on average instead of 4.5)
 DDGI_D size_t box_index(uint32_t texel, uint32_t slot, uint32_t texels_per_tile, uint32_t n_slots)
 {
+    if (DDGI_BOX_LAYOUT == 3)  // brick-major: [brick][texel][the brick's 8 probes] — a brick's lines of all texels are one contiguous run (the build streams)
+        return (static_cast<size_t>(slot >> 3) * texels_per_tile + texel) * 8u + (slot & 7u);
     return DDGI_BOX_LAYOUT != 0 ? static_cast<size_t>(texel) * n_slots + slot : static_cast<size_t>(slot) * texels_per_tile + texel;
 }
 // the table slot of reference probe index p = y*cx*cz + z*cx + x (decoded: two integer divisions)

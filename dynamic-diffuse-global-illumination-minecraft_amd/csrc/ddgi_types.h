@@ -66,20 +66,20 @@ struct GridK
 // table slots per texel plane (bricks: the counts rounded up to even)
 inline __host__ __device__ uint32_t box_slots(int cx, int cy, int cz)
 {
-    return DDGI_BOX_LAYOUT == 2 ? 8u * static_cast<uint32_t>((cx + 1) / 2) * static_cast<uint32_t>((cy + 1) / 2) * static_cast<uint32_t>((cz + 1) / 2)
+    return DDGI_BOX_LAYOUT >= 2 ? 8u * static_cast<uint32_t>((cx + 1) / 2) * static_cast<uint32_t>((cy + 1) / 2) * static_cast<uint32_t>((cz + 1) / 2)
                                 : static_cast<uint32_t>(cx) * static_cast<uint32_t>(cy) * static_cast<uint32_t>(cz);
 }
 // the table slot of probe (x, y, z) (z: the whole grid's, as in a slab slot (z cy + y) cx + x)
 inline __host__ __device__ uint32_t box_slot_xyz(int cx, int cy, int x, int y, int z)
 {
-    if (DDGI_BOX_LAYOUT != 2) return static_cast<uint32_t>((z * cy + y) * cx + x);
+    if (DDGI_BOX_LAYOUT < 2) return static_cast<uint32_t>((z * cy + y) * cx + x);
     const int cxh = (cx + 1) >> 1, cyh = (cy + 1) >> 1;
     return static_cast<uint32_t>((((z >> 1) * cyh + (y >> 1)) * cxh + (x >> 1)) * 8 + ((z & 1) << 2 | (y & 1) << 1 | (x & 1)));
 }
 // ... and back: table slot -> slab slot, or -1 for a slot of the padding (odd counts)
 inline __host__ __device__ int box_slot_to_slab_slot(int cx, int cy, int cz, uint32_t b)
 {
-    if (DDGI_BOX_LAYOUT != 2) return static_cast<int>(b);
+    if (DDGI_BOX_LAYOUT < 2) return static_cast<int>(b);
     const int cxh = (cx + 1) >> 1, cyh = (cy + 1) >> 1;
     const int sub = static_cast<int>(b & 7u), br = static_cast<int>(b >> 3);
     const int x = 2 * (br % cxh) + (sub & 1), y = 2 * ((br / cxh) % cyh) + ((sub >> 1) & 1), z = 2 * (br / (cxh * cyh)) + (sub >> 2);
