@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import pytest
 
-from tests.common import CONFIGS, c3_oracle_albedo
+from tests.common import CONFIGS, c3_oracle_albedo, shading_points
 
 pytestmark = pytest.mark.gpu
 
@@ -46,8 +46,17 @@ def _frame_settings(ddgi, scene, frame):
     return ddgi.make_settings(scene, 8, time=2.0 * (frame + 1))
 
 
-def _run_frames(ddgi, eng, mode, scene, frames, read_at):
-    """Drives `frames` updates (+ exchanges when the handle has one) and returns {frame: digest of the full field}."""
+def _table_batch(name):
+    """A batch of shading points large enough for the REF sampler's per-texel table (csrc/ddgi_engine.cpp: sample_box_pays) on this grid."""
+    counts, side, s, origin, _ = SHAPES[name]
+    tx, ty = TILES.get(name, (s, s))
+    texels = counts[0] * counts[1] * counts[2] * tx * ty
+    return shading_points(np.random.default_rng(41), counts, side, origin, max(70000, texels // 8 + 1000))
+
+
+def _run_frames(ddgi, eng, mode, scene, frames, read_at, name=None):
+    """Drives `frames` updates (+ exchanges when the handle has one) and returns {frame: digest of the full field}; REF modes: and
+    {"sample": digest of a batch sampled through the per-texel table of the GATHERED field} — the table spans the whole grid on every rank."""
     out = {}
     has_exchange = eng.exchange_transport()[0] != "none"
     if mode in ("ref_static", "ref_static_engine"):
@@ -60,6 +69,8 @@ def _run_frames(ddgi, eng, mode, scene, frames, read_at):
             eng.exchange()
         if frame in read_at:
             out[frame] = _digest(*(eng.read_tiles() if mode == "ddgi" else eng.read_textures()))
+    if mode != "ddgi" and name is not None:
+        out["sample"] = _digest(*eng.sample(*_table_batch(name)))   # (a consumer: waits for the last exchange by itself)
     return out
 
 
@@ -72,11 +83,13 @@ def _expected(ddgi, name, mode, frames, read_at, oracle=None):
         else:
             f = oracle.make_field(counts, side, s, origin)
             want = oracle.probe_update(f, oracle.make_settings(scene, 8), oracle.generate_probe_rays(f, oracle.new_rand_state(1)))[0]
-        return {frame: _digest(want, np.zeros_like(want)) for frame in read_at}
+        out = {frame: _digest(want, np.zeros_like(want)) for frame in read_at}
+        out["sample"] = _digest(*oracle.sample(oracle.make_field(counts, side, s, origin), want, np.zeros_like(want), *_table_batch(name)))
+        return out
     with _engine(ddgi, name) as eng:
         if mode == "ddgi":
             eng.set_mode(ddgi.MODE_DDGI)
-        return _run_frames(ddgi, eng, mode, scene, frames, read_at)
+        return _run_frames(ddgi, eng, mode, scene, frames, read_at, name)
 
 
 SCENARIOS = [
@@ -118,7 +131,7 @@ def _worker(rank, world, conn, scenarios):
                     eng.probe_update()
             conn.send(("address", eng.exchange_p2p_export(pipelined)))
             eng.exchange_p2p_init(conn.recv())
-            results.append(_run_frames(ddgi, eng, mode, scene, frames, read_at))
+            results.append(_run_frames(ddgi, eng, mode, scene, frames, read_at, name))
             eng.exchange_finish()
             eng.synchronize()
             conn.send(("done", None))   # host barrier before any rank tears its buffers down
