@@ -1147,7 +1147,11 @@ __global__ __launch_bounds__(kBlendBlock) void k_probe_blend(const BlendArgs A)
 // ------------------------------------------------------------------------------------------------
 
 template <int kMode>  // 0: a texel's floats one by one, 1: one load per texel (aligned buffers), 2: and 32-bit offsets from the buffers' bases (both below 4 GiB)
-__global__ __launch_bounds__(256) void k_probe_sample_ddgi(const SampleArgs A)
+#ifndef DDGI_SAMPLE_WAVES
+#define DDGI_SAMPLE_WAVES 1  // waves per SIMD the register allocation must leave room for.  The pipelined corner loop holds two corners' texels: 162 VGPRs = 3 waves per
+                            // SIMD left alone, 7.41 G points/s (one corner at a time: 94 VGPRs, 5 waves, 7.21); forced to 128 VGPRs it spills 38 registers: 4.6 G
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDGI_SAMPLE_WAVES, 8))) void k_probe_sample_ddgi(const SampleArgs A)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= A.n) return;

@@ -6,6 +6,8 @@
 #include "ddgi_device.h"
 #include "ddgi_oct.h"
 
+#include <type_traits>
+
 namespace ddgi {
 
 // rgba8 UNORM -> float: c / 255 (IEEE division).  The 256 possible quotients are tabulated in LDS
@@ -296,6 +298,38 @@ struct TilesGlobal
         tile_gather<4, kVec>(irradiance + static_cast<size_t>(slot) * (kIrrTile * kIrrTile * 4), c, o);
         return f3{o[0], o[1], o[2]};
     }
+    // the same in two halves — the four texels asked for, and mixed later (tile_gather's order of operations) — for the sampler's pipelined
+    // corner loop (diffuse_gi_ddgi_from): a corner's texels travel while the corner before it is weighed
+    static constexpr bool kSplit = kVec;
+    struct DepthTexels
+    {
+        float2 a, b, c, d;
+    };
+    struct IrrTexels
+    {
+        float4 a, b, c, d;
+    };
+    DDGI_D DepthTexels load_depth(uint32_t slot, const TileCoords& c) const
+    {
+        const float* tile = depth + static_cast<size_t>(slot) * (kDepTile * kDepTile * 2);
+        return DepthTexels{*reinterpret_cast<const float2*>(tile + c.o00 * 2), *reinterpret_cast<const float2*>(tile + c.o01 * 2), *reinterpret_cast<const float2*>(tile + c.o10 * 2),
+                           *reinterpret_cast<const float2*>(tile + c.o11 * 2)};
+    }
+    DDGI_D IrrTexels load_irradiance(uint32_t slot, const TileCoords& c) const
+    {
+        const float* tile = irradiance + static_cast<size_t>(slot) * (kIrrTile * kIrrTile * 4);
+        return IrrTexels{*reinterpret_cast<const float4*>(tile + c.o00 * 4), *reinterpret_cast<const float4*>(tile + c.o01 * 4), *reinterpret_cast<const float4*>(tile + c.o10 * 4),
+                         *reinterpret_cast<const float4*>(tile + c.o11 * 4)};
+    }
+    static DDGI_D f2 mix_depth(const DepthTexels& t, const TileCoords& c)
+    {
+        return f2{gl_mix(gl_mix(t.a.x, t.b.x, c.tx), gl_mix(t.c.x, t.d.x, c.tx), c.ty), gl_mix(gl_mix(t.a.y, t.b.y, c.tx), gl_mix(t.c.y, t.d.y, c.tx), c.ty)};
+    }
+    static DDGI_D f3 mix_irradiance(const IrrTexels& t, const TileCoords& c)
+    {
+        return f3{gl_mix(gl_mix(t.a.x, t.b.x, c.tx), gl_mix(t.c.x, t.d.x, c.tx), c.ty), gl_mix(gl_mix(t.a.y, t.b.y, c.tx), gl_mix(t.c.y, t.d.y, c.tx), c.ty),
+                  gl_mix(gl_mix(t.a.z, t.b.z, c.tx), gl_mix(t.c.z, t.d.z, c.tx), c.ty)};
+    }
 };
 
 // The same for tile buffers below 4 GiB each (every grid up to 2 M probes; the engine's own, aligned buffers): a texel's address is the buffer's base —
@@ -322,6 +356,16 @@ struct TilesGlobal32
         return f3{gl_mix(gl_mix(a.x, b.x, c.tx), gl_mix(cc.x, d.x, c.tx), c.ty), gl_mix(gl_mix(a.y, b.y, c.tx), gl_mix(cc.y, d.y, c.tx), c.ty),
                   gl_mix(gl_mix(a.z, b.z, c.tx), gl_mix(cc.z, d.z, c.tx), c.ty)};
     }
+};
+
+// does a tile source offer its fetches in two halves (load_*, mix_*)?
+template <class T, class = void>
+struct tiles_split : std::false_type
+{
+};
+template <class T>
+struct tiles_split<T, std::enable_if_t<T::kSplit>> : std::true_type
+{
 };
 
 template <class Tiles>
@@ -368,6 +412,69 @@ DDGI_D f3 diffuse_gi_ddgi_from(const GridK& G, const Tiles& tiles, f3 pos, f3 nr
             ok = ok && idx >= 0 && idx < n_probes;
             cage[k] = idx;
         }
+#ifndef DDGI_SAMPLE_PIPELINED
+#define DDGI_SAMPLE_PIPELINED 1
+#endif
+        if constexpr (DDGI_SAMPLE_PIPELINED && tiles_split<Tiles>::value)
+        {
+            // THE PIPELINED CORNER LOOP.  A corner is a round trip to memory — its tile slot and direction, eight texels, then the weight that
+            // needs them — and corner by corner a lane makes eight of them in a row (the counters: 60 % of the kernel's wave cycles at a wait
+            // for memory).  Here a corner's texels are asked for BEFORE the corner in front of it is weighed: two corners' requests in flight
+            // per lane, the arithmetic of one under the latency of the other.  Same operations in the same order per corner.
+            if (ok)
+            {
+                struct Corner
+                {
+                    f3 tri;
+                    float weight0, dist;
+                    TileCoords dep_at;
+                    typename Tiles::DepthTexels dt;
+                    typename Tiles::IrrTexels it;
+                };
+                auto ask = [&](int k, Corner& c) {
+                    const int ox = (k >> 2) & 1, oy = (k >> 1) & 1, oz = k & 1;                            // Q7
+                    const int sx = bx + ox + G.cx / 2, sy = by + oy + G.cy / 2, sz = bz + oz + G.cz / 2;  // Q4
+                    const int idx = sy * G.cx * G.cz + sz * G.cx + sx;
+                    c.tri = f3{ox ? alpha.x : 1.0f - alpha.x, oy ? alpha.y : 1.0f - alpha.y, oz ? alpha.z : 1.0f - alpha.z};
+                    const f3 probe_pos = base_world + f3{static_cast<float>(ox * G.side), static_cast<float>(oy * G.side), static_cast<float>(oz * G.side)};
+                    const f3 dir = normalize3(probe_pos - pos);
+                    const float tmp = gl_max(0.0001f, (dot3(dir, N) + 1.0f) * 0.5f);
+                    c.weight0 = tmp * tmp + 0.2f;
+                    const uint32_t slot = static_cast<uint32_t>(slab_slot_of_corner(G, sx, sy, sz, idx));
+                    c.dist = length3(pos - probe_pos);
+                    c.dep_at = tile_coords<kDepTile>(f3{-dir.x, -dir.y, -dir.z});
+                    c.dt = tiles.load_depth(slot, c.dep_at);
+                    c.it = tiles.load_irradiance(slot, irr_at);
+                };
+                auto weigh = [&](const Corner& c) {
+                    float weight = c.weight0;
+                    const f2 mms = Tiles::mix_depth(c.dt, c.dep_at);  // moment visibility test (intersection.glsl:1363-1383, enabled)
+                    const float mean = mms.x;
+                    const float variance = fabsf(mean * mean - mms.y);
+                    const float tmp = gl_max(c.dist - mean, 0.0f);
+                    float cheb = variance / (variance + tmp * tmp);
+                    cheb = gl_max(cheb * cheb * cheb, 0.0f);
+                    if (!(c.dist <= mean)) weight *= cheb;
+                    weight = gl_max(0.000001f, weight);
+                    const float crush = 0.2f;
+                    if (weight < crush) weight *= weight * weight * (1.f / (crush * crush));
+                    weight *= c.tri.x * c.tri.y * c.tri.z;
+                    irr = irr + Tiles::mix_irradiance(c.it, irr_at) * weight;
+                    sum_w += weight;
+                };
+                Corner c0, c1;
+                ask(0, c0);
+#pragma unroll 1  // (two corners per trip: each of the two sets of registers is asked for while the other is weighed)
+                for (int k = 0; k < 8; k += 2)
+                {
+                    ask(k + 1, c1);
+                    weigh(c0);
+                    if (k + 2 < 8) ask(k + 2, c0);
+                    weigh(c1);
+                }
+            }
+        }
+        else
 #pragma unroll 1  // (eight copies of the corner's body and its two tile fetches do not fit the register file)
         for (int k = 0; k < 8 && ok; ++k)
         {
