@@ -70,3 +70,21 @@ def test_invalid_configurations_are_rejected(ddgi):
     assert b"divisible" in lib.ddgi_last_error()
     st = ddgi.make_settings(scene=7)
     assert lib.ddgi_create(C.byref(ok), C.byref(st), 0, C.byref(h)) == -1
+
+
+def test_sample_table_layout_is_a_bijection(tmp_path):
+    """The REF sampler's per-texel table stores the probes of a texel's plane in 2x2x2 bricks (csrc/ddgi_types.h): tests/box_layout_check.cpp
+    walks grids with even and odd counts — one slot per probe, the inverse leads back, padding slots say so, a brick is one line, a slot is
+    the sum of its axes' terms.  Host code only: built with hipcc (the header is the kernels' own), run on the CPU."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "box_layout_check"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O1", "-std=c++17", "-x", "hip", "-I" + os.path.join(root, "dynamic-diffuse-global-illumination-minecraft_amd", "csrc"),
+                    os.path.join(root, "tests", "box_layout_check.cpp"), "-o", str(exe)], check=True, timeout=600)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0 and res.stdout.strip() == "ok", res.stdout + res.stderr
