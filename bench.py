@@ -808,7 +808,7 @@ def main():
                          "inside_grid": float((cage[:, 0] >= 0).float().mean()),
                          "note": "1.44 M shading points scattered over the grid, DDGI mode (irradiance + depth tiles, Chebyshev visibility); bytes_per_point is algorithmic: "
                                  "68 B of point I/O + 8 corners x (4 irradiance texels of 16 B + 4 depth texels of 8 B); the batch is grouped by cage first "
-                                 "(three small kernels, a fifth of the time: profiles/r05_g_sample_kernels.txt)"}
+                                 "(three small kernels, a fifth of the time: profiles/r05_k_sample_kernels.txt)"}
         del pos, nrm, rgb, cage
     if extras and not ddgi_mode and not sharded:
         # ---- what frames in flight is worth: the same loop with every launch tracing its own update only, and with four ----
