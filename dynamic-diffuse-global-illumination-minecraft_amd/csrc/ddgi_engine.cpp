@@ -563,6 +563,11 @@ int ddgi_destroy(ddgi_handle e)
     if (e->d_blend_w) (void)hipFree(e->d_blend_w);
     if (e->d_work) (void)hipFree(e->d_work);
     if (e->pub) (void)hipHostFree(e->pub);
+    if (e->prep_stream2)
+    {
+        (void)hipStreamSynchronize(e->prep_stream2);
+        (void)hipStreamDestroy(e->prep_stream2);
+    }
     if (e->prep_stream)
     {
         (void)hipStreamSynchronize(e->prep_stream);
@@ -1248,6 +1253,22 @@ static int prepare_ahead(ddgi_engine* e, const TracePlan& p, const BlendArgs& b,
         after = e->prep_after;
     }
     HIP_TRY(hipStreamWaitEvent(e->prep_stream, after, 0));
+    // THE TABLES' OWN STREAM (tuning "prep_stream" 2, the default).  On one preparation stream the feeler tables' kernel stands behind the weight
+    // kernels, which start with the blend: it starts when the blend ends — and the NEXT update's launch, which needs every CU EMPTY for a
+    // moment (a persistent 1 024-lane workgroup takes a whole CU's registers and LDS) even when it has nothing left to trace, waits for it to
+    // drain: a continued update cost 60 us on a slab of an 8-way sharded C3 grid (blend 25, then the tables 29 with the empty launch stuck
+    // behind them: tools/slab_timeline.sh).  On a stream of their own the tables start beside the blend and are nearly done when it is:
+    // 60 -> 50 us per continued update, a G = 8 DDGI slab 0.341 -> 0.334 ms.  Only where the blend is the small merged kernel (few probes per
+    // rank: launch_probe_blend's own test) — beside the whole grid's persistent depth workgroups the tables' kernel takes their CUs and the
+    // update gets 1.5 % SLOWER (profiles/r05_k_prep_stream_ab.txt); "prep_stream" 3: always, 1: never.
+    const bool small_blend = ((b.n_local_probes + 15u) / 16u) * 2u <= static_cast<uint32_t>(e->num_cus) * b.merge_below;
+    hipStream_t tables_stream = e->prep_stream;
+    if (e->tuning.prep_stream >= 3 || (e->tuning.prep_stream == 2 && small_blend))
+    {
+        if (!e->prep_stream2) HIP_TRY(hipStreamCreateWithFlags(&e->prep_stream2, hipStreamNonBlocking));
+        HIP_TRY(hipStreamWaitEvent(e->prep_stream2, after, 0));
+        tables_stream = e->prep_stream2;
+    }
     const TraceArgs& a = p.a;
     {
         BlendArgs nb = b;
@@ -1278,10 +1299,10 @@ static int prepare_ahead(ddgi_engine* e, const TracePlan& p, const BlendArgs& b,
             if (coming) continue;
             const int k = kAqChainMax + static_cast<int>((e->updates + static_cast<unsigned long long>(u)) % kAqChainMax);
             if (e->dev_scene[scene].vis_set[k].on_prep_stream) continue;  // (still waiting for the next chain to start: left alone)
-            if (int rc = fill_vis_set(e, scene, a.scene, pl, a.nl, k, e->prep_stream)) return rc;
+            if (int rc = fill_vis_set(e, scene, a.scene, pl, a.nl, k, tables_stream)) return rc;
         }
     }
-    HIP_TRY(hipEventRecord(e->prep_done, e->prep_stream));
+    HIP_TRY(hipEventRecord(e->prep_done, tables_stream));  // (the tables; the weights have their own event)
     e->prep_pending = true;
     return DDGI_OK;
 }

@@ -40,7 +40,8 @@ struct Tuning
     int lut_off = 0;        // profiling: 1 = no wall table, 2 = no random1 table
     int reserve_cus = 0;    // the queue kernel leaves this many CUs without a workgroup — its persistent workgroups fill a CU's registers and LDS, so a copy or
                             // collective KERNEL of a multi-GPU exchange otherwise finds no CU until a launch ends (copy-engine transfers need none)
-    int prep_stream = 1;    // DDGI mode: the next frame's weight tiles and the predicted light-feeler tables are made on a second stream beside the blend (0: in line)
+    int prep_stream = 2;    // DDGI mode: the next frame's weight tiles and the predicted light-feeler tables are made on a second stream beside the blend (0: in line;
+                            // 2: the tables on a THIRD stream where the blend is the small merged kernel — a rank's slab —, 3: always, 1: never)
     int verbose = 0;
     int ablate = 0;         // profiling build only (-DDDGI_PROFILING): ablations / fault injection
 };
@@ -180,6 +181,7 @@ struct ddgi_engine
     // follow from its ray rotation alone) and the light-feeler tables of the light positions the coming updates are expected to have —
     // is made beside this update's blend, whose kernels leave room on every CU (the trace kernel's persistent workgroups do not)
     hipStream_t prep_stream = nullptr;
+    hipStream_t prep_stream2 = nullptr;  // the feeler tables' own (tuning "prep_stream" 2)
     hipEvent_t prep_after = nullptr;  // handle's stream: this update's trace launch has ended (the preparation starts behind it)
     hipEvent_t prep_w_done = nullptr; // preparation stream: the next frame's weight tiles are made (the next update waits for it — its blend reads them)
     hipEvent_t prep_done = nullptr;   // preparation stream: everything given to it so far is done — the tables too (the next CHAIN's first launch waits for it)

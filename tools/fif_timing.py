@@ -12,8 +12,10 @@ fast = os.environ.get("FIF_FAST", "0") == "1"
 ddgi_mode = os.environ.get("FIF_MODE", "ref") == "ddgi"   # DDGI mode: in-kernel rays, time += 2 per update (the light moves with it), trace + blend per update
 clock = [0.0]
 base = {}
-for world in (1, 2, 4, 8):
-    for fif in (1, 2, 4, 8):
+WORLDS = tuple(int(x) for x in os.environ.get("FIF_WORLDS", "1,2,4,8").split(","))   # (a subset: e.g. FIF_WORLDS=8 FIF_FIFS=8 under rocprofv3 for a timeline)
+FIFS = tuple(int(x) for x in os.environ.get("FIF_FIFS", "1,2,4,8").split(","))
+for world in WORLDS:
+    for fif in FIFS:
         eng = ddgi_amd.ProbeEngine(ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"]),
                                    ddgi_amd.make_settings(w["scene"], w["max_bounces"]), rank=world // 2, world=world)
         eng.set_tuning("frames_in_flight", fif)
@@ -46,8 +48,8 @@ for world in (1, 2, 4, 8):
             dt = (time.perf_counter() - t0) / N * 1e3
             cont = eng.get_tuning("continued_workgroups") - before
             best = dt if best is None else min(best, dt)
-        if world == 1:
-            base[fif] = best
+        if world == 1 or 1 not in base:
+            base.setdefault(fif, best), base.setdefault(1, best)
         print("%sworld %d frames_in_flight %d%s: %.4f ms per update (march waves %d, %d workgroup continuations in %d updates)  -> %.2fx of one GPU's %.3f ms (fif 1)" % (
             "DDGI " if ddgi_mode else "", world, fif, " fast-march" if fast else "", best, eng.get_tuning("march_waves_measured"), cont, N, base[1] / best, base[1]), flush=True)
         eng.close()
