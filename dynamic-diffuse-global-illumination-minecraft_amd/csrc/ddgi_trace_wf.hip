@@ -1302,6 +1302,9 @@ constexpr int kAqFastSteps = DDGI_AQ_FAST_STEPS;  // steps per burst of the fast
     {                   \
     } while (0)
 #endif
+#ifndef DDGI_AQ_MIX_PICK
+#define DDGI_AQ_MIX_PICK 0  // which update's rays an event group that holds rays of two updates keeps (k_probe_trace_aq, records instantiations)
+#endif
 #ifndef DDGI_AQ_ROLE_PERM
 #define DDGI_AQ_ROLE_PERM 0xFEDCBA9876543210ull  // rank of every wave in the order in which waves become march waves (k_probe_trace_aq: `role`)
 #endif
@@ -2433,6 +2436,18 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                     // end of the queue they came from (their state is untouched) and are shaded with a later group.
                     const uint32_t tagv = valid ? P.dst[slot] >> kDstPairShift : 0u;
                     t = lane_bcast(tagv, 0);  // (lane 0 is valid: k > 0)
+#if DDGI_AQ_MIX_PICK
+                    {
+                        // WHICH update's rays a mixed group keeps (DDGI_AQ_MIX_PICK; 0: the first ray's).  1: the OLDER update's — its rays are the
+                        // ones the pool is waiting to see the back of: while they last, every group of every queue is mixed —, 2: the majority's.
+                        const unsigned long long m_valid = __ballot(valid), m_same = __ballot(valid && tagv == t);
+                        if (m_same != m_valid)
+                        {
+                            const uint32_t t1 = lane_bcast(tagv, __ffsll(static_cast<long long>(m_valid & ~m_same)) - 1);
+                            if (DDGI_AQ_MIX_PICK == 1 ? t1 < t : 2 * __popcll(m_same) < __popcll(m_valid)) t = t1;
+                        }
+                    }
+#endif
                     const bool other = valid && tagv != t;
                     if (__ballot(other) != 0ull)
                     {
