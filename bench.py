@@ -753,7 +753,9 @@ def main():
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / k
 
-        first = sample_batches(1)               # builds the per-texel table of sample_probe (k_sample_box_filter) for the new textures
+        sample_batches(1)                       # (the handle's first large batch also ALLOCATES the per-texel table: once per handle, not per update)
+        eng.probe_update()                      # REF, static rays: the same texels again (Q18) — and the table is stale, as after every update
+        first = sample_batches(1)               # rebuilds the per-texel table of sample_probe (k_sample_box_filter) for the new textures: what a host pays per update
         sample_batches(3)
         steady = sample_batches(20)
         setup_ms["sample_box_table_first_batch_after_an_update"] = (first - steady) * 1e3
