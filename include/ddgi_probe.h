@@ -327,7 +327,9 @@ int ddgi_set_stream(ddgi_handle h, void* hip_stream);
  * exchanges.  The handle owns a ring of texture pairs (tuning "frames_in_flight") and moves on to the next
  * one with every update; a host that asks for the addresses may keep them: from this call on the handle STAYS on the pair it
  * returns (no frames in flight; the sampler's per-texel table is no longer cached, since the host may write through the
- * pointers) — except under the pipelined exchange, which alternates pairs by contract (call this after every update there). */
+ * pointers) — except under the pipelined exchange, which alternates pairs by contract (call this after every update there).
+ * The first such call on a handle with a ring of several pairs blocks once: the ring shrinks to the one pair a pinned handle uses
+ * (the textures carry over; the addresses returned are the new ones) instead of holding seven more pairs for nothing. */
 int ddgi_device_textures(ddgi_handle h, void** tex0, size_t* tex0_bytes, void** tex1,
                          size_t* tex1_bytes, size_t* slab_offset0, size_t* slab_bytes0,
                          size_t* slab_offset1, size_t* slab_bytes1);
