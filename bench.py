@@ -811,7 +811,22 @@ def main():
                          "note": "1.44 M shading points scattered over the grid, DDGI mode (irradiance + depth tiles, Chebyshev visibility); bytes_per_point is algorithmic: "
                                  "68 B of point I/O + 8 corners x (4 irradiance texels of 16 B + 4 depth texels of 8 B); the batch is grouped by cage first "
                                  "(three small kernels, a fifth of the time: profiles/r05_k_sample_kernels.txt)"}
-        del pos, nrm, rgb, cage
+        # the same points in cage-cell order — what a frame's pixels are
+        cell = np.floor((pos.cpu().numpy() - np.array(w["origin"], dtype=np.float32)) / w["side"]).astype(np.int64)
+        order = torch.from_numpy(np.lexsort((cell[:, 0], cell[:, 1], cell[:, 2]))).cuda()
+        pos, nrm = pos[order].contiguous(), nrm[order].contiguous()
+        ddgi_batches(3)
+        ordered = ddgi_batches(20)
+        out["sample"]["cell_ordered"] = {"ms": ordered * 1e3, "points_per_s": n_pts / ordered, "achieved_GBps": n_pts * bpp / ordered / 1e9,
+                                         "frac_of_hbm_peak": n_pts * bpp / ordered / 1e9 / HBM_PEAK_GBS,
+                                         "note": "the same 1.44 M points sorted by the grid cell they lie in (the grouping kernels still run: the library does not know)"}
+        eng.set_tuning("sample_group", 0)   # what a host that knows its points are coherent (a G-buffer in pixel order) asks for
+        ddgi_batches(3)
+        ungrouped = ddgi_batches(20)
+        eng.set_tuning("sample_group", 1)
+        out["sample"]["cell_ordered"]["without_grouping"] = {"ms": ungrouped * 1e3, "points_per_s": n_pts / ungrouped,
+                                                             "note": "tuning \"sample_group\" 0: the batch goes as it comes"}
+        del pos, nrm, rgb, cage, order
     if extras and not ddgi_mode and not sharded:
         # ---- what frames in flight is worth: the same loop with every launch tracing its own update only, and with four ----
         sweep = {}

@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDGI_SAMPLE
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= A.n) return;
-    const uint32_t i = A.perm ? A.perm[k] : k;
+    const uint32_t i = (A.perm && !(DDGI_SAMPLE_COHERENCE && A.perm_off && *A.perm_off)) ? A.perm[k] : k;
     int cage[8];
     const f3 p{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]}, nr{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]};
     f3 out;

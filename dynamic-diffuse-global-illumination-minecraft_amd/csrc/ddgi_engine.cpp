@@ -42,7 +42,7 @@ hipError_t launch_probe_sample_ddgi(const SampleArgs& args, hipStream_t stream);
 hipError_t launch_render_primary(const RenderArgs& args, hipStream_t stream);
 size_t sample_group_scratch_words(uint32_t n, uint32_t n_probes);
 hipError_t launch_sample_box_filter(const GridK& grid, const uint32_t* albedo, float4* box, int num_cus, hipStream_t stream);
-hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t n, uint32_t* scratch, const uint32_t** perm_out, hipStream_t stream);
+hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t n, uint32_t* scratch, const uint32_t** perm_out, const uint32_t** perm_off_out, hipStream_t stream);
 hipError_t launch_light_visibility(const SceneK& scene, const float light_pos[3], const int32_t* list, int n_list, uint8_t* out, uint32_t* out_occ, hipStream_t stream);
 
 hipError_t ensure_dynamic_lds(const void* kernel, int bytes)
@@ -2004,7 +2004,7 @@ static int sample_device(ddgi_engine* e, const float* d_pos, const float* d_nrm,
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_sample_scratch), words * sizeof(uint32_t)));
             e->sample_scratch_words = words;
         }
-        HIP_TRY(launch_sample_grouping(a.grid, d_pos, a.n, e->d_sample_scratch, &a.perm, e->stream));
+        HIP_TRY(launch_sample_grouping(a.grid, d_pos, a.n, e->d_sample_scratch, &a.perm, &a.perm_off, e->stream));
     }
     if (e->mode == DDGI_MODE_DDGI)
     {

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_probe_sample_ref(const SampleArgs A)
     __syncthreads();
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= A.n) return;
-    const uint32_t i = A.perm ? A.perm[k] : k;
+    const uint32_t i = (A.perm && !(DDGI_SAMPLE_COHERENCE && A.perm_off && *A.perm_off)) ? A.perm[k] : k;
     int cage[8];
     const f3 p{A.pos[3 * i], A.pos[3 * i + 1], A.pos[3 * i + 2]}, nr{A.nrm[3 * i], A.nrm[3 * i + 1], A.nrm[3 * i + 2]};
     const f3 out = A.box ? diffuse_gi_ref<true>(A.grid, A.albedo, p, nr, s_unorm, cage, A.box) : diffuse_gi_ref<false>(A.grid, A.albedo, p, nr, s_unorm, cage, nullptr);
@@ -402,7 +402,7 @@ DDGI_D uint32_t sample_key(const GridK& G, const float* __restrict__ pos, uint32
 }
 // run r = points [r * per_run, (r + 1) * per_run): keys[i], rank[i] (arrival number inside its run and bin), counts[r][bin]
 __global__ __launch_bounds__(1024) void k_sample_count(const GridK G, const float* __restrict__ pos, uint32_t n, uint32_t per_run, uint32_t shift, uint32_t n_probes, uint32_t n_bins,
-                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ rank, uint32_t* __restrict__ counts)
+                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ rank, uint32_t* __restrict__ counts, uint32_t* __restrict__ run_nz)
 {
     // 16-bit counters, two to a word (LDS has 32-bit atomics): the add returns the word, the bin's half of it is the rank
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
@@ -418,7 +418,19 @@ __global__ __launch_bounds__(1024) void k_sample_count(const GridK G, const floa
         rank[i] = (atomicAdd(&hist[key >> 1], 1u << sh) >> sh) & 0xffffu;
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < n_bins; b += 1024) counts[static_cast<size_t>(blockIdx.x) * n_bins + b] = (hist[b >> 1] >> ((b & 1u) * 16u)) & 0xffffu;
+    uint32_t nz = 0;  // bins of this run that hold a point: few of them = the run's points came cage by cage already (k_sample_place)
+    for (uint32_t b = threadIdx.x; b < n_bins; b += 1024)
+    {
+        const uint32_t c = (hist[b >> 1] >> ((b & 1u) * 16u)) & 0xffffu;
+        counts[static_cast<size_t>(blockIdx.x) * n_bins + b] = c;
+        nz += c != 0u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) hist[0] = 0u;
+    __syncthreads();
+    if (nz) atomicAdd(&hist[0], nz);
+    __syncthreads();
+    if (threadIdx.x == 0) run_nz[blockIdx.x] = hist[0];
 }
 // counts[r][bin] -> the exclusive sum over the runs before r, per bin (in place); totals[bin] = the bin's points.
 // A workgroup = 16 bins x 16 lanes per bin, each lane scanning kSampleRuns / 16 consecutive runs (a chain of 16 instead of 256).
@@ -458,10 +470,27 @@ __global__ __launch_bounds__(256) void k_sample_scan_runs(uint32_t n_runs, uint3
 // sum of totals[] over the bins before it: every workgroup scans the totals itself (at most kSampleBins words, in LDS) and keeps
 // its run's row of `before` beside them — the bins' bases need no kernel of their own, and a point's two table look-ups are LDS reads.
 __global__ __launch_bounds__(1024) void k_sample_place(uint32_t n, uint32_t per_run, uint32_t n_bins, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ rank,
-                                                       const uint32_t* __restrict__ before, const uint32_t* __restrict__ totals, uint32_t* __restrict__ perm)
+                                                       const uint32_t* __restrict__ before, const uint32_t* __restrict__ totals, uint32_t* __restrict__ perm,
+                                                       const uint32_t* __restrict__ run_nz, uint32_t n_runs, uint32_t* __restrict__ perm_off)
 {
     __shared__ uint32_t start[kSampleBins];  // base[bin] + before[run][bin]
     __shared__ uint32_t scan[1024];
+    // A BATCH THAT CAME IN CAGE ORDER — a frame's pixels, a G-buffer — gains nothing from the permutation: its runs each touch a few bins.
+    // Every workgroup adds up the runs' occupied bins (k_sample_count); at 32 points or more per occupied (run, bin) the batch goes as it
+    // came: no permutation is written, the sample kernels are told so (*perm_off), and the scatter's 25 us of a 1.44 M-point batch stay unspent.
+    {
+        scan[threadIdx.x] = threadIdx.x < n_runs ? run_nz[threadIdx.x] : 0u;  // (n_runs <= kSampleRuns <= 1024)
+        __syncthreads();
+        for (uint32_t off = 512; off >= 1; off >>= 1)
+        {
+            if (threadIdx.x < off) scan[threadIdx.x] += scan[threadIdx.x + off];
+            __syncthreads();
+        }
+        const bool in_order = DDGI_SAMPLE_COHERENCE && static_cast<unsigned long long>(scan[0]) * 32ull <= static_cast<unsigned long long>(n);
+        __syncthreads();  // (scan[] is written again below)
+        if (blockIdx.x == 0 && threadIdx.x == 0) *perm_off = in_order ? 1u : 0u;
+        if (in_order) return;
+    }
     constexpr uint32_t kPer = kSampleBins / 1024;
     uint32_t v[kPer], mine = 0;
 #pragma unroll
@@ -507,10 +536,10 @@ size_t sample_group_scratch_words(uint32_t n, uint32_t n_probes)
 {
     uint32_t shift, n_bins;
     sample_bins(n_probes, shift, n_bins);
-    return 3 * static_cast<size_t>(n) + static_cast<size_t>(kSampleRuns + 1) * n_bins;
+    return 3 * static_cast<size_t>(n) + static_cast<size_t>(kSampleRuns + 1) * n_bins + kSampleRuns + 4;  // (+ run_nz[kSampleRuns] | perm_off)
 }
 
-hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t n, uint32_t* scratch, const uint32_t** perm_out, hipStream_t stream)
+hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t n, uint32_t* scratch, const uint32_t** perm_out, const uint32_t** perm_off_out, hipStream_t stream)
 {
     uint32_t shift, n_bins;
     const uint32_t n_probes = static_cast<uint32_t>(grid.cx) * grid.cy * grid.cz;
@@ -521,10 +550,12 @@ hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t 
     const uint32_t per_run = (n + n_runs - 1u) / n_runs;
     uint32_t *keys = scratch, *rank = keys + n, *perm = rank + n, *counts = perm + n, *totals = counts + static_cast<size_t>(kSampleRuns) * n_bins;
     const size_t lds = static_cast<size_t>((n_bins + 1u) / 2u) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_sample_count, dim3(n_runs), dim3(1024), lds, stream, grid, pos, n, per_run, shift, n_probes, n_bins, keys, rank, counts);
+    uint32_t *run_nz = totals + n_bins, *perm_off = run_nz + kSampleRuns;
+    hipLaunchKernelGGL(k_sample_count, dim3(n_runs), dim3(1024), lds, stream, grid, pos, n, per_run, shift, n_probes, n_bins, keys, rank, counts, run_nz);
     hipLaunchKernelGGL(k_sample_scan_runs, dim3((n_bins + 15u) / 16u), dim3(256), 0, stream, n_runs, n_bins, counts, totals);
-    hipLaunchKernelGGL(k_sample_place, dim3(n_runs), dim3(1024), 0, stream, n, per_run, n_bins, keys, rank, counts, totals, perm);
+    hipLaunchKernelGGL(k_sample_place, dim3(n_runs), dim3(1024), 0, stream, n, per_run, n_bins, keys, rank, counts, totals, perm, run_nz, n_runs, perm_off);
     *perm_out = perm;
+    *perm_off_out = perm_off;
     return hipGetLastError();
 }
 

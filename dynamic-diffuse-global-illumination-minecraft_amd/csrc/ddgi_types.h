@@ -231,6 +231,9 @@ struct BlendArgs
                               // outside pm::div_prepared's domain) — tuning "blend_kernel" 2, the cross-check of that path
 };
 
+#ifndef DDGI_SAMPLE_COHERENCE
+#define DDGI_SAMPLE_COHERENCE 1  // the grouping kernels notice a batch that comes in cage order and write no permutation for it (k_sample_place)
+#endif
 struct SampleArgs
 {
     GridK grid;
@@ -244,6 +247,7 @@ struct SampleArgs
     const float* irradiance;  // DDGI mode tiles (slab-major), else null
     const float* depth;
     const uint32_t* perm;     // processing order: lane k handles point perm[k] (points grouped by cage, see k_sample_*), or null
+    const uint32_t* perm_off; // with perm: *perm_off != 0 = the batch came in cage order already (k_sample_place found so and wrote no permutation): perm is not used
     const float4* box;        // REF mode: sample_probe tabulated per texel (k_sample_box_filter), or null: evaluate it per point
 };
 

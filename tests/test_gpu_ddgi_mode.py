@@ -74,10 +74,17 @@ def test_ddgi_sample_paths_agree_on_edge_cages_and_grouped_batches(ddgi, oracle,
         for group in (1, 0):
             eng.set_tuning("sample_group", group)
             got[group] = eng.sample(pos, nrm)
+        # the same batch in cage order (what a frame's pixels are): the grouping finds every run in a few bins and writes no permutation
+        # (k_sample_place: *perm_off) — same results at the same indices
+        cell = np.floor((pos - o) / np.float32(side)).astype(np.int64)
+        order = np.lexsort((cell[:, 0], cell[:, 1], cell[:, 2]))
+        eng.set_tuning("sample_group", 1)
+        rgb_o, cage_o = eng.sample(pos[order], nrm[order])
     want_rgb, want_cage = oracle.ddgi_sample(f, irr, dep, pos, nrm)
     for group, (rgb, cage) in got.items():
         assert np.array_equal(cage, want_cage), f"sample_group {group}"
         assert np.array_equal(_bits(rgb), _bits(want_rgb)), f"sample_group {group}"
+    assert np.array_equal(cage_o, want_cage[order]) and np.array_equal(_bits(rgb_o), _bits(want_rgb[order]))
     inside = want_cage[:, 0] >= 0
     assert 0.02 < inside.mean() < 1.0, inside.mean()
 

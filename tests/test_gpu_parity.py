@@ -150,6 +150,12 @@ def test_sample_paths_agree(ddgi, oracle, name):
                 eng.set_tuning("sample_box", box)
                 eng.set_tuning("sample_group", group)
                 got[(box, group)] = eng.sample(pos, nrm)
+            # (the grouped path on a batch that comes in cage order: no permutation is written, k_sample_place — same results)
+            cell = np.floor((pos - o) / np.float32(side)).astype(np.int64)
+            order = np.lexsort((cell[:, 0], cell[:, 1], cell[:, 2]))
+            eng.set_tuning("sample_box", 0)
+            eng.set_tuning("sample_group", 1)
+            in_order = eng.sample(pos[order], nrm[order])
             eng.set_tuning("sample_box", 1)
             small = eng.sample(pos[:777], nrm[:777])                         # a small batch reuses the table that is there
             albedo, distance = eng.read_textures()
@@ -158,6 +164,7 @@ def test_sample_paths_agree(ddgi, oracle, name):
                 assert np.array_equal(cage, want_cage), f"seed {seed}, (sample_box, sample_group) = {key}"
                 assert np.array_equal(rgb.view(np.uint32), want_rgb.view(np.uint32)), f"seed {seed}, (sample_box, sample_group) = {key}"
             assert np.array_equal(small[0].view(np.uint32), want_rgb[:777].view(np.uint32)) and np.array_equal(small[1], want_cage[:777])
+            assert np.array_equal(in_order[0].view(np.uint32), want_rgb[order].view(np.uint32)) and np.array_equal(in_order[1], want_cage[order])
     inside = want_cage[:, 0] >= 0
     assert 0.02 < inside.mean() < 1.0, inside.mean()
 
