@@ -428,16 +428,31 @@ __global__ __launch_bounds__(1024) void k_sample_count(const GridK G, const floa
     __syncthreads();
     if (threadIdx.x == 0) hist[0] = 0u;
     __syncthreads();
-    if (nz) atomicAdd(&hist[0], nz);
+    for (int m = 32; m >= 1; m >>= 1) nz += __shfl_xor(nz, m);  // (a wave's sum first: sixteen LDS atomics per run, not a thousand on one word)
+    if ((threadIdx.x & 63u) == 0u && nz) atomicAdd(&hist[0], nz);
     __syncthreads();
     if (threadIdx.x == 0) run_nz[blockIdx.x] = hist[0];
 }
 // counts[r][bin] -> the exclusive sum over the runs before r, per bin (in place); totals[bin] = the bin's points.
 // A workgroup = 16 bins x 16 lanes per bin, each lane scanning kSampleRuns / 16 consecutive runs (a chain of 16 instead of 256).
-__global__ __launch_bounds__(256) void k_sample_scan_runs(uint32_t n_runs, uint32_t n_bins, uint32_t* __restrict__ counts, uint32_t* __restrict__ totals)
+// the batch's points per occupied (run, bin): at 32 or more it came cage by cage already (k_sample_place)
+DDGI_D bool sample_batch_in_order(uint32_t occupied, uint32_t n) { return DDGI_SAMPLE_COHERENCE && static_cast<unsigned long long>(occupied) * 32ull <= static_cast<unsigned long long>(n); }
+
+__global__ __launch_bounds__(256) void k_sample_scan_runs(uint32_t n_runs, uint32_t n_bins, uint32_t* __restrict__ counts, uint32_t* __restrict__ totals,
+                                                          const uint32_t* __restrict__ run_nz, uint32_t n)
 {
     constexpr uint32_t kPer = kSampleRuns / 16;
     __shared__ uint32_t part[16][17];
+    static_assert(kSampleRuns <= 256, "one thread per run adds up the runs' occupied bins");
+    {
+        // (a batch in cage order needs no offsets: k_sample_place comes to the same verdict from the same numbers and writes no permutation)
+        __shared__ uint32_t occ[4];
+        uint32_t v = threadIdx.x < n_runs ? run_nz[threadIdx.x] : 0u;
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        if ((threadIdx.x & 63u) == 0u) occ[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (sample_batch_in_order(occ[0] + occ[1] + occ[2] + occ[3], n)) return;
+    }
     const uint32_t bl = threadIdx.x & 15u, chunk = threadIdx.x >> 4, b = blockIdx.x * 16u + bl;
     uint32_t c[kPer];
     uint32_t acc = 0;
@@ -486,7 +501,7 @@ __global__ __launch_bounds__(1024) void k_sample_place(uint32_t n, uint32_t per_
             if (threadIdx.x < off) scan[threadIdx.x] += scan[threadIdx.x + off];
             __syncthreads();
         }
-        const bool in_order = DDGI_SAMPLE_COHERENCE && static_cast<unsigned long long>(scan[0]) * 32ull <= static_cast<unsigned long long>(n);
+        const bool in_order = sample_batch_in_order(scan[0], n);
         __syncthreads();  // (scan[] is written again below)
         if (blockIdx.x == 0 && threadIdx.x == 0) *perm_off = in_order ? 1u : 0u;
         if (in_order) return;
@@ -552,7 +567,7 @@ hipError_t launch_sample_grouping(const GridK& grid, const float* pos, uint32_t 
     const size_t lds = static_cast<size_t>((n_bins + 1u) / 2u) * sizeof(uint32_t);
     uint32_t *run_nz = totals + n_bins, *perm_off = run_nz + kSampleRuns;
     hipLaunchKernelGGL(k_sample_count, dim3(n_runs), dim3(1024), lds, stream, grid, pos, n, per_run, shift, n_probes, n_bins, keys, rank, counts, run_nz);
-    hipLaunchKernelGGL(k_sample_scan_runs, dim3((n_bins + 15u) / 16u), dim3(256), 0, stream, n_runs, n_bins, counts, totals);
+    hipLaunchKernelGGL(k_sample_scan_runs, dim3((n_bins + 15u) / 16u), dim3(256), 0, stream, n_runs, n_bins, counts, totals, run_nz, n);
     hipLaunchKernelGGL(k_sample_place, dim3(n_runs), dim3(1024), 0, stream, n, per_run, n_bins, keys, rank, counts, totals, perm, run_nz, n_runs, perm_off);
     *perm_out = perm;
     *perm_off_out = perm_off;
