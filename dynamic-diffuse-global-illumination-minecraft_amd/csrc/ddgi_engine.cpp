@@ -96,6 +96,7 @@ static const TuningKey kTuningKeys[] = {
     {"frames_in_flight", &Tuning::frames_in_flight, "DDGI_FRAMES_IN_FLIGHT"},
     {"reserve_cus", &Tuning::reserve_cus, "DDGI_RESERVE_CUS"},
     {"prep_stream", &Tuning::prep_stream, "DDGI_PREP_STREAM"},
+    {"wait_timeout_ms", &Tuning::wait_timeout_ms, "DDGI_WAIT_TIMEOUT_MS"},
     {"verbose", &Tuning::verbose, "DDGI_VERBOSE"},
 #ifdef DDGI_PROFILING
     {"ablate", &Tuning::ablate, "DDGI_ABLATE"},
@@ -302,7 +303,7 @@ int ddgi_resize_ring(ddgi_engine* e, int np)
 {
     if (e->caller_tex) return fail(DDGI_ERR_INVALID_ARGUMENT, "the handle is on caller-bound textures: unbind them first");
     if (np == e->np) return DDGI_OK;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     void* fresh[2];
     if (int rc = alloc_texture_pair(e, e->tex_bytes, np, fresh)) return rc;
     hipError_t he = hipSuccess;
@@ -328,11 +329,11 @@ int ddgi_resize_ring(ddgi_engine* e, int np)
 int ddgi_rebase_ring(ddgi_engine* e)
 {
     if (e->caller_tex) return DDGI_OK;
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     if (e->pair_cur != 0)
     {
         for (int i = 0; i < 2; ++i) HIP_TRY(hipMemcpyAsync(e->own_tex[i], ddgi_pair_ptr(e, e->pair_cur, i), e->tex_bytes[i], hipMemcpyDeviceToDevice, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        DDGI_TRY(ddgi_sync_stream(e, e->stream));
     }
     for (int i = 0; i < 2; ++i) e->tex[i] = e->own_tex[i], e->tex_prev[i] = nullptr;
     e->pair_cur = 0, e->ring_k = 0, e->chain_break = true;
@@ -477,7 +478,7 @@ static int upload_local_rays(ddgi_engine* e)
         HIP_TRY(hipMemcpyAsync(reinterpret_cast<ddgi_probe_ray*>(e->d_rays) + dst, e->host_rays.data() + src,
                                run * sizeof(ddgi_probe_ray), hipMemcpyHostToDevice, e->stream));
     }
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     e->n_local_rays = static_cast<uint32_t>(local_rays);
     return DDGI_OK;
 }
@@ -552,7 +553,7 @@ int ddgi_destroy(ddgi_handle e)
 {
     if (!e) return DDGI_OK;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->stream) (void)ddgi_sync_stream(e, e->stream);  // (bounded while an exchange is attached: a peer that is gone must not keep the handle from being destroyed)
     ddgi_exchange_release(e);
     for (int i = 0; i < 2; ++i)
         if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
@@ -605,7 +606,7 @@ int ddgi_configure(ddgi_handle e, const ddgi_irradiance_field* field, const ddgi
     e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     if (int rc = validate_config(field, settings, e->world)) return rc;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     e->field = *field;
     e->tile[0] = e->tile[1] = 0;  // the new field's square tile; ddgi_set_ray_tile changes it
     e->settings = *settings;
@@ -628,7 +629,7 @@ int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const dd
     if (!carry_over) return ddgi_configure(e, field, settings);
     if (int rc = validate_config(field, settings, e->world)) return rc;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     const ddgi_irradiance_field old = e->field;
     // a tile can be carried over only if it has the same size: always in DDGI mode (8x8 / 16x16
     // octahedral tiles), in REF mode when the rays per probe did not change
@@ -719,7 +720,7 @@ int ddgi_set_mode(ddgi_handle e, int mode)
     if (mode != DDGI_MODE_REF && mode != DDGI_MODE_DDGI) return fail(DDGI_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
     if (mode == e->mode) return DDGI_OK;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     if (e->caller_tex) return fail(DDGI_ERR_INVALID_ARGUMENT, "unbind caller textures before changing the mode");
     e->mode = mode;
     e->updates = 0;
@@ -735,7 +736,7 @@ int ddgi_set_ray_tile(ddgi_handle e, int tile_x, int tile_y)
     const GridK g = make_grid(e);
     if (g.sx == tile_x && g.sy == tile_y) return DDGI_OK;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     if (e->caller_tex) return fail(DDGI_ERR_INVALID_ARGUMENT, "unbind caller textures before changing the ray tile");
     e->tile[0] = tile_x, e->tile[1] = tile_y;
     e->host_rays.clear();
@@ -1356,7 +1357,7 @@ static int launch_aq_numbered(ddgi_engine* e, const TracePlan& p, int march_wave
     if (e->counters_dirty)
     {
         // a launch failed after its number was handed out: the counter it was to zero may be stale.  Start over on a clean ring.
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        DDGI_TRY(ddgi_sync_stream(e, e->stream));
         HIP_TRY(hipMemsetAsync(e->d_work + 8, 0, kAqCounters * sizeof(uint32_t), e->stream));
         e->launch_seq = (e->launch_seq + 2u * kAqCounters - 1u) & ~(kAqCounters - 1u);
         e->counters_dirty = false;
@@ -1367,7 +1368,7 @@ static int launch_aq_numbered(ddgi_engine* e, const TracePlan& p, int march_wave
     if ((seq & 15u) == 0u)
     {
         const int m = static_cast<int>((seq >> 4) & 1u);
-        if (seq >= 32u) HIP_TRY(hipEventSynchronize(e->milestone[m]));  // (recorded 32 launches ago)
+        if (seq >= 32u) DDGI_TRY(ddgi_sync_event(e, e->milestone[m]));  // (recorded 32 launches ago)
         HIP_TRY(hipEventRecord(e->milestone[m], e->stream));
     }
     // The update's record (ddgi_types.h: UpdK), written before the release store that publishes the update: its own launch's
@@ -1673,7 +1674,7 @@ int ddgi_synchronize(ddgi_handle e)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     e->chain_break = true;  // nothing is in flight: the next update starts a group of its own —
     {
         // — of its own in the ring as well: the next update's number moves up to the next group's first
@@ -1694,7 +1695,7 @@ int ddgi_last_update_ms(ddgi_handle e, float* trace_ms, float* blend_ms, float* 
     if (!e->ev_valid[slot]) return fail(DDGI_ERR_NOT_READY, "the last update was not timed (tuning \"timing\" is 0)");
     hipEvent_t* ev = e->ev[slot];
     const bool blend = e->ev_has_blend[slot];
-    HIP_TRY(hipEventSynchronize(ev[blend ? 2 : 1]));
+    DDGI_TRY(ddgi_sync_event(e, ev[blend ? 2 : 1]));
     float t01 = 0.f, t12 = 0.f, t02 = 0.f;
     HIP_TRY(hipEventElapsedTime(&t01, ev[0], ev[1]));
     if (blend) HIP_TRY(hipEventElapsedTime(&t12, ev[1], ev[2]));
@@ -1709,7 +1710,7 @@ int ddgi_update_history_ms(ddgi_handle e, float* trace_ms, float* blend_ms, int 
 {
     if (!e || !n_out || capacity < 0) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle/n_out");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     unsigned long long have = e->updates < static_cast<unsigned long long>(ddgi_engine::kRing) ? e->updates : ddgi_engine::kRing;
     if (have > static_cast<unsigned long long>(capacity)) have = capacity;
     for (unsigned long long i = 0; i < have; ++i)
@@ -1732,7 +1733,7 @@ int ddgi_trace_stats(ddgi_handle e, int enable, unsigned long long* out64)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     if (out64)
     {
         std::memset(out64, 0, 64 * sizeof(unsigned long long));
@@ -1764,7 +1765,7 @@ int ddgi_read_textures(ddgi_handle e, uint8_t* albedo, uint8_t* distance)
     {
         if (!outs[t]) continue;
         HIP_TRY(hipMemcpyAsync(slab.data(), e->tex[t], e->tex_bytes[t], hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        DDGI_TRY(ddgi_sync_stream(e, e->stream));
         if (int rc = check_kernel_status(e)) return rc;
         uint32_t* raster = reinterpret_cast<uint32_t*>(outs[t]);
         // slab-major [z][y][x][ty][tx] -> reference raster: tile of probe p at ((p mod cx*cz)*s, (p div cx*cz)*s)
@@ -1797,7 +1798,7 @@ int ddgi_read_tiles(ddgi_handle e, float* irradiance, float* depth)
         if (!outs[t]) continue;
         std::vector<float> slab(e->tex_bytes[t] / sizeof(float));
         HIP_TRY(hipMemcpyAsync(slab.data(), e->tex[t], e->tex_bytes[t], hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        DDGI_TRY(ddgi_sync_stream(e, e->stream));
         if (int rc = check_kernel_status(e)) return rc;
         // slab-major [z][y][x] -> reference probe order p = y*cx*cz + z*cx + x
         for (int z = 0; z < g.cz; ++z)
@@ -1858,7 +1859,7 @@ int ddgi_get_tuning(ddgi_handle e, const char* name, int* value)
         if (e->d_work)
         {
             HIP_TRY(hipSetDevice(e->device));
-            HIP_TRY(hipStreamSynchronize(e->stream));
+            DDGI_TRY(ddgi_sync_stream(e, e->stream));
             HIP_TRY(hipMemcpy(&v, e->d_work + 4, sizeof v, hipMemcpyDeviceToHost));
         }
         *value = static_cast<int>(v);
@@ -1913,7 +1914,7 @@ static int ensure_sample_box(ddgi_engine* e, const GridK& grid, bool* usable)
     const size_t texels = static_cast<size_t>(box_slots(grid.cx, grid.cy, grid.cz)) * static_cast<size_t>(grid.n);
     if (texels > e->box_texels)
     {
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        DDGI_TRY(ddgi_sync_stream(e, e->stream));
         if (e->d_box) (void)hipFree(e->d_box);
         e->d_box = nullptr, e->box_texels = 0, e->box_of = nullptr;
         if (hipMalloc(reinterpret_cast<void**>(&e->d_box), texels * sizeof(float4)) != hipSuccess)
@@ -1998,7 +1999,7 @@ static int sample_device(ddgi_engine* e, const float* d_pos, const float* d_nrm,
         const size_t words = sample_group_scratch_words(a.n, static_cast<uint32_t>(a.grid.cx) * a.grid.cy * a.grid.cz);
         if (words > e->sample_scratch_words)
         {
-            HIP_TRY(hipStreamSynchronize(e->stream));  // (an earlier batch may still be using the old scratch)
+            DDGI_TRY(ddgi_sync_stream(e, e->stream));  // (an earlier batch may still be using the old scratch)
             if (e->d_sample_scratch) (void)hipFree(e->d_sample_scratch);
             e->d_sample_scratch = nullptr, e->sample_scratch_words = 0;
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_sample_scratch), words * sizeof(uint32_t)));
@@ -2058,10 +2059,11 @@ int ddgi_sample(ddgi_handle e, const float* pos, const float* nrm, size_t n, flo
     }
     TRY_OR_CLEAN(hipMemcpyAsync(rgb, d_rgb, n * 12, hipMemcpyDeviceToHost, e->stream));
     if (cage) TRY_OR_CLEAN(hipMemcpyAsync(cage, d_cage, n * 32, hipMemcpyDeviceToHost, e->stream));
-    TRY_OR_CLEAN(hipStreamSynchronize(e->stream));
+    rc = ddgi_sync_stream(e, e->stream);
 #undef TRY_OR_CLEAN
+    if (rc == DDGI_ERR_TIMEOUT) return rc;  // (the device buffers are LEFT: whatever still stands on the stream may write them)
     cleanup();
-    return DDGI_OK;
+    return rc;
 }
 
 int ddgi_render_device(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_settings* st, uint32_t* d_rgba8, float* d_rgb_f32)
@@ -2142,7 +2144,8 @@ int ddgi_render(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_setting
     hipError_t he = hipSuccess;
     if (rc == DDGI_OK) he = hipMemcpyAsync(rgba8, d_img, n * 4, hipMemcpyDeviceToHost, e->stream);
     if (rc == DDGI_OK && he == hipSuccess && rgb_f32) he = hipMemcpyAsync(rgb_f32, d_f, n * 12, hipMemcpyDeviceToHost, e->stream);
-    if (rc == DDGI_OK && he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    if (rc == DDGI_OK && he == hipSuccess) rc = ddgi_sync_stream(e, e->stream);
+    if (rc == DDGI_ERR_TIMEOUT) return rc;  // (the device image is LEFT: whatever still stands on the stream may write it)
     (void)hipFree(d_img);
     if (d_f) (void)hipFree(d_f);
     if (rc != DDGI_OK) return rc;
@@ -2155,7 +2158,7 @@ int ddgi_set_stream(ddgi_handle e, void* hip_stream)
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     e->tex_ops_since_update = true;  // (ddgi_exchange: something besides the update may be using the textures on the stream)
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     if (e->own_stream) (void)hipStreamDestroy(e->stream);
     e->own_stream = false;
     e->stream = static_cast<hipStream_t>(hip_stream);
@@ -2200,7 +2203,7 @@ int ddgi_bind_textures(ddgi_handle e, void* tex0, void* tex1)
     if ((tex0 == nullptr) != (tex1 == nullptr)) return fail(DDGI_ERR_INVALID_ARGUMENT, "bind both textures or neither");
     if (e->xch.pipelined || e->xch.p2p) return fail(DDGI_ERR_INVALID_ARGUMENT, "the pipelined / peer-to-peer exchange owns the texture pairs: ddgi_exchange_init(h, NULL, 0) first");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     e->caller_tex = tex0 != nullptr;
     e->tex[0] = tex0 ? tex0 : ddgi_pair_ptr(e, e->pair_cur, 0);
     e->tex[1] = tex1 ? tex1 : ddgi_pair_ptr(e, e->pair_cur, 1);
@@ -2313,7 +2316,7 @@ static int fill_user_scene(ddgi_engine* e, const int lo[3], const int dim[3], co
         }
     b.face_empty = fe;
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    DDGI_TRY(ddgi_sync_stream(e, e->stream));
     ddgi_engine::DevScene& d = e->dev_scene[3];
     if (d.bits) (void)hipFree(d.bits);
     if (d.types) (void)hipFree(d.types);

@@ -42,6 +42,7 @@ struct Tuning
                             // collective KERNEL of a multi-GPU exchange otherwise finds no CU until a launch ends (copy-engine transfers need none)
     int prep_stream = 2;    // DDGI mode: the next frame's weight tiles and the predicted light-feeler tables are made on a second stream beside the blend (0: in line;
                             // 2: the tables on a THIRD stream where the blend is the small merged kernel — a rank's slab —, 3: always, 1: never)
+    int wait_timeout_ms = 10000;  // the deadline of every host wait of a handle with a multi-GPU exchange attached (ddgi_exchange.cpp: ddgi_sync_stream); 0: none
     int verbose = 0;
     int ablate = 0;         // profiling build only (-DDDGI_PROFILING): ablations / fault injection
 };
@@ -201,6 +202,7 @@ struct ddgi_engine
         void* comm = nullptr;   // RCCL: ncclComm_t; caller-owned unless made by ddgi_comm_create
         P2P* p2p = nullptr;     // peer-to-peer: mapped peer buffers, flags, per-peer streams
         bool pipelined = false;                 // the exchange of a pair runs on comm_stream while later updates write other pairs of the ring
+        bool broken = false;                    // a wait for another rank ran into its deadline (DDGI_ERR_TIMEOUT): refuses until attached again
         bool desync = false;                    // an update failed while attached: this rank's update count no longer matches its peers' (ddgi_exchange refuses)
         hipStream_t comm_stream = nullptr;
         hipEvent_t written = nullptr;           // handle's stream: the update's kernels have finished
@@ -225,6 +227,16 @@ int ddgi_group_len(const ddgi_engine* e);           // updates one launch may wo
 int ddgi_pairs_wanted(const ddgi_engine* e, bool pipelined);
 int ddgi_resize_ring(ddgi_engine* e, int np);       // blocks; the current pair's contents move to pair 0 of the new ring
 int ddgi_rebase_ring(ddgi_engine* e);               // blocks; the same ring, counted from update 0 again: the current pair's contents move to pair 0
+// Host waits.  A handle on its own: hipStreamSynchronize / hipEventSynchronize.  With an exchange attached the stream may stand at a wait for
+// ANOTHER RANK: polled against tuning "wait_timeout_ms"; on expiry DDGI_ERR_TIMEOUT with the lagging peer named, the exchange marked broken and
+// (peer-to-peer) the handle's own waits released (ddgi_exchange.cpp).
+int ddgi_sync_stream(ddgi_engine* e, hipStream_t s);
+int ddgi_sync_event(ddgi_engine* e, hipEvent_t ev);
+#define DDGI_TRY(expr)                  \
+    do                                  \
+    {                                   \
+        if (int rc_ = (expr)) return rc_; \
+    } while (0)
 // exchange hooks called by the engine (no-ops without an initialised exchange)
 int ddgi_exchange_before_update(ddgi_engine* e, int first_pair, int n_pairs);  // pipelined: the stream waits for the last exchanges of the pairs a launch may write
 int ddgi_exchange_wait_latest(ddgi_engine* e);     // consumers: the handle's stream waits until the latest pair is complete

@@ -54,6 +54,7 @@ struct Rccl
     int (*CommInitRank)(void** comm, int nranks, NcclId id, int rank) = nullptr;
     int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
     int (*CommDestroy)(void* comm) = nullptr;
+    int (*CommAbort)(void* comm) = nullptr;
     int (*CommCount)(void* comm, int* count) = nullptr;
     int (*CommUserRank)(void* comm, int* rank) = nullptr;
     int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) = nullptr;
@@ -88,6 +89,7 @@ Rccl& rccl()
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));  // (optional: only used to get a stream back from a collective a peer never joined)
         r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
         r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
@@ -157,6 +159,12 @@ struct ddgi_engine::P2P
         hipEvent_t done = nullptr;  // this peer's copy of the latest exchange has been issued and finished
     };
     uint32_t* flags = nullptr;   // own: [q] = ready, written by rank q; [kP2PMaxWorld + r] = arrived, written by rank r
+    // when a wait for a peer runs into its deadline (ddgi_sync_stream): a stream of its own PRIORITY — HIP keeps a pool of hardware queues per
+    // priority, so nothing it carries can stand behind a wait packet of the handle's normal-priority streams — reads the flag words into
+    // pinned host memory (who is behind?) and then writes them itself (the handle's own waits end; the exchange is broken from then on)
+    hipStream_t diag = nullptr;
+    uint32_t* diag_host = nullptr;
+    uint32_t waited_arrived = 0;  // the highest exchange number any consumer of this handle has been made to wait for
     std::vector<Peer> peers;     // [world]; the own rank's entry is unused
     uint32_t seq = 0;            // exchanges issued (the flags carry it and are compared with >=: good for 2^32 exchanges per attachment — 50 days at 1000 per second)
     uint32_t pair_seq[ddgi_engine::kMaxPairs] = {};  // exchange number that last filled pair i
@@ -186,13 +194,60 @@ int p2p_wait_flag(hipStream_t s, uint32_t* flag, uint32_t v)
     return DDGI_OK;
 }
 
+// hipStreamQuery / hipEventQuery until done or `ms` have passed (hipErrorNotReady).  The first polls spin (a wait that is about to end costs
+// what hipStreamSynchronize costs), later ones sleep 50 us.
+template <class Query>
+hipError_t poll_until(Query query, int ms)
+{
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(ms);
+    for (unsigned polls = 0;; ++polls)
+    {
+        const hipError_t he = query();
+        if (he != hipErrorNotReady) return he;
+        (void)hipGetLastError();
+        if (std::chrono::steady_clock::now() >= t_end) return hipErrorNotReady;
+        if (polls < 4000u)
+            std::this_thread::yield();
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// Ends every wait this rank's own streams stand at: all of them are waits on THIS rank's flag words (a rank waits on its own memory and
+// writes into its peers').  True when the write is known to have landed.
+bool p2p_force_own_flags(ddgi_engine::P2P& p)
+{
+    if (!p.flags || !p.diag) return false;
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p.flags), static_cast<int>(0xffffffffu), 2 * kP2PMaxWorld, p.diag) != hipSuccess) return false;
+    return poll_until([&] { return hipStreamQuery(p.diag); }, 2000) == hipSuccess;
+}
+
 void p2p_release(ddgi_engine* e)
 {
     ddgi_engine::P2P* p = e->xch.p2p;
     if (!p) return;
+    // a peer that is gone leaves this rank's copy streams at a wait for its `ready`: bounded, then released by this rank itself
+    const int limit = e->tuning.wait_timeout_ms;
+    bool forced = false;
     for (auto& peer : p->peers)
     {
-        if (peer.stream) (void)hipStreamSynchronize(peer.stream);
+        if (!peer.stream) continue;
+        if (limit <= 0)
+        {
+            (void)hipStreamSynchronize(peer.stream);
+            continue;
+        }
+        if (poll_until([&] { return hipStreamQuery(peer.stream); }, forced ? 2000 : limit) == hipErrorNotReady && !forced)
+        {
+            forced = true;
+            (void)p2p_force_own_flags(*p);
+            (void)poll_until([&] { return hipStreamQuery(peer.stream); }, 2000);
+        }
+    }
+    if (p->diag) (void)hipStreamDestroy(p->diag);
+    if (p->diag_host) (void)hipHostFree(p->diag_host);
+    for (auto& peer : p->peers)
+    {
         if (peer.ipc)
         {
             for (void* q : peer.ring)
@@ -212,6 +267,7 @@ int p2p_wait_arrived(ddgi_engine* e, uint32_t seq)
 {
     ddgi_engine::P2P& p = *e->xch.p2p;
     if (seq == 0) return DDGI_OK;
+    if (seq > p.waited_arrived) p.waited_arrived = seq;
     for (int r = 0; r < e->world; ++r)
         if (r != e->rank)
             if (int rc = p2p_wait_flag(e->stream, p.flags + kP2PMaxWorld + r, seq)) return rc;
@@ -289,6 +345,95 @@ int p2p_exchange(ddgi_engine* e)
 
 }  // namespace
 
+// ---- host waits with a deadline ---------------------------------------------------------------------------------
+//
+// The reference's fences give up after DEFAULT_FENCE_TIMEOUT = 1 s (src/rvpt/vk_util.cpp:65, 94-97).  A handle with an exchange attached
+// waits for other ranks: its streams stand at hipStreamWaitValue32 packets (peer-to-peer) or inside a collective (RCCL) that only a
+// live peer ends.  Round 5's driver run showed what the missing deadline costs (GPUTEST_r05: one rank silent for 180 s, 79 tests lost).
+
+namespace {
+
+int exchange_timed_out(ddgi_engine* e, const char* waited_for)
+{
+    ddgi_engine::Exchange& x = e->xch;
+    const int limit = e->tuning.wait_timeout_ms;
+    x.broken = true;
+    e->chain_break = true;
+    if (x.transport == DDGI_EXCHANGE_P2P || x.p2p)
+    {
+        ddgi_engine::P2P& p = *x.p2p;
+        char who[256] = "the flag words could not be read";
+        bool have = false;
+        if (p.diag && p.diag_host && p.flags &&
+            hipMemcpyAsync(p.diag_host, p.flags, 2 * kP2PMaxWorld * sizeof(uint32_t), hipMemcpyDeviceToHost, p.diag) == hipSuccess)
+            have = poll_until([&] { return hipStreamQuery(p.diag); }, 2000) == hipSuccess;
+        if (have)
+        {
+            // the peer furthest behind, `arrived` (what consumers wait for) before `ready` (what this rank's pushes wait for)
+            int lag_rank = -1;
+            const char* lag_flag = "";
+            uint32_t lag_want = 0, lag_seen = 0;
+            for (int pass = 0; pass < 2 && lag_rank < 0; ++pass)
+                for (int q = 0; q < e->world; ++q)
+                {
+                    if (q == e->rank) continue;
+                    const uint32_t seen = p.diag_host[(pass == 0 ? kP2PMaxWorld : 0) + q];
+                    const uint32_t want = pass == 0 ? p.waited_arrived : p.seq;
+                    if (seen < want && (lag_rank < 0 || seen < lag_seen)) lag_rank = q, lag_flag = pass == 0 ? "arrived" : "ready", lag_want = want, lag_seen = seen;
+                }
+            if (lag_rank >= 0)
+                std::snprintf(who, sizeof who, "rank %d is behind: its `%s` flag stands at exchange %u, this rank (%d of %d) waits for %u", lag_rank, lag_flag, lag_seen, e->rank, e->world, lag_want);
+            else
+                std::snprintf(who, sizeof who, "every peer's flags are up to date (exchange %u): the wait is not for a peer", p.seq);
+        }
+        // end this rank's own waits: the streams drain, the handle can be detached / reconfigured / destroyed
+        const bool forced = p2p_force_own_flags(p);
+        bool drained = forced;
+        if (forced)
+        {
+            for (auto& peer : p.peers)
+                if (peer.stream) drained = drained && poll_until([&] { return hipStreamQuery(peer.stream); }, 2000) == hipSuccess;
+            if (x.comm_stream) drained = drained && poll_until([&] { return hipStreamQuery(x.comm_stream); }, 2000) == hipSuccess;
+            drained = drained && poll_until([&] { return hipStreamQuery(e->stream); }, 2000) == hipSuccess;
+        }
+        return fail(DDGI_ERR_TIMEOUT, "%s did not end within %d ms (tuning \"wait_timeout_ms\"): %s.  The exchange is broken — attach it again on every rank; %s", waited_for, limit, who,
+                    drained ? "this rank's own waits were released and its streams have drained" : "this rank's streams could NOT be drained");
+    }
+    return fail(DDGI_ERR_TIMEOUT, "%s did not end within %d ms (tuning \"wait_timeout_ms\"): an RCCL all-gather of this handle (rank %d of %d) has not completed — a peer rank is not taking part.  The exchange is broken: "
+                                  "abort the communicator (ncclCommAbort) and attach a new one on every rank",
+                waited_for, limit, e->rank, e->world);
+}
+
+}  // namespace
+
+int ddgi_sync_stream(ddgi_engine* e, hipStream_t s)
+{
+    const int limit = e->tuning.wait_timeout_ms;
+    if (limit <= 0 || (!e->xch.transport && !e->xch.p2p))
+    {
+        HIP_TRY(hipStreamSynchronize(s));
+        return DDGI_OK;
+    }
+    const hipError_t he = poll_until([&] { return hipStreamQuery(s); }, limit);
+    if (he == hipSuccess) return DDGI_OK;
+    if (he != hipErrorNotReady) return fail(DDGI_ERR_HIP, "hipStreamQuery failed: %s", hipGetErrorString(he));
+    return exchange_timed_out(e, "a wait for the handle's stream");
+}
+
+int ddgi_sync_event(ddgi_engine* e, hipEvent_t ev)
+{
+    const int limit = e->tuning.wait_timeout_ms;
+    if (limit <= 0 || (!e->xch.transport && !e->xch.p2p))
+    {
+        HIP_TRY(hipEventSynchronize(ev));
+        return DDGI_OK;
+    }
+    const hipError_t he = poll_until([&] { return hipEventQuery(ev); }, limit);
+    if (he == hipSuccess) return DDGI_OK;
+    if (he != hipErrorNotReady) return fail(DDGI_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(he));
+    return exchange_timed_out(e, "a wait for an event of the handle's stream");
+}
+
 // ---- hooks for the engine -------------------------------------------------------------------------------
 
 namespace {
@@ -323,6 +468,9 @@ int ddgi_exchange_before_update(ddgi_engine* e, int first_pair, int n_pairs)
 int ddgi_exchange_wait_latest(ddgi_engine* e)
 {
     ddgi_engine::Exchange& x = e->xch;
+    if (x.broken)
+        return fail(DDGI_ERR_TIMEOUT, "the multi-GPU exchange of this handle is broken (a wait for another rank ran into \"wait_timeout_ms\" earlier): the other ranks' slabs are not valid — attach the "
+                                      "exchange again on every rank, or detach it (ddgi_exchange_init(h, NULL, 0))");
     if (!x.transport || !x.pipelined) return DDGI_OK;  // in-order exchange: stream order already covers it
     if (x.transport == DDGI_EXCHANGE_P2P) return p2p_wait_arrived(e, x.p2p->pair_seq[e->pair_cur]);
     if (x.sent_valid[e->pair_cur]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[e->pair_cur], 0));
@@ -339,8 +487,18 @@ void ddgi_exchange_release(ddgi_engine* e)
             it = it->e == e ? g_group_pending.erase(it) : it + 1;
     }
     e->chain_break = true;
-    if (x.comm_stream) (void)hipStreamSynchronize(x.comm_stream);
-    p2p_release(e);
+    p2p_release(e);  // (first: it ends this rank's waits for peers that are gone)
+    if (x.comm_stream)
+    {
+        if (e->tuning.wait_timeout_ms <= 0) (void)hipStreamSynchronize(x.comm_stream);
+        else if (poll_until([&] { return hipStreamQuery(x.comm_stream); }, e->tuning.wait_timeout_ms) == hipErrorNotReady && x.transport == DDGI_EXCHANGE_RCCL && x.comm && rccl().CommAbort)
+        {
+            // an all-gather that a peer never joined: the only way to get the stream back is to abort the communicator's kernels (the caller
+            // still owns the ncclComm_t and may only ncclCommDestroy it from here on)
+            (void)rccl().CommAbort(x.comm);
+            (void)poll_until([&] { return hipStreamQuery(x.comm_stream); }, 2000);
+        }
+    }
     // (the ring keeps the pairs the pipelined exchange asked for: the handle goes on alternating them, which costs memory only;
     // the next configuration or "frames_in_flight" change sizes it anew)
     if (x.comm_stream) (void)hipStreamDestroy(x.comm_stream);
@@ -521,6 +679,13 @@ int ddgi_exchange_p2p_export(ddgi_handle e, int pipelined, uint8_t address[DDGI_
     a.np = static_cast<uint32_t>(e->np);
     hipError_t he = hipMalloc(reinterpret_cast<void**>(&p.flags), 2 * kP2PMaxWorld * sizeof(uint32_t));
     if (he == hipSuccess) he = hipMemset(p.flags, 0, 2 * kP2PMaxWorld * sizeof(uint32_t));
+    if (he == hipSuccess)
+    {
+        int lo = 0, hi = 0;  // (numerically lower = higher priority)
+        he = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (he == hipSuccess) he = hipStreamCreateWithPriority(&p.diag, hipStreamNonBlocking, hi);
+        if (he == hipSuccess) he = hipHostMalloc(reinterpret_cast<void**>(&p.diag_host), 2 * kP2PMaxWorld * sizeof(uint32_t), hipHostMallocDefault);
+    }
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);  // (the second pair's first contents)
     if (he == hipSuccess) he = hipIpcGetMemHandle(&a.flags, p.flags);
     for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipIpcGetMemHandle(&a.ring[i], e->own_tex[i]);
@@ -619,6 +784,8 @@ int ddgi_exchange(ddgi_handle e)
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
     ddgi_engine::Exchange& x = e->xch;
     if (!x.transport) return fail(DDGI_ERR_NOT_READY, "ddgi_exchange before ddgi_exchange_init / ddgi_exchange_p2p_init");
+    if (x.broken)
+        return fail(DDGI_ERR_TIMEOUT, "the multi-GPU exchange of this handle is broken (a wait for another rank ran into \"wait_timeout_ms\" earlier): attach it again on every rank");
     if (x.desync)
         return fail(DDGI_ERR_NOT_READY, "an update of this rank failed while the exchange was attached: its count of updates — which texture pair an update writes and a "
                                         "peer's slab lands in — no longer matches the other ranks'.  Attach the exchange again on EVERY rank (ddgi_exchange_init / ddgi_exchange_p2p_export + _init)");

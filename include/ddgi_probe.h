@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define DDGI_ABI_VERSION 5 /* 5: ddgi_exchange_ranks; frames in flight in DDGI mode (per-update records, a ring of ray-record buffers); attaching an exchange
+#define DDGI_ABI_VERSION 6 /* 6: DDGI_ERR_TIMEOUT + tuning "wait_timeout_ms": every host wait of a handle with an exchange attached has a deadline; the peer-to-peer
+                              transport publishes a two-pair RECEIVE ring (what a peer maps no longer grows with "frames_in_flight");
+                              5: ddgi_exchange_ranks; frames in flight in DDGI mode (per-update records, a ring of ray-record buffers); attaching an exchange
                               rebases the ring of texture pairs (every rank starts at pair 0, update 0); d_cage of ddgi_sample_device: 16-byte aligned or slower;
                               4: tuning "frames_in_flight" (default 8): the handle owns a ring of texture pairs, ddgi_device_textures pins the current one;
                               3: ddgi_exchange_p2p_*, ddgi_exchange_transport, ddgi_scene_skip_field; tuning "fast_march", "sample_box"; "autotune" off by default */
@@ -91,7 +93,10 @@ typedef enum ddgi_status
     DDGI_ERR_HIP = -3,         /* a HIP runtime call failed; see ddgi_last_error() */
     DDGI_ERR_OUT_OF_MEMORY = -4,
     DDGI_ERR_NOT_READY = -5,   /* e.g. probe_update before any rays were generated/uploaded */
-    DDGI_ERR_UNSUPPORTED = -6
+    DDGI_ERR_UNSUPPORTED = -6,
+    DDGI_ERR_TIMEOUT = -7      /* a wait that depends on ANOTHER RANK of a multi-GPU exchange did not end within tuning "wait_timeout_ms"
+                                  (≙ the reference's fence timeout, vk_util.cpp:65,94-97: DEFAULT_FENCE_TIMEOUT); ddgi_last_error() names
+                                  the peer, the flag and the exchange numbers expected and seen */
 } ddgi_status;
 
 /* Pipeline selection.
@@ -232,13 +237,24 @@ int ddgi_tune(ddgi_handle h);
  *   "blend_kernel"  0 auto, 1 one probe per workgroup (cross-check), 2 auto but every quotient by the compiler's
  *                   division — the path a probe group takes whose sums lie outside the short division's domain
  *                   (cross-check)                                                   [DDGI_BLEND_KERNEL=probe|division]
+ *   "wait_timeout_ms"  the deadline of every host wait of a handle that has a multi-GPU exchange attached (ddgi_synchronize above);
+ *                   default 10 000, 0 = none                                                        [DDGI_WAIT_TIMEOUT_MS]
  *   "verbose", "noise_lut", "aq_pool", "wf_pool", ... (profiling; see ddgi_engine.cpp: kTuningKeys)
  * ddgi_get_tuning also answers "march_waves_measured": the split most recently measured (0 = none yet), so a
  * host can persist it and pin it next time. */
 int ddgi_set_tuning(ddgi_handle h, const char* name, int value);
 int ddgi_get_tuning(ddgi_handle h, const char* name, int* value);
 
-/* Waits for the stream (≙ Fence::wait, vk_util.cpp:94-97; here without the 1 s timeout). */
+/* Waits for the stream (≙ Fence::wait, vk_util.cpp:94-97).  The reference's fences give up after DEFAULT_FENCE_TIMEOUT = 1 s
+ * (vk_util.cpp:65).  Here: a handle on its own cannot wait for anybody but its own kernels (whose queue waits have their own safety
+ * net) and waits without a limit; a handle with a multi-GPU exchange attached waits for OTHER RANKS — a peer that died, was never
+ * started or stopped taking part must not turn this call into a silent forever: every host wait of such a handle (this call, the
+ * consumers, the reads, the timing queries, detaching, destroying) polls with the deadline of tuning "wait_timeout_ms" (default
+ * 10 000; 0 = no limit) and on expiry returns DDGI_ERR_TIMEOUT — ddgi_last_error() names the peer rank that is behind, the flag
+ * (`ready`: it has not released the pair for exchange n; `arrived`: its slab of exchange n has not landed), the exchange number
+ * expected and the one seen.  The exchange is then BROKEN: ddgi_exchange and the consumers refuse until it is attached again on every
+ * rank; with the peer-to-peer transport the library releases its own streams' waits itself (it writes the flag words they stand at),
+ * so the handle drains and can be detached, reconfigured or destroyed — the textures hold whatever had arrived.                         */
 int ddgi_synchronize(ddgi_handle h);
 
 /* Device time of the kernels of the most recent completed ddgi_probe_update, measured with HIP

@@ -54,7 +54,7 @@ def _table_batch(name):
     return shading_points(np.random.default_rng(41), counts, side, origin, max(70000, texels // 8 + 1000))
 
 
-def _run_frames(ddgi, eng, mode, scene, frames, read_at, name=None):
+def _run_frames(ddgi, eng, mode, scene, frames, read_at, name=None, progress=None):
     """Drives `frames` updates (+ exchanges when the handle has one) and returns {frame: digest of the full field}; REF modes: and
     {"sample": digest of a batch sampled through the per-texel table of the GATHERED field} — the table spans the whole grid on every rank."""
     out = {}
@@ -67,14 +67,31 @@ def _run_frames(ddgi, eng, mode, scene, frames, read_at, name=None):
         eng.probe_update(_frame_settings(ddgi, scene, frame))      # (DDGI mode: new rotation, animated light, hysteresis)
         if has_exchange:
             eng.exchange()
+        if progress:
+            progress(f"frame {frame} submitted")
         if frame in read_at:
             out[frame] = _digest(*(eng.read_tiles() if mode == "ddgi" else eng.read_textures()))
+            if progress:
+                progress(f"frame {frame} read back")
     if mode != "ddgi" and name is not None:
         out["sample"] = _digest(*eng.sample(*_table_batch(name)))   # (a consumer: waits for the last exchange by itself)
+        if progress:
+            progress("sampled")
     return out
 
 
+_EXPECTED = {}
+
+
 def _expected(ddgi, name, mode, frames, read_at, oracle=None):
+    """What every rank's gathered field must be (computed once per scenario and session: world 2, 4 and 8 share it)."""
+    key = (name, mode, frames, tuple(read_at))
+    if key not in _EXPECTED:
+        _EXPECTED[key] = _expected_now(ddgi, name, mode, frames, read_at, oracle)
+    return _EXPECTED[key]
+
+
+def _expected_now(ddgi, name, mode, frames, read_at, oracle=None):
     counts, side, s, origin, scene = SHAPES[name]
     if mode == "ref_static":
         # the oracle's raster (every frame writes the same texels: Q18); `distances` is never assigned
@@ -110,76 +127,158 @@ SCENARIOS = [
 ]
 
 
-def _worker(rank, world, conn, scenarios):
-    """One rank = one process (what bench.py / a real host does); `conn` carries the 512-byte addresses and the results."""
+def _worker(rank, world, conn, scenario, log_path):
+    """One rank = one process (what bench.py / a real host does); `conn` carries the 512-byte addresses, the progress notes and
+    the results.  Every stage is reported with its time, so that a rank that stops answering can be placed; `log_path` receives a
+    Python traceback of all threads every 30 s while the worker lives (faulthandler), i.e. where a blocked call was made from."""
+    import faulthandler
+    import time
+
     sys.path.insert(0, ROOT)
+    log = open(log_path, "w")
+    faulthandler.enable(log)
+    faulthandler.dump_traceback_later(30, repeat=True, file=log)
+    t0 = time.monotonic()
+
+    def progress(stage):
+        conn.send(("progress", (stage, round(time.monotonic() - t0, 2))))
+
     try:
         import ddgi_amd as ddgi
 
         ddgi.load_library()
-        results = []
-        for name, mode, pipelined, frames, read_at in scenarios:
-            scene = SHAPES[name][4]
-            eng = _engine(ddgi, name, device=0, rank=rank, world=world)
-            if mode == "ddgi":
-                eng.set_mode(ddgi.MODE_DDGI)
-            else:
-                # ranks that have done DIFFERENT numbers of updates before they attach (asymmetric warm-up): attaching starts
-                # every rank's count over, on pair 0 — a push must land in the pair its receiver reads (csrc/ddgi_exchange.cpp)
-                eng.generate_probe_rays(seed=77)
-                for _ in range(1 + rank % 3):
-                    eng.probe_update()
-            conn.send(("address", eng.exchange_p2p_export(pipelined)))
-            eng.exchange_p2p_init(conn.recv())
-            results.append(_run_frames(ddgi, eng, mode, scene, frames, read_at, name))
-            eng.exchange_finish()
-            eng.synchronize()
-            conn.send(("done", None))   # host barrier before any rank tears its buffers down
-            conn.recv()
-            eng.close()
-        conn.send(("results", results))
+        progress("library loaded")
+        name, mode, pipelined, frames, read_at = scenario
+        scene = SHAPES[name][4]
+        eng = _engine(ddgi, name, device=0, rank=rank, world=world)
+        if mode == "ddgi":
+            eng.set_mode(ddgi.MODE_DDGI)
+        else:
+            # ranks that have done DIFFERENT numbers of updates before they attach (asymmetric warm-up): attaching starts
+            # every rank's count over, on pair 0 — a push must land in the pair its receiver reads (csrc/ddgi_exchange.cpp)
+            eng.generate_probe_rays(seed=77)
+            for _ in range(1 + rank % 3):
+                eng.probe_update()
+        progress("engine ready")
+        conn.send(("address", eng.exchange_p2p_export(pipelined)))
+        progress("exported")
+        addresses = conn.recv()
+        eng.exchange_p2p_init(addresses)
+        progress("peers mapped")
+        result = _run_frames(ddgi, eng, mode, scene, frames, read_at, name, progress)
+        eng.exchange_finish()
+        eng.synchronize()
+        progress("finished + synchronized")
+        conn.send(("done", None))   # host barrier before any rank tears its buffers down
+        conn.recv()
+        eng.close()
+        conn.send(("results", result))
     except Exception as exc:  # noqa: BLE001 — reported to the parent, which fails the test
         conn.send(("error", repr(exc)))
+    finally:
+        faulthandler.cancel_dump_traceback_later()
+        log.close()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_one_process_per_rank_through_ipc_handles(ddgi, oracle, world):
-    """2 / 4 processes, one GPU: the peers' textures are mapped with hipIpcOpenMemHandle, the flags cross the process
-    boundary.  This is the multi-rank path of bench.py --exchange p2p, executed at ranks > 0 on the test box."""
-    want = [_expected(ddgi, name, mode, frames, read_at, oracle) for name, mode, _, frames, read_at in SCENARIOS]
-    ctx = mp.get_context("spawn")
-    pipes = [ctx.Pipe() for _ in range(world)]
-    procs = [ctx.Process(target=_worker, args=(r, world, pipes[r][1], SCENARIOS), daemon=True) for r in range(world)]
-    for p in procs:
-        p.start()
-    conns = [pp[0] for pp in pipes]
+class _Ranks:
+    """The parent's side: `world` worker processes and what each was last heard doing."""
 
-    def gather(kind, timeout=180):
+    def __init__(self, world, scenario, tmp_path):
+        ctx = mp.get_context("spawn")
+        self.world = world
+        self.logs = [str(tmp_path / f"rank{r}.log") for r in range(world)]
+        pipes = [ctx.Pipe() for _ in range(world)]
+        self.procs = [ctx.Process(target=_worker, args=(r, world, pipes[r][1], scenario, self.logs[r]), daemon=True) for r in range(world)]
+        for p in self.procs:
+            p.start()
+        self.conns = [pp[0] for pp in pipes]
+        self.last = [("spawned", 0.0)] * world
+
+    def _report(self):
+        lines = []
+        for r in range(self.world):
+            p = self.procs[r]
+            state = "alive" if p.is_alive() else f"exited with {p.exitcode}"
+            lines.append(f"  rank {r}: {state}; last heard: {self.last[r][0]!r} at {self.last[r][1]} s")
+            try:
+                with open(self.logs[r]) as fh:
+                    tail = fh.read()[-1500:]
+                if tail.strip():
+                    lines.append("    where it stands (faulthandler, newest last):\n      " + tail.strip().replace("\n", "\n      "))
+            except OSError:
+                pass
+        return "\n".join(lines)
+
+    def gather(self, kind, deadline):
+        """One message of `kind` from every rank before `deadline` (time.monotonic()); progress notes are kept on the way."""
+        import time
+
         out = []
-        for r, c in enumerate(conns):
-            assert c.poll(timeout), f"rank {r} did not answer within {timeout} s (waiting for {kind})"
-            tag, payload = c.recv()
-            assert tag == kind, f"rank {r}: {tag} {payload}"
-            out.append(payload)
+        for r, c in enumerate(self.conns):
+            while True:
+                left = deadline - time.monotonic()
+                if left <= 0 or not c.poll(left):
+                    pytest.fail(f"rank {r} did not send {kind!r} in time.\n" + self._report(), pytrace=False)
+                tag, payload = c.recv()
+                if tag == "progress":
+                    self.last[r] = payload
+                    continue
+                if tag != kind:
+                    pytest.fail(f"rank {r}: {tag} {payload}\n" + self._report(), pytrace=False)
+                out.append(payload)
+                break
         return out
 
-    try:
-        for _ in SCENARIOS:
-            addresses = gather("address")
-            for c in conns:
-                c.send(addresses)
-            gather("done")
-            for c in conns:
-                c.send("go")
-        results = gather("results")
-        for r in range(world):
-            for k, (name, mode, pipelined, _, _) in enumerate(SCENARIOS):
-                assert results[r][k] == want[k], f"rank {r}, {name} {mode} pipelined={pipelined}: gathered field differs from the unsharded engine's / the oracle's"
-    finally:
-        for p in procs:
-            p.join(timeout=20)
+    def send(self, what):
+        for c in self.conns:
+            c.send(what)
+
+    def close(self):
+        for p in self.procs:
+            p.join(timeout=10)
             if p.is_alive():
                 p.kill()  # (exactly the process started above)
+
+
+# seconds one scenario may take from the first spawn to the last result, by configuration (spawn + library + engine: a few seconds per process
+# on the test box, where every rank shares ONE GPU; C3's frames: ~10 ms each); the deadline covers the mapping of the peers' rings too
+BUDGET_S = {"cave_small": 60, "c2_cornell": 60, "c3_cave": 90, "c4_slab": 90}
+
+
+def _ids():
+    return [f"{name}-{mode}-{'pipelined' if pl else 'in_order'}" for name, mode, pl, _, _ in SCENARIOS]
+
+
+def _run_scenario(ddgi, oracle, tmp_path, world, scenario):
+    import time
+
+    name, mode, pipelined, frames, read_at = scenario
+    want = _expected(ddgi, name, mode, frames, read_at, oracle)
+    ranks = _Ranks(world, scenario, tmp_path)
+    deadline = time.monotonic() + BUDGET_S[name] * (2 if world > 4 else 1)
+    try:
+        ranks.send(ranks.gather("address", deadline))
+        ranks.gather("done", deadline)
+        ranks.send("go")
+        results = ranks.gather("results", deadline)
+        for r in range(world):
+            assert results[r] == want, f"rank {r}, {name} {mode} pipelined={pipelined}: gathered field differs from the unsharded engine's / the oracle's"
+    finally:
+        ranks.close()
+
+
+@pytest.mark.parametrize("scenario", SCENARIOS, ids=_ids())
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_process_per_rank_through_ipc_handles(ddgi, oracle, tmp_path, world, scenario):
+    """2 / 4 processes, one GPU: the peers' textures are mapped with hipIpcOpenMemHandle, the flags cross the process
+    boundary.  This is the multi-rank path of bench.py --exchange p2p, executed at ranks > 0 on the test box.  One test per
+    scenario, each with its own budget; a rank that stops answering is reported with the last stage it reached."""
+    _run_scenario(ddgi, oracle, tmp_path, world, scenario)
+
+
+def test_eight_ranks_on_one_gpu(ddgi, oracle, tmp_path):
+    """World 8 — BASELINE's node size — on the one-GPU box: C2 (8 z-layers: one per rank), pipelined, updates back to back, against the oracle."""
+    _run_scenario(ddgi, oracle, tmp_path, 8, ("c2_cornell", "ref_static", True, 6, (2, 5)))
 
 
 def test_p2p_addresses_are_checked(ddgi):
