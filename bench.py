@@ -332,11 +332,14 @@ def main():
     exchanging = False
     transport = "none"
     fallback = None
+    bring_up_s = {}   # seconds per stage of a transport's (latest) bring-up on this rank: multi_gpu.bring_up_s
 
     def try_rccl():
         # the engine issues the RCCL all-gather itself (include/ddgi_probe.h: ddgi_exchange_*): rank 0 makes the
         # 128-byte RCCL id, torch.distributed carries it to the other ranks, every rank joins the communicator.
         # Bounded: an error or no answer within --rccl-timeout on ANY rank makes every rank give the transport up.
+        t_up = time.perf_counter()
+
         def bring_up():
             with _c_stdout_to_stderr():
                 c = ddgi_amd.comm_create(ids[0], world, rank, local_rank)
@@ -350,6 +353,7 @@ def main():
         ok = ids[0] is not None
         if ok:
             ok, res = _call_bounded(bring_up, args.rccl_timeout)
+        bring_up_s["rccl"] = {"unique_id_comm_init_rank_attach": time.perf_counter() - t_up}
         if all_ok(ok):
             return True, res, None
         if ok:
@@ -364,14 +368,20 @@ def main():
         import hashlib
 
         why = None
+        t_up = time.perf_counter()
+        stages = bring_up_s.setdefault("p2p", {})
         try:
             if os.environ.get("DDGI_BENCH_FAIL_P2P") == "1":   # (fault injection: exercises the fallback's control flow)
                 raise RuntimeError("DDGI_BENCH_FAIL_P2P")
             mine = eng.exchange_p2p_export(pipelined=True)
         except Exception as e:                      # noqa: BLE001 (whatever the binding raises: the transport is not available)
             mine, why = None, "export: " + str(e)[:160]
+        stages["export_receive_ring"] = time.perf_counter() - t_up
+        t_up = time.perf_counter()
         everyone = [None] * world
         dist.all_gather_object(everyone, mine)
+        stages["addresses_over_gloo"] = time.perf_counter() - t_up
+        t_up = time.perf_counter()
         ok = all(a is not None for a in everyone)
         if ok:
             # (bounded like RCCL's bring-up: mapping the peers' rings is a driver call per buffer — 4 ranks' rings of a C5-sized grid,
@@ -379,6 +389,8 @@ def main():
             done, res = _call_bounded(lambda: eng.exchange_p2p_init(everyone), args.p2p_timeout)
             if not done:
                 ok, why = False, "init: " + str(res)[:160]
+        stages["map_peers"] = time.perf_counter() - t_up
+        t_up = time.perf_counter()
         attached = ok
         ok = all_ok(ok)
         if ok and not ddgi_mode:
@@ -399,6 +411,7 @@ def main():
             if not ok and why is None:
                 why = "the ranks' gathered fields differ after the first exchange"
             ok = all_ok(ok)
+            stages["first_two_exchanges_checked"] = time.perf_counter() - t_up
         if ok:
             return True, None
         if attached:
@@ -503,9 +516,10 @@ def main():
         for cand in order:
             ok, why = attach(cand)
             if not ok:
-                by_transport[cand] = {"available": False, "reason": why}
+                by_transport[cand] = {"available": False, "reason": why, "bring_up_s": {k: round(v, 4) for k, v in bring_up_s.get(cand, {}).items()}}
                 continue
-            info = {"available": True, "ranks_in_communicator": eng.exchange_ranks() if cand == "rccl" else world}
+            info = {"available": True, "ranks_in_communicator": eng.exchange_ranks() if cand == "rccl" else world,
+                    "bring_up_s": {k: round(v, 4) for k, v in bring_up_s.get(cand, {}).items()}}
             if world > 1:
                 sweep = {}
                 r0 = eng.get_tuning("reserve_cus")

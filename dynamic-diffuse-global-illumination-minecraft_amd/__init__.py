@@ -20,6 +20,7 @@ from .probe_engine import (  # noqa: F401
     LIGHT_DTYPE,
     MODE_REF,
     MODE_DDGI,
+    ERR_TIMEOUT,
     P2P_ADDRESS_BYTES,
     comm_create,
     comm_destroy,

@@ -182,6 +182,7 @@ static int validate_tile(const ddgi_irradiance_field* f, int tx, int ty)
 constexpr int kMaxDdgiRays = 4096;  // DDGI mode: rays per probe (the cross-check blend kernel keeps 28 B per ray in LDS)
 
 static int check_kernel_status(ddgi_engine* e);
+static int peers_done_before_host_copies(ddgi_engine* e);
 static void free_vis_tables(ddgi_engine::DevScene& d);
 
 // Byte sizes of the two probe textures of a configuration.
@@ -990,18 +991,22 @@ static int plan_trace(ddgi_engine* e, TracePlan& p)
         p.rec_rgb = rec_rgb_floats(local_probes, static_cast<uint32_t>(a.grid.n));
         const size_t rec_floats = p.rec_rgb + rec_dd_floats(local_probes, static_cast<uint32_t>(a.grid.n));
         int want = rec_ring_len(e, rec_floats * sizeof(float), local_rays);
+        // (a ring that did not fit once is not asked for again on every update — each try would free, wait for the device and fail a
+        //  multi-GB hipMalloc: the fallback to one buffer is remembered until the records' size changes)
+        if (e->nrec_cap > 0 && rec_floats == e->rec_stride && e->d_radiance_rays == a.grid.n && want > e->nrec_cap) want = e->nrec_cap;
         if (!e->d_radiance || rec_floats != e->rec_stride || want != e->nrec || e->d_radiance_rays != a.grid.n)
         {
             // (re)allocated zeroed: the records of padding rays / padding probes are never written and must read as 0.  A ring of
             // `want` buffers (frames in flight); if that much memory is not to be had, one buffer and no continuation.
             if (e->d_radiance) (void)hipFree(e->d_radiance);  // (waits for the device: no launch is still writing records)
             e->d_radiance = nullptr;
-            e->d_radiance_capacity = 0, e->rec_stride = 0, e->nrec = 1;
+            e->d_radiance_capacity = 0, e->rec_stride = 0, e->nrec = 1, e->nrec_cap = 0;
             hipError_t he = hipMalloc(reinterpret_cast<void**>(&e->d_radiance), rec_floats * sizeof(float) * static_cast<size_t>(want));
             if (he == hipErrorOutOfMemory && want > 1)
             {
                 (void)hipGetLastError();
                 want = 1;
+                e->nrec_cap = 1;
                 he = hipMalloc(reinterpret_cast<void**>(&e->d_radiance), rec_floats * sizeof(float));
             }
             HIP_TRY(he);
@@ -1270,6 +1275,10 @@ static int prepare_ahead(ddgi_engine* e, const TracePlan& p, const BlendArgs& b,
         HIP_TRY(hipStreamWaitEvent(e->prep_stream2, after, 0));
         tables_stream = e->prep_stream2;
     }
+    // (the stream that serves the tables can change between updates — tuning "prep_stream", a slab that becomes a whole grid —, and prep_done is
+    //  ONE event: whatever an earlier update put on the other stream and nobody has joined yet is ordered in front of this call's record)
+    if (e->prep_pending && e->prep_tables_last && e->prep_tables_last != tables_stream) HIP_TRY(hipStreamWaitEvent(tables_stream, e->prep_done, 0));
+    e->prep_tables_last = tables_stream;
     const TraceArgs& a = p.a;
     {
         BlendArgs nb = b;
@@ -1606,8 +1615,8 @@ int ddgi_probe_update(ddgi_handle e, const ddgi_render_settings* settings)
         // frame f's weight tiles live in buffer f & 1: they depend on the frame's ray directions only, and the NEXT frame's are made
         // beside this frame's blend (below) — here only if that did not happen (the first update, ddgi_set_frame, another ray count)
         const int wb = static_cast<int>(e->frame & 1u);
-        b.w_sum = e->d_blend_w + static_cast<size_t>(wb) * need;
-        b.w = b.w_sum + 256;
+        b.w_sum = e->d_blend_w + static_cast<size_t>(wb) * e->d_blend_w_floats;  // (the buffers' stride is the ALLOCATION's — it never shrinks —, here and in
+        b.w = b.w_sum + 256;                                                        //  prepare_ahead: `need` is smaller after a reconfiguration to fewer rays)
         if (e->tuning.blend_kernel == 1) b.w = b.w_sum = nullptr;  // one probe per workgroup, weights in place
         b.force_division = e->tuning.blend_kernel == 2 ? 1u : 0u;
         b.merge_below = static_cast<uint32_t>(e->tuning.blend_merge < 0 ? 0 : e->tuning.blend_merge);
@@ -1749,6 +1758,16 @@ int ddgi_trace_stats(ddgi_handle e, int enable, unsigned long long* out64)
     return DDGI_OK;
 }
 
+// The host-side consumers copy into the CALLER's (or a local) host buffer with hipMemcpyAsync and then wait.  With an exchange attached that
+// wait has a deadline (ddgi_sync_stream) — and a call that gives up must not leave a copy in flight into memory it is about to hand
+// back.  So: whatever depends on another rank is waited for FIRST, with the deadline, before any host copy is enqueued; after it nothing
+// on the stream waits for anybody but this GPU.
+static int peers_done_before_host_copies(ddgi_engine* e)
+{
+    if (!e->xch.transport && !e->xch.p2p) return DDGI_OK;
+    return ddgi_sync_stream(e, e->stream);
+}
+
 int ddgi_read_textures(ddgi_handle e, uint8_t* albedo, uint8_t* distance)
 {
     if (!e) return fail(DDGI_ERR_INVALID_ARGUMENT, "null handle");
@@ -1759,6 +1778,7 @@ int ddgi_read_textures(ddgi_handle e, uint8_t* albedo, uint8_t* distance)
     const size_t s = g.sx, sh = g.sy, s2 = g.n;
     const size_t W = static_cast<size_t>(g.cx) * g.cz * s;
     if (int rc = ddgi_exchange_wait_latest(e)) return rc;
+    if (int rc = peers_done_before_host_copies(e)) return rc;
     std::vector<uint32_t> slab(e->tex_bytes[0] / 4);
     uint8_t* outs[2] = {albedo, distance};
     for (int t = 0; t < 2; ++t)
@@ -1791,6 +1811,7 @@ int ddgi_read_tiles(ddgi_handle e, float* irradiance, float* depth)
     HIP_TRY(hipSetDevice(e->device));
     const GridK g = make_grid(e);
     if (int rc = ddgi_exchange_wait_latest(e)) return rc;
+    if (int rc = peers_done_before_host_copies(e)) return rc;
     float* outs[2] = {irradiance, depth};
     const size_t per_probe[2] = {8 * 8 * 4, 16 * 16 * 2};
     for (int t = 0; t < 2; ++t)
@@ -2045,6 +2066,8 @@ int ddgi_sample(ddgi_handle e, const float* pos, const float* nrm, size_t n, flo
                         "%s failed: %s", #expr, hipGetErrorString(e_));                        \
         }                                                                                      \
     } while (0)
+    if (int rc0 = ddgi_exchange_wait_latest(e)) return rc0;
+    if (int rc0 = peers_done_before_host_copies(e)) return rc0;
     TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_pos), n * 12));
     TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_nrm), n * 12));
     TRY_OR_CLEAN(hipMalloc(reinterpret_cast<void**>(&d_rgb), n * 12));
@@ -2134,6 +2157,8 @@ int ddgi_render(ddgi_handle e, const ddgi_camera* cam, const ddgi_render_setting
     uint32_t* d_img = nullptr;
     float* d_f = nullptr;
     if (n == 0) return fail(DDGI_ERR_INVALID_ARGUMENT, "bad image size");
+    if (int rc0 = ddgi_exchange_wait_latest(e)) return rc0;
+    if (int rc0 = peers_done_before_host_copies(e)) return rc0;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_img), n * 4));
     if (rgb_f32 && hipMalloc(reinterpret_cast<void**>(&d_f), n * 12) != hipSuccess)
     {

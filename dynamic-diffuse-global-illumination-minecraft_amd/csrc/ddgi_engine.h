@@ -158,6 +158,7 @@ struct ddgi_engine
     bool have_last_time = false;
     int nrec = 1;                           // DDGI mode: ray-record buffers in d_radiance — an update writes buffer (its number % nrec), so that the blend of
                                             // update k can read its records while a launch is already tracing update k + 1 (frames in flight)
+    int nrec_cap = 0;                       // > 0: a longer ring did not fit in memory (remembered until the records' size changes)
     size_t rec_stride = 0;                  // ... floats per buffer
     unsigned long long ring_k = 0;          // updates since the ring of texture pairs was made: update k writes pair k % np
     bool chain_break = true;                // something other than a probe update has touched the handle since: the next update starts a group
@@ -183,6 +184,7 @@ struct ddgi_engine
     // is made beside this update's blend, whose kernels leave room on every CU (the trace kernel's persistent workgroups do not)
     hipStream_t prep_stream = nullptr;
     hipStream_t prep_stream2 = nullptr;  // the feeler tables' own (tuning "prep_stream" 2)
+    hipStream_t prep_tables_last = nullptr;  // the stream the latest prep_done was recorded on
     hipEvent_t prep_after = nullptr;  // handle's stream: this update's trace launch has ended (the preparation starts behind it)
     hipEvent_t prep_w_done = nullptr; // preparation stream: the next frame's weight tiles are made (the next update waits for it — its blend reads them)
     hipEvent_t prep_done = nullptr;   // preparation stream: everything given to it so far is done — the tables too (the next CHAIN's first launch waits for it)

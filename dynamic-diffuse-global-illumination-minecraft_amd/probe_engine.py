@@ -15,6 +15,8 @@ from .build import build_library, library_path
 
 MODE_REF = 0
 MODE_DDGI = 1
+# ddgi_status (include/ddgi_probe.h)
+ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_NOT_READY, ERR_UNSUPPORTED, ERR_TIMEOUT = -1, -2, -3, -4, -5, -6, -7
 P2P_ADDRESS_BYTES = 512  # DDGI_P2P_ADDRESS_BYTES
 
 

@@ -83,3 +83,32 @@ def test_ref_reconfigure_carry_and_clear(ddgi):
             else:
                 assert not t1[:, :, z * 3 + x].any()
     assert a0.any() and not a2.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("s_old,s_new", [(32, 16), (16, 32)])
+def test_ddgi_reconfigure_to_another_ray_count_keeps_the_weight_tiles_right(ddgi, oracle, s_old, s_new):
+    """Round 5's advisor finding: the two DDGI blend-weight buffers (frame f's tiles in buffer f & 1; the NEXT frame's are made on the
+    preparation stream beside this frame's blend) were addressed with the current ray count's size by ddgi_probe_update and with the
+    allocation's — which never shrinks — by the preparation: after a reconfiguration to FEWER rays every odd frame blended from stale
+    weights.  1024 -> 256 rays (and back up), six frames each, against the oracle frame by frame."""
+    counts, side, origin, scene, hyst = (4, 3, 4), 8, (1.4, 0.0, 1.0), 0, 0.8
+
+    def field(mod, s):
+        return mod.make_field(counts, side, s, origin, hysteresis=hyst)
+
+    want_irr, want_dep = oracle.new_tiles(field(oracle, s_old))
+    with ddgi.ProbeEngine(field(ddgi, s_old), ddgi.make_settings(scene, 8)) as eng:
+        eng.set_mode(ddgi.MODE_DDGI)
+        frame = 0
+        for s in (s_old, s_new):
+            if s != s_old:
+                eng.reconfigure(field(ddgi, s), carry_over=True)   # (same probes: every tile is carried)
+            for _ in range(6):
+                st = dict(time=2.0 * (frame + 1))
+                eng.probe_update(ddgi.make_settings(scene, 8, **st))   # back to back: the next frame's weights are made ahead
+                oracle.ddgi_update(field(oracle, s), oracle.make_settings(scene, 8, **st), frame, want_irr, want_dep)
+                frame += 1
+            irr, dep = eng.read_tiles()
+            assert np.array_equal(_bits(irr), _bits(want_irr)), f"irradiance tiles differ after the frames at {s * s} rays"
+            assert np.array_equal(_bits(dep), _bits(want_dep)), f"depth tiles differ after the frames at {s * s} rays"

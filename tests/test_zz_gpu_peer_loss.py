@@ -1,0 +1,123 @@
+"""A rank that dies in the middle of an exchange must not hang the others (round 6).
+
+The reference's fences give up after DEFAULT_FENCE_TIMEOUT = 1 s (src/rvpt/vk_util.cpp:65, 94-97).  Here every host wait of a handle
+with a multi-GPU exchange attached has the deadline of tuning "wait_timeout_ms": on expiry the call returns DDGI_ERR_TIMEOUT naming the
+peer that is behind, the flag, and the exchange numbers expected and seen; the exchange is broken (ddgi_exchange and the consumers
+refuse), and — peer-to-peer transport — the survivors' own waits are released by the library itself, so their handles drain and can be
+detached, used alone and destroyed.  Three processes on the test box's one GPU; rank 1 leaves with os._exit after the first frame."""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from tests.common import CONFIGS
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORLD, VICTIM, TIMEOUT_MS = 3, 1, 3000
+NAME = "cave_odd"   # 3 x 3 x 3 probes: one z-layer per rank
+
+
+def _worker(rank, conn, pipelined):
+    sys.path.insert(0, ROOT)
+    try:
+        import ddgi_amd as ddgi
+
+        ddgi.load_library()
+        counts, side, s, origin, scene = CONFIGS[NAME]
+        eng = ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8), device=0, rank=rank, world=WORLD)
+        eng.set_tuning("wait_timeout_ms", TIMEOUT_MS)
+        eng.generate_probe_rays(seed=1)
+        conn.send(("address", eng.exchange_p2p_export(pipelined)))
+        eng.exchange_p2p_init(conn.recv())
+        eng.probe_update()
+        eng.exchange()
+        whole = eng.read_textures()[0].copy()       # frame 0: every rank is there
+        conn.send(("frame0", int(whole.astype(np.uint64).sum())))
+        conn.recv()                                 # (host barrier: everybody has read frame 0)
+        if rank == VICTIM:
+            os._exit(0)                             # no teardown, no goodbye: the process is gone
+        report = {}
+        eng.generate_probe_rays(seed=2, reseed=True)
+        eng.probe_update()
+        t0 = time.monotonic()
+        try:
+            eng.exchange()
+            eng.read_textures()
+            report["first"] = "no error"
+        except ddgi.DDGIError as exc:
+            report["first"] = (exc.code, str(exc))
+        report["first_s"] = time.monotonic() - t0
+        t0 = time.monotonic()
+        for what, call in (("exchange", eng.exchange), ("sample", lambda: eng.sample(np.zeros((4, 3), np.float32), np.ones((4, 3), np.float32) / np.sqrt(3).astype(np.float32)))):
+            try:
+                call()
+                report[what] = "no error"
+            except ddgi.DDGIError as exc:
+                report[what] = (exc.code, str(exc))
+        report["refusals_s"] = time.monotonic() - t0
+        # detached, the handle is a slab of its own again: an update and a read of it work
+        t0 = time.monotonic()
+        eng.exchange_init(None)
+        eng.probe_update()
+        eng.synchronize()
+        own = eng.read_textures()[0]
+        report["alone_ok"] = bool(own.any())
+        eng.close()
+        report["alone_s"] = time.monotonic() - t0
+        conn.send(("report", report))
+    except Exception as exc:  # noqa: BLE001 — reported to the parent, which fails the test
+        conn.send(("error", repr(exc)))
+
+
+@pytest.mark.parametrize("pipelined", [False, True], ids=["in_order", "pipelined"])
+def test_survivors_of_a_lost_rank_time_out_name_it_and_stay_usable(ddgi, pipelined):
+    ctx = mp.get_context("spawn")
+    pipes = [ctx.Pipe() for _ in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, pipes[r][1], pipelined), daemon=True) for r in range(WORLD)]
+    for p in procs:
+        p.start()
+    conns = [pp[0] for pp in pipes]
+    deadline = time.monotonic() + 90
+
+    def gather(kind, ranks):
+        out = {}
+        for r in ranks:
+            assert conns[r].poll(max(0.0, deadline - time.monotonic())), f"rank {r} did not send {kind!r} in time"
+            tag, payload = conns[r].recv()
+            assert tag == kind, f"rank {r}: {tag} {payload}"
+            out[r] = payload
+        return out
+
+    try:
+        everybody = range(WORLD)
+        addresses = gather("address", everybody)
+        for c in conns:
+            c.send([addresses[r] for r in everybody])
+        sums = gather("frame0", everybody)
+        assert len(set(sums.values())) == 1 and sums[0] > 0      # frame 0 was a real, complete exchange
+        for c in conns:
+            c.send("go")
+        survivors = [r for r in everybody if r != VICTIM]
+        reports = gather("report", survivors)
+        for r in survivors:
+            rep = reports[r]
+            code, text = rep["first"]
+            assert code == ddgi.ERR_TIMEOUT, rep
+            assert f"rank {VICTIM} is behind" in text and ("`arrived`" in text or "`ready`" in text), text
+            assert "stands at exchange 1" in text and "waits for 2" in text, text
+            assert "streams have drained" in text, text
+            # within the deadline (+ the bounded clean-up: reading the flags, releasing the waits, draining)
+            assert TIMEOUT_MS / 1000 * 0.9 <= rep["first_s"] <= TIMEOUT_MS / 1000 + 8, rep
+            for what in ("exchange", "sample"):
+                assert rep[what][0] == ddgi.ERR_TIMEOUT and "broken" in rep[what][1], rep
+            assert rep["refusals_s"] < 2 and rep["alone_ok"] and rep["alone_s"] < 15, rep
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()  # (exactly the process started above)
