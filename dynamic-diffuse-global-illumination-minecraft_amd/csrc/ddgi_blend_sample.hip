@@ -1153,7 +1153,7 @@ template <int kMode>  // 0: a texel's floats one by one, 1: one load per texel (
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DDGI_SAMPLE_WAVES, 8))) void k_probe_sample_ddgi(const SampleArgs A)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;  // (ddgi_device.h: consecutive points of a sorted batch behind ONE L2)
     if (k >= A.n) return;
     const uint32_t i = (A.perm && !(DDGI_SAMPLE_COHERENCE && A.perm_off && *A.perm_off)) ? A.perm[k] : k;
     int cage[8];

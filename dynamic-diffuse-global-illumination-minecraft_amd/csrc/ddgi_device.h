@@ -56,6 +56,24 @@ DDGI_D float axis_inv(float d) { return d == 0.0f ? __builtin_inff() : pm::rcp_u
 // or 0 / inf / NaN when that normalisation was degenerate — never in (0, 2^-96), the part of the line pm::rcp_sqrt_core gets wrong
 DDGI_D f3 normalize3_of_unit(f3 d) { return d * pm::rcp_sqrt_core(dot3(d, d)); }
 
+// ---- XCD-aware block order ---------------------------------------------------------------------------------------------------------
+// The hardware deals consecutive workgroups round-robin over the chip's 8 XCDs, each with its own L2 (MI355X_MICROARCH.md): blocks b, b + 1, ...
+// b + 7 of a launch run on 8 different L2s.  A kernel whose CONSECUTIVE blocks share data (a batch of shading points in cage order: neighbouring
+// rows of cages share half their probes' tiles) wants them behind ONE L2: XCD x takes the x-th contiguous eighth of the logical blocks.
+// -> the logical block of hardware block b of nb; a bijection for every nb.
+#ifndef DDGI_XCD_ORDER
+#define DDGI_XCD_ORDER 1
+#endif
+DDGI_D uint32_t xcd_block(uint32_t b, uint32_t nb)
+{
+#if DDGI_XCD_ORDER
+    const uint32_t q = nb >> 3, r = nb & 7u, x = b & 7u, j = b >> 3;
+    return x * q + (x < r ? x : r) + j;
+#else
+    return b;
+#endif
+}
+
 // ---- the per-update part of a launch's arguments (ddgi_types.h: UpdK), as the trace code reads it ----------------------------
 // UpdOfArgs: straight from the kernel's own arguments (k_probe_trace_ref, k_probe_trace_wf, k_render_primary).
 // UpdOfRing: from a record of the queue kernel's per-update ring, through the constant address space — with a wave-uniform

@@ -127,7 +127,7 @@ static thread_local std::string g_last_error;
 
 int ddgi_fail(int code, const char* fmt, ...)
 {
-    char buf[512];
+    char buf[1024];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);

@@ -32,6 +32,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <random>
@@ -362,29 +363,37 @@ int exchange_timed_out(ddgi_engine* e, const char* waited_for)
     if (x.transport == DDGI_EXCHANGE_P2P || x.p2p)
     {
         ddgi_engine::P2P& p = *x.p2p;
-        char who[256] = "the flag words could not be read";
+        char who[384] = "the flag words could not be read";
         bool have = false;
         if (p.diag && p.diag_host && p.flags &&
             hipMemcpyAsync(p.diag_host, p.flags, 2 * kP2PMaxWorld * sizeof(uint32_t), hipMemcpyDeviceToHost, p.diag) == hipSuccess)
             have = poll_until([&] { return hipStreamQuery(p.diag); }, 2000) == hipSuccess;
         if (have)
         {
-            // the peer furthest behind, `arrived` (what consumers wait for) before `ready` (what this rank's pushes wait for)
-            int lag_rank = -1;
-            const char* lag_flag = "";
-            uint32_t lag_want = 0, lag_seen = 0;
-            for (int pass = 0; pass < 2 && lag_rank < 0; ++pass)
-                for (int q = 0; q < e->world; ++q)
+            // Every peer that is behind, the one furthest behind first.  A peer that is gone is behind in BOTH flags; a live peer whose slab has
+            // not arrived may itself be waiting for the one that is gone (its pushes share hardware queues with its waits) — so the order is by
+            // `ready` (what it releases as soon as its own update is done), then by `arrived`.
+            const uint32_t want_ready = p.seq, want_arrived = p.waited_arrived;
+            int order[kP2PMaxWorld], n_lag = 0;
+            for (int q = 0; q < e->world && q < kP2PMaxWorld; ++q)
+                if (q != e->rank && (p.diag_host[q] < want_ready || p.diag_host[kP2PMaxWorld + q] < want_arrived)) order[n_lag++] = q;
+            for (int a = 1; a < n_lag; ++a)
+                for (int b = a; b > 0; --b)
                 {
-                    if (q == e->rank) continue;
-                    const uint32_t seen = p.diag_host[(pass == 0 ? kP2PMaxWorld : 0) + q];
-                    const uint32_t want = pass == 0 ? p.waited_arrived : p.seq;
-                    if (seen < want && (lag_rank < 0 || seen < lag_seen)) lag_rank = q, lag_flag = pass == 0 ? "arrived" : "ready", lag_want = want, lag_seen = seen;
+                    const int x = order[b], y = order[b - 1];
+                    const bool less = p.diag_host[x] != p.diag_host[y] ? p.diag_host[x] < p.diag_host[y] : p.diag_host[kP2PMaxWorld + x] < p.diag_host[kP2PMaxWorld + y];
+                    if (!less) break;
+                    order[b] = y, order[b - 1] = x;
                 }
-            if (lag_rank >= 0)
-                std::snprintf(who, sizeof who, "rank %d is behind: its `%s` flag stands at exchange %u, this rank (%d of %d) waits for %u", lag_rank, lag_flag, lag_seen, e->rank, e->world, lag_want);
+            if (n_lag > 0)
+            {
+                int at = std::snprintf(who, sizeof who, "rank %d is behind: `ready` at exchange %u, `arrived` at exchange %u; this rank (%d of %d) waits for exchange %u / %u", order[0], p.diag_host[order[0]],
+                                       p.diag_host[kP2PMaxWorld + order[0]], e->rank, e->world, want_ready, want_arrived);
+                for (int a = 1; a < n_lag && at > 0 && at < static_cast<int>(sizeof who) - 48; ++a)
+                    at += std::snprintf(who + at, sizeof who - static_cast<size_t>(at), "%s rank %d (%u / %u)", a == 1 ? "; also behind:" : ",", order[a], p.diag_host[order[a]], p.diag_host[kP2PMaxWorld + order[a]]);
+            }
             else
-                std::snprintf(who, sizeof who, "every peer's flags are up to date (exchange %u): the wait is not for a peer", p.seq);
+                std::snprintf(who, sizeof who, "every peer's flags are up to date (exchange %u / %u): the wait is not for a peer", want_ready, want_arrived);
         }
         // end this rank's own waits: the streams drain, the handle can be detached / reconfigured / destroyed
         const bool forced = p2p_force_own_flags(p);
@@ -734,9 +743,24 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
         }
         peer.ipc = true;
         void* fl = nullptr;
+        // (tuning "verbose": every mapping with its time on stderr — round 5's two bring-ups that never came back are placed by this)
+        const bool say = e->tuning.verbose != 0;
+        auto stamp = [&](const char* what, int i, const std::chrono::steady_clock::time_point& t0, hipError_t r) {
+            if (say)
+                std::fprintf(stderr, "[ddgi p2p, rank %d of %d] %s %d of rank %d: %s after %.3f s\n", e->rank, world, what, i, q, hipGetErrorString(r),
+                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        };
+        auto t0 = std::chrono::steady_clock::now();
+        if (say) std::fprintf(stderr, "[ddgi p2p, rank %d of %d] mapping rank %d (pid %d): flags, then 2 rings of %u pairs, %.1f + %.1f MB per pair\n", e->rank, world, q, a.pid, a.np, a.tex_bytes[0] / 1e6, a.tex_bytes[1] / 1e6);
         he = hipIpcOpenMemHandle(&fl, a.flags, hipIpcMemLazyEnablePeerAccess);
+        stamp("flags", 0, t0, he);
         peer.flags = static_cast<uint32_t*>(fl);
-        for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipIpcOpenMemHandle(&peer.ring[i], a.ring[i], hipIpcMemLazyEnablePeerAccess);
+        for (int i = 0; i < 2 && he == hipSuccess; ++i)
+        {
+            t0 = std::chrono::steady_clock::now();
+            he = hipIpcOpenMemHandle(&peer.ring[i], a.ring[i], hipIpcMemLazyEnablePeerAccess);
+            stamp("ring", i, t0, he);
+        }
         if (he == hipSuccess) he = hipStreamCreateWithFlags(&peer.stream, hipStreamNonBlocking);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&peer.done, hipEventDisableTiming);
         if (he != hipSuccess && rc == DDGI_OK) rc = fail(DDGI_ERR_HIP, "mapping rank %d's probe textures failed: %s", q, hipGetErrorString(he));

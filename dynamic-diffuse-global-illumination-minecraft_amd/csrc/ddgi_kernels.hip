@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_probe_sample_ref(const SampleArgs A)
     __shared__ float s_unorm[256];
     s_unorm[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;  // blockDim.x == 256
     __syncthreads();
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t k = xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;  // (ddgi_device.h: consecutive points of a sorted batch behind ONE L2)
     if (k >= A.n) return;
     const uint32_t i = (A.perm && !(DDGI_SAMPLE_COHERENCE && A.perm_off && *A.perm_off)) ? A.perm[k] : k;
     int cage[8];

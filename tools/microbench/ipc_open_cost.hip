@@ -133,8 +133,10 @@ static int child(int rank, int world, int rfd, int wfd, const std::vector<size_t
 int main(int argc, char** argv)
 {
     const double limit_s = argc > 1 ? std::atof(argv[1]) : 120.0;
-    const std::vector<size_t> sizes = {16ull << 20, 128ull << 20, 805ull << 20, 2048ull << 20, 6400ull << 20};
-    const int worlds[] = {2, 4, 8};
+    std::vector<size_t> sizes = {16ull << 20, 128ull << 20, 805ull << 20, 2048ull << 20, 6400ull << 20};
+    if (argc > 2) sizes = {static_cast<size_t>(std::atoll(argv[2])) << 20};  // one size in MB (e.g. 8600: the depth-tile ring of C5 DDGI at 4 pairs)
+    std::vector<int> worlds = {2, 4, 8};
+    if (argc > 3) worlds = {std::atoi(argv[3])};
     std::printf("# hipIpcOpenMemHandle cost, W processes on one GPU, each opening the W-1 peers' buffers of B bytes (seconds; maximum over the ranks)\n");
     std::printf("# %5s %9s | %9s %9s | %12s %12s %12s | %12s %10s | %9s\n", "W", "B (MB)", "malloc", "export", "open (sum)", "open (max 1)", "s per GB", "first 4 KB", "slab copy", "close");
     for (int world : worlds)

@@ -7,17 +7,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import ddgi_amd
-from bench import WORKLOAD as w
+from bench import WORKLOADS
 
+w = WORKLOADS[os.environ.get("SAMPLE_WORKLOAD", "c3")]   # SAMPLE_WORKLOAD=c5 SAMPLE_MODES=1: the DDGI sampler beyond the caches (3.2 GB of tiles)
 n = 1600 * 900  # one full-HD-ish frame of shading points (the reference's window, main.cpp:40-41)
 rng = np.random.default_rng(0)
-pos = torch.from_numpy((rng.uniform(-1, 1, size=(n, 3)) * np.array([30, 14, 30]) + np.array(w["origin"])).astype(np.float32)).cuda()
+half = np.array(w["counts"], dtype=np.float64) * w["side"] * 0.47
+pos = torch.from_numpy((rng.uniform(-1, 1, size=(n, 3)) * half + np.array(w["origin"])).astype(np.float32)).cuda()
 nrm = torch.from_numpy(rng.normal(size=(n, 3)).astype(np.float32)).cuda()
 rgb = torch.empty((n, 3), dtype=torch.float32, device="cuda")
 cage = torch.empty((n, 8), dtype=torch.int32, device="cuda")
-for mode in (ddgi_amd.MODE_REF, ddgi_amd.MODE_DDGI):
+for mode in [int(m) for m in os.environ.get("SAMPLE_MODES", "0,1").split(",")]:
     eng = ddgi_amd.ProbeEngine(ddgi_amd.make_field(w["counts"], w["side"], w["s"], w["origin"]), ddgi_amd.make_settings(w["scene"], 8))
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    if w["tile"] != (w["s"], w["s"]):
+        eng.set_ray_tile(*w["tile"])
     eng.set_mode(mode)
     if mode == ddgi_amd.MODE_REF:
         eng.generate_probe_rays(seed=1)
