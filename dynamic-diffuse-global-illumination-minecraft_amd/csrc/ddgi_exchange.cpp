@@ -120,6 +120,10 @@ int rccl_ready()
 
 constexpr uint32_t kP2PMagic = 0x32503244u;  // "D2P2"
 constexpr int kP2PMaxWorld = 64;
+#ifndef DDGI_P2P_FLAGS_ALLOC
+#define DDGI_P2P_FLAGS_ALLOC (4u << 20)
+#endif
+constexpr size_t kP2PFlagsAlloc = DDGI_P2P_FLAGS_ALLOC;
 
 // What a rank publishes (ddgi_exchange_p2p_export): where its buffers are, as IPC handles for its peers' processes.
 // Fits DDGI_P2P_ADDRESS_BYTES.
@@ -686,7 +690,10 @@ int ddgi_exchange_p2p_export(ddgi_handle e, int pipelined, uint8_t address[DDGI_
     a.pid = static_cast<int32_t>(getpid()), a.device = e->device;
     a.process = process_nonce();
     a.np = static_cast<uint32_t>(e->np);
-    hipError_t he = hipMalloc(reinterpret_cast<void**>(&p.flags), 2 * kP2PMaxWorld * sizeof(uint32_t));
+    // The flag words are 512 bytes — allocated as kP2PFlagsAlloc: ROCr serves small device allocations from 2 MB blocks it carves up itself
+    // ("fragments"), and exporting a fragment exports its block, shared with whatever else the process keeps there.  A block of its own
+    // keeps the peers' mappings of this handle's flags apart from every other allocation's life cycle (round 6, docs/LAB_NOTES.md).
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&p.flags), kP2PFlagsAlloc);
     if (he == hipSuccess) he = hipMemset(p.flags, 0, 2 * kP2PMaxWorld * sizeof(uint32_t));
     if (he == hipSuccess)
     {
