@@ -102,7 +102,21 @@ struct UpdOfRing
     static constexpr int kLights = offsetof(UpdK, lights) / 4, kRot = offsetof(UpdK, rot) / 4, kKey = offsetof(UpdK, frame_key) / 4, kRays = offsetof(UpdK, rays) / 4,
                          kRgb = offsetof(UpdK, rad_rgb) / 4, kDd = offsetof(UpdK, rad_dd) / 4, kVis = offsetof(UpdK, vis) / 4, kOcc = offsetof(UpdK, vis_occ) / 4,
                          kMore = offsetof(UpdK, vis_more) / 4;
-    DDGI_D explicit UpdOfRing(const uint32_t* record) : w(reinterpret_cast<Words>(reinterpret_cast<uintptr_t>(record))) {}
+    // The record was WRITTEN by this kernel (k_probe_trace_aq: copy_record), and the constant address space promises LLVM memory that never changes:
+    // nothing but the pointer ties these loads to the copy.  So the pointer comes out of an asm the optimizer cannot see through and that clobbers
+    // memory, placed where the record is known to be complete (behind the workgroup barrier / the acquire of the group's slots): a load of the
+    // record cannot be hoisted above it or merged with one made through an earlier UpdOfRing — by the language's rules, not by the code's layout.
+    DDGI_D explicit UpdOfRing(const uint32_t* record)
+    {
+        uintptr_t a = reinterpret_cast<uintptr_t>(record);
+#if !defined(DDGI_UPD_LAUNDER) || DDGI_UPD_LAUNDER
+        // (the record is one per event group, wave-uniform by construction — k_probe_trace_aq — where the compiler cannot always see it)
+        uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));
+        asm volatile("" : "+s"(lo), "+s"(hi) : : "memory");
+        a = static_cast<uintptr_t>(lo) | (static_cast<uintptr_t>(hi) << 32);
+#endif
+        w = reinterpret_cast<Words>(a);
+    }
     DDGI_D float f(int i) const { return __uint_as_float(w[i]); }
     template <class T>
     DDGI_D T* ptr(int i) const

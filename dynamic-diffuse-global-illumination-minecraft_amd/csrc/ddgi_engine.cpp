@@ -1673,7 +1673,7 @@ static int check_kernel_status(ddgi_engine* e)
     if (status != 0)
     {
         // reported once: the flag is cleared so that later (clean) updates on this handle are usable again
-        (void)hipMemset(e->d_work + 1, 0, sizeof(uint32_t));
+        (void)hipMemsetAsync(e->d_work + 1, 0, sizeof(uint32_t), e->stream);  // (in stream order: in front of the next launch, not beside it)
         return fail(DDGI_ERR_HIP, "the trace kernel aborted (status %u): the probe textures are not valid", status);
     }
     return DDGI_OK;
@@ -1749,7 +1749,7 @@ int ddgi_trace_stats(ddgi_handle e, int enable, unsigned long long* out64)
         if (e->d_stats) HIP_TRY(hipMemcpy(out64, e->d_stats, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     }
     if (enable && !e->d_stats) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_stats), 64 * sizeof(unsigned long long)));
-    if (e->d_stats) HIP_TRY(hipMemset(e->d_stats, 0, 64 * sizeof(unsigned long long)));
+    if (e->d_stats) HIP_TRY(hipMemsetAsync(e->d_stats, 0, 64 * sizeof(unsigned long long), e->stream));  // (in stream order)
     if (!enable && e->d_stats)
     {
         (void)hipFree(e->d_stats);

@@ -29,10 +29,13 @@
 //         It needs no RCCL, and — unlike RCCL, which refuses two ranks on one device — it runs with several
 //         ranks on ONE GPU, which is how the one-GPU test box executes a rank > 0 at all.
 #include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
 #include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <random>
@@ -42,6 +45,28 @@
 #include "ddgi_engine.h"
 
 namespace {
+
+// Debugging aid (DDGI_DEBUG_BACKTRACE=1 in the environment when the library is loaded): SIGUSR2 sent to a THREAD (tgkill) prints that thread's native
+// backtrace on stderr — where a driver call that does not come back stands, in a container without ptrace (tools/p2p_hang_hunt5.sh).
+struct BacktraceOnSignal
+{
+    static void handler(int)
+    {
+        void* frames[48];
+        const int n = backtrace(frames, 48);
+        const char head[] = "[ddgi] native backtrace of the signalled thread:\n";
+        (void)!write(2, head, sizeof head - 1);
+        backtrace_symbols_fd(frames, n, 2);
+    }
+    BacktraceOnSignal()
+    {
+        if (!std::getenv("DDGI_DEBUG_BACKTRACE")) return;
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof sa);
+        sa.sa_handler = handler;
+        sigaction(SIGUSR2, &sa, nullptr);
+    }
+} g_backtrace_on_signal;
 
 // the few RCCL entry points used, with the signatures of rccl.h (ROCm 7.2: rccl/rccl.h:220-236, 678)
 struct NcclId  // ncclUniqueId (rccl.h:40-43): 128 opaque bytes, passed by value
@@ -694,7 +719,12 @@ int ddgi_exchange_p2p_export(ddgi_handle e, int pipelined, uint8_t address[DDGI_
     // ("fragments"), and exporting a fragment exports its block, shared with whatever else the process keeps there.  A block of its own
     // keeps the peers' mappings of this handle's flags apart from every other allocation's life cycle (round 6, docs/LAB_NOTES.md).
     hipError_t he = hipMalloc(reinterpret_cast<void**>(&p.flags), kP2PFlagsAlloc);
-    if (he == hipSuccess) he = hipMemset(p.flags, 0, 2 * kP2PMaxWorld * sizeof(uint32_t));
+    // ON THE HANDLE'S STREAM, which is synchronised below before the address leaves this call.  (Rounds 3 - 5 zeroed the words with hipMemset: asynchronous
+    // for device memory, on the null stream, which nothing here ever waited for.  On a GPU that other processes keep full — four ranks' persistent trace
+    // kernels on the test box's one GPU — the fill could run AFTER the peers' first flag writes had landed and wipe them: `ready` 0 / `arrived` 1 from every
+    // peer at once in round 6's logs, a state no peer can produce; with the in-order exchange nobody writes a higher number later, and the rank waits
+    // forever.  That is GPUTEST_r05's hang: docs/LAB_NOTES.md "Round 6".)
+    if (he == hipSuccess) he = hipMemsetAsync(p.flags, 0, 2 * kP2PMaxWorld * sizeof(uint32_t), e->stream);
     if (he == hipSuccess)
     {
         int lo = 0, hi = 0;  // (numerically lower = higher priority)

@@ -73,8 +73,9 @@ static int child(int rank, int world, int rfd, int wfd, const std::vector<size_t
     {
         Report rep;
         std::memset(&rep, 0, sizeof rep);
-        void* own = nullptr;
-        std::vector<void*> mapped(static_cast<size_t>(world), nullptr);
+        void *own = nullptr, *own2 = nullptr;
+        std::vector<void*> mapped(static_cast<size_t>(world), nullptr), mapped2(static_cast<size_t>(world), nullptr);
+        std::vector<hipIpcMemHandle_t> all2(static_cast<size_t>(world));
         std::vector<hipIpcMemHandle_t> all(static_cast<size_t>(world));
         hipIpcMemHandle_t mine;
         double t0 = now_s();
@@ -86,11 +87,21 @@ static int child(int rank, int world, int rfd, int wfd, const std::vector<size_t
         CK(hipIpcGetMemHandle(&mine, own));
         rep.export_s = now_s() - t0;
         if (!write_all(wfd, &mine, sizeof mine) || !read_all(rfd, all.data(), sizeof(hipIpcMemHandle_t) * all.size())) return 4;
+        if (std::getenv("IPC_PAIR"))
+        {
+            // the engine's shape: a SECOND buffer of twice the size per process (the depth tiles' ring), exported and opened after the first
+            CK(hipMalloc(&own2, 2 * bytes));
+            CK(hipMemsetAsync(own2, 0, 2 * bytes, s));
+            CK(hipStreamSynchronize(s));
+            CK(hipIpcGetMemHandle(&mine, own2));
+            if (!write_all(wfd, &mine, sizeof mine) || !read_all(rfd, all2.data(), sizeof(hipIpcMemHandle_t) * all2.size())) return 4;
+        }
         for (int step = 1; step < world; ++step)
         {
             const int q = (rank + step) % world;
             t0 = now_s();
             CK(hipIpcOpenMemHandle(&mapped[static_cast<size_t>(q)], all[static_cast<size_t>(q)], hipIpcMemLazyEnablePeerAccess));
+            if (own2) CK(hipIpcOpenMemHandle(&mapped2[static_cast<size_t>(q)], all2[static_cast<size_t>(q)], hipIpcMemLazyEnablePeerAccess));
             const double dt = now_s() - t0;
             rep.open_sum_s += dt;
             if (dt > rep.open_max_s) rep.open_max_s = dt;
@@ -121,6 +132,9 @@ static int child(int rank, int world, int rfd, int wfd, const std::vector<size_t
         t0 = now_s();
         for (void* m : mapped)
             if (m) (void)hipIpcCloseMemHandle(m);
+        for (void* m : mapped2)
+            if (m) (void)hipIpcCloseMemHandle(m);
+        if (own2) (void)hipFree(own2);
         rep.close_s = now_s() - t0;
         if (own) (void)hipFree(own);
         if (!write_all(wfd, &rep, sizeof rep)) return 4;
@@ -178,6 +192,12 @@ int main(int argc, char** argv)
             wait_all(handles.data(), sizeof(hipIpcMemHandle_t), "exported", bytes);
             if (dead) break;
             for (int r = 0; r < world; ++r) write_all(to_child[static_cast<size_t>(r)], handles.data(), sizeof(hipIpcMemHandle_t) * handles.size());
+            if (std::getenv("IPC_PAIR"))
+            {
+                wait_all(handles.data(), sizeof(hipIpcMemHandle_t), "exported the second buffer", bytes);
+                if (dead) break;
+                for (int r = 0; r < world; ++r) write_all(to_child[static_cast<size_t>(r)], handles.data(), sizeof(hipIpcMemHandle_t) * handles.size());
+            }
             std::vector<char> tok(static_cast<size_t>(world));
             wait_all(tok.data(), 1, "opened + copied", bytes);
             if (dead) break;
