@@ -403,7 +403,15 @@ def main():
         if ok:
             # (bounded like RCCL's bring-up: mapping the peers' rings is a driver call per buffer — 4 ranks' rings of a C5-sized grid,
             # 12.8 GB each, did not come back within seven minutes on the one-GPU test box)
-            done, res = _call_bounded(lambda: eng.exchange_p2p_init(everyone), args.p2p_timeout)
+            # ONE RANK AT A TIME.  Round 6 placed the bring-up that never came back (C5's rings, four ranks): every rank stood in hipIpcOpenMemHandle ->
+            # hsa_amd_ipc_memory_attach -> recvmsg, waiting for the EXPORTING process to hand the buffer's dmabuf over its socket — while that process
+            # stood in the same call towards somebody else (profiles/r06_c5_bring_up_backtrace.txt).  Mapping is milliseconds per peer
+            # (profiles/r06_ipc_open_cost.txt); taking turns costs nothing and no two ranks ever attach to each other at the same time.
+            done, res = True, None
+            for turn in range(world):
+                if turn == rank:
+                    done, res = _call_bounded(lambda: eng.exchange_p2p_init(everyone), args.p2p_timeout)
+                dist.barrier()
             if not done:
                 ok, why = False, "init: " + str(res)[:160]
         stages["map_peers"] = time.perf_counter() - t_up

@@ -205,6 +205,24 @@ struct ddgi_engine::P2P
 
 namespace {
 
+// The exchange's own streams — one per peer, and the one that collects them — are created at the LOWEST stream priority.  Not for the scheduling: HIP maps a
+// process's streams onto a few hardware queues PER PRIORITY (GPU_MAX_HW_QUEUES, 4), and a hipStreamWaitValue32 packet holds its queue — whatever
+// another stream has put behind it included.  At the handle's own priority a peer stream that stands at a slow peer's `ready` can hold the queue the
+// handle's next update is in (round 6's lost-rank test showed the effect between two peer streams: the push to a LIVE peer stood behind the wait for the
+// dead one); in a pool of their own the exchange's waits can only hold each other.
+hipError_t create_exchange_stream(hipStream_t* s)
+{
+    int least = 0, greatest = 0;  // (numerically higher = lower priority)
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    hipError_t he = hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+    if (he != hipSuccess)
+    {
+        (void)hipGetLastError();
+        he = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    }
+    return he;
+}
+
 // one flag word of a peer := v, in stream order
 int p2p_write_flag(ddgi_engine::P2P& p, hipStream_t s, uint32_t* flag, uint32_t v)
 {
@@ -569,7 +587,8 @@ int exchange_common_setup(ddgi_engine* e, bool pipelined, bool always_streams)
     }
     if (pipelined || always_streams)
     {
-        hipError_t he = hipStreamCreateWithFlags(&x.comm_stream, hipStreamNonBlocking);
+        // (peer-to-peer: the stream only collects the peer streams' events — in their pool; RCCL: it carries the all-gather's KERNEL, at the handle's priority)
+        hipError_t he = always_streams ? create_exchange_stream(&x.comm_stream) : hipStreamCreateWithFlags(&x.comm_stream, hipStreamNonBlocking);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&x.written, hipEventDisableTiming);
         for (int i = 0; i < ddgi_engine::kMaxPairs && he == hipSuccess; ++i) he = hipEventCreateWithFlags(&x.sent[i], hipEventDisableTiming);
         if (he != hipSuccess)
@@ -798,7 +817,7 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
             he = hipIpcOpenMemHandle(&peer.ring[i], a.ring[i], hipIpcMemLazyEnablePeerAccess);
             stamp("ring", i, t0, he);
         }
-        if (he == hipSuccess) he = hipStreamCreateWithFlags(&peer.stream, hipStreamNonBlocking);
+        if (he == hipSuccess) he = create_exchange_stream(&peer.stream);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&peer.done, hipEventDisableTiming);
         if (he != hipSuccess && rc == DDGI_OK) rc = fail(DDGI_ERR_HIP, "mapping rank %d's probe textures failed: %s", q, hipGetErrorString(he));
     }

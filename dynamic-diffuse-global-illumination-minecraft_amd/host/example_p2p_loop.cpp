@@ -119,9 +119,12 @@ int main(int argc, char** argv)
         parent_side[static_cast<size_t>(r)] = Wire{down[1], up[0]};  // (to the rank, from the rank)
         pids[static_cast<size_t>(r)] = pid;
     }
-    // relay: the addresses (DDGI_P2P_ADDRESS_BYTES per rank), then the shutdown barrier (1 byte per rank)
+    // relay: the addresses (DDGI_P2P_ADDRESS_BYTES per rank), one 1-byte round per rank (the turns in which the ranks map their peers, one at a time:
+    // RVPTProbePath::attach_exchange), then the shutdown barrier (1 byte per rank)
     bool good = true;
-    for (size_t bytes : {static_cast<size_t>(DDGI_P2P_ADDRESS_BYTES), static_cast<size_t>(1)})
+    std::vector<size_t> rounds{static_cast<size_t>(DDGI_P2P_ADDRESS_BYTES)};
+    rounds.insert(rounds.end(), static_cast<size_t>(world) + 1, static_cast<size_t>(1));
+    for (size_t bytes : rounds)
     {
         std::vector<uint8_t> all(bytes * static_cast<size_t>(world));
         for (int r = 0; r < world && good; ++r) good = read_all(parent_side[static_cast<size_t>(r)].from_parent, all.data() + bytes * static_cast<size_t>(r), bytes);

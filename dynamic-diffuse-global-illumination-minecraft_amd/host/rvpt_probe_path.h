@@ -128,7 +128,23 @@ private:
             std::fprintf(stderr, "the host's address all-gather failed\n");
             return false;
         }
-        return ok(ddgi_exchange_p2p_init(handle_, all.data(), world_), "ddgi_exchange_p2p_init");
+        // The ranks map their peers' buffers ONE AFTER THE OTHER (the same all-gather, one byte, as the barrier between the turns): a rank inside
+        // hipIpcOpenMemHandle waits for the EXPORTING process to hand a buffer over, and on the stack measured two processes that attach to each
+        // other at the same time can wait for each other forever (docs/LAB_NOTES.md "Round 6"); a turn costs milliseconds.
+        bool good = true;
+        std::vector<uint8_t> turn_done(static_cast<size_t>(world_));
+        for (int turn = 0; turn < world_; ++turn)
+        {
+            if (turn == rank_) good = ok(ddgi_exchange_p2p_init(handle_, all.data(), world_), "ddgi_exchange_p2p_init");
+            const uint8_t mine_done = good ? 1 : 0;
+            if (!gather_(&mine_done, turn_done.data(), 1, gather_user_))
+            {
+                std::fprintf(stderr, "the host's all-gather failed (turn %d of the peer mapping)\n", turn);
+                return false;
+            }
+            if (!turn_done[static_cast<size_t>(turn)]) return false;  // (that rank could not map its peers: every rank gives the transport up)
+        }
+        return good;
     }
     bool flush_rays()
     {

@@ -165,6 +165,7 @@ def _worker(rank, world, conn, scenario, log_path):
         addresses = conn.recv()
         eng.exchange_p2p_init(addresses)
         progress("peers mapped")
+        conn.recv()                 # ("start": every rank has mapped its peers)
         result = _run_frames(ddgi, eng, mode, scene, frames, read_at, name, progress)
         eng.exchange_finish()
         eng.synchronize()
@@ -233,6 +234,23 @@ class _Ranks:
         for c in self.conns:
             c.send(what)
 
+    def send_in_turn(self, what, stage, deadline):
+        """`what` to one rank at a time, the next when the one before has reported `stage`: the ranks map their peers' buffers ONE AFTER THE OTHER (round 6:
+        with every rank inside hipIpcOpenMemHandle at once, each waiting for its exporter's process to hand a dmabuf over, a bring-up can stand forever
+        — bench.py's C5 case, profiles/r06_c5_bring_up_backtrace.txt; a real host takes turns over whatever channel carries the addresses)."""
+        import time
+
+        for r, c in enumerate(self.conns):
+            c.send(what)
+            while self.last[r][0] != stage:
+                left = deadline - time.monotonic()
+                if left <= 0 or not c.poll(left):
+                    pytest.fail(f"rank {r} did not reach {stage!r} in time.\n" + self._report(), pytrace=False)
+                tag, payload = c.recv()
+                if tag != "progress":
+                    pytest.fail(f"rank {r}: {tag} {payload}\n" + self._report(), pytrace=False)
+                self.last[r] = payload
+
     def close(self):
         for p in self.procs:
             p.join(timeout=10)
@@ -257,7 +275,8 @@ def _run_scenario(ddgi, oracle, tmp_path, world, scenario):
     ranks = _Ranks(world, scenario, tmp_path)
     deadline = time.monotonic() + BUDGET_S[name] * (2 if world > 4 else 1)
     try:
-        ranks.send(ranks.gather("address", deadline))
+        ranks.send_in_turn(ranks.gather("address", deadline), "peers mapped", deadline)
+        ranks.send("start")
         ranks.gather("done", deadline)
         ranks.send("go")
         results = ranks.gather("results", deadline)

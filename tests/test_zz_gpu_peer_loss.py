@@ -34,6 +34,8 @@ def _worker(rank, conn, pipelined):
         eng.generate_probe_rays(seed=1)
         conn.send(("address", eng.exchange_p2p_export(pipelined)))
         eng.exchange_p2p_init(conn.recv())
+        conn.send(("mapped", None))                 # (the ranks map their peers one after the other: tests/test_zz_gpu_exchange_p2p.py: send_in_turn)
+        conn.recv()
         eng.probe_update()
         eng.exchange()
         whole = eng.read_textures()[0].copy()       # frame 0: every rank is there
@@ -96,8 +98,11 @@ def test_survivors_of_a_lost_rank_time_out_name_it_and_stay_usable(ddgi, pipelin
     try:
         everybody = range(WORLD)
         addresses = gather("address", everybody)
+        for r in everybody:
+            conns[r].send([addresses[q] for q in everybody])
+            gather("mapped", [r])
         for c in conns:
-            c.send([addresses[r] for r in everybody])
+            c.send("start")
         sums = gather("frame0", everybody)
         assert len(set(sums.values())) == 1 and sums[0] > 0      # frame 0 was a real, complete exchange
         for c in conns:
@@ -111,6 +116,9 @@ def test_survivors_of_a_lost_rank_time_out_name_it_and_stay_usable(ddgi, pipelin
             # the rank that is gone is named FIRST (a live peer may be listed behind it: its pushes can stand behind its own wait for the victim)
             assert f"rank {VICTIM} is behind: `ready` at exchange 1, `arrived` at exchange 1; this rank ({r} of {WORLD}) waits for exchange 2 / 2" in text, text
             assert "streams have drained" in text, text
+            # the live peer is NOT behind: its slab came, and this rank's push to it went out — the exchange's streams have hardware queues of their own
+            # priority (csrc/ddgi_exchange.cpp: create_exchange_stream), two peer streams do not share one, and nothing stands behind the wait for the victim
+            assert "also behind" not in text, text
             # within the deadline (+ the bounded clean-up: reading the flags, releasing the waits, draining)
             assert TIMEOUT_MS / 1000 * 0.9 <= rep["first_s"] <= TIMEOUT_MS / 1000 + 8, rep
             for what in ("exchange", "sample"):
