@@ -34,6 +34,8 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -798,25 +800,66 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
             break;
         }
         peer.ipc = true;
-        void* fl = nullptr;
-        // (tuning "verbose": every mapping with its time on stderr — round 5's two bring-ups that never came back are placed by this)
-        const bool say = e->tuning.verbose != 0;
-        auto stamp = [&](const char* what, int i, const std::chrono::steady_clock::time_point& t0, hipError_t r) {
-            if (say)
-                std::fprintf(stderr, "[ddgi p2p, rank %d of %d] %s %d of rank %d: %s after %.3f s\n", e->rank, world, what, i, q, hipGetErrorString(r),
-                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-        };
-        auto t0 = std::chrono::steady_clock::now();
-        if (say) std::fprintf(stderr, "[ddgi p2p, rank %d of %d] mapping rank %d (pid %d): flags, then 2 rings of %u pairs, %.1f + %.1f MB per pair\n", e->rank, world, q, a.pid, a.np, a.tex_bytes[0] / 1e6, a.tex_bytes[1] / 1e6);
-        he = hipIpcOpenMemHandle(&fl, a.flags, hipIpcMemLazyEnablePeerAccess);
-        stamp("flags", 0, t0, he);
-        peer.flags = static_cast<uint32_t*>(fl);
-        for (int i = 0; i < 2 && he == hipSuccess; ++i)
+        // hipIpcOpenMemHandle is a driver call that can stand forever (round 6: the HIP runtime PyTorch ships, a buffer of 2 GiB or more — the importer waits in recvmsg
+        // for the exporter's process, profiles/r06_c5_bring_up_backtrace.txt).  A blocking call cannot be given a deadline, so it runs on a helper thread that
+        // this call waits for with tuning "wait_timeout_ms"; one that does not come back is LEFT BEHIND (with its result block, which it owns) and the call
+        // returns DDGI_ERR_TIMEOUT naming the peer and the buffer.  (tuning "verbose": every mapping with its time on stderr.)
+        struct MapJob
         {
-            t0 = std::chrono::steady_clock::now();
-            he = hipIpcOpenMemHandle(&peer.ring[i], a.ring[i], hipIpcMemLazyEnablePeerAccess);
-            stamp("ring", i, t0, he);
+            hipIpcMemHandle_t flags, ring[2];
+            int device = 0, rank = 0, world = 0, q = 0;
+            bool say = false;
+            std::mutex mu;
+            std::condition_variable cv;
+            int stage = 0;  // 0 flags, 1 ring 0, 2 ring 1, 3 done
+            bool finished = false;
+            hipError_t he = hipSuccess;
+            void *fl = nullptr, *rg[2] = {nullptr, nullptr};
+        };
+        auto job = std::make_shared<MapJob>();
+        job->flags = a.flags, job->ring[0] = a.ring[0], job->ring[1] = a.ring[1];
+        job->device = e->device, job->rank = e->rank, job->world = world, job->q = q, job->say = e->tuning.verbose != 0;
+        if (job->say) std::fprintf(stderr, "[ddgi p2p, rank %d of %d] mapping rank %d (pid %d): flags, then 2 rings of %u pairs, %.1f + %.1f MB per pair\n", e->rank, world, q, a.pid, a.np, a.tex_bytes[0] / 1e6, a.tex_bytes[1] / 1e6);
+        auto work = [job]() {
+            hipError_t r = hipSetDevice(job->device);
+            for (int i = 0; i < 3 && r == hipSuccess; ++i)
+            {
+                {
+                    std::lock_guard<std::mutex> lock(job->mu);
+                    job->stage = i;
+                }
+                const auto t0 = std::chrono::steady_clock::now();
+                r = i == 0 ? hipIpcOpenMemHandle(&job->fl, job->flags, hipIpcMemLazyEnablePeerAccess) : hipIpcOpenMemHandle(&job->rg[i - 1], job->ring[i - 1], hipIpcMemLazyEnablePeerAccess);
+                if (job->say)
+                    std::fprintf(stderr, "[ddgi p2p, rank %d of %d] %s of rank %d: %s after %.3f s\n", job->rank, job->world, i == 0 ? "flags" : (i == 1 ? "ring 0" : "ring 1"), job->q, hipGetErrorString(r),
+                                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            }
+            std::lock_guard<std::mutex> lock(job->mu);
+            job->he = r, job->stage = 3, job->finished = true;
+            job->cv.notify_all();
+        };
+        const int limit = e->tuning.wait_timeout_ms;
+        if (limit <= 0)
+            work();
+        else
+        {
+            std::thread(work).detach();
+            std::unique_lock<std::mutex> lock(job->mu);
+            if (!job->cv.wait_for(lock, std::chrono::milliseconds(limit), [&] { return job->finished; }))
+            {
+                const int at = job->stage;
+                const double gb = at == 0 ? 0.0 : static_cast<double>(a.tex_bytes[at - 1]) * a.np / 1e9;
+                rc = fail(DDGI_ERR_TIMEOUT, "hipIpcOpenMemHandle of rank %d's %s (%.2f GB) did not return within %d ms (tuning \"wait_timeout_ms\"): the call is left behind on a helper thread.  "
+                                            "Known: the HIP runtime PyTorch ships does not come back from mapping a buffer of 2 GiB or more on this stack, the system's does (docs/LAB_NOTES.md \"Round 6\"); "
+                                            "use the RCCL transport for such grids there",
+                          q, at == 0 ? "flag words" : (at == 1 ? "first texture ring" : "second texture ring"), gb, limit);
+                peer.ipc = false;  // (nothing of this peer is mapped as far as this handle knows: the helper thread owns whatever it gets)
+                break;
+            }
         }
+        he = job->he;
+        peer.flags = static_cast<uint32_t*>(job->fl);
+        peer.ring[0] = job->rg[0], peer.ring[1] = job->rg[1];
         if (he == hipSuccess) he = create_exchange_stream(&peer.stream);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&peer.done, hipEventDisableTiming);
         if (he != hipSuccess && rc == DDGI_OK) rc = fail(DDGI_ERR_HIP, "mapping rank %d's probe textures failed: %s", q, hipGetErrorString(he));
