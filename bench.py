@@ -387,6 +387,22 @@ def main():
         why = None
         t_up = time.perf_counter()
         stages = bring_up_s.setdefault("p2p", {})
+        # The largest buffer a peer would have to map: the larger texture's ring (2 pairs at least under the pipelined exchange).  On the stack measured,
+        # hipIpcOpenMemHandle of a buffer of 2 GiB or more does not come back (round 6: bisected on ring sizes, tools/r06_probe4.sh; the library gives the call
+        # a deadline, but the helper thread it leaves behind stands inside the HIP runtime) — such grids (C5) go straight to RCCL.
+        if ddgi_mode:
+            per_pair, pairs = eng.num_probes * 2048, 2          # the depth tiles; DDGI's frames in flight are record buffers, not texture pairs
+        else:
+            per_pair = eng.num_rays * 4                         # (the rule of csrc/ddgi_engine.cpp: chain_len_for under the pipelined exchange)
+            n = max(1, min(8, eng.get_tuning("frames_in_flight")))
+            while n > 2 and per_pair * 2 * n * 2 > (2 << 30):
+                n //= 2
+            while n > 1 and eng.num_rays * n > (64 << 20):
+                n //= 2
+            pairs = max(2, 2 * n)
+        if per_pair * pairs >= (2 << 30) and os.environ.get("DDGI_BENCH_P2P_ANY_SIZE") != "1":
+            dist.barrier()
+            return False, "peer-to-peer transport not attempted: a peer would map a ring of %.1f GB, and mappings of 2 GiB or more do not come back on this stack (profiles/r06_p2p_ring_size_bisection.txt)" % (per_pair * pairs / 1e9)
         try:
             if os.environ.get("DDGI_BENCH_FAIL_P2P") == "1":   # (fault injection: exercises the fallback's control flow)
                 raise RuntimeError("DDGI_BENCH_FAIL_P2P")

@@ -800,8 +800,8 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
             break;
         }
         peer.ipc = true;
-        // hipIpcOpenMemHandle is a driver call that can stand forever (round 6: the HIP runtime PyTorch ships, a buffer of 2 GiB or more — the importer waits in recvmsg
-        // for the exporter's process, profiles/r06_c5_bring_up_backtrace.txt).  A blocking call cannot be given a deadline, so it runs on a helper thread that
+        // hipIpcOpenMemHandle is a driver call that can stand forever (round 6: a texture ring of 2 GiB or more — the importer waits in recvmsg for the exporter's
+        // process, profiles/r06_c5_bring_up_backtrace.txt, r06_p2p_ring_size_bisection.txt).  A blocking call cannot be given a deadline, so it runs on a helper thread that
         // this call waits for with tuning "wait_timeout_ms"; one that does not come back is LEFT BEHIND (with its result block, which it owns) and the call
         // returns DDGI_ERR_TIMEOUT naming the peer and the buffer.  (tuning "verbose": every mapping with its time on stderr.)
         struct MapJob
@@ -850,8 +850,8 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
                 const int at = job->stage;
                 const double gb = at == 0 ? 0.0 : static_cast<double>(a.tex_bytes[at - 1]) * a.np / 1e9;
                 rc = fail(DDGI_ERR_TIMEOUT, "hipIpcOpenMemHandle of rank %d's %s (%.2f GB) did not return within %d ms (tuning \"wait_timeout_ms\"): the call is left behind on a helper thread.  "
-                                            "Known: the HIP runtime PyTorch ships does not come back from mapping a buffer of 2 GiB or more on this stack, the system's does (docs/LAB_NOTES.md \"Round 6\"); "
-                                            "use the RCCL transport for such grids there",
+                                            "Known: inside an engine's process a texture ring of 2 GiB or more never comes back from this call on the stack measured (profiles/r06_p2p_ring_size_bisection.txt); "
+                                            "use the RCCL transport for such grids",
                           q, at == 0 ? "flag words" : (at == 1 ? "first texture ring" : "second texture ring"), gb, limit);
                 peer.ipc = false;  // (nothing of this peer is mapped as far as this handle knows: the helper thread owns whatever it gets)
                 break;
