@@ -881,6 +881,19 @@ static int find_vis_set(const ddgi_engine* e, int scene, const LightK* lights, i
 
 // Makes set `k` hold the tables of these light positions: allocates what is missing, runs k_light_visibility for every light whose
 // table is missing or stale (on the handle's stream: complete before the next launch starts).
+// How many of each half's kAqChainMax sets of light-feeler tables a scene may fill: a set is 8 bytes per voxel and light plus light 0's lists of up to
+// 512 MB, allocated on first use and kept until the scene changes — with animated lights all sixteen fill within a few frames (the cave: 16 x 29 MB;
+// a 4 M-voxel user scene would come to 8.7 GB).  Each half gets 1 GiB; at least one set per half (a scene that large traces its moving lights' updates
+// one per launch: no predictions, nothing wrong).
+static int vis_sets_allowed(const SceneK& sk, int nl)
+{
+    const size_t n_vox = static_cast<size_t>(sk.hi[0] - sk.lo[0] + 1) * (sk.hi[1] - sk.lo[1] + 1) * (sk.hi[2] - sk.lo[2] + 1);
+    const size_t occ_bytes = n_vox * 8 * kVisListMax * sizeof(uint32_t);
+    const size_t set_bytes = n_vox * 8 * static_cast<size_t>(std::max(1, std::min(nl, static_cast<int>(kVisLights)))) + (occ_bytes <= (static_cast<size_t>(512) << 20) ? occ_bytes : 0);
+    const size_t fit = (static_cast<size_t>(1) << 30) / std::max<size_t>(1, set_bytes);
+    return static_cast<int>(std::max<size_t>(1, std::min<size_t>(fit, kAqChainMax)));
+}
+
 static int fill_vis_set(ddgi_engine* e, int scene, const SceneK& sk, const LightK* lights, int nl, int k, hipStream_t stream = nullptr)
 {
     if (!stream) stream = e->stream;
@@ -1173,9 +1186,10 @@ static int assign_vis(ddgi_engine* e, TracePlan& p, bool* follows, int chain_ahe
     {
         k = find_vis_set(e, scene, a.lights, a.nl, true, 0u);
         unsigned used = 0u;
+        const int n_sets = vis_sets_allowed(a.scene, a.nl);  // (of this half's kAqChainMax: a large scene's tables are bounded in memory)
         auto victim = [&]() {  // a set this call has not used: the least recently computed one
             int best = -1;
-            for (int i = 0; i < kAqChainMax; ++i)
+            for (int i = 0; i < n_sets; ++i)
                 if (!((used >> i) & 1u) && (best < 0 || static_cast<int32_t>(d.vis_set[i].launch_seq - d.vis_set[best].launch_seq) < 0)) best = i;
             return best;
         };
@@ -1185,7 +1199,7 @@ static int assign_vis(ddgi_engine* e, TracePlan& p, bool* follows, int chain_ahe
             if (int rc = fill_vis_set(e, scene, a.scene, a.lights, a.nl, k)) return rc;
         }
         used |= 1u << k;
-        const int n_pred = follows ? std::min(e->runahead, std::min(chain_ahead, kAqChainMax - 1)) : 0;
+        const int n_pred = follows ? std::min(e->runahead, std::min(chain_ahead, n_sets - 1)) : 0;
         if (n_pred > 0 && p.ddgi_mode)
         {
             const float dt = e->have_last_time ? e->settings.time - e->last_time : 0.0f;
@@ -1307,6 +1321,9 @@ static int prepare_ahead(ddgi_engine* e, const TracePlan& p, const BlendArgs& b,
             bool coming = false;  // (already on its way on the preparation stream)
             for (int k = kAqChainMax; k < 2 * kAqChainMax; ++k) coming = coming || (e->dev_scene[scene].vis_set[k].on_prep_stream && vis_set_holds(e->dev_scene[scene].vis_set[k], pl, a.nl));
             if (coming) continue;
+            // (a scene whose tables are bounded in memory gets NO sets on this stream: with fewer than kAqChainMax of them a set would be rewritten here, beside
+            //  the launches, while a launch that went on with an earlier update may still read it — its moving lights' updates start chains of their own, as before round 5)
+            if (vis_sets_allowed(a.scene, a.nl) < kAqChainMax) break;
             const int k = kAqChainMax + static_cast<int>((e->updates + static_cast<unsigned long long>(u)) % kAqChainMax);
             if (e->dev_scene[scene].vis_set[k].on_prep_stream) continue;  // (still waiting for the next chain to start: left alone)
             if (int rc = fill_vis_set(e, scene, a.scene, pl, a.nl, k, tables_stream)) return rc;
