@@ -1390,18 +1390,38 @@ constexpr int kAqThinTrip = DDGI_AQ_THIN;    // a march wave with fewer lanes in
 constexpr uint32_t kAqPartialBelow = DDGI_AQ_PARTIAL_BELOW;  // an event wave takes a partial group only while fewer marches than this are queued
 constexpr int kAqEventQueues = 7;  // buckets 0..6 (kBucketRefill is served from FQ)
 
-struct AqShared  // control block at the start of dynamic LDS (32 dwords)
+// STAGING RINGS (round 6, experiment: -DDDGI_AQ_STAGING=1; records instantiations with frames in flight only).  An event group is shaded with ONE update's
+// record; where the pool holds rays of two updates (two thirds of a slab's update) a group drawn from a bucket's ring is mixed, the others go round again.
+// In front of every bucket's ring stand two small rings, one per PARITY of the update a ray belongs to: a push goes there while there is room (a counting
+// semaphore per ring: a reservation that fails must not consume a ring index), else into the bucket's ring as before; event waves serve the staging rings first.
+// A group from a staging ring is pure unless three updates meet (k and k + 2 share a parity): the mixed-group handling stays for every queue.
+#ifndef DDGI_AQ_STAGING
+#define DDGI_AQ_STAGING 0
+#endif
+#if DDGI_AQ_STAGING && (DDGI_AQ_UNIFIED || DDGI_AQ_REFILL_FIRST || DDGI_AQ_REQUEUE || (DDGI_AQ_PICK != 1) || !DDGI_AQ_QUICK)
+#error "DDGI_AQ_STAGING is written for the default event-wave loop (DDGI_AQ_PICK 1, DDGI_AQ_QUICK 1, no unified waves / refill-first / requeue experiments)"
+#endif
+constexpr uint32_t kAqSq = 128;                                  // entries per staging ring (a power of two)
+constexpr int kAqStagingQueues = 2 * kAqEventQueues;             // (bucket, parity)
+constexpr int kAqAllQueues = DDGI_AQ_STAGING ? kAqEventQueues + kAqStagingQueues : kAqEventQueues;
+constexpr int kAqCtrlDwords = DDGI_AQ_STAGING ? 64 : 32;
+
+struct AqShared  // control block at the start of dynamic LDS (kAqCtrlDwords dwords)
 {
     uint32_t mq_head, mq_tail;
     uint32_t fq_head, fq_tail;
-    uint32_t eq_head[kAqEventQueues], eq_tail[kAqEventQueues];
+    uint32_t eq_head[kAqAllQueues], eq_tail[kAqAllQueues];  // [0, kAqEventQueues): the buckets' rings; then the staging rings, index kAqEventQueues + 2 bucket + parity
     uint32_t live;     // rays in flight (claimed and not yet finished)
     uint32_t no_more;  // the launch's ray counter is used up
     uint32_t abort;    // safety net tripped: every wave leaves
     uint32_t cur_seq;  // the update whose rays the workgroup claims (frames in flight: the launch's own, then the ones chained to it)
+#if DDGI_AQ_STAGING
+    uint32_t sq_room[kAqStagingQueues];  // free entries of a staging ring (taken by a producer before it reserves an index, given back by the consumer)
+#else
     uint32_t pad[32 - 4 - 2 * kAqEventQueues - 4];
+#endif
 };
-static_assert(sizeof(AqShared) == 32 * 4, "control block is 32 dwords");
+static_assert(sizeof(AqShared) == kAqCtrlDwords * 4, "the control block's size");
 
 // The queue kernel's arguments as an event group reads them.  The kernel is one persistent loop around a very large body; its
 // arguments are invariant loads, which the optimizer hoists out of that loop — a hundred scalars live across everything, most
@@ -1535,7 +1555,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
     const int scene_words = Cfg::kFast ? A.scene.nwords_skip : A.scene.nwords;
     const uint32_t* __restrict__ scene_src = Cfg::kFast ? A.scene.skip : A.scene.bits;
     AqShared* sh = reinterpret_cast<AqShared*>(wf_lds);
-    uint32_t* s_bits = wf_lds + 32;
+    uint32_t* s_bits = wf_lds + kAqCtrlDwords;
     uint32_t* cursor = s_bits + ((scene_words + 3) & ~3);
     WfPool P;
     auto takef = [&]() { float* p = reinterpret_cast<float*>(cursor); cursor += PS; return p; };
@@ -1556,16 +1576,50 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
     uint16_t* ring_mq = reinterpret_cast<uint16_t*>(cursor);
     uint16_t* ring_fq = ring_mq + kCap;
     uint16_t* ring_eq = ring_fq + kCap;  // kAqEventQueues rings
+    [[maybe_unused]] uint16_t* ring_sq = ring_eq + kCap * kAqEventQueues;  // DDGI_AQ_STAGING: kAqStagingQueues rings of kAqSq entries
+    // (staging is used by the records instantiations while a launch may go on with later updates; the rings exist in every instantiation of a staging build)
+    [[maybe_unused]] const bool staging = DDGI_AQ_STAGING && Cfg::kRecords && C.chain_max != 0u;
 
     for (int i = tid; i < scene_words; i += T) s_bits[i] = scene_src[i];
     for (uint32_t i = tid; i < PS; i += T) P.flags[i] = kSlotEmpty;
-    for (uint32_t i = tid; i < kCap * (2 + kAqEventQueues); i += T) ring_mq[i] = 0xffffu;
+    for (uint32_t i = tid; i < kCap * (2 + kAqEventQueues) + (DDGI_AQ_STAGING ? kAqSq * kAqStagingQueues : 0u); i += T) ring_mq[i] = 0xffffu;
     __syncthreads();
     for (uint32_t i = tid; i < PS; i += T) ring_fq[i] = static_cast<uint16_t>(i);  // every slot starts free
-    if (tid < 32) wf_lds[tid] = 0u;
+    if (tid < kAqCtrlDwords) wf_lds[tid] = 0u;
     __syncthreads();
     if (tid == 0) sh->fq_tail = PS, sh->cur_seq = C.seq;
+#if DDGI_AQ_STAGING
+    if (tid < kAqStagingQueues) sh->sq_room[tid] = kAqSq;
+#endif
     __syncthreads();
+
+    // One lane: an event-queue entry for bucket `bk`.  Staging build: into the staging ring of the ray's update's parity while that ring has room.
+    auto push_event = [&](uint32_t bk, uint32_t slot_) {
+#if DDGI_AQ_STAGING
+        if (staging)
+        {
+            const uint32_t si = bk * 2u + ((P.dst[slot_] >> kDstPairShift) & 1u);
+            if (static_cast<int32_t>(atomicSub(&sh->sq_room[si], 1u)) > 0)
+            {
+                const uint32_t at = atomicAdd(&sh->eq_tail[kAqEventQueues + si], 1u);
+                uint16_t* const q = ring_sq + si * kAqSq + (at & (kAqSq - 1u));
+                // (a 128-entry ring wraps onto entries a slow wave has claimed and not yet read: wait for the place to be empty.  The claimer only has to
+                //  read it — it waits for nobody)
+                for (int spins = 0; __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0xffffu; ++spins)
+                    if (spins > (1 << 22))
+                    {
+                        sh->abort = 1u;
+                        break;
+                    }
+                __hip_atomic_store(q, static_cast<uint16_t>(slot_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return;
+            }
+            atomicAdd(&sh->sq_room[si], 1u);
+        }
+#endif
+        const uint32_t at = atomicAdd(&sh->eq_tail[bk], 1u);
+        (ring_eq + bk * kCap)[at % kCap] = static_cast<uint16_t>(slot_);
+    };
 
     // (the march waves' only use of a record is the routing HINT of a hit — dead_feeler_hint, never a result: the launch's own)
     const typename Upd::Type U0 = Upd::make(A, upd_record(0u));
@@ -1665,11 +1719,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             if (__ballot(finished) != 0ull)
             {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (finished)
-                {
-                    const uint32_t at = atomicAdd(&sh->eq_tail[bucket], 1u);
-                    (ring_eq + bucket * kCap)[at % kCap] = static_cast<uint16_t>(slot);
-                }
+                if (finished) push_event(bucket, slot);
             }
         }
     }
@@ -2088,11 +2138,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 // cheaper than six wave-aggregated appends
 #pragma unroll
                 for (int q = 0; q < kM; ++q)
-                    if (finished[q])
-                    {
-                        const uint32_t at = atomicAdd(&sh->eq_tail[bucket[q]], 1u);
-                        (ring_eq + bucket[q] * kCap)[at % kCap] = static_cast<uint16_t>(slot[q]);
-                    }
+                    if (finished[q]) push_event(bucket[q], slot[q]);
             }
             DDGI_MARK("march_trip_end");
         }
@@ -2117,9 +2163,16 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             // Which group?  Lanes 0..5 look at one event queue each (polling is paid in VALU issue slots that
             // the marching waves of the same SIMD want, so it is kept to a handful of instructions).
             uint32_t b = 0, base = 0, k = 0;
+            [[maybe_unused]] uint32_t qi = 0;  // the queue the group comes from (== b unless it is a staging ring)
             uint32_t avail = 0;
             uint32_t head_seen = 0;
+            // (staging build, records + frames in flight: lanes kAqEventQueues .. also look at the staging rings — the same two loads, more lanes)
+            [[maybe_unused]] const int n_queues = staging ? kAqAllQueues : kAqEventQueues;
+#if DDGI_AQ_STAGING
+            if (lane < n_queues) head_seen = aq_load(&sh->eq_head[lane]), avail = aq_load(&sh->eq_tail[lane]) - head_seen;
+#else
             if (lane < kAqEventQueues) head_seen = aq_load(&sh->eq_head[lane]), avail = aq_load(&sh->eq_tail[lane]) - head_seen;
+#endif
 #if DDGI_AQ_UNIFIED
             // UNIFIED WAVES.  With waves set aside for marching, a march wave steps whatever the queue holds at that moment (30 of 64 lanes
             // per burst, 0.30 of a burst's lane-steps useful: 54 % of the kernel's VALU instructions) while the slots pile up in front of
@@ -2135,7 +2188,11 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             if (lane == kAqEventQueues) avail = aq_load(&sh->fq_tail) - aq_load(&sh->fq_head);
 #endif
             if (avail > kCap) avail = 0;  // a claim in flight can make tail - head wrap for an instant
+#if DDGI_AQ_STAGING
+            const unsigned long long full = __ballot(avail >= 64u && lane < n_queues);
+#else
             const unsigned long long full = __ballot(avail >= 64u && lane < kAqEventQueues);
+#endif
             const bool no_more = aq_load(&sh->no_more) != 0u;
 #if DDGI_AQ_UNIFIED
             bool uni_chosen = false;
@@ -2296,7 +2353,24 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             {
                 // 1) a full group
 #if DDGI_AQ_PICK == 1   // the highest full bucket first: dead hits, feelers, misses (short events that free slots or unblock a ray) before the shading buckets
-                b = static_cast<uint32_t>(63 - __clzll(static_cast<long long>(full)));
+                b = static_cast<uint32_t>(63 - __clzll(static_cast<long long>(full)));  // (staging build: a QUEUE index — the staging rings lie above the buckets' and are served first)
+                qi = b;
+#if DDGI_AQ_STAGING == 2
+                // (variant 2) bucket by bucket, the highest first; within a bucket its own ring before its staging rings: what did not fit the staging rings is the older
+                if (staging)
+                {
+                    bool found = false;
+#pragma unroll
+                    for (int bb = kAqEventQueues - 1; bb >= 0; --bb)
+                    {
+                        const uint32_t s1 = static_cast<uint32_t>(kAqEventQueues + 2 * bb + 1), s0 = s1 - 1u;
+                        const uint32_t pick = ((full >> bb) & 1ull) ? static_cast<uint32_t>(bb) : (((full >> s1) & 1ull) ? s1 : (((full >> s0) & 1ull) ? s0 : 0xffu));
+                        if (!found && pick != 0xffu) qi = pick, found = true;
+                    }
+                }
+#endif
+                if (DDGI_AQ_STAGING && qi >= static_cast<uint32_t>(kAqEventQueues)) b = (qi - static_cast<uint32_t>(kAqEventQueues)) >> 1;
+                else b = qi;
 #elif DDGI_AQ_PICK == 3  // (experiment) a fixed order of the buckets, DDGI_AQ_PICK_ORDER
                 {
                     constexpr int order[kAqEventQueues] = {DDGI_AQ_PICK_ORDER};
@@ -2317,11 +2391,11 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
 #if DDGI_AQ_QUICK
                 // the queue held 64 entries above the head this wave has just read: claim them with that value (one trip to the LDS
                 // instead of aq_claim's two); only if another wave got there first is the queue looked at again
-                const uint32_t h0 = lane_bcast(head_seen, static_cast<int>(b));
+                const uint32_t h0 = lane_bcast(head_seen, static_cast<int>(qi));
                 if (lane == 0)
                 {
-                    if (atomicCAS(&sh->eq_head[b], h0, h0 + 64u) == h0) k = 64u, base = h0;
-                    else k = aq_claim(&sh->eq_head[b], &sh->eq_tail[b], 64u, base);
+                    if (atomicCAS(&sh->eq_head[qi], h0, h0 + 64u) == h0) k = 64u, base = h0;
+                    else k = aq_claim(&sh->eq_head[qi], &sh->eq_tail[qi], 64u, base);
                 }
 #else
                 if (lane == 0) k = aq_claim(&sh->eq_head[b], &sh->eq_tail[b], 64u, base);
@@ -2342,14 +2416,15 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 {
                     uint32_t best = 0, best_n = 0;
 #pragma unroll
-                    for (int bb = 0; bb < kAqEventQueues; ++bb)
+                    for (int bb = 0; bb < kAqAllQueues; ++bb)
                     {
-                        const uint32_t n = lane_bcast(avail, bb);
+                        const uint32_t n = (!DDGI_AQ_STAGING || bb < n_queues) ? lane_bcast(avail, bb) : 0u;
                         if (n > best_n) best = static_cast<uint32_t>(bb), best_n = n;
                     }
                     if (best_n >= (no_more ? 1u : static_cast<uint32_t>(DDGI_AQ_PARTIAL_MIN)))
                     {
-                        b = best;
+                        b = qi = best;
+                        if (DDGI_AQ_STAGING && qi >= static_cast<uint32_t>(kAqEventQueues)) b = (qi - static_cast<uint32_t>(kAqEventQueues)) >> 1;
                         if (lane == 0) k = aq_claim(&sh->eq_head[best], &sh->eq_tail[best], 64u, base);
                     }
                 }
@@ -2426,7 +2501,15 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 uint32_t t = 0u;  // which update after the launch's own the group's rays belong to
                 if (valid)
                 {
-                    slot = aq_take<kCap>(ring_eq + b * kCap, base + lane, &sh->abort);
+#if DDGI_AQ_STAGING
+                    if (qi >= static_cast<uint32_t>(kAqEventQueues))
+                    {
+                        slot = aq_take<kAqSq>(ring_sq + (qi - static_cast<uint32_t>(kAqEventQueues)) * kAqSq, base + lane, &sh->abort);
+                        if (lane == 0) atomicAdd(&sh->sq_room[qi - static_cast<uint32_t>(kAqEventQueues)], k);  // (behind this wave's reads of the entries: LDS operations of a wave are in order)
+                    }
+                    else
+#endif
+                        slot = aq_take<kCap>(ring_eq + b * kCap, base + lane, &sh->abort);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
                 if (Cfg::kRecords && C.chain_max)
@@ -2479,11 +2562,20 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 uint32_t b_mq = 0, b_fq = 0, at_eq = 0;
                 if (m_mq != 0ull && lane == l_mq) b_mq = atomicAdd(&sh->mq_tail, static_cast<uint32_t>(__popcll(m_mq)));
                 if (m_fq != 0ull && lane == l_fq) b_fq = atomicAdd(&sh->fq_tail, static_cast<uint32_t>(__popcll(m_fq)));
-                if (ev_bucket >= 0) at_eq = atomicAdd(&sh->eq_tail[ev_bucket], 1u);
+                [[maybe_unused]] bool ev_staged = false;
+#if DDGI_AQ_STAGING
+                // (a finished march's entry: the staging ring of its update's parity while that has room — one more trip to the LDS than the bucket's ring)
+                if (ev_bucket >= 0 && staging)
+                {
+                    push_event(static_cast<uint32_t>(ev_bucket), slot);
+                    ev_staged = true;
+                }
+#endif
+                if (ev_bucket >= 0 && !ev_staged) at_eq = atomicAdd(&sh->eq_tail[ev_bucket], 1u);
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (to_mq) ring_mq[(lane_bcast(b_mq, l_mq) + static_cast<uint32_t>(__popcll(m_mq & below))) % kCap] = static_cast<uint16_t>(slot);
                 if (freed) ring_fq[(lane_bcast(b_fq, l_fq) + static_cast<uint32_t>(__popcll(m_fq & below))) % kCap] = static_cast<uint16_t>(slot);
-                if (ev_bucket >= 0) (ring_eq + ev_bucket * kCap)[at_eq % kCap] = static_cast<uint16_t>(slot);
+                if (ev_bucket >= 0 && !ev_staged) (ring_eq + ev_bucket * kCap)[at_eq % kCap] = static_cast<uint16_t>(slot);
             }
 #else
             aq_push<kCap>(ring_mq, &sh->mq_tail, posted && !(Cfg::ablate(A) & 8), slot, lane);  // DDGI_ABLATE=8: fault injection for the safety-net test
@@ -2536,7 +2628,8 @@ static size_t aq_lds_bytes(int nwords, int pool, bool fast = false, size_t ring_
 #ifdef DDGI_LAP
     extra += 16 * 32 * 4;  // the lap timers' scratch, one row per wave
 #endif
-    return (32 + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * (fast ? kPoolDwordsFast : kPoolDwords) * 4 + ring_cap * 2 * (2 + kAqEventQueues) + extra;
+    if (DDGI_AQ_STAGING) extra += kAqSq * 2 * kAqStagingQueues;  // the staging rings (the cave leaves 3.8 KB beside a pool of 1 344: 3.6 KB of rings + 128 B of control block fit)
+    return (kAqCtrlDwords + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * (fast ? kPoolDwordsFast : kPoolDwords) * 4 + ring_cap * 2 * (2 + kAqEventQueues) + extra;
 }
 
 int aq_pool_size(int nwords, size_t lds_limit)
