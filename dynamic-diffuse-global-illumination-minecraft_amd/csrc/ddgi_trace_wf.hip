@@ -1395,15 +1395,22 @@ constexpr int kAqEventQueues = 7;  // buckets 0..6 (kBucketRefill is served from
 // In front of every bucket's ring stand two small rings, one per PARITY of the update a ray belongs to: a push goes there while there is room (a counting
 // semaphore per ring: a reservation that fails must not consume a ring index), else into the bucket's ring as before; event waves serve the staging rings first.
 // A group from a staging ring is pure unless three updates meet (k and k + 2 share a parity): the mixed-group handling stays for every queue.
+// MEASURED (profiles/r06_staging_ab.txt, same box, bit-exact: 69 tests): C3 DDGI at eight frames in flight 1.656 -> 1.960 ms per update, a G = 8 slab 0.328 -> 0.369 - 0.410 ms,
+// unchanged where no launch goes on with a later update.  Every event entry pays three more trips to the LDS (the ray's update, the semaphore, the ring's place) on the waves that
+// bound the kernel, and what does not fit a 128-entry ring waits in the bucket's own ring behind it.  Serving a bucket's own ring first was no better (1.93 ms).  OFF.
 #ifndef DDGI_AQ_STAGING
 #define DDGI_AQ_STAGING 0
 #endif
 #if DDGI_AQ_STAGING && (DDGI_AQ_UNIFIED || DDGI_AQ_REFILL_FIRST || DDGI_AQ_REQUEUE || (DDGI_AQ_PICK != 1) || !DDGI_AQ_QUICK)
 #error "DDGI_AQ_STAGING is written for the default event-wave loop (DDGI_AQ_PICK 1, DDGI_AQ_QUICK 1, no unified waves / refill-first / requeue experiments)"
 #endif
+// VARIANT 3 (-DDDGI_AQ_STAGING=3 -DDDGI_AQ_POOL_CT=1216): no staging in front of anything — the event rings themselves are one per (bucket, parity), each deep enough
+// for the whole pool (kAqEvCap3 entries: pool + 256), paid for with 128 of the pool's slots; where no launch goes on with a later update the first seven serve as the
+// buckets' rings.  One ring per entry, no semaphore: an entry costs what it costs today plus the read of its ray's update.
 constexpr uint32_t kAqSq = 128;                                  // entries per staging ring (a power of two)
+constexpr uint32_t kAqEvCap3 = 1472;                             // variant 3: entries per event ring
 constexpr int kAqStagingQueues = 2 * kAqEventQueues;             // (bucket, parity)
-constexpr int kAqAllQueues = DDGI_AQ_STAGING ? kAqEventQueues + kAqStagingQueues : kAqEventQueues;
+constexpr int kAqAllQueues = DDGI_AQ_STAGING == 3 ? kAqStagingQueues : (DDGI_AQ_STAGING ? kAqEventQueues + kAqStagingQueues : kAqEventQueues);
 constexpr int kAqCtrlDwords = DDGI_AQ_STAGING ? 64 : 32;
 
 struct AqShared  // control block at the start of dynamic LDS (kAqCtrlDwords dwords)
@@ -1415,7 +1422,9 @@ struct AqShared  // control block at the start of dynamic LDS (kAqCtrlDwords dwo
     uint32_t no_more;  // the launch's ray counter is used up
     uint32_t abort;    // safety net tripped: every wave leaves
     uint32_t cur_seq;  // the update whose rays the workgroup claims (frames in flight: the launch's own, then the ones chained to it)
-#if DDGI_AQ_STAGING
+#if DDGI_AQ_STAGING == 3
+    uint32_t pad[64 - 4 - 2 * kAqAllQueues - 4];
+#elif DDGI_AQ_STAGING
     uint32_t sq_room[kAqStagingQueues];  // free entries of a staging ring (taken by a producer before it reserves an index, given back by the consumer)
 #else
     uint32_t pad[32 - 4 - 2 * kAqEventQueues - 4];
@@ -1582,20 +1591,28 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
 
     for (int i = tid; i < scene_words; i += T) s_bits[i] = scene_src[i];
     for (uint32_t i = tid; i < PS; i += T) P.flags[i] = kSlotEmpty;
-    for (uint32_t i = tid; i < kCap * (2 + kAqEventQueues) + (DDGI_AQ_STAGING ? kAqSq * kAqStagingQueues : 0u); i += T) ring_mq[i] = 0xffffu;
+    constexpr uint32_t kEvCap = DDGI_AQ_STAGING == 3 ? kAqEvCap3 : kCap;  // entries per event ring
+    for (uint32_t i = tid; i < (DDGI_AQ_STAGING == 3 ? kCap * 2 + kAqEvCap3 * kAqStagingQueues : kCap * (2 + kAqEventQueues) + (DDGI_AQ_STAGING ? kAqSq * kAqStagingQueues : 0u)); i += T) ring_mq[i] = 0xffffu;
     __syncthreads();
     for (uint32_t i = tid; i < PS; i += T) ring_fq[i] = static_cast<uint16_t>(i);  // every slot starts free
     if (tid < kAqCtrlDwords) wf_lds[tid] = 0u;
     __syncthreads();
     if (tid == 0) sh->fq_tail = PS, sh->cur_seq = C.seq;
-#if DDGI_AQ_STAGING
+#if DDGI_AQ_STAGING && DDGI_AQ_STAGING != 3
     if (tid < kAqStagingQueues) sh->sq_room[tid] = kAqSq;
 #endif
     __syncthreads();
 
     // One lane: an event-queue entry for bucket `bk`.  Staging build: into the staging ring of the ray's update's parity while that ring has room.
     auto push_event = [&](uint32_t bk, uint32_t slot_) {
-#if DDGI_AQ_STAGING
+#if DDGI_AQ_STAGING == 3
+        {
+            const uint32_t r = staging ? bk * 2u + ((P.dst[slot_] >> kDstPairShift) & 1u) : bk;
+            const uint32_t at = atomicAdd(&sh->eq_tail[r], 1u);
+            (ring_eq + r * kEvCap)[at % kEvCap] = static_cast<uint16_t>(slot_);
+            return;
+        }
+#elif DDGI_AQ_STAGING
         if (staging)
         {
             const uint32_t si = bk * 2u + ((P.dst[slot_] >> kDstPairShift) & 1u);
@@ -1618,7 +1635,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
         }
 #endif
         const uint32_t at = atomicAdd(&sh->eq_tail[bk], 1u);
-        (ring_eq + bk * kCap)[at % kCap] = static_cast<uint16_t>(slot_);
+        (ring_eq + bk * kEvCap)[at % kEvCap] = static_cast<uint16_t>(slot_);
     };
 
     // (the march waves' only use of a record is the routing HINT of a hit — dead_feeler_hint, never a result: the launch's own)
@@ -2167,7 +2184,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             uint32_t avail = 0;
             uint32_t head_seen = 0;
             // (staging build, records + frames in flight: lanes kAqEventQueues .. also look at the staging rings — the same two loads, more lanes)
-            [[maybe_unused]] const int n_queues = staging ? kAqAllQueues : kAqEventQueues;
+            [[maybe_unused]] const int n_queues = staging ? kAqAllQueues : kAqEventQueues;  // (variant 3: 14 rings by (bucket, parity), or the first 7 by bucket)
 #if DDGI_AQ_STAGING
             if (lane < n_queues) head_seen = aq_load(&sh->eq_head[lane]), avail = aq_load(&sh->eq_tail[lane]) - head_seen;
 #else
@@ -2355,22 +2372,12 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
 #if DDGI_AQ_PICK == 1   // the highest full bucket first: dead hits, feelers, misses (short events that free slots or unblock a ray) before the shading buckets
                 b = static_cast<uint32_t>(63 - __clzll(static_cast<long long>(full)));  // (staging build: a QUEUE index — the staging rings lie above the buckets' and are served first)
                 qi = b;
-#if DDGI_AQ_STAGING == 2
-                // (variant 2) bucket by bucket, the highest first; within a bucket its own ring before its staging rings: what did not fit the staging rings is the older
-                if (staging)
-                {
-                    bool found = false;
-#pragma unroll
-                    for (int bb = kAqEventQueues - 1; bb >= 0; --bb)
-                    {
-                        const uint32_t s1 = static_cast<uint32_t>(kAqEventQueues + 2 * bb + 1), s0 = s1 - 1u;
-                        const uint32_t pick = ((full >> bb) & 1ull) ? static_cast<uint32_t>(bb) : (((full >> s1) & 1ull) ? s1 : (((full >> s0) & 1ull) ? s0 : 0xffu));
-                        if (!found && pick != 0xffu) qi = pick, found = true;
-                    }
-                }
-#endif
+#if DDGI_AQ_STAGING == 3
+                b = staging ? qi >> 1 : qi;
+#else
                 if (DDGI_AQ_STAGING && qi >= static_cast<uint32_t>(kAqEventQueues)) b = (qi - static_cast<uint32_t>(kAqEventQueues)) >> 1;
                 else b = qi;
+#endif
 #elif DDGI_AQ_PICK == 3  // (experiment) a fixed order of the buckets, DDGI_AQ_PICK_ORDER
                 {
                     constexpr int order[kAqEventQueues] = {DDGI_AQ_PICK_ORDER};
@@ -2424,7 +2431,11 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                     if (best_n >= (no_more ? 1u : static_cast<uint32_t>(DDGI_AQ_PARTIAL_MIN)))
                     {
                         b = qi = best;
+#if DDGI_AQ_STAGING == 3
+                        b = staging ? qi >> 1 : qi;
+#else
                         if (DDGI_AQ_STAGING && qi >= static_cast<uint32_t>(kAqEventQueues)) b = (qi - static_cast<uint32_t>(kAqEventQueues)) >> 1;
+#endif
                         if (lane == 0) k = aq_claim(&sh->eq_head[best], &sh->eq_tail[best], 64u, base);
                     }
                 }
@@ -2501,15 +2512,19 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 uint32_t t = 0u;  // which update after the launch's own the group's rays belong to
                 if (valid)
                 {
-#if DDGI_AQ_STAGING
+#if DDGI_AQ_STAGING == 3
+                    slot = aq_take<kEvCap>(ring_eq + qi * kEvCap, base + lane, &sh->abort);
+#elif DDGI_AQ_STAGING
                     if (qi >= static_cast<uint32_t>(kAqEventQueues))
                     {
                         slot = aq_take<kAqSq>(ring_sq + (qi - static_cast<uint32_t>(kAqEventQueues)) * kAqSq, base + lane, &sh->abort);
                         if (lane == 0) atomicAdd(&sh->sq_room[qi - static_cast<uint32_t>(kAqEventQueues)], k);  // (behind this wave's reads of the entries: LDS operations of a wave are in order)
                     }
                     else
-#endif
                         slot = aq_take<kCap>(ring_eq + b * kCap, base + lane, &sh->abort);
+#else
+                    slot = aq_take<kCap>(ring_eq + b * kCap, base + lane, &sh->abort);
+#endif
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
                 if (Cfg::kRecords && C.chain_max)
@@ -2534,8 +2549,12 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                     const bool other = valid && tagv != t;
                     if (__ballot(other) != 0ull)
                     {
+#if DDGI_AQ_STAGING == 3
+                        if (other) push_event(b, slot);  // (variant 3: each to the ring of its own update's parity — three updates meeting: k and k + 2 share one)
+#else
                         const uint32_t at = wave_append(other, &sh->eq_tail[b], lane);
                         if (other) (ring_eq + b * kCap)[at % kCap] = static_cast<uint16_t>(slot);
+#endif
                         mine = valid && !other;
                     }
                 }
@@ -2563,7 +2582,13 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 if (m_mq != 0ull && lane == l_mq) b_mq = atomicAdd(&sh->mq_tail, static_cast<uint32_t>(__popcll(m_mq)));
                 if (m_fq != 0ull && lane == l_fq) b_fq = atomicAdd(&sh->fq_tail, static_cast<uint32_t>(__popcll(m_fq)));
                 [[maybe_unused]] bool ev_staged = false;
-#if DDGI_AQ_STAGING
+#if DDGI_AQ_STAGING == 3
+                if (ev_bucket >= 0)
+                {
+                    push_event(static_cast<uint32_t>(ev_bucket), slot);
+                    ev_staged = true;
+                }
+#elif DDGI_AQ_STAGING
                 // (a finished march's entry: the staging ring of its update's parity while that has room — one more trip to the LDS than the bucket's ring)
                 if (ev_bucket >= 0 && staging)
                 {
@@ -2628,8 +2653,9 @@ static size_t aq_lds_bytes(int nwords, int pool, bool fast = false, size_t ring_
 #ifdef DDGI_LAP
     extra += 16 * 32 * 4;  // the lap timers' scratch, one row per wave
 #endif
-    if (DDGI_AQ_STAGING) extra += kAqSq * 2 * kAqStagingQueues;  // the staging rings (the cave leaves 3.8 KB beside a pool of 1 344: 3.6 KB of rings + 128 B of control block fit)
-    return (kAqCtrlDwords + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * (fast ? kPoolDwordsFast : kPoolDwords) * 4 + ring_cap * 2 * (2 + kAqEventQueues) + extra;
+    if (DDGI_AQ_STAGING && DDGI_AQ_STAGING != 3) extra += kAqSq * 2 * kAqStagingQueues;  // the staging rings (the cave leaves 3.8 KB beside a pool of 1 344: 3.6 KB of rings + 128 B of control block fit)
+    const size_t rings = DDGI_AQ_STAGING == 3 ? ring_cap * 2 * 2 + static_cast<size_t>(kAqEvCap3) * 2 * kAqStagingQueues : ring_cap * 2 * (2 + kAqEventQueues);
+    return (kAqCtrlDwords + ((nwords + 3) & ~3)) * sizeof(uint32_t) + static_cast<size_t>(pool) * (fast ? kPoolDwordsFast : kPoolDwords) * 4 + rings + extra;
 }
 
 int aq_pool_size(int nwords, size_t lds_limit)
