@@ -1407,6 +1407,8 @@ constexpr int kAqEventQueues = 7;  // buckets 0..6 (kBucketRefill is served from
 // VARIANT 3 (-DDDGI_AQ_STAGING=3 -DDDGI_AQ_POOL_CT=1216): no staging in front of anything — the event rings themselves are one per (bucket, parity), each deep enough
 // for the whole pool (kAqEvCap3 entries: pool + 256), paid for with 128 of the pool's slots; where no launch goes on with a later update the first seven serve as the
 // buckets' rings.  One ring per entry, no semaphore: an entry costs what it costs today plus the read of its ray's update.
+// MEASURED (profiles/r06_staging_ab.txt, bit-exact): a G = 8 DDGI slab 0.325 - 0.340 -> 0.329 ms (nothing), the whole grid at eight frames in flight 1.654 -> 1.819 ms, REF 1.487 -> 1.537:
+// rays split over twice as many rings fill a 64-lane group half as often — the lanes a mixed group loses become groups that wait or go partial.  OFF.
 constexpr uint32_t kAqSq = 128;                                  // entries per staging ring (a power of two)
 constexpr uint32_t kAqEvCap3 = 1472;                             // variant 3: entries per event ring
 constexpr int kAqStagingQueues = 2 * kAqEventQueues;             // (bucket, parity)
