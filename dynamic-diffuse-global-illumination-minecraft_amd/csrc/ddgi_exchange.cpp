@@ -820,7 +820,12 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
         job->flags = a.flags, job->ring[0] = a.ring[0], job->ring[1] = a.ring[1];
         job->device = e->device, job->rank = e->rank, job->world = world, job->q = q, job->say = e->tuning.verbose != 0;
         if (job->say) std::fprintf(stderr, "[ddgi p2p, rank %d of %d] mapping rank %d (pid %d): flags, then 2 rings of %u pairs, %.1f + %.1f MB per pair\n", e->rank, world, q, a.pid, a.np, a.tex_bytes[0] / 1e6, a.tex_bytes[1] / 1e6);
-        auto work = [job]() {
+        bool stall = false;
+#ifdef DDGI_PROFILING
+        stall = (e->tuning.ablate & 64) != 0;  // fault injection (profiling build only, tuning "ablate" 64): the mapping thread does not come back for a minute
+#endif
+        auto work = [job, stall]() {
+            if (stall) std::this_thread::sleep_for(std::chrono::seconds(60));
             hipError_t r = hipSetDevice(job->device);
             for (int i = 0; i < 3 && r == hipSuccess; ++i)
             {

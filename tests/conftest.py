@@ -18,7 +18,7 @@ def pytest_configure(config):
 # that spawns PROCESSES comes last, so that plumbing can never again hide parity.  Files not listed keep their alphabetical place in the middle.
 _FIRST = ["test_golden", "test_gpu_parity", "test_gpu_ray_tile", "test_gpu_ddgi_mode", "test_gpu_ddgi_frames_in_flight", "test_gpu_render",
           "test_gpu_user_scene", "test_gpu_reconfigure", "test_gpu_edge_cases", "test_gpu_frames_in_flight", "test_gpu_fast_march"]
-_LAST = ["test_gpu_exchange", "test_gpu_timeout", "test_host_cpp", "test_zz_gpu_exchange_p2p", "test_zz_gpu_peer_loss"]
+_LAST = ["test_gpu_exchange", "test_host_cpp", "test_zz_gpu_exchange_p2p", "test_zz_gpu_peer_loss"]
 
 
 def _file_rank(item):

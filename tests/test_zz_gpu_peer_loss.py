@@ -129,3 +129,76 @@ def test_survivors_of_a_lost_rank_time_out_name_it_and_stay_usable(ddgi, pipelin
             p.join(timeout=10)
             if p.is_alive():
                 p.kill()  # (exactly the process started above)
+
+
+def _mapping_worker(rank, conn, limit_ms):
+    sys.path.insert(0, ROOT)
+    try:
+        import ddgi_amd as ddgi
+
+        ddgi.load_library()
+        counts, side, s, origin, scene = CONFIGS[NAME]
+        eng = ddgi.ProbeEngine(ddgi.make_field(counts, side, s, origin), ddgi.make_settings(scene, 8), device=0, rank=rank, world=WORLD)
+        eng.set_tuning("wait_timeout_ms", limit_ms)
+        eng.set_tuning("ablate", 64)               # (profiling build: the thread that maps a peer's buffers sleeps for a minute)
+        eng.generate_probe_rays(seed=1)
+        conn.send(("address", eng.exchange_p2p_export(True)))
+        everyone = conn.recv()
+        t0 = time.monotonic()
+        try:
+            eng.exchange_p2p_init(everyone)
+            outcome = "no error"
+        except ddgi.DDGIError as exc:
+            outcome = (exc.code, str(exc))
+        seconds = time.monotonic() - t0
+        eng.set_tuning("ablate", 0)
+        eng.probe_update()                         # the handle is on its own again (the failed init released the exchange) and works
+        eng.synchronize()
+        alone = bool(eng.read_textures()[0].any())
+        conn.send(("report", dict(outcome=outcome, seconds=seconds, transport=eng.exchange_transport()[0], alone=alone)))
+        conn.recv()
+        eng.close()
+    except Exception as exc:  # noqa: BLE001
+        conn.send(("error", repr(exc)))
+
+
+def test_a_peer_mapping_that_does_not_come_back_is_a_timeout_not_a_hang(ddgi):
+    """hipIpcOpenMemHandle is a driver call that can stand forever (round 6: a texture ring of 2 GiB or more inside an engine's process,
+    profiles/r06_p2p_ring_size_bisection.txt).  ddgi_exchange_p2p_init runs it on a helper thread and waits with tuning "wait_timeout_ms":
+    here the profiling build's fault injection (tuning "ablate" 64) keeps that thread asleep — every rank must get DDGI_ERR_TIMEOUT naming
+    the peer and the buffer within the deadline, be left without an exchange, and go on working alone."""
+    limit_ms = 1500
+    os.environ["DDGI_LIB"] = ddgi.build_profiling_library()
+    try:
+        ctx = mp.get_context("spawn")
+        pipes = [ctx.Pipe() for _ in range(WORLD)]
+        procs = [ctx.Process(target=_mapping_worker, args=(r, pipes[r][1], limit_ms), daemon=True) for r in range(WORLD)]
+        for p in procs:
+            p.start()
+    finally:
+        os.environ.pop("DDGI_LIB", None)
+    conns = [pp[0] for pp in pipes]
+    try:
+        addresses = []
+        for r in range(WORLD):
+            assert conns[r].poll(60), f"rank {r} did not export in time"
+            tag, payload = conns[r].recv()
+            assert tag == "address", (r, tag, payload)
+            addresses.append(payload)
+        for c in conns:
+            c.send(addresses)
+        for r in range(WORLD):
+            assert conns[r].poll(60), f"rank {r} did not report in time"
+            tag, rep = conns[r].recv()
+            assert tag == "report", (r, tag, rep)
+            code, text = rep["outcome"]
+            assert code == ddgi.ERR_TIMEOUT and "hipIpcOpenMemHandle of rank" in text and "did not return within 1500 ms" in text, rep
+            assert limit_ms / 1000 * 0.9 <= rep["seconds"] <= limit_ms / 1000 + 5, rep
+            assert rep["transport"] == "none" and rep["alone"], rep
+        for c in conns:
+            c.send("bye")
+    finally:
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()  # (exactly the process started above)
