@@ -269,6 +269,9 @@ def main():
                          "region runs under the faster (multi_gpu.by_transport reports both).  A transport that cannot be brought up (an error, "
                          "or for RCCL no answer within --rccl-timeout seconds) is reported by name with the reason (config.exchange_fallback)")
     ap.add_argument("--rccl-timeout", type=float, default=90.0)
+    ap.add_argument("--wait-timeout", type=float, default=30.0,
+                    help="N > 1: seconds any wait for another rank may take inside the library (tuning \"wait_timeout_ms\"; the library's own default is 10 s — "
+                         "a first collective over a fresh communicator may take longer than a frame ever does) before it returns DDGI_ERR_TIMEOUT naming the rank that is behind")
     ap.add_argument("--p2p-timeout", type=float, default=120.0, help="seconds the peer-to-peer transport gets to map its peers' buffers")
     ap.add_argument("--frames-in-flight", type=int, default=None, help="tuning \"frames_in_flight\" (default: the library's, 8; the reference's host runs MAX_FRAMES_IN_FLIGHT = 2 ahead)")
     args = ap.parse_args()
@@ -334,6 +337,8 @@ def main():
     eng.set_stream(stream.cuda_stream)          # kernels + collectives share torch's stream
     if args.frames_in_flight is not None:
         eng.set_tuning("frames_in_flight", args.frames_in_flight)
+    if sharded:
+        eng.set_tuning("wait_timeout_ms", int(args.wait_timeout * 1000))   # every cross-rank wait of the timed loop is bounded (DDGI_ERR_TIMEOUT, not a hang)
     ddgi_mode = args.mode == "ddgi"
     setup_ms["create_handle_and_textures"] = (time.perf_counter() - t_setup) * 1e3
     t_setup = time.perf_counter()
