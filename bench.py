@@ -392,22 +392,15 @@ def main():
         why = None
         t_up = time.perf_counter()
         stages = bring_up_s.setdefault("p2p", {})
-        # The largest buffer a peer would have to map: the larger texture's ring (2 pairs at least under the pipelined exchange).  On the stack measured,
-        # hipIpcOpenMemHandle of a buffer of 2 GiB or more does not come back (round 6: bisected on ring sizes, tools/r06_probe4.sh; the library gives the call
-        # a deadline, but the helper thread it leaves behind stands inside the HIP runtime) — such grids (C5) go straight to RCCL.
-        if ddgi_mode:
-            per_pair, pairs = eng.num_probes * 2048, 2          # the depth tiles; DDGI's frames in flight are record buffers, not texture pairs
-        else:
-            per_pair = eng.num_rays * 4                         # (the rule of csrc/ddgi_engine.cpp: chain_len_for under the pipelined exchange)
-            n = max(1, min(8, eng.get_tuning("frames_in_flight")))
-            while n > 2 and per_pair * 2 * n * 2 > (2 << 30):
-                n //= 2
-            while n > 1 and eng.num_rays * n > (64 << 20):
-                n //= 2
-            pairs = max(2, 2 * n)
-        if per_pair * pairs >= (2 << 30) and os.environ.get("DDGI_BENCH_P2P_ANY_SIZE") != "1":
+        # The largest buffer a peer would have to map.  On the stack measured a buffer of 2 GiB or more is not handed to another process reliably (round 6:
+        # hipIpcOpenMemHandle that does not come back, bisected on ring sizes, tools/r06_probe4.sh; the library gives the call a deadline, but the helper thread it
+        # leaves behind stands inside the HIP runtime).  A grid whose RING reaches that size (C5: one pair of depth tiles is 2^31 bytes) publishes LANDING ZONES
+        # instead (csrc/ddgi_exchange.cpp: (world - 1) / world of one pair per texture and parity) — only a grid whose zones would reach it too goes straight to RCCL.
+        per_pair = eng.num_probes * 2048 if ddgi_mode else eng.num_rays * 4
+        zone = per_pair // world * (world - 1)
+        if zone >= (2 << 30) and os.environ.get("DDGI_BENCH_P2P_ANY_SIZE") != "1":
             dist.barrier()
-            return False, "peer-to-peer transport not attempted: a peer would map a ring of %.1f GB, and mappings of 2 GiB or more do not come back on this stack (profiles/r06_p2p_ring_size_bisection.txt)" % (per_pair * pairs / 1e9)
+            return False, "peer-to-peer transport not attempted: a peer would map a landing zone of %.1f GB, and mappings of 2 GiB or more do not come back on this stack (profiles/r06_p2p_ring_size_bisection.txt)" % (zone / 1e9)
         try:
             if os.environ.get("DDGI_BENCH_FAIL_P2P") == "1":   # (fault injection: exercises the fallback's control flow)
                 raise RuntimeError("DDGI_BENCH_FAIL_P2P")
@@ -566,6 +559,9 @@ def main():
                 continue
             info = {"available": True, "ranks_in_communicator": eng.exchange_ranks() if cand == "rccl" else world,
                     "bring_up_s": {k: round(v, 4) for k, v in bring_up_s.get(cand, {}).items()}}
+            if cand == "p2p":
+                # what a peer maps of this rank: its rings (their pushes land where consumers read), or — a ring of 2 GiB and more — landing zones
+                info.update(exported_mb_per_rank=eng.get_tuning("p2p_exported_mb"), landing_zones=eng.get_tuning("p2p_landing_zones") > 0)
             if world > 1:
                 sweep = {}
                 r0 = eng.get_tuning("reserve_cus")

@@ -1908,6 +1908,13 @@ int ddgi_get_tuning(ddgi_handle e, const char* name, int* value)
         *value = e->np;
         return DDGI_OK;
     }
+    if (!std::strcmp(name, "p2p_landing_zones") || !std::strcmp(name, "p2p_exported_mb"))  // peer-to-peer exchange: textures whose pushes land in zones (0: in the ring itself); MB a peer maps of this rank
+    {
+        int zones = 0, mb = 0;
+        ddgi_exchange_p2p_info(e, &zones, &mb);
+        *value = name[4] == 'l' ? zones : mb;
+        return DDGI_OK;
+    }
     if (!std::strcmp(name, "fast_march_active"))  // did the most recent update run the fast march ("fast_march" is a request)
     {
         *value = e->fast_march_active ? 1 : 0;

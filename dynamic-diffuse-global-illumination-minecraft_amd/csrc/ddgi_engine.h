@@ -227,6 +227,7 @@ inline void* ddgi_pair_ptr(const ddgi_engine* e, int pair, int i) { return stati
 int ddgi_chain_len(const ddgi_engine* e);           // REF mode: updates one launch may work on = texture pairs a group takes (1: no continuation)
 int ddgi_group_len(const ddgi_engine* e);           // updates one launch may work on in the handle's mode (REF: pairs of the ring; DDGI: ray-record buffers)
 int ddgi_pairs_wanted(const ddgi_engine* e, bool pipelined);
+void ddgi_exchange_p2p_info(const ddgi_engine* e, int* landing_textures, int* exported_mb);  // (ddgi_exchange.cpp; zeros without a peer-to-peer export)
 int ddgi_resize_ring(ddgi_engine* e, int np);       // blocks; the current pair's contents move to pair 0 of the new ring
 int ddgi_rebase_ring(ddgi_engine* e);               // blocks; the same ring, counted from update 0 again: the current pair's contents move to pair 0
 // Host waits.  A handle on its own: hipStreamSynchronize / hipEventSynchronize.  With an exchange attached the stream may stand at a wait for

@@ -28,6 +28,10 @@
 //             arrived[r]  rank r's slab of exchange number `seq` has landed                      (sender -> receiver)
 //         It needs no RCCL, and — unlike RCCL, which refuses two ranks on one device — it runs with several
 //         ranks on ONE GPU, which is how the one-GPU test box executes a rank > 0 at all.
+//         A ring of 2 GiB or more is not published itself (such buffers do not reach another process reliably on the
+//         stack measured): the peers push into LANDING ZONES — per texture and parity of the exchange's number one
+//         buffer of world - 1 slabs — and a third phase on a stream of the receiver's own copies them into the pair
+//         (ddgi_exchange_p2p_export, p2p_exchange).  The flag words live in fine-grained device memory.
 #include <dlfcn.h>
 #include <execinfo.h>
 #include <signal.h>
@@ -159,11 +163,12 @@ struct P2PAddress
     uint32_t magic, rank, world, pipelined;
     int32_t pid, device;
     uint64_t tex_bytes[2];
-    uint32_t np, pad;            // texture pairs in the rank's ring
+    uint32_t np, landing;        // texture pairs in the rank's ring; landing != 0: the handles below are LANDING ZONES (ring = parity 0, ring_b = parity 1)
     uint64_t process;            // a random number drawn once per process: two ranks with the same one share a process (a pid would
                                  // not do: one container per rank with a shared IPC namespace makes every rank pid 1)
     hipIpcMemHandle_t ring[2];   // the two textures' rings (pair k of texture i at k * tex_bytes[i])
     hipIpcMemHandle_t flags;
+    hipIpcMemHandle_t ring_b[2]; // landing zones of parity 1 (landing != 0 only)
 };
 static_assert(sizeof(P2PAddress) <= DDGI_P2P_ADDRESS_BYTES, "the published address must fit the ABI's blob");
 
@@ -184,7 +189,8 @@ struct ddgi_engine::P2P
 {
     struct Peer
     {
-        void* ring[2] = {nullptr, nullptr};  // the peer's texture rings, mapped
+        void* ring[2] = {nullptr, nullptr};  // the peer's texture rings, mapped (landing zones: those of parity 0)
+        void* ring_b[2] = {nullptr, nullptr};  // landing zones of parity 1
         uint32_t* flags = nullptr;
         bool ipc = false;  // mapped with hipIpcOpenMemHandle (to be closed)
         hipStream_t stream = nullptr;
@@ -203,6 +209,18 @@ struct ddgi_engine::P2P
     bool exported_pipelined = false;
     bool connected = false;
     bool write_value_ok = true;  // hipStreamWriteValue32 accepts peer memory (else a one-word fill)
+    bool flags_fine = false;     // the own flag words live in fine-grained device memory (ddgi_exchange_p2p_export)
+    // LANDING ZONES (a ring of 2 GiB or more, or DDGI_P2P_LANDING=1): what the peers map and push into is not the handle's ring but, per texture and
+    // parity of the exchange's number, one buffer of world - 1 slabs (rank r's slab in slot r, the own rank's slot left out); this rank copies them
+    // into the pair the exchange belongs to on a stream of its own (`gather`) once they have all arrived.  See p2p_exchange.
+    bool landing = false;
+    int land_ntex = 0;                                   // textures with zones (1: REF mode at export, 2: DDGI mode)
+    void* land[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [texture][parity]
+    hipStream_t gather = nullptr;
+    hipEvent_t gathered[ddgi_engine::kMaxPairs] = {};    // gather stream: the other ranks' slabs of pair i's last exchange are in the pair
+    bool gathered_valid[ddgi_engine::kMaxPairs] = {};
+    hipEvent_t drained[2] = {nullptr, nullptr};          // gather stream: the zones of this parity have been copied out (the peers may push the exchange after next)
+    bool drained_valid[2] = {false, false};
 };
 
 namespace {
@@ -294,6 +312,21 @@ void p2p_release(ddgi_engine* e)
             (void)poll_until([&] { return hipStreamQuery(peer.stream); }, 2000);
         }
     }
+    if (p->gather)
+    {
+        if (limit <= 0) (void)hipStreamSynchronize(p->gather);
+        else if (poll_until([&] { return hipStreamQuery(p->gather); }, forced ? 2000 : limit) == hipErrorNotReady && !forced)
+        {
+            forced = true;
+            (void)p2p_force_own_flags(*p);
+            (void)poll_until([&] { return hipStreamQuery(p->gather); }, 2000);
+        }
+        (void)hipStreamDestroy(p->gather);
+    }
+    for (auto& ev : p->gathered)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : p->drained)
+        if (ev) (void)hipEventDestroy(ev);
     if (p->diag) (void)hipStreamDestroy(p->diag);
     if (p->diag_host) (void)hipHostFree(p->diag_host);
     for (auto& peer : p->peers)
@@ -302,12 +335,17 @@ void p2p_release(ddgi_engine* e)
         {
             for (void* q : peer.ring)
                 if (q) (void)hipIpcCloseMemHandle(q);
+            for (void* q : peer.ring_b)
+                if (q) (void)hipIpcCloseMemHandle(q);
             if (peer.flags) (void)hipIpcCloseMemHandle(peer.flags);
         }
         if (peer.done) (void)hipEventDestroy(peer.done);
         if (peer.stream) (void)hipStreamDestroy(peer.stream);
     }
     if (p->flags) (void)hipFree(p->flags);
+    for (auto& tex : p->land)
+        for (void* zone : tex)
+            if (zone) (void)hipFree(zone);
     delete p;
     e->xch.p2p = nullptr;
 }
@@ -318,6 +356,14 @@ int p2p_wait_arrived(ddgi_engine* e, uint32_t seq)
     ddgi_engine::P2P& p = *e->xch.p2p;
     if (seq == 0) return DDGI_OK;
     if (seq > p.waited_arrived) p.waited_arrived = seq;
+    if (p.landing)
+    {
+        // the flag words are waited for by the gather stream (p2p_exchange); a consumer waits for the copies out of the landing zones.  Every pair's latest:
+        // those of older exchanges have long fired, and an event is only recorded behind the waits for ITS exchange's slabs.
+        for (int k = 0; k < ddgi_engine::kMaxPairs; ++k)
+            if (p.gathered_valid[k] && p.pair_seq[k] <= seq) HIP_TRY(hipStreamWaitEvent(e->stream, p.gathered[k], 0));
+        return DDGI_OK;
+    }
     for (int r = 0; r < e->world; ++r)
         if (r != e->rank)
             if (int rc = p2p_wait_flag(e->stream, p.flags + kP2PMaxWorld + r, seq)) return rc;
@@ -355,6 +401,8 @@ int p2p_exchange(ddgi_engine* e)
     if (int rc = update_written_event(e, &written)) return rc;
     // REF mode: the reference never assigns its `distances` image — every rank's copy is all zeros already
     const int n_tex = e->mode == DDGI_MODE_DDGI ? 2 : 1;
+    if (p.landing && n_tex > p.land_ntex)
+        return fail(DDGI_ERR_NOT_READY, "the handle's mode changed after ddgi_exchange_p2p_export: its landing zones hold %d texture(s), the mode exchanges %d — attach the exchange again on every rank", p.land_ntex, n_tex);
     // Phase 1, receiver -> every sender: everything this rank enqueued that reads the pair is done (`written` follows it in
     // stream order), the peers may write their slabs of exchange `seq` into it.  ALL of these go out before the first wait
     // below: HIP may map several streams onto one hardware queue, where a waiting packet holds back whatever is queued
@@ -364,6 +412,8 @@ int p2p_exchange(ddgi_engine* e)
         const int q = (e->rank + step) % e->world;  // every rank starts with a different peer
         ddgi_engine::P2P::Peer& peer = p.peers[static_cast<size_t>(q)];
         HIP_TRY(hipStreamWaitEvent(peer.stream, written, 0));
+        // (landing zones: what the peers write is the zone of this exchange's parity — free once the exchange before last has been copied out of it)
+        if (p.landing && p.drained_valid[seq & 1u]) HIP_TRY(hipStreamWaitEvent(peer.stream, p.drained[seq & 1u], 0));
         if (int rc = p2p_write_flag(p, peer.stream, peer.flags + e->rank, seq)) return rc;
     }
     // Phase 2, sender: once q is ready, push the slab and tell q that it has landed
@@ -376,7 +426,10 @@ int p2p_exchange(ddgi_engine* e)
         {
             const size_t slab = e->tex_bytes[i] / static_cast<size_t>(e->world);
             const size_t off = slab * static_cast<size_t>(e->rank);
-            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(peer.ring[i]) + static_cast<size_t>(cur) * e->tex_bytes[i] + off, static_cast<const uint8_t*>(e->tex[i]) + off, slab, hipMemcpyDeviceToDevice, peer.stream));
+            // the pair in the peer's ring — or, landing zones, this rank's slot in the peer's zone of the exchange's parity (q's own slot is left out)
+            uint8_t* dst = !p.landing ? static_cast<uint8_t*>(peer.ring[i]) + static_cast<size_t>(cur) * e->tex_bytes[i] + off
+                                      : static_cast<uint8_t*>((seq & 1u) ? peer.ring_b[i] : peer.ring[i]) + slab * static_cast<size_t>(e->rank < q ? e->rank : e->rank - 1);
+            HIP_TRY(hipMemcpyAsync(dst, static_cast<const uint8_t*>(e->tex[i]) + off, slab, hipMemcpyDeviceToDevice, peer.stream));
         }
         if (int rc = p2p_write_flag(p, peer.stream, peer.flags + kP2PMaxWorld + e->rank, seq)) return rc;
         HIP_TRY(hipEventRecord(peer.done, peer.stream));
@@ -384,6 +437,29 @@ int p2p_exchange(ddgi_engine* e)
     }
     HIP_TRY(hipEventRecord(x.sent[cur], x.comm_stream));  // this rank's slab has left: the update after next may overwrite it
     x.sent_valid[cur] = true;
+    if (p.landing)
+    {
+        // Phase 3, receiver (landing zones only): once every other rank's slab of exchange `seq` has landed in this parity's zones, copy them into the pair
+        // the exchange belongs to — slots [0, rank) are slabs [0, rank), slots [rank, world - 1) are slabs (rank, world) — on a stream of its own (the
+        // waits would hold `sent` back on the communication stream).  Nothing this rank enqueued before `written` still reads the pair's other slabs.
+        HIP_TRY(hipStreamWaitEvent(p.gather, written, 0));
+        for (int r = 0; r < e->world; ++r)
+            if (r != e->rank)
+                if (int rc = p2p_wait_flag(p.gather, p.flags + kP2PMaxWorld + r, seq)) return rc;
+        for (int i = 0; i < n_tex; ++i)
+        {
+            const size_t slab = e->tex_bytes[i] / static_cast<size_t>(e->world);
+            const uint8_t* zone = static_cast<const uint8_t*>(p.land[i][seq & 1u]);
+            uint8_t* pair = static_cast<uint8_t*>(e->tex[i]);
+            const size_t below = static_cast<size_t>(e->rank), above = static_cast<size_t>(e->world - 1 - e->rank);
+            if (below) HIP_TRY(hipMemcpyAsync(pair, zone, slab * below, hipMemcpyDeviceToDevice, p.gather));
+            if (above) HIP_TRY(hipMemcpyAsync(pair + slab * (below + 1), zone + slab * below, slab * above, hipMemcpyDeviceToDevice, p.gather));
+        }
+        HIP_TRY(hipEventRecord(p.gathered[cur], p.gather));
+        p.gathered_valid[cur] = true;
+        HIP_TRY(hipEventRecord(p.drained[seq & 1u], p.gather));
+        p.drained_valid[seq & 1u] = true;
+    }
     if (!x.pipelined)
     {
         // in order: what follows on the handle's stream sees the whole field, and does not touch the slab before it has left
@@ -452,6 +528,7 @@ int exchange_timed_out(ddgi_engine* e, const char* waited_for)
             for (auto& peer : p.peers)
                 if (peer.stream) drained = drained && poll_until([&] { return hipStreamQuery(peer.stream); }, 2000) == hipSuccess;
             if (x.comm_stream) drained = drained && poll_until([&] { return hipStreamQuery(x.comm_stream); }, 2000) == hipSuccess;
+            if (p.gather) drained = drained && poll_until([&] { return hipStreamQuery(p.gather); }, 2000) == hipSuccess;
             drained = drained && poll_until([&] { return hipStreamQuery(e->stream); }, 2000) == hipSuccess;
         }
         return fail(DDGI_ERR_TIMEOUT, "%s did not end within %d ms (tuning \"wait_timeout_ms\"): %s.  The exchange is broken — attach it again on every rank; %s", waited_for, limit, who,
@@ -533,6 +610,20 @@ int ddgi_exchange_wait_latest(ddgi_engine* e)
     if (x.transport == DDGI_EXCHANGE_P2P) return p2p_wait_arrived(e, x.p2p->pair_seq[e->pair_cur]);
     if (x.sent_valid[e->pair_cur]) HIP_TRY(hipStreamWaitEvent(e->stream, x.sent[e->pair_cur], 0));
     return DDGI_OK;
+}
+
+void ddgi_exchange_p2p_info(const ddgi_engine* e, int* landing_textures, int* exported_mb)
+{
+    *landing_textures = 0, *exported_mb = 0;
+    const ddgi_engine::P2P* p = e->xch.p2p;
+    if (!p) return;
+    *landing_textures = p->landing ? p->land_ntex : 0;
+    double bytes = static_cast<double>(kP2PFlagsAlloc);
+    if (p->landing)
+        for (int i = 0; i < p->land_ntex; ++i) bytes += 2.0 * static_cast<double>(e->tex_bytes[i]) / e->world * (e->world - 1);
+    else
+        for (int i = 0; i < 2; ++i) bytes += static_cast<double>(e->tex_bytes[i]) * e->np;
+    *exported_mb = static_cast<int>(bytes / 1048576.0 + 0.5);
 }
 
 void ddgi_exchange_release(ddgi_engine* e)
@@ -739,7 +830,35 @@ int ddgi_exchange_p2p_export(ddgi_handle e, int pipelined, uint8_t address[DDGI_
     // The flag words are 512 bytes — allocated as kP2PFlagsAlloc: ROCr serves small device allocations from 2 MB blocks it carves up itself
     // ("fragments"), and exporting a fragment exports its block, shared with whatever else the process keeps there.  A block of its own
     // keeps the peers' mappings of this handle's flags apart from every other allocation's life cycle (round 6, docs/LAB_NOTES.md).
-    hipError_t he = hipMalloc(reinterpret_cast<void**>(&p.flags), kP2PFlagsAlloc);
+    // FINE-GRAINED device memory where the runtime offers it: the words are written by ANOTHER GPU over xGMI and polled by this GPU's command
+    // processor (hipStreamWaitValue32) — coarse-grained memory is only guaranteed coherent at kernel boundaries of its own device, which a
+    // wait packet is not.  (On the one-GPU test box both kinds behave alike; RCCL keeps its own cross-GPU flags in fine-grained memory too.)
+    // DDGI_P2P_COARSE_FLAGS=1 in the environment keeps plain hipMalloc (A/B).
+    hipError_t he = hipErrorUnknown;
+    const char* coarse = std::getenv("DDGI_P2P_COARSE_FLAGS");
+    if (!coarse || coarse[0] != '1')
+    {
+        he = hipExtMallocWithFlags(reinterpret_cast<void**>(&p.flags), kP2PFlagsAlloc, hipDeviceMallocFinegrained);
+        if (he == hipSuccess)
+        {
+            hipIpcMemHandle_t probe;
+            if (hipIpcGetMemHandle(&probe, p.flags) != hipSuccess)  // (a runtime that cannot publish such memory: back to plain memory)
+            {
+                (void)hipGetLastError();
+                (void)hipFree(p.flags);
+                p.flags = nullptr;
+                he = hipErrorUnknown;
+            }
+        }
+        else
+        {
+            (void)hipGetLastError();
+            p.flags = nullptr;
+        }
+    }
+    p.flags_fine = he == hipSuccess;
+    if (he != hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&p.flags), kP2PFlagsAlloc);
+    if (e->tuning.verbose) std::fprintf(stderr, "[ddgi p2p, rank %d of %d] flag words in %s device memory\n", e->rank, e->world, p.flags_fine ? "fine-grained" : "coarse-grained");
     // ON THE HANDLE'S STREAM, which is synchronised below before the address leaves this call.  (Rounds 3 - 5 zeroed the words with hipMemset: asynchronous
     // for device memory, on the null stream, which nothing here ever waited for.  On a GPU that other processes keep full — four ranks' persistent trace
     // kernels on the test box's one GPU — the fill could run AFTER the peers' first flag writes had landed and wipe them: `ready` 0 / `arrived` 1 from every
@@ -755,7 +874,48 @@ int ddgi_exchange_p2p_export(ddgi_handle e, int pipelined, uint8_t address[DDGI_
     }
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);  // (the second pair's first contents)
     if (he == hipSuccess) he = hipIpcGetMemHandle(&a.flags, p.flags);
-    for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipIpcGetMemHandle(&a.ring[i], e->own_tex[i]);
+    // What the peers map: the handle's own rings (their pushes land where consumers read) — unless a ring reaches 2 GiB: on the stack measured a buffer of
+    // 2^31 bytes or more is not handed to another process reliably (round 6: hipIpcOpenMemHandle that never returns, hipIpcGetMemHandle that refuses;
+    // profiles/r06_p2p_ring_size_bisection.txt, r06_ipc_stage_probe.txt).  Then — or with DDGI_P2P_LANDING=1 in the environment (tests) — the peers get
+    // LANDING ZONES: per texture and parity of the exchange's number a buffer of world - 1 slabs, (world - 1) / world of ONE pair, whatever the ring's depth.
+    const int n_tex_now = e->mode == DDGI_MODE_DDGI ? 2 : 1;
+    bool landing = false;
+    {
+        const char* force = std::getenv("DDGI_P2P_LANDING");
+        landing = force && force[0] == '1';
+        for (int i = 0; i < n_tex_now; ++i)
+            if (e->tex_bytes[i] * static_cast<size_t>(e->np) >= (static_cast<size_t>(2) << 30)) landing = true;
+        if (e->world < 2) landing = false;
+    }
+    if (he == hipSuccess && landing)
+    {
+        p.landing = true, p.land_ntex = n_tex_now;
+        for (int i = 0; i < n_tex_now && he == hipSuccess; ++i)
+        {
+            const size_t zone = e->tex_bytes[i] / static_cast<size_t>(e->world) * static_cast<size_t>(e->world - 1);
+            if (zone >= (static_cast<size_t>(2) << 30))
+            {
+                const int rc = fail(DDGI_ERR_UNSUPPORTED, "the peer-to-peer exchange of this grid needs landing zones of %.2f GB; buffers of 2 GiB and more are not shared between processes reliably on this stack — use the RCCL transport", zone / 1e9);
+                ddgi_exchange_release(e);
+                return rc;
+            }
+            for (int b = 0; b < 2 && he == hipSuccess; ++b)
+            {
+                he = hipMalloc(&p.land[i][b], zone);
+                if (he == hipSuccess) he = hipIpcGetMemHandle(b ? &a.ring_b[i] : &a.ring[i], p.land[i][b]);
+            }
+        }
+        if (he == hipSuccess) he = create_exchange_stream(&p.gather);
+        for (int k = 0; k < ddgi_engine::kMaxPairs && he == hipSuccess; ++k) he = hipEventCreateWithFlags(&p.gathered[k], hipEventDisableTiming);
+        for (int b = 0; b < 2 && he == hipSuccess; ++b) he = hipEventCreateWithFlags(&p.drained[b], hipEventDisableTiming);
+        a.landing = static_cast<uint32_t>(n_tex_now);
+        if (e->tuning.verbose)
+            std::fprintf(stderr, "[ddgi p2p, rank %d of %d] landing zones: %d texture(s) x 2 parities, %.1f + %.1f MB each (the rings: %d pairs of %.1f + %.1f MB)\n", e->rank, e->world, n_tex_now,
+                         e->tex_bytes[0] / static_cast<double>(e->world) * (e->world - 1) / 1e6, n_tex_now > 1 ? e->tex_bytes[1] / static_cast<double>(e->world) * (e->world - 1) / 1e6 : 0.0, e->np,
+                         e->tex_bytes[0] / 1e6, e->tex_bytes[1] / 1e6);
+    }
+    else
+        for (int i = 0; i < 2 && he == hipSuccess; ++i) he = hipIpcGetMemHandle(&a.ring[i], e->own_tex[i]);
     for (int i = 0; i < 2; ++i) a.tex_bytes[i] = e->tex_bytes[i];
     if (he != hipSuccess)
     {
@@ -783,9 +943,9 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
         P2PAddress a;
         std::memcpy(&a, addresses + static_cast<size_t>(q) * DDGI_P2P_ADDRESS_BYTES, sizeof a);
         if (a.magic != kP2PMagic || static_cast<int>(a.rank) != q || static_cast<int>(a.world) != world || (a.pipelined != 0) != x.pipelined || a.tex_bytes[0] != e->tex_bytes[0] ||
-            a.tex_bytes[1] != e->tex_bytes[1] || static_cast<int>(a.np) != e->np)
+            a.tex_bytes[1] != e->tex_bytes[1] || static_cast<int>(a.np) != e->np || static_cast<int>(a.landing) != (p.landing ? p.land_ntex : 0))
         {
-            rc = fail(DDGI_ERR_INVALID_ARGUMENT, "address %d does not describe rank %d of %d with this handle's textures, pipelining and frames in flight", q, q, world);
+            rc = fail(DDGI_ERR_INVALID_ARGUMENT, "address %d does not describe rank %d of %d with this handle's textures, mode, pipelining and frames in flight (and landing zones on every rank or on none)", q, q, world);
             break;
         }
         if (q == e->rank) continue;
@@ -806,20 +966,27 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
         // returns DDGI_ERR_TIMEOUT naming the peer and the buffer.  (tuning "verbose": every mapping with its time on stderr.)
         struct MapJob
         {
-            hipIpcMemHandle_t flags, ring[2];
+            hipIpcMemHandle_t buf[5];  // flags, then the rings (or: the landing zones of texture 0 / 1, parity 0, then parity 1)
+            bool have[5] = {true, false, false, false, false};
             int device = 0, rank = 0, world = 0, q = 0;
             bool say = false;
             std::mutex mu;
             std::condition_variable cv;
-            int stage = 0;  // 0 flags, 1 ring 0, 2 ring 1, 3 done
+            int stage = 0;  // the buffer being mapped; 5 done
             bool finished = false;
             hipError_t he = hipSuccess;
-            void *fl = nullptr, *rg[2] = {nullptr, nullptr};
+            void* ptr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         };
         auto job = std::make_shared<MapJob>();
-        job->flags = a.flags, job->ring[0] = a.ring[0], job->ring[1] = a.ring[1];
+        job->buf[0] = a.flags, job->buf[1] = a.ring[0], job->buf[2] = a.ring[1], job->buf[3] = a.ring_b[0], job->buf[4] = a.ring_b[1];
+        if (p.landing)
+            for (int i = 0; i < p.land_ntex; ++i) job->have[1 + i] = job->have[3 + i] = true;
+        else
+            job->have[1] = job->have[2] = true;
         job->device = e->device, job->rank = e->rank, job->world = world, job->q = q, job->say = e->tuning.verbose != 0;
-        if (job->say) std::fprintf(stderr, "[ddgi p2p, rank %d of %d] mapping rank %d (pid %d): flags, then 2 rings of %u pairs, %.1f + %.1f MB per pair\n", e->rank, world, q, a.pid, a.np, a.tex_bytes[0] / 1e6, a.tex_bytes[1] / 1e6);
+        if (job->say)
+            std::fprintf(stderr, "[ddgi p2p, rank %d of %d] mapping rank %d (pid %d): flags, then %s (%u pairs of %.1f + %.1f MB in its rings)\n", e->rank, world, q, a.pid, p.landing ? "its landing zones" : "its 2 rings", a.np,
+                         a.tex_bytes[0] / 1e6, a.tex_bytes[1] / 1e6);
         bool stall = false;
 #ifdef DDGI_PROFILING
         stall = (e->tuning.ablate & 64) != 0;  // fault injection (profiling build only, tuning "ablate" 64): the mapping thread does not come back for a minute
@@ -827,20 +994,22 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
         auto work = [job, stall]() {
             if (stall) std::this_thread::sleep_for(std::chrono::seconds(60));
             hipError_t r = hipSetDevice(job->device);
-            for (int i = 0; i < 3 && r == hipSuccess; ++i)
+            static const char* const names[5] = {"flags", "ring / zone 0", "ring / zone 1", "zone 0 (odd exchanges)", "zone 1 (odd exchanges)"};
+            for (int i = 0; i < 5 && r == hipSuccess; ++i)
             {
+                if (!job->have[i]) continue;
                 {
                     std::lock_guard<std::mutex> lock(job->mu);
                     job->stage = i;
                 }
                 const auto t0 = std::chrono::steady_clock::now();
-                r = i == 0 ? hipIpcOpenMemHandle(&job->fl, job->flags, hipIpcMemLazyEnablePeerAccess) : hipIpcOpenMemHandle(&job->rg[i - 1], job->ring[i - 1], hipIpcMemLazyEnablePeerAccess);
+                r = hipIpcOpenMemHandle(&job->ptr[i], job->buf[i], hipIpcMemLazyEnablePeerAccess);
                 if (job->say)
-                    std::fprintf(stderr, "[ddgi p2p, rank %d of %d] %s of rank %d: %s after %.3f s\n", job->rank, job->world, i == 0 ? "flags" : (i == 1 ? "ring 0" : "ring 1"), job->q, hipGetErrorString(r),
+                    std::fprintf(stderr, "[ddgi p2p, rank %d of %d] %s of rank %d: %s after %.3f s\n", job->rank, job->world, names[i], job->q, hipGetErrorString(r),
                                  std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
             }
             std::lock_guard<std::mutex> lock(job->mu);
-            job->he = r, job->stage = 3, job->finished = true;
+            job->he = r, job->stage = 5, job->finished = true;
             job->cv.notify_all();
         };
         const int limit = e->tuning.wait_timeout_ms;
@@ -853,18 +1022,19 @@ int ddgi_exchange_p2p_init(ddgi_handle e, const uint8_t* addresses, int world)
             if (!job->cv.wait_for(lock, std::chrono::milliseconds(limit), [&] { return job->finished; }))
             {
                 const int at = job->stage;
-                const double gb = at == 0 ? 0.0 : static_cast<double>(a.tex_bytes[at - 1]) * a.np / 1e9;
+                const int ti = at == 0 ? 0 : (at - 1) & 1;
+                const double gb = at == 0 ? 0.0 : (p.landing ? static_cast<double>(a.tex_bytes[ti]) / world * (world - 1) : static_cast<double>(a.tex_bytes[ti]) * a.np) / 1e9;
                 rc = fail(DDGI_ERR_TIMEOUT, "hipIpcOpenMemHandle of rank %d's %s (%.2f GB) did not return within %d ms (tuning \"wait_timeout_ms\"): the call is left behind on a helper thread.  "
-                                            "Known: inside an engine's process a texture ring of 2 GiB or more never comes back from this call on the stack measured (profiles/r06_p2p_ring_size_bisection.txt); "
+                                            "Known: inside an engine's process a buffer of 2 GiB or more never comes back from this call on the stack measured (profiles/r06_p2p_ring_size_bisection.txt); "
                                             "use the RCCL transport for such grids",
-                          q, at == 0 ? "flag words" : (at == 1 ? "first texture ring" : "second texture ring"), gb, limit);
+                          q, at == 0 ? "flag words" : (p.landing ? (ti ? "landing zone of the second texture" : "landing zone of the first texture") : (ti ? "second texture ring" : "first texture ring")), gb, limit);
                 peer.ipc = false;  // (nothing of this peer is mapped as far as this handle knows: the helper thread owns whatever it gets)
                 break;
             }
         }
         he = job->he;
-        peer.flags = static_cast<uint32_t*>(job->fl);
-        peer.ring[0] = job->rg[0], peer.ring[1] = job->rg[1];
+        peer.flags = static_cast<uint32_t*>(job->ptr[0]);
+        peer.ring[0] = job->ptr[1], peer.ring[1] = job->ptr[2], peer.ring_b[0] = job->ptr[3], peer.ring_b[1] = job->ptr[4];
         if (he == hipSuccess) he = create_exchange_stream(&peer.stream);
         if (he == hipSuccess) he = hipEventCreateWithFlags(&peer.done, hipEventDisableTiming);
         if (he != hipSuccess && rc == DDGI_OK) rc = fail(DDGI_ERR_HIP, "mapping rank %d's probe textures failed: %s", q, hipGetErrorString(he));

@@ -406,7 +406,15 @@ int ddgi_exchange_group_end(void);
  *     ddgi_exchange_p2p_init(h, all, world);                 map the peers' buffers
  * then ddgi_probe_update / ddgi_exchange / consumers exactly as with RCCL (`pipelined` means the same).  The ranks
  * must all still be alive when any of them detaches (ddgi_exchange_init(h, NULL, 0), reconfiguration, destroy):
- * put a host barrier before tearing down, as before ncclCommDestroy. */
+ * put a host barrier before tearing down, as before ncclCommDestroy.
+ * What a peer maps is the handle's ring of texture pairs — its push lands where this rank's consumers read —, unless a
+ * ring reaches 2 GiB (a buffer of 2^31 bytes or more is not handed to another process reliably on the ROCm stack
+ * measured): then the peers get LANDING ZONES — per texture and parity of the exchange's number a buffer of world - 1
+ * slabs — and a stream of this rank's own copies what has landed into the pair (DDGI_P2P_LANDING=1 in the environment
+ * asks for zones on grids of any size).  ddgi_get_tuning "p2p_landing_zones" (textures with zones, 0: none) and
+ * "p2p_exported_mb" (MB of this rank a peer maps) tell which; every rank must come to the same answer (same grid, mode,
+ * frames in flight, environment), ddgi_exchange_p2p_init checks it.  The flag words live in fine-grained device memory
+ * where the runtime offers it (another GPU writes them, this GPU's command processor polls them). */
 #define DDGI_P2P_ADDRESS_BYTES 512
 int ddgi_exchange_p2p_export(ddgi_handle h, int pipelined, uint8_t address[DDGI_P2P_ADDRESS_BYTES]);
 int ddgi_exchange_p2p_init(ddgi_handle h, const uint8_t* addresses_rank_major, int world);

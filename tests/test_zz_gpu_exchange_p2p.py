@@ -170,7 +170,7 @@ def _worker(rank, world, conn, scenario, log_path):
         eng.exchange_finish()
         eng.synchronize()
         progress("finished + synchronized")
-        conn.send(("done", None))   # host barrier before any rank tears its buffers down
+        conn.send(("done", (eng.get_tuning("p2p_landing_zones"), eng.get_tuning("p2p_exported_mb"))))   # host barrier before any rank tears its buffers down
         conn.recv()
         eng.close()
         conn.send(("results", result))
@@ -267,7 +267,7 @@ def _ids():
     return [f"{name}-{mode}-{'pipelined' if pl else 'in_order'}" for name, mode, pl, _, _ in SCENARIOS]
 
 
-def _run_scenario(ddgi, oracle, tmp_path, world, scenario):
+def _run_scenario(ddgi, oracle, tmp_path, world, scenario, landing=False):
     import time
 
     name, mode, pipelined, frames, read_at = scenario
@@ -277,7 +277,10 @@ def _run_scenario(ddgi, oracle, tmp_path, world, scenario):
     try:
         ranks.send_in_turn(ranks.gather("address", deadline), "peers mapped", deadline)
         ranks.send("start")
-        ranks.gather("done", deadline)
+        exported = ranks.gather("done", deadline)
+        for r in range(world):
+            # (textures whose pushes land in zones instead of the ring, MB of this rank a peer maps)
+            assert (exported[r][0] > 0) == landing and exported[r][1] > 0, exported
         ranks.send("go")
         results = ranks.gather("results", deadline)
         for r in range(world):
@@ -293,6 +296,19 @@ def test_one_process_per_rank_through_ipc_handles(ddgi, oracle, tmp_path, world,
     boundary.  This is the multi-rank path of bench.py --exchange p2p, executed at ranks > 0 on the test box.  One test per
     scenario, each with its own budget; a rank that stops answering is reported with the last stage it reached."""
     _run_scenario(ddgi, oracle, tmp_path, world, scenario)
+
+
+# Landing zones (csrc/ddgi_exchange.cpp): a grid whose ring reaches 2 GiB (BASELINE's C5: the depth tiles of ONE pair are 2^31 bytes) cannot hand the ring itself
+# to its peers on the stack measured; the peers then push into per-parity zones of world - 1 slabs and a stream of the receiver's own copies them into the pair.
+# DDGI_P2P_LANDING=1 switches that path on for grids of any size: the same scenarios, the same expectations.
+LANDING = [SCENARIOS[i] for i in (0, 1, 3, 5, 6)]
+
+
+@pytest.mark.parametrize("world, scenario", [(4, sc) for sc in LANDING] + [(2, LANDING[1]), (2, LANDING[4])],
+                         ids=lambda v: v if isinstance(v, int) else f"{v[0]}-{v[1]}-{'pipelined' if v[2] else 'in_order'}")
+def test_landing_zones_gather_the_same_field(ddgi, oracle, tmp_path, monkeypatch, world, scenario):
+    monkeypatch.setenv("DDGI_P2P_LANDING", "1")
+    _run_scenario(ddgi, oracle, tmp_path, world, scenario, landing=True)
 
 
 def test_eight_ranks_on_one_gpu(ddgi, oracle, tmp_path):

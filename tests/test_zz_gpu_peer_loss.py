@@ -76,8 +76,12 @@ def _worker(rank, conn, pipelined):
         conn.send(("error", repr(exc)))
 
 
-@pytest.mark.parametrize("pipelined", [False, True], ids=["in_order", "pipelined"])
-def test_survivors_of_a_lost_rank_time_out_name_it_and_stay_usable(ddgi, pipelined):
+@pytest.mark.parametrize("pipelined, landing", [(False, False), (True, False), (True, True)], ids=["in_order", "pipelined", "pipelined-landing_zones"])
+def test_survivors_of_a_lost_rank_time_out_name_it_and_stay_usable(ddgi, monkeypatch, pipelined, landing):
+    if landing:
+        # the peers push into landing zones and a stream of this rank's own copies them out (what grids with rings of 2 GiB and more get): ITS waits for
+        # the lost rank's slab must end with the others
+        monkeypatch.setenv("DDGI_P2P_LANDING", "1")
     ctx = mp.get_context("spawn")
     pipes = [ctx.Pipe() for _ in range(WORLD)]
     procs = [ctx.Process(target=_worker, args=(r, pipes[r][1], pipelined), daemon=True) for r in range(WORLD)]
