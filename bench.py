@@ -907,6 +907,27 @@ def main():
             out["value_at_reference_frames_in_flight"] = sweep["2"]["value"]
         out["frames_in_flight"] = dict(sweep, note="tuning \"frames_in_flight\": 1 = every launch traces its own update and drains; n = a launch goes on with up to n - 1 "
                                                    "updates submitted behind it (the timed loop submits its steps back to back, as the contract asks). The headline uses the library's default")
+    if extras and not ddgi_mode and not sharded:
+        # ---- the boundary handing over HOST buffers: the reference re-uploads its rays every frame (src/rvpt/rvpt.cpp:285) ----
+        # ddgi_upload_probe_rays checks every ray's probe_info against the grid, keeps a host copy and copies 48 B/ray over PCIe; then the update.
+        # Never `value` (the timed region above starts with the rays resident in HBM): the PCIe-inclusive rate of a host that does what the reference's does.
+        host_rays = eng.get_probe_rays()
+        n_host = max(2, min(5, args.steps))
+        eng.upload_probe_rays(host_rays); step(); fence()
+        t_up = 0.0
+        t0 = time.perf_counter()
+        for _ in range(n_host):
+            t1 = time.perf_counter()
+            eng.upload_probe_rays(host_rays)
+            t_up += time.perf_counter() - t1
+            step()
+        fence()
+        dt = (time.perf_counter() - t0) / n_host
+        out["host_buffers"] = {"ms_per_step": dt * 1e3, "value": total_rays / dt, "unit": "rays/s", "upload_ms": t_up / n_host * 1e3, "bytes_per_step": int(host_rays.nbytes),
+                               "upload_GBps": host_rays.nbytes / (t_up / n_host) / 1e9, "steps": n_host,
+                               "note": "every step = ddgi_upload_probe_rays (validation of every ray on the host + host copy + 48 B/ray over PCIe from pageable memory, synchronous) + ddgi_probe_update, "
+                                       "as the reference's host does per frame (rvpt.cpp:285); PCIe-inclusive, reported beside `value`, never as it"}
+        del host_rays
     fast_albedo = None
     if world == 1 and not ddgi_mode and not args.no_fast_march:
         # the opt-in tolerance-mode march on the same workload, timed the same way (the headline `value` above is the exact march)

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdarg>
 #include <cmath>
 #include <cstdio>
@@ -455,6 +457,44 @@ static void release_noise(ddgi_engine* e)
     e->noise = NoiseLut{};
 }
 
+// The host copy of the rays (what RVPT::probe_rays holds) is page-locked while it keeps its place: the per-frame upload of a host that does what the
+// reference's does (rvpt.cpp:285: the whole buffer, every frame) then goes over PCIe by DMA straight from it instead of through the runtime's staging
+// of pageable memory.  Registered lazily by ddgi_upload_probe_rays (201 MB on C3: tens of milliseconds, once), dropped before anything may move the vector.
+static void unpin_host_rays(ddgi_engine* e)
+{
+    if (!e->host_rays_pinned) return;
+    (void)hipHostUnregister(e->host_rays_pinned);
+    e->host_rays_pinned = nullptr;
+}
+
+static void pin_host_rays(ddgi_engine* e)
+{
+    if (e->host_rays.empty() || e->host_rays_pinned == e->host_rays.data()) return;
+    unpin_host_rays(e);
+    if (hipHostRegister(e->host_rays.data(), e->host_rays.size() * sizeof(ddgi_probe_ray), hipHostRegisterDefault) == hipSuccess)
+        e->host_rays_pinned = e->host_rays.data();
+    else
+        (void)hipGetLastError();  // (a locked-memory limit: the copies below still work, through the runtime's staging)
+}
+
+// fn(first, last) over [0, n) on up to 16 host threads (one per 64 Ki items at least); returns when all are done
+template <class Fn>
+static void parallel_ranges(size_t n, Fn fn)
+{
+    const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t t = std::max<size_t>(1, std::min<size_t>({16, hw, (n + 65535) >> 16}));
+    if (t == 1)
+    {
+        fn(static_cast<size_t>(0), n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(t - 1);
+    for (size_t k = 1; k < t; ++k) pool.emplace_back(fn, n * k / t, n * (k + 1) / t);
+    fn(static_cast<size_t>(0), n / t);
+    for (auto& th : pool) th.join();
+}
+
 static int upload_local_rays(ddgi_engine* e)
 {
     e->chain_break = true;  // new rays: the next update is not a continuation of the last (frames in flight)
@@ -558,6 +598,7 @@ int ddgi_destroy(ddgi_handle e)
     ddgi_exchange_release(e);
     for (int i = 0; i < 2; ++i)
         if (e->own_tex[i]) (void)hipFree(e->own_tex[i]);
+    unpin_host_rays(e);
     if (e->d_rays) (void)hipFree(e->d_rays);
     if (e->d_stats) (void)hipFree(e->d_stats);
     if (e->d_sample_scratch) (void)hipFree(e->d_sample_scratch);
@@ -611,6 +652,7 @@ int ddgi_configure(ddgi_handle e, const ddgi_irradiance_field* field, const ddgi
     e->field = *field;
     e->tile[0] = e->tile[1] = 0;  // the new field's square tile; ddgi_set_ray_tile changes it
     e->settings = *settings;
+    unpin_host_rays(e);
     e->host_rays.clear();
     e->n_local_rays = 0;
     e->updates = 0;
@@ -708,6 +750,7 @@ int ddgi_reconfigure(ddgi_handle e, const ddgi_irradiance_field* field, const dd
     e->field = *field;
     e->tile[0] = e->tile[1] = 0;
     e->settings = *settings;
+    unpin_host_rays(e);
     e->host_rays.clear();
     e->n_local_rays = 0;
     e->updates = 0;  // (the DDGI frame sequence — ray rotation, RNG keys — goes on: e->frame is kept)
@@ -740,6 +783,7 @@ int ddgi_set_ray_tile(ddgi_handle e, int tile_x, int tile_y)
     DDGI_TRY(ddgi_sync_stream(e, e->stream));
     if (e->caller_tex) return fail(DDGI_ERR_INVALID_ARGUMENT, "unbind caller textures before changing the ray tile");
     e->tile[0] = tile_x, e->tile[1] = tile_y;
+    unpin_host_rays(e);
     e->host_rays.clear();
     e->n_local_rays = 0;
     e->updates = 0;
@@ -792,6 +836,7 @@ int ddgi_generate_probe_rays(ddgi_handle e, uint32_t seed, int reseed)
         e->rand_seeded = true;
     }
     const GridK g = make_grid(e);
+    unpin_host_rays(e);  // (the generator may grow the vector)
     generate_probe_rays(e->field, g.sx, g.sy, e->rand, e->host_rays);
     return upload_local_rays(e);
 }
@@ -805,15 +850,35 @@ int ddgi_upload_probe_rays(ddgi_handle e, const ddgi_probe_ray* rays, size_t n)
     const size_t expect = probes * g.n;
     if (n != expect) return fail(DDGI_ERR_INVALID_ARGUMENT, "expected %zu rays (full grid), got %zu", expect, n);
     // the reference's shader trusts probe_info blindly (Q13); an out-of-range tile would write
-    // outside the texture, so reject it here
-    for (size_t i = 0; i < n; ++i)
+    // outside the texture, so reject it here.  The reference's host uploads the whole buffer EVERY frame (rvpt.cpp:285): the check and the copy
+    // into the handle's own (page-locked) buffer run on up to 16 host threads — C3's 201 MB: ~70 ms single-threaded through pageable memory, a fifth of that so.
+    std::atomic<size_t> first_bad{n};
+    const float fp = static_cast<float>(probes), fx = static_cast<float>(g.sx), fy = static_cast<float>(g.sy);
+    parallel_ranges(n, [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; ++i)
+        {
+            const float p = rays[i].probe_info[0], tx = rays[i].probe_info[1], ty = rays[i].probe_info[2];
+            if (!(p >= 0.0f && p < fp && tx >= 0.0f && tx < fx && ty >= 0.0f && ty < fy))
+            {
+                size_t seen = first_bad.load();
+                while (i < seen && !first_bad.compare_exchange_weak(seen, i)) {}
+                return;
+            }
+        }
+    });
+    if (first_bad.load() < n)
     {
-        const float p = rays[i].probe_info[0], tx = rays[i].probe_info[1], ty = rays[i].probe_info[2];
-        if (!(p >= 0.0f && p < static_cast<float>(probes) && tx >= 0.0f && tx < static_cast<float>(g.sx) && ty >= 0.0f &&
-              ty < static_cast<float>(g.sy)))
-            return fail(DDGI_ERR_INVALID_ARGUMENT, "ray %zu: probe_info (%g,%g,%g) outside the grid", i, p, tx, ty);
+        const size_t i = first_bad.load();  // (the first one of SOME thread's range; the lowest of those)
+        return fail(DDGI_ERR_INVALID_ARGUMENT, "ray %zu: probe_info (%g,%g,%g) outside the grid", i, rays[i].probe_info[0], rays[i].probe_info[1], rays[i].probe_info[2]);
     }
-    e->host_rays.assign(rays, rays + n);
+    if (e->host_rays.size() != n)
+    {
+        unpin_host_rays(e);
+        e->host_rays.resize(n);
+    }
+    ddgi_probe_ray* own = e->host_rays.data();
+    parallel_ranges(n, [&](size_t a, size_t b) { std::memcpy(own + a, rays + a, (b - a) * sizeof(ddgi_probe_ray)); });
+    pin_host_rays(e);
     return upload_local_rays(e);
 }
 

@@ -116,6 +116,7 @@ struct ddgi_engine
     GlibcRand rand;
     bool rand_seeded = false;
     std::vector<ddgi_probe_ray> host_rays;  // full grid (what RVPT::probe_rays holds)
+    void* host_rays_pinned = nullptr;       // host_rays.data() while that memory is page-locked (hipHostRegister): the per-frame upload's DMA source
     float4* d_rays = nullptr;               // local slab
     size_t d_rays_capacity = 0;             // in rays
     uint32_t n_local_rays = 0;

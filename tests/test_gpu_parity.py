@@ -92,6 +92,42 @@ def test_uploaded_rays_and_readback_of_generated_rays(ddgi, oracle):
     assert np.array_equal(albedo, want_a)
 
 
+def test_per_frame_upload_of_a_large_ray_buffer(ddgi):
+    """What the reference's host does every frame (probe_buffer.copy_to of the WHOLE buffer, rvpt.cpp:285) on a grid large enough for the upload's host
+    threads (C2: 131 072 rays, 6 MB — two ranges): a second and third upload go through the page-locked host copy; a bad ray in EACH range is rejected
+    naming the LOWEST index, and leaves the rays uploaded before in place; textures equal those of the generated rays they are."""
+    with _engine(ddgi, "c2_cornell") as eng:
+        eng.generate_probe_rays(seed=5)
+        rays = eng.get_probe_rays()
+        eng.probe_update()
+        want = eng.read_textures()[0].copy()
+        other = rays.copy()
+        other["direction"] = -other["direction"]
+        for upload in (other, rays, rays):
+            eng.upload_probe_rays(upload)
+            assert eng.get_probe_rays().tobytes() == upload.tobytes()
+        eng.probe_update()
+        assert np.array_equal(eng.read_textures()[0], want)
+        bad = other.copy()
+        bad["probe_info"][40001, 0] = -1.0           # (both ranges hold one: the lower index is the one named)
+        bad["probe_info"][120000, 2] = 1e9
+        with pytest.raises(ddgi.DDGIError, match="ray 40001:"):
+            eng.upload_probe_rays(bad)
+        bad["probe_info"][3, 0] = float("nan")
+        with pytest.raises(ddgi.DDGIError, match="ray 3:"):
+            eng.upload_probe_rays(bad)
+        assert eng.get_probe_rays().tobytes() == rays.tobytes()
+        eng.probe_update()
+        assert np.array_equal(eng.read_textures()[0], want)
+        # a reconfiguration moves the host copy (it is unpinned first); uploads go on
+        eng.set_ray_tile(8, 8)
+        eng.generate_probe_rays(seed=5)
+        small = eng.get_probe_rays()
+        eng.upload_probe_rays(small)
+        eng.probe_update()
+        eng.synchronize()
+
+
 def test_generated_rays_match_oracle_and_sequence_continues(ddgi, oracle):
     counts, side, s, origin, _ = CONFIGS["c1_cornell"]
     st = oracle.new_rand_state(1)
