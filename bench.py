@@ -393,7 +393,7 @@ def main():
         t_up = time.perf_counter()
         stages = bring_up_s.setdefault("p2p", {})
         # The largest buffer a peer would have to map.  On the stack measured a buffer of 2 GiB or more is not handed to another process reliably (round 6:
-        # hipIpcOpenMemHandle that does not come back, bisected on ring sizes, tools/r06_probe4.sh; the library gives the call a deadline, but the helper thread it
+        # hipIpcOpenMemHandle that does not come back, bisected on ring sizes, tools/hunt/r06_probe4.sh; the library gives the call a deadline, but the helper thread it
         # leaves behind stands inside the HIP runtime).  A grid whose RING reaches that size (C5: one pair of depth tiles is 2^31 bytes) publishes LANDING ZONES
         # instead (csrc/ddgi_exchange.cpp: (world - 1) / world of one pair per texture and parity) — only a grid whose zones would reach it too goes straight to RCCL.
         per_pair = eng.num_probes * 2048 if ddgi_mode else eng.num_rays * 4

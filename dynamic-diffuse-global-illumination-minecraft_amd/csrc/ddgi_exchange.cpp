@@ -53,7 +53,7 @@
 namespace {
 
 // Debugging aid (DDGI_DEBUG_BACKTRACE=1 in the environment when the library is loaded): SIGUSR2 sent to a THREAD (tgkill) prints that thread's native
-// backtrace on stderr — where a driver call that does not come back stands, in a container without ptrace (tools/p2p_hang_hunt5.sh).
+// backtrace on stderr — where a driver call that does not come back stands, in a container without ptrace (tools/hunt/p2p_hang_hunt5.sh).
 struct BacktraceOnSignal
 {
     static void handler(int)
