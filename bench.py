@@ -912,21 +912,32 @@ def main():
         # ddgi_upload_probe_rays checks every ray's probe_info against the grid, keeps a host copy and copies 48 B/ray over PCIe; then the update.
         # Never `value` (the timed region above starts with the rays resident in HBM): the PCIe-inclusive rate of a host that does what the reference's does.
         host_rays = eng.get_probe_rays()
-        n_host = max(2, min(5, args.steps))
-        eng.upload_probe_rays(host_rays); step(); fence()
-        t_up = 0.0
-        t0 = time.perf_counter()
-        for _ in range(n_host):
-            t1 = time.perf_counter()
-            eng.upload_probe_rays(host_rays)
-            t_up += time.perf_counter() - t1
-            step()
-        fence()
-        dt = (time.perf_counter() - t0) / n_host
-        out["host_buffers"] = {"ms_per_step": dt * 1e3, "value": total_rays / dt, "unit": "rays/s", "upload_ms": t_up / n_host * 1e3, "bytes_per_step": int(host_rays.nbytes),
-                               "upload_GBps": host_rays.nbytes / (t_up / n_host) / 1e9, "steps": n_host,
-                               "note": "every step = ddgi_upload_probe_rays (validation of every ray on the host + host copy + 48 B/ray over PCIe from pageable memory, synchronous) + ddgi_probe_update, "
-                                       "as the reference's host does per frame (rvpt.cpp:285); PCIe-inclusive, reported beside `value`, never as it"}
+        other_rays = host_rays.copy()
+        other_rays["direction"] = -other_rays["direction"]   # (a second, different ray set: every chunk of the buffer changes between two frames)
+        n_host = max(2, min(6, args.steps)) & ~1
+
+        def host_loop(buffers):
+            eng.upload_probe_rays(buffers[0]); step(); fence()
+            t_up, t0 = 0.0, time.perf_counter()
+            for k in range(n_host):
+                t1 = time.perf_counter()
+                eng.upload_probe_rays(buffers[(k + 1) % len(buffers)])
+                t_up += time.perf_counter() - t1
+                step()
+            fence()
+            dt = (time.perf_counter() - t0) / n_host
+            return {"ms_per_step": dt * 1e3, "value": total_rays / dt, "unit": "rays/s", "upload_ms": t_up / n_host * 1e3, "upload_GBps": host_rays.nbytes / (t_up / n_host) / 1e9}
+
+        new_rays = host_loop([host_rays, other_rays])
+        same_rays = host_loop([host_rays])
+        out["host_buffers"] = {"bytes_per_step": int(host_rays.nbytes), "steps": n_host,
+                               "same_rays_every_frame": dict(same_rays, note="the reference's host: one ray set, generated at start-up (main.cpp:47), the whole buffer handed over every frame — chunks equal to "
+                                                                              "the handle's host copy are recognised (two reads of the buffer on host threads) and nothing crosses PCIe; upload_GBps is the buffer's size over the call's time"),
+                               "new_rays_every_frame": dict(new_rays, note="two ray sets in turn: every chunk is checked, copied into the page-locked host copy and sent (48 B/ray over PCIe, synchronous)"),
+                               "note": "every step = ddgi_upload_probe_rays + ddgi_probe_update, as the reference's host does per frame (probe_buffer.copy_to of the whole buffer, rvpt.cpp:285); "
+                                       "PCIe-inclusive, reported beside `value`, never as it"}
+        eng.upload_probe_rays(host_rays)
+        del other_rays
         del host_rays
     fast_albedo = None
     if world == 1 and not ddgi_mode and not args.no_fast_march:

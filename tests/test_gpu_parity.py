@@ -108,6 +108,22 @@ def test_per_frame_upload_of_a_large_ray_buffer(ddgi):
             assert eng.get_probe_rays().tobytes() == upload.tobytes()
         eng.probe_update()
         assert np.array_equal(eng.read_textures()[0], want)
+        # a buffer that changed in ONE chunk only (64 Ki rays each): that run alone crosses PCIe; an unchanged buffer touches neither the GPU nor the
+        # frames in flight
+        part = rays.copy()
+        part["direction"][100000:100010] = -part["direction"][100000:100010]
+        eng.upload_probe_rays(part)
+        assert eng.get_probe_rays().tobytes() == part.tobytes()
+        eng.probe_update()
+        changed = eng.read_textures()[0].copy()
+        assert not np.array_equal(changed, want)
+        for _ in range(4):
+            eng.upload_probe_rays(part)          # what the reference's host does per frame: the same rays again
+            eng.probe_update()
+        assert np.array_equal(eng.read_textures()[0], changed)
+        eng.upload_probe_rays(rays)
+        eng.probe_update()
+        assert np.array_equal(eng.read_textures()[0], want)
         bad = other.copy()
         bad["probe_info"][40001, 0] = -1.0           # (both ranges hold one: the lower index is the one named)
         bad["probe_info"][120000, 2] = 1e9
