@@ -240,6 +240,22 @@ DDGI_D bool march_step(March& m, const SceneK& S, const uint32_t* __restrict__ s
 // iteration counter is left to the caller (one add per burst instead of one per step) and the
 // occupancy bit is extracted with v_bfe_u32 (which takes the bit offset modulo 32 by itself).
 typedef float f2v __attribute__((ext_vector_type(2)));
+// The voxel id's clamp into the baked box, per axis.  DDGI_EXP_NOCLAMP (experiment, round 6: what the three v_med3 of a step cost — NOT exact, a march that leaves
+// the box looks up whatever lies beside the bitmap): 1 = no clamp at all (the bound), 2 = x and z as they come, y against the box's top only (what a scene whose
+// side and bottom layers are solid would need).
+#if defined(DDGI_EXP_NOCLAMP) && DDGI_EXP_NOCLAMP == 1
+#define DDGI_CLAMP_X(v, lo, hi) (v)
+#define DDGI_CLAMP_Y(v, lo, hi) (v)
+#define DDGI_CLAMP_Z(v, lo, hi) (v)
+#elif defined(DDGI_EXP_NOCLAMP) && DDGI_EXP_NOCLAMP == 2
+#define DDGI_CLAMP_X(v, lo, hi) (v)
+#define DDGI_CLAMP_Y(v, lo, hi) fminf(v, hi)
+#define DDGI_CLAMP_Z(v, lo, hi) (v)
+#else
+#define DDGI_CLAMP_X(v, lo, hi) __builtin_amdgcn_fmed3f(v, lo, hi)
+#define DDGI_CLAMP_Y(v, lo, hi) __builtin_amdgcn_fmed3f(v, lo, hi)
+#define DDGI_CLAMP_Z(v, lo, hi) __builtin_amdgcn_fmed3f(v, lo, hi)
+#endif
 // ray_at with the y and z components as ONE v_pk_fma_f32 (the same two IEEE fused multiply-adds, one issue slot instead of two)
 DDGI_D f3 ray_at_pk(f3 o, f3 d, float t)
 {
@@ -259,9 +275,9 @@ DDGI_D bool march_step_burst(March& m, const SceneK& S, const uint32_t* __restri
     const float step = fminf(fminf(tx, tyz.x), tyz.y) + 0.0001f;
     m.t += step;
     m.p = ray_at_pk(m.ro, m.dn, m.t);
-    const float kx = __builtin_amdgcn_fmed3f(ceilf(m.p.x), S.lo_f[0], hi.x);
-    const float ky = __builtin_amdgcn_fmed3f(ceilf(m.p.y), S.lo_f[1], hi.y);
-    const float kz = __builtin_amdgcn_fmed3f(ceilf(m.p.z), S.lo_f[2], hi.z);
+    const float kx = DDGI_CLAMP_X(ceilf(m.p.x), S.lo_f[0], hi.x);
+    const float ky = DDGI_CLAMP_Y(ceilf(m.p.y), S.lo_f[1], hi.y);
+    const float kz = DDGI_CLAMP_Z(ceilf(m.p.z), S.lo_f[2], hi.z);
     const int idx = static_cast<int>(fmaf(kz, S.nxy_f, fmaf(ky, S.nx_f, kx)));
     m.cell = idx;
     const uint32_t* __restrict__ base = s_bits - (S.bias32 >> 5);
@@ -279,9 +295,9 @@ DDGI_D bool march_step_frozen(March& m, const SceneK& S, const uint32_t* __restr
     const float step = fminf(fminf(tx, tyz.x), tyz.y) + 0.0001f;
     m.t += frozen ? 0.0f : step;
     m.p = ray_at_pk(m.ro, m.dn, m.t);
-    const float kx = __builtin_amdgcn_fmed3f(ceilf(m.p.x), S.lo_f[0], hi.x);
-    const float ky = __builtin_amdgcn_fmed3f(ceilf(m.p.y), S.lo_f[1], hi.y);
-    const float kz = __builtin_amdgcn_fmed3f(ceilf(m.p.z), S.lo_f[2], hi.z);
+    const float kx = DDGI_CLAMP_X(ceilf(m.p.x), S.lo_f[0], hi.x);
+    const float ky = DDGI_CLAMP_Y(ceilf(m.p.y), S.lo_f[1], hi.y);
+    const float kz = DDGI_CLAMP_Z(ceilf(m.p.z), S.lo_f[2], hi.z);
     const int idx = static_cast<int>(fmaf(kz, S.nxy_f, fmaf(ky, S.nx_f, kx)));
     m.cell = idx;
     const uint32_t* __restrict__ base = s_bits - (S.bias32 >> 5);
@@ -307,9 +323,9 @@ DDGI_D void march_step_masked(March& m, const SceneK& S, const uint32_t* __restr
     asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(step_bits) : "v"(occ), "v"(__float_as_uint(step)));  // occ ? +0.0f : step
     m.t += __uint_as_float(step_bits);
     m.p = ray_at_pk(m.ro, m.dn, m.t);
-    const float kx = __builtin_amdgcn_fmed3f(ceilf(m.p.x), S.lo_f[0], hi.x);
-    const float ky = __builtin_amdgcn_fmed3f(ceilf(m.p.y), S.lo_f[1], hi.y);
-    const float kz = __builtin_amdgcn_fmed3f(ceilf(m.p.z), S.lo_f[2], hi.z);
+    const float kx = DDGI_CLAMP_X(ceilf(m.p.x), S.lo_f[0], hi.x);
+    const float ky = DDGI_CLAMP_Y(ceilf(m.p.y), S.lo_f[1], hi.y);
+    const float kz = DDGI_CLAMP_Z(ceilf(m.p.z), S.lo_f[2], hi.z);
     const int idx = static_cast<int>(fmaf(kz, S.nxy_f, fmaf(ky, S.nx_f, kx)));
     m.cell = idx;
     const uint32_t* __restrict__ base = s_bits - (S.bias32 >> 5);
