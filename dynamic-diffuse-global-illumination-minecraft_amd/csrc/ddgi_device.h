@@ -256,6 +256,11 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 #define DDGI_CLAMP_Y(v, lo, hi) __builtin_amdgcn_fmed3f(v, lo, hi)
 #define DDGI_CLAMP_Z(v, lo, hi) __builtin_amdgcn_fmed3f(v, lo, hi)
 #endif
+#if defined(DDGI_EXP_NOCLAMP) && DDGI_EXP_NOCLAMP
+#define DDGI_EXP_RECLAMP(m, S, hi) ((m).cell = static_cast<int>(fmaf(__builtin_amdgcn_fmed3f(ceilf((m).p.z), (S).lo_f[2], (hi).z), (S).nxy_f, fmaf(__builtin_amdgcn_fmed3f(ceilf((m).p.y), (S).lo_f[1], (hi).y), (S).nx_f, __builtin_amdgcn_fmed3f(ceilf((m).p.x), (S).lo_f[0], (hi).x)))))
+#else
+#define DDGI_EXP_RECLAMP(m, S, hi) ((void)0)
+#endif
 // ray_at with the y and z components as ONE v_pk_fma_f32 (the same two IEEE fused multiply-adds, one issue slot instead of two)
 DDGI_D f3 ray_at_pk(f3 o, f3 d, float t)
 {

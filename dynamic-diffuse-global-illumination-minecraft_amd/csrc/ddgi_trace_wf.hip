@@ -414,6 +414,7 @@ DDGI_D int wf_post_march(const WfPool& P, uint32_t slot, WfCold& c, f3 o, f3 d, 
                     occ = march_step_burst(m, A.scene, s_bits, hi);
                     fin = occ | (m.t >= m.tl);
                 }
+            DDGI_EXP_RECLAMP(m, A.scene, hi);
             t_end = m.t, p_end = m.p, cell_end = m.cell;
         }
         P.t[slot] = t_end;
@@ -1832,6 +1833,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
             if (have)
             {
                 const uint32_t* __restrict__ bits_base = s_bits - (A.scene.bias32 >> 5);
+                DDGI_EXP_RECLAMP(m, A.scene, hi_v);
                 const bool occ = __builtin_amdgcn_ubfe(bits_base[m.cell >> 5], static_cast<uint32_t>(m.cell), 1u) != 0u;  // (march_step_frozen's own test)
                 m.it += kAqStepsPerTrip;
                 bool f = fin;
@@ -2130,6 +2132,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                 for (int q = 0; q < kM; ++q)
                 {
                     if (!have[q]) continue;
+                    DDGI_EXP_RECLAMP(m[q], A.scene, hi_v);
                     const bool occ = __builtin_amdgcn_ubfe(bits_base[m[q].cell >> 5], static_cast<uint32_t>(m[q].cell), 1u) != 0u;  // (march_step_frozen's own test)
                     m[q].it += kAqStepsPerTrip;
                     bool f = fin[q];
@@ -2321,6 +2324,7 @@ __global__ __launch_bounds__(kAqThreads, kAqThreads * kAqWgsPerCU / 256) void k_
                     if (have)
                     {
                         const uint32_t* __restrict__ bits_base = s_bits - (A.scene.bias32 >> 5);
+                        DDGI_EXP_RECLAMP(m, A.scene, hi_v);
                         const bool occ = __builtin_amdgcn_ubfe(bits_base[m.cell >> 5], static_cast<uint32_t>(m.cell), 1u) != 0u;  // (march_step_frozen's own test)
                         m.it += kAqStepsPerTrip;
                         bool f = fin;
