@@ -177,7 +177,13 @@ int ddgi_generate_probe_rays(ddgi_handle h, uint32_t seed, int reseed);
 /* Replaces probe_buffer.copy_to(probe_rays) (rvpt.cpp:285, vk_util.h:508-518) for caller-made
  * rays.  n must equal the (local slab's) probe count * s*s for the current configuration, in
  * the reference's order: probe-major (p = py*cx*cz + pz*cx + px), ray i = y*s + x.
- * For a sharded handle pass the FULL-grid array; the handle keeps only its slab. */
+ * For a sharded handle pass the FULL-grid array; the handle keeps only its slab.
+ * Meant to be called every frame, as the reference does — with the same rays each time (it generates them at start-up and
+ * after a reconfiguration only: main.cpp:47, rvpt.cpp:721-726): per chunk of 64 Ki rays, on host threads, a chunk whose bytes
+ * equal the handle's host copy is left alone; any other is checked (probe_info inside the grid: the reference's shader trusts
+ * it blindly — a bad ray rejects the call and leaves the previous rays in place), copied into the handle's page-locked host
+ * copy and sent.  An unchanged buffer touches neither the GPU nor the frames in flight.  Synchronous: `rays` may be reused
+ * on return. */
 int ddgi_upload_probe_rays(ddgi_handle h, const ddgi_probe_ray* rays, size_t n);
 
 /* Copies the handle's current host-side ray array (what generate produced) into `rays`
