@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define DDGI_ABI_VERSION 6 /* 6: DDGI_ERR_TIMEOUT + tuning "wait_timeout_ms": every host wait of a handle with an exchange attached has a deadline; the peer-to-peer
-                              transport publishes a two-pair RECEIVE ring (what a peer maps no longer grows with "frames_in_flight");
+#define DDGI_ABI_VERSION 7 /* 7: the peer-to-peer transport publishes LANDING ZONES instead of a ring of 2 GiB or more (tuning "p2p_landing_zones", "p2p_exported_mb" tell), its flag
+                              words live in fine-grained device memory; ddgi_upload_probe_rays leaves chunks equal to the handle's host copy alone (a buffer handed over every frame);
+                              6: DDGI_ERR_TIMEOUT + tuning "wait_timeout_ms": every host wait of a handle with an exchange attached has a deadline;
                               5: ddgi_exchange_ranks; frames in flight in DDGI mode (per-update records, a ring of ray-record buffers); attaching an exchange
                               rebases the ring of texture pairs (every rank starts at pair 0, update 0); d_cage of ddgi_sample_device: 16-byte aligned or slower;
                               4: tuning "frames_in_flight" (default 8): the handle owns a ring of texture pairs, ddgi_device_textures pins the current one;

@@ -40,7 +40,7 @@ def test_wire_format_sizes(ddgi):
 
 def test_abi_version_and_geometry_helpers(ddgi):
     lib = ddgi.load_library()
-    assert lib.ddgi_abi_version() == 6
+    assert lib.ddgi_abi_version() == 7
     f = ddgi.make_field((9, 7, 9), 11, 20)
     assert ddgi.texture_size(f) == (9 * 9 * 20, 7 * 20)  # rvpt.cpp:873-874
     assert ddgi.probe_tile_origin(f, 0) == (0, 0)
