@@ -497,6 +497,7 @@ static void parallel_chunks(size_t n_chunks, Fn fn)
 static int upload_local_rays(ddgi_engine* e)
 {
     e->chain_break = true;  // new rays: the next update is not a continuation of the last (frames in flight)
+    e->n_local_rays = 0;    // (until the copies below are through: a failed upload leaves a handle WITHOUT rays, not with rays its host copy does not match)
     const GridK g = make_grid(e);
     const size_t n = static_cast<size_t>(g.n);
     const size_t local_probes = static_cast<size_t>(g.cx) * g.cy * g.czl;
@@ -901,6 +902,8 @@ int ddgi_upload_probe_rays(ddgi_handle e, const ddgi_probe_ray* rays, size_t n)
     if (!have_copy || e->world != 1) return upload_local_rays(e);
     // an unsharded handle's device order is the host's: only the runs of chunks that changed go over PCIe
     e->chain_break = true;  // new rays: the next update is not a continuation of the last (frames in flight)
+    const uint32_t n_held = e->n_local_rays;
+    e->n_local_rays = 0;    // (as in upload_local_rays: a copy that fails leaves the handle without rays)
     for (size_t c = 0; c < n_chunks;)
     {
         if (!dirty[c])
@@ -915,6 +918,7 @@ int ddgi_upload_probe_rays(ddgi_handle e, const ddgi_probe_ray* rays, size_t n)
         c = c_end;
     }
     DDGI_TRY(ddgi_sync_stream(e, e->stream));
+    e->n_local_rays = n_held;
     return DDGI_OK;
 }
 
