@@ -671,7 +671,8 @@ def main():
         },
         "roofline": {
             "kernel": {"lane": "k_probe_trace_ref", "rounds": "k_probe_trace_wf"}.get(os.environ.get("DDGI_TRACE_KERNEL", ""), "k_probe_trace_aq"),
-            "bound": "valu",
+            "bound": "hbm",          # the roofline achieved / peak / frac are priced against (the contract's: "hbm" | "mfma")
+            "limited_by": "valu",    # what the kernel really sits at (below)
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -684,7 +685,7 @@ def main():
             "issue": issue,
             "note": "achieved / peak / frac are the HBM figures the task defines (algorithmic bytes per update / mean launch duration of the timed updates, HIP events on the launch "
                     "stream; with frames in flight a launch traces up to `frames_in_flight` updates and the continued updates' own launches are empty — the mean is per update); "
-                    "`bound` says what the kernel really sits at: its waves' dependent VALU instruction streams (voxel steps + hit shading, DESIGN.md section 4), `valu` prices it against the lane peak. "
+                    "`limited_by` says what the kernel really sits at: its waves' dependent VALU instruction streams (voxel steps + hit shading, DESIGN.md section 4), `valu` prices it against the lane peak. "
                     "`traffic`, `issue` and the instruction count inside `valu` are REPLAYED from the committed rocprofv3 --pmc passes named beside them (counters need their own passes)",
         },
     }
